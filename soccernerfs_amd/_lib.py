@@ -1,0 +1,77 @@
+"""ctypes binding of libsnerf.so (C ABI: include/snerf.h).  The product path has NO fallback:
+if the HIP library is missing or stale the import fails loudly."""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- FIRST: libsnerf must bind to the HIP runtime torch already loaded (same SONAME)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libsnerf.so")
+
+MAX_SCALES = 8
+ABI_VERSION = 1
+
+
+class KPlanesDesc(C.Structure):
+    _fields_ = [
+        ("n_scales", C.c_int32),
+        ("C", C.c_int32),
+        ("concat", C.c_int32),
+        ("n_coords", C.c_int32),
+        ("res", (C.c_int32 * 4) * MAX_SCALES),
+        ("off", (C.c_int64 * 6) * MAX_SCALES),
+    ]
+
+
+class Coords(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("S", C.c_int32),
+        ("rescale", C.c_int32),
+        ("_pad", C.c_int32),
+        ("pts", C.c_void_p),
+        ("origins", C.c_void_p),
+        ("dirs", C.c_void_p),
+        ("times", C.c_void_p),
+        ("ebins", C.c_void_p),
+        ("aabb_min", C.c_float * 3),
+        ("aabb_max", C.c_float * 3),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Returns the loaded library, raising a RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP library is the product path and has no fallback. "
+            "Build it with `python -m soccernerfs_amd.build` (or __graft_entry__.build())."
+        )
+    l = C.CDLL(LIB_PATH)
+    l.snerf_last_error.restype = C.c_char_p
+    l.snerf_target_arch.restype = C.c_char_p
+    if l.snerf_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
+    _lib = l
+    return l
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().snerf_last_error().decode()
+        raise RuntimeError(f"libsnerf {what} failed (code {rc}): {msg}")
+
+
+# every symbol include/snerf.h declares; tests/test_abi.py checks the list against the header
+EXPORTS = [
+    "snerf_abi_version",
+    "snerf_last_error",
+    "snerf_target_arch",
+    "snerf_kplanes_gather_fwd",
+    "snerf_kplanes_gather_bwd",
+]

@@ -1,0 +1,61 @@
+// Shared host/device helpers for libsnerf (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/snerf.h"
+
+namespace snerf {
+
+// ---- error plumbing: integer codes across the C ABI, never exceptions ----
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define SNERF_REQUIRE(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::snerf::set_error(__VA_ARGS__);           \
+      return SNERF_ERR_ARG;                      \
+    }                                            \
+  } while (0)
+
+#define SNERF_LAUNCH_CHECK(name)                                  \
+  do {                                                            \
+    int _rc = ::snerf::check_hip(hipGetLastError(), name);        \
+    if (_rc) return _rc;                                          \
+  } while (0)
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+constexpr int WAVE = 64;  // CDNA wavefront
+
+// ---- wave-level primitives (64 lanes) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// inclusive prefix sum across the 64 lanes (Hillis-Steele; association order differs from sequential)
+__device__ __forceinline__ float wave_inclusive_scan(float v, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    float t = __shfl_up(v, off, 64);
+    if (lane >= off) v += t;
+  }
+  return v;
+}
+
+// nan_to_num with torch defaults (nan->0, +inf->FLT_MAX, -inf->-FLT_MAX)
+__device__ __forceinline__ float nan_to_num(float v) {
+  if (v != v) return 0.f;
+  if (v == INFINITY) return 3.4028234663852886e38f;
+  if (v == -INFINITY) return -3.4028234663852886e38f;
+  return v;
+}
+
+}  // namespace snerf

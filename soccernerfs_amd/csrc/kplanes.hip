@@ -1,0 +1,299 @@
+// K-Planes multiscale bilinear plane gather (forward) and atomic scatter (backward).
+//
+// Replaces interpolate_kplanes + grid_sample_wrapper (NS/fields/kplanes_field.py:77-126,
+// NS/utils/interpolation.py:5-33): the reference issues 6 F.grid_sample launches per scale on NCHW
+// planes (a texel's C features strided by H*W) and materialises an [N,C] tensor per plane.  Here planes
+// are channel-last, one texel = C contiguous floats (128 B for C=32 = one cache line), C/4 lanes own one
+// sample and each lane moves a float4, so every texel fetch is a single coalesced line; the 6-plane
+// Hadamard product and the scale concat stay in registers.  HBM-bound: algorithmic bytes per sample =
+// n_scales * 6 planes * 4 texels * C * 4 B.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+namespace snerf {
+
+struct AxisTap {
+  int i0, i1;    // texel indices along the axis (i1 clamped for addressing)
+  float w0, w1;  // weights of i0 / i1:  (i1 - x), (x - i0); w1 forced to 0 when i0+1 is out of range
+};
+
+// ATen grid_sampler semantics for align_corners=True + padding_mode="border":
+//   x_pix = ((x + 1) / 2) * (size - 1), clipped to [0, size-1]; taps floor / floor+1.
+__device__ __forceinline__ AxisTap axis_tap(float x, int size) {
+  float fx = ((x + 1.f) / 2.f) * (float)(size - 1);
+  fx = fminf((float)(size - 1), fmaxf(fx, 0.f));
+  float f0 = floorf(fx);
+  AxisTap t;
+  t.i0 = (int)f0;
+  t.w0 = (f0 + 1.f) - fx;
+  t.w1 = fx - f0;
+  bool in = (t.i0 + 1) <= (size - 1);
+  t.i1 = in ? t.i0 + 1 : t.i0;
+  if (!in) t.w1 = 0.f;  // out-of-range corner contributes nothing (ATen within_bounds_2d)
+  return t;
+}
+
+// coordinate of sample n along x,y,z,t in grid_sample's [-1,1] convention
+template <int NP>
+__device__ __forceinline__ void load_coords(const snerf_coords& c, int64_t n, float p[4]) {
+  if (c.mode == 0) {
+    if (NP == 6) {
+      float4 v = *reinterpret_cast<const float4*>(c.pts + n * 4);
+      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+    } else {  // static scene: pts is [N,3]
+      p[0] = c.pts[n * 3]; p[1] = c.pts[n * 3 + 1]; p[2] = c.pts[n * 3 + 2]; p[3] = 0.f;
+    }
+  } else {
+    int64_t r = n / c.S;
+    int s = (int)(n - r * c.S);
+    const float* eb = c.ebins + r * (c.S + 1) + s;
+    float mid = eb[0] + eb[1];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float pos = c.origins[r * 3 + k] + (c.dirs[r * 3 + k] * mid) / 2.f;
+      float q = (pos - c.aabb_min[k]) / (c.aabb_max[k] - c.aabb_min[k]);
+      p[k] = c.rescale ? q * 2.f - 1.f : q;
+    }
+    p[3] = c.times[r] * 2.f - 1.f;
+  }
+}
+
+template <int NP> struct PlanePairs;
+template <> struct PlanePairs<6> {  // XY XZ XT YZ YT ZT
+  static constexpr int a[6] = {0, 0, 0, 1, 1, 2};
+  static constexpr int b[6] = {1, 2, 3, 2, 3, 3};
+};
+template <> struct PlanePairs<3> {  // static scene: XY XZ YZ
+  static constexpr int a[3] = {0, 0, 1};
+  static constexpr int b[3] = {1, 2, 2};
+};
+
+__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// bilinear value of plane p for this lane's 4 channels
+template <int C>
+__device__ __forceinline__ float4 plane_sample(const float* __restrict__ base, int W, const AxisTap& tx, const AxisTap& ty, int cg) {
+  const float* r0 = base + ((int64_t)ty.i0 * W) * C + cg * 4;
+  const float* r1 = base + ((int64_t)ty.i1 * W) * C + cg * 4;
+  float4 nw = *reinterpret_cast<const float4*>(r0 + (int64_t)tx.i0 * C);
+  float4 ne = *reinterpret_cast<const float4*>(r0 + (int64_t)tx.i1 * C);
+  float4 sw = *reinterpret_cast<const float4*>(r1 + (int64_t)tx.i0 * C);
+  float4 se = *reinterpret_cast<const float4*>(r1 + (int64_t)tx.i1 * C);
+  float4 acc = f4_scale(nw, tx.w0 * ty.w0);
+  acc = f4_add(acc, f4_scale(ne, tx.w1 * ty.w0));
+  acc = f4_add(acc, f4_scale(sw, tx.w0 * ty.w1));
+  acc = f4_add(acc, f4_scale(se, tx.w1 * ty.w1));
+  return acc;
+}
+
+template <int C, int NP>
+__global__ __launch_bounds__(256) void kplanes_gather_fwd_kernel(snerf_kplanes_desc d, const float* __restrict__ planes,
+                                                                snerf_coords c, int64_t N, float* __restrict__ out) {
+  constexpr int LPS = C / 4;  // lanes per sample
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t n = gid / LPS;
+  int cg = (int)(gid % LPS);
+  if (n >= N) return;
+  float p[4];
+  load_coords<NP>(c, n, p);
+  const int out_w = d.concat ? C * d.n_scales : C;
+  float* orow = out + n * out_w + cg * 4;
+  float4 total = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < d.n_scales; ++s) {
+    AxisTap tap[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tap[k] = axis_tap(p[k], d.res[s][k] > 0 ? d.res[s][k] : 1);
+    float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      constexpr auto& A = PlanePairs<NP>::a;
+      constexpr auto& B = PlanePairs<NP>::b;
+      float4 v = plane_sample<C>(planes + d.off[s][q], d.res[s][A[q]], tap[A[q]], tap[B[q]], cg);
+      prod = f4_mul(prod, v);
+    }
+    if (d.concat) {
+      *reinterpret_cast<float4*>(orow + s * C) = prod;
+    } else {
+      total = f4_add(total, prod);
+    }
+  }
+  if (!d.concat) *reinterpret_cast<float4*>(orow) = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward: scatter-add into the plane gradients.
+//
+// Float atomics on gfx950 execute at the memory side in 64-B requests (MI355X_MICROARCH.md "Global float
+// atomics"): cost ~ number of 64-B requests, so (1) every request must be full and (2) there must be few.
+// Layout: 2*C lanes own one sample -- lane = half*C + ch, half 0/1 = x-corner x0 / x0+1.  Channel-last
+// storage makes texels (y,x0) and (y,x0+1) adjacent, so ONE atomic wave-instruction covers 2*C contiguous
+// floats (256 B for C=32: the full-rate shape).  Each lane group walks RUN consecutive samples (consecutive
+// along a ray => spatially coherent) and run-length-combines: while the (plane,row) texel key stays the same
+// the contribution is summed in a register; it is flushed with one atomic only when the key changes.
+// (v1 of this kernel used float4-per-lane atomics at a 16-B lane stride: quarter-full requests, 12.8 ms at
+// config-2 size vs. 0.5 ms for the forward -- profiles/r01_kernels.md.)
+// ---------------------------------------------------------------------------------------------
+template <int C, int NP>
+__global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_desc d, const float* __restrict__ planes,
+                                                                snerf_coords c, int64_t N, const float* __restrict__ gout,
+                                                                float* __restrict__ gplanes, int run) {
+  constexpr int LPS = 2 * C;  // lanes per sample
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t group = gid / LPS;
+  const int li = (int)(gid % LPS);
+  const int half = li / C;
+  const int ch = li % C;
+  const int64_t n0 = group * run;
+  if (n0 >= N) return;
+  const int cnt = (int)((N - n0) < run ? (N - n0) : run);
+  const int out_w = d.concat ? C * d.n_scales : C;
+  constexpr auto& A = PlanePairs<NP>::a;
+  constexpr auto& B = PlanePairs<NP>::b;
+
+  for (int s = 0; s < d.n_scales; ++s) {
+    int pend_key[NP][2];
+    float pend_val[NP][2];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      pend_key[q][0] = pend_key[q][1] = -1;
+      pend_val[q][0] = pend_val[q][1] = 0.f;
+    }
+    int res[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) res[k] = d.res[s][k] > 0 ? d.res[s][k] : 1;
+
+    for (int i = 0; i < cnt; ++i) {
+      const int64_t n = n0 + i;
+      float p[4];
+      load_coords<NP>(c, n, p);
+      AxisTap tap[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) tap[k] = axis_tap(p[k], res[k]);
+      float v[NP];
+      float wx[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const AxisTap& tx = tap[A[q]];
+        const AxisTap& ty = tap[B[q]];
+        const int W = res[A[q]];
+        const int xi = half ? tx.i1 : tx.i0;
+        wx[q] = half ? tx.w1 : tx.w0;
+        const float* base = planes + d.off[s][q] + ch;
+        float a = base[((int64_t)ty.i0 * W + xi) * C];
+        float b = base[((int64_t)ty.i1 * W + xi) * C];
+        float part = wx[q] * (ty.w0 * a + ty.w1 * b);
+        v[q] = part + __shfl_xor(part, C, 64);
+      }
+      const float g = gout[n * out_w + (d.concat ? s * C : 0) + ch];
+      float suf[NP + 1];
+      suf[NP] = 1.f;
+#pragma unroll
+      for (int q = NP - 1; q >= 0; --q) suf[q] = suf[q + 1] * v[q];
+      float pre = g;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const float gq = pre * suf[q + 1] * wx[q];
+        pre *= v[q];
+        const AxisTap& tx = tap[A[q]];
+        const AxisTap& ty = tap[B[q]];
+        const int W = res[A[q]];
+        float* gbase = gplanes + d.off[s][q] + li;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int key = (r ? ty.i1 : ty.i0) * W + tx.i0;
+          const float val = gq * (r ? ty.w1 : ty.w0);
+          if (key != pend_key[q][r]) {
+            if (pend_val[q][r] != 0.f) atomicAdd(gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
+            pend_key[q][r] = key;
+            pend_val[q][r] = val;
+          } else {
+            pend_val[q][r] += val;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      float* gbase = gplanes + d.off[s][q] + li;
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        if (pend_val[q][r] != 0.f) atomicAdd(gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
+    }
+  }
+}
+
+static int validate(const snerf_kplanes_desc* d, const snerf_coords* c, int64_t N) {
+  SNERF_REQUIRE(d && c, "kplanes: null descriptor");
+  SNERF_REQUIRE(d->n_scales >= 1 && d->n_scales <= SNERF_MAX_SCALES, "kplanes: n_scales=%d out of range", d->n_scales);
+  SNERF_REQUIRE(d->C == 8 || d->C == 16 || d->C == 32, "kplanes: C=%d unsupported (8, 16, 32)", d->C);
+  SNERF_REQUIRE(d->n_coords == 3 || d->n_coords == 4, "kplanes: n_coords=%d unsupported", d->n_coords);
+  SNERF_REQUIRE(N >= 0, "kplanes: negative N");
+  for (int s = 0; s < d->n_scales; ++s)
+    for (int k = 0; k < d->n_coords; ++k) SNERF_REQUIRE(d->res[s][k] >= 1, "kplanes: res[%d][%d]=%d", s, k, d->res[s][k]);
+  if (c->mode == 0) {
+    SNERF_REQUIRE(c->pts || N == 0, "kplanes: pts is null");
+  } else if (c->mode == 1) {
+    SNERF_REQUIRE(c->S >= 1 && N % c->S == 0, "kplanes: N=%lld not a multiple of S=%d", (long long)N, c->S);
+    SNERF_REQUIRE((c->origins && c->dirs && c->times && c->ebins) || N == 0, "kplanes: null ray buffers");
+  } else {
+    SNERF_REQUIRE(false, "kplanes: coords.mode=%d unsupported", c->mode);
+  }
+  return 0;
+}
+
+template <int C, int NP>
+static int launch_fwd(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, float* out, hipStream_t st) {
+  int64_t threads = N * (C / 4);
+  hipLaunchKernelGGL((kplanes_gather_fwd_kernel<C, NP>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, out);
+  SNERF_LAUNCH_CHECK("kplanes_gather_fwd");
+  return 0;
+}
+template <int C, int NP>
+static int launch_bwd(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, float* gp,
+                      hipStream_t st) {
+  // consecutive samples walked (and run-length-combined) by one lane group; SNERF_BWD_RUN is a tuning knob
+  static const int run = [] { const char* e = getenv("SNERF_BWD_RUN"); int v = e ? atoi(e) : 16; return v > 0 ? v : 16; }();
+  int64_t groups = (N + run - 1) / run;
+  int64_t threads = groups * (2 * C);
+  hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, run);
+  SNERF_LAUNCH_CHECK("kplanes_gather_bwd");
+  return 0;
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+#define DISPATCH_C_NP(FN, ...)                                                          \
+  do {                                                                                  \
+    if (desc->n_coords == 4) {                                                          \
+      if (desc->C == 32) return FN<32, 6>(__VA_ARGS__);                                 \
+      if (desc->C == 16) return FN<16, 6>(__VA_ARGS__);                                 \
+      return FN<8, 6>(__VA_ARGS__);                                                     \
+    } else {                                                                            \
+      if (desc->C == 32) return FN<32, 3>(__VA_ARGS__);                                 \
+      if (desc->C == 16) return FN<16, 3>(__VA_ARGS__);                                 \
+      return FN<8, 3>(__VA_ARGS__);                                                     \
+    }                                                                                   \
+  } while (0)
+
+extern "C" int snerf_kplanes_gather_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                                        float* out, snerf_stream_t stream) {
+  int rc = validate(desc, coords, N);
+  if (rc) return rc;
+  if (N == 0) return 0;
+  SNERF_REQUIRE(planes && out, "kplanes_gather_fwd: null buffer");
+  DISPATCH_C_NP(launch_fwd, desc, planes, coords, N, out, (hipStream_t)stream);
+}
+
+extern "C" int snerf_kplanes_gather_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                                        const float* grad_out, float* grad_planes, snerf_stream_t stream) {
+  int rc = validate(desc, coords, N);
+  if (rc) return rc;
+  if (N == 0) return 0;
+  SNERF_REQUIRE(planes && grad_out && grad_planes, "kplanes_gather_bwd: null buffer");
+  DISPATCH_C_NP(launch_bwd, desc, planes, coords, N, grad_out, grad_planes, (hipStream_t)stream);
+}

@@ -1,0 +1,140 @@
+"""GPU parity: K-Planes gather fwd/bwd (HIP, through the C ABI) vs the CPU oracle and the golden vectors.
+Tolerances: features rtol 1e-5 / atol 1e-6; plane gradients (atomic order) rtol 1e-4."""
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU test needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def _plane_set_from_reference(grids, C, concat):
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    reso = []
+    for g in grids:
+        # plane 0 = XY: [1,C,Y,X]; plane 1 = XZ: [1,C,Z,X]; plane 2 = XT: [1,C,T,X]
+        reso.append([g[0].shape[3], g[0].shape[2], g[1].shape[2], g[2].shape[2]])
+    ps = PlaneSet(C, reso, concat=concat)
+    ps.load_reference(grids)
+    return ps.to(_dev())
+
+
+@pytest.mark.parametrize("tag", ["single", "multi", "prop"])
+def test_gather_matches_golden(tag):
+    from soccernerfs_amd import ops
+
+    g = load_golden("g5_interp")
+    C, n_scales, concat = [int(v) for v in g[f"{tag}_meta"]]
+    grids = [[g[f"{tag}_plane_{s}_{p}"] for p in range(6)] for s in range(n_scales)]
+    ps = _plane_set_from_reference(grids, C, bool(concat))
+    pts = g[f"{tag}_pts"].to(_dev())
+    feats = ops.interpolate_kplanes(pts, ps)
+    torch.testing.assert_close(feats.cpu(), g[f"{tag}_feats"], rtol=1e-5, atol=1e-6)
+    feats.backward(g[f"{tag}_gout"].to(_dev()))
+    got = ps.to_reference(ps.planes.grad.cpu())
+    for s in range(n_scales):
+        for p in range(6):
+            torch.testing.assert_close(got[s][p], g[f"{tag}_grad_{s}_{p}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("C,ms,concat,lo,hi", [(32, (1, 2, 4), True, -1.2, 1.2), (8, (1,), False, -0.1, 1.1), (16, (1, 3), False, -1.0, 1.0)])
+def test_gather_matches_oracle_random(C, ms, concat, lo, hi):
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd import ops
+
+    gen = torch.Generator().manual_seed(7)
+    base = (11, 9, 7, 5)
+    grids = []
+    for m in ms:
+        reso = [r * m for r in base[:3]] + [base[3]]
+        grids.append([torch.rand(1, C, reso[b], reso[a], generator=gen) + 0.2 for (a, b) in KO.COO_COMBS])
+    N = 3001  # ragged: not a multiple of the block size
+    pts = torch.rand(N, 4, generator=gen) * (hi - lo) + lo
+    leaves = [[t.clone().requires_grad_(True) for t in sc] for sc in grids]
+    ref = KO.interpolate_kplanes(pts, leaves, concat)
+    gout = torch.rand(ref.shape, generator=gen) - 0.5
+    ref.backward(gout)
+    ps = _plane_set_from_reference(grids, C, concat)
+    out = ops.interpolate_kplanes(pts.to(_dev()), ps)
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    out.backward(gout.to(_dev()))
+    got = ps.to_reference(ps.planes.grad.cpu())
+    for s in range(len(ms)):
+        for p in range(6):
+            torch.testing.assert_close(got[s][p], leaves[s][p].grad, rtol=1e-4, atol=2e-6)
+
+
+def test_gather_from_rays_matches_oracle():
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd import ops
+
+    gen = torch.Generator().manual_seed(11)
+    R, S, C = 37, 48, 8
+    grids = [torch.rand(1, C, r2, r1, generator=gen) + 0.1 for (r1, r2) in [(12, 10), (12, 8), (12, 4), (10, 8), (10, 4), (8, 4)]]
+    aabb = torch.tensor([[-1.5, -1.5, -1.5], [1.5, 1.5, 1.5]])
+    o = torch.rand(R, 3, generator=gen) * 2 - 1
+    d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)
+    times = torch.rand(R, 1, generator=gen)
+    eb = torch.cumsum(torch.rand(R, S + 1, generator=gen) * 0.06, -1)
+    pos = KO.sample_positions(o, d, eb[:, :-1], eb[:, 1:])
+    for rescale in (True, False):
+        p = KO.normalize_positions(pos, aabb)
+        p = p * 2 - 1 if rescale else p
+        pts = torch.cat([p, (times * 2 - 1)[:, None, :].expand(R, S, 1)], -1).reshape(-1, 4)
+        ref = KO.interpolate_kplanes(pts, [grids], False)
+        ps = _plane_set_from_reference([grids], C, False)
+        dev = _dev()
+        out = ops.interpolate_kplanes_rays(ps, o.to(dev), d.to(dev), times.to(dev), eb.to(dev), aabb, rescale)
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_gather_full_size_properties():
+    """BASELINE config-2 sizes (5 scales x 6 planes, C=32, 64*4096 samples): size-independent properties.
+    Constant planes k => every feature equals k^6 and every plane's gradient sums to k^5 * sum(gout)."""
+    from soccernerfs_amd import ops
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    dev = _dev()
+    reso = [[64 * m, 64 * m, 64 * m, 100] for m in (1, 2, 4, 8, 16)]
+    ps = PlaneSet(32, reso, concat=True, device=dev)
+    k = 1.25
+    with torch.no_grad():
+        ps.planes.fill_(k)
+    N = 64 * 4096
+    pts = torch.rand(N, 4, device=dev) * 2.2 - 1.1
+    out = ops.interpolate_kplanes(pts, ps)
+    assert out.shape == (N, 160)
+    torch.testing.assert_close(out, torch.full_like(out, k**6), rtol=2e-6, atol=0)
+    gout = torch.rand_like(out) - 0.25
+    out.backward(gout)
+    g = ps.planes.grad
+    for s in range(5):
+        expect = (gout[:, s * 32:(s + 1) * 32].double().sum(0) * k**5).cpu()
+        for p in range(6):
+            got = ps.plane_view(s, p, g).double().sum((0, 1)).cpu()
+            torch.testing.assert_close(got, expect, rtol=2e-4, atol=1e-3)
+    # linearity of the backward in grad_out
+    ps.planes.grad = None
+    out2 = ops.interpolate_kplanes(pts, ps)
+    out2.backward(2.0 * gout)
+    torch.testing.assert_close(ps.planes.grad, 2.0 * g, rtol=1e-3, atol=1e-3)
+
+
+def test_gather_empty_and_errors():
+    from soccernerfs_amd import ops
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    dev = _dev()
+    ps = PlaneSet(8, [[4, 4, 4, 2]], concat=False, device=dev)
+    out = ops.interpolate_kplanes(torch.zeros(0, 4, device=dev), ps)
+    assert out.shape == (0, 8)
+    bad = PlaneSet(8, [[4, 4, 4, 2]], concat=False, device=dev)
+    bad.C = 12
+    with pytest.raises(RuntimeError, match="unsupported"):
+        ops.interpolate_kplanes(torch.zeros(4, 4, device=dev), bad)
