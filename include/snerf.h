@@ -88,6 +88,84 @@ int snerf_kplanes_gather_fwd(const snerf_kplanes_desc* desc, const float* planes
 int snerf_kplanes_gather_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords,
                              int64_t N, const float* grad_out, float* grad_planes, snerf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-ray sampling ops.  One wavefront per ray; S <= 320 samples per ray.
+ * "sbins" = bin edges in the normalised spacing domain [0,1]; "ebins" = the same edges in euclidean
+ * distance along the ray (what RaySamples.frustums.starts/ends hold).  kind: 0 = uniform spacing
+ * (UniformSampler), 1 = uniform/linear-disparity piecewise (UniformLinDispPiecewiseSampler).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* SpacedSampler.generate_ray_samples (NS/model_components/ray_samplers.py:79-126).
+ * t_rand: NULL (eval, no jitter) or uniform draws [R, rand_cols], rand_cols = S+1, or 1 (single_jitter).
+ * Outputs sbins, ebins: [R, S+1]. */
+int snerf_spaced_bins(const float* nears, const float* fars, const float* t_rand, int32_t rand_cols, int32_t R, int32_t S,
+                      int32_t kind, float* sbins, float* ebins, snerf_stream_t stream);
+
+/* RaySamples.get_weights (NS/cameras/rays.py:127-149): density [R,S], ebins [R,S+1] -> weights [R,S].
+ * deltas = ebins[:,1:] - ebins[:,:-1]. */
+int snerf_weights_fwd(const float* density, const float* ebins, int32_t R, int32_t S, float* weights, snerf_stream_t stream);
+
+/* Backward of get_weights w.r.t. density.  accumulate != 0: grad_density += ...; else overwritten. */
+int snerf_weights_bwd(const float* density, const float* ebins, const float* grad_weights, int32_t R, int32_t S,
+                      float* grad_density, int32_t accumulate, snerf_stream_t stream);
+
+/* PDFSampler.generate_ray_samples with include_original=False (ray_samplers.py:274-369) preceded by the
+ * weight annealing of ProposalNetworkSampler (:584), optionally fused behind get_weights.
+ *   weights source: `density`+`ebins_prev` (weights are computed in-kernel and, if weights_out != NULL,
+ *                   stored) or `weights_in` [R,S_prev].
+ *   u_mode 0: `u_or_rand` is u [R,S+1] itself (parity mode: every random draw is an input);
+ *          1: `u_or_rand` holds uniform draws [R,rand_cols] (rand_cols = S+1 or 1); u = linspace + rand/(S+1);
+ *          2: eval, u = bin centres.
+ * The CDF is accumulated strictly left to right in fp32, so `inds_out` (int64, searchsorted(cdf,u,"right"))
+ * is bit-exact against the CPU oracle.  Outputs: sbins_out, ebins_out [R,S+1]; inds_out optional. */
+typedef struct {
+  const float* density;     /* [R,S_prev] or NULL */
+  const float* weights_in;  /* [R,S_prev] or NULL */
+  const float* ebins_prev;  /* [R,S_prev+1] (with density) */
+  float* weights_out;       /* [R,S_prev] or NULL */
+  const float* sbins_prev;  /* [R,S_prev+1] */
+  const float* u_or_rand;
+  const float* nears;       /* [R] */
+  const float* fars;        /* [R] */
+  float* sbins_out;         /* [R,S+1] */
+  float* ebins_out;         /* [R,S+1] */
+  int64_t* inds_out;        /* [R,S+1] or NULL */
+  int32_t R, S_prev, S;
+  int32_t u_mode, rand_cols, kind;
+  float anneal;             /* weights ** anneal; 1.0 = off */
+  float histogram_padding;  /* 0.01 */
+  float eps;                /* 1e-5 */
+} snerf_resample_args;
+int snerf_pdf_resample(const snerf_resample_args* args, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tiny bias-free MLP = the reference's tcnn.Network(FullyFusedMLP) call sites
+ * (NS/fields/kplanes_field.py:249-273,397-407; NS/fields/nerfplayer_nerfacto_field.py:94-104,238-248,301-311).
+ * d_in -> hidden x n_hidden (ReLU/None) -> d_out (None/Sigmoid); d_out <= 16; hidden in {16,64,128}.
+ * Parameters: ONE flat fp32 buffer, layer l stored row-major [d_l][d_{l+1}] (input-major), layers back to back.
+ * Computed in exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t d_in, hidden, n_hidden, d_out;
+  int32_t hidden_act; /* 0 none, 1 ReLU */
+  int32_t out_act;    /* 0 none, 1 Sigmoid */
+} snerf_mlp_desc;
+
+int64_t snerf_mlp_param_count(const snerf_mlp_desc* desc);
+
+/* Y[N,d_out] (row stride ldy) = MLP(X[N,d_in] (row stride ldx)).  If aux_out != NULL:
+ * aux_out[n] = exp(raw output column aux_col) -- trunc_exp's forward (NS/field_components/activations.py:25-41),
+ * i.e. the density head of sigma_net (kplanes_field.py:308-311). */
+int snerf_mlp_fwd(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, float* Y, int32_t ldy,
+                  int32_t aux_col, float* aux_out, snerf_stream_t stream);
+
+/* Backward.  Incoming gradients: gY [N,d_out] (row stride ldgy, may be NULL = zeros) w.r.t. the activated output,
+ * and/or gaux [N] w.r.t. aux_out (applies trunc_exp's clamped backward g*exp(clamp(y,-15,15))).
+ * Outputs: gX [N,d_in] (row stride ldgx; NULL = not needed, overwritten otherwise) and gW (flat, ACCUMULATED atomically;
+ * NULL = not needed).  The forward is recomputed tile by tile; nothing is saved between fwd and bwd. */
+int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                  int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

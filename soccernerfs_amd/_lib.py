@@ -39,6 +39,22 @@ class Coords(C.Structure):
     ]
 
 
+class ResampleArgs(C.Structure):
+    _fields_ = [
+        ("density", C.c_void_p), ("weights_in", C.c_void_p), ("ebins_prev", C.c_void_p), ("weights_out", C.c_void_p),
+        ("sbins_prev", C.c_void_p), ("u_or_rand", C.c_void_p), ("nears", C.c_void_p), ("fars", C.c_void_p),
+        ("sbins_out", C.c_void_p), ("ebins_out", C.c_void_p), ("inds_out", C.c_void_p),
+        ("R", C.c_int32), ("S_prev", C.c_int32), ("S", C.c_int32),
+        ("u_mode", C.c_int32), ("rand_cols", C.c_int32), ("kind", C.c_int32),
+        ("anneal", C.c_float), ("histogram_padding", C.c_float), ("eps", C.c_float),
+    ]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("d_in", C.c_int32), ("hidden", C.c_int32), ("n_hidden", C.c_int32), ("d_out", C.c_int32),
+                ("hidden_act", C.c_int32), ("out_act", C.c_int32)]
+
+
 _lib = None
 
 
@@ -55,6 +71,7 @@ def lib():
     l = C.CDLL(LIB_PATH)
     l.snerf_last_error.restype = C.c_char_p
     l.snerf_target_arch.restype = C.c_char_p
+    l.snerf_mlp_param_count.restype = C.c_int64
     if l.snerf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
     _lib = l
@@ -74,4 +91,11 @@ EXPORTS = [
     "snerf_target_arch",
     "snerf_kplanes_gather_fwd",
     "snerf_kplanes_gather_bwd",
+    "snerf_spaced_bins",
+    "snerf_weights_fwd",
+    "snerf_weights_bwd",
+    "snerf_pdf_resample",
+    "snerf_mlp_param_count",
+    "snerf_mlp_fwd",
+    "snerf_mlp_bwd",
 ]

@@ -80,3 +80,140 @@ def interpolate_kplanes_rays(plane_set: PlaneSet, origins, dirs, times, ebins, a
     R, S = ebins.shape[0], ebins.shape[1] - 1
     c = coords_from_rays(origins, dirs, times, ebins, aabb, rescale)
     return _KPlanesGather.apply(plane_set.planes, plane_set, (origins, dirs, times, ebins), c, R * S)
+
+
+# ----------------------------------------------------------------------------------------------
+# per-ray sampling ops
+# ----------------------------------------------------------------------------------------------
+SPACING_KIND = {"uniform": 0, "piecewise": 1}
+
+
+def spaced_bins(nears, fars, num_samples: int, t_rand=None, kind: str = "uniform"):
+    """SpacedSampler bins (ray_samplers.py:79-126). nears/fars [R] or [R,1]; t_rand None | [R,S+1] | [R,1].
+    Returns (sbins, ebins) [R,S+1]."""
+    nears, fars = _f32c(nears, "nears").reshape(-1), _f32c(fars, "fars").reshape(-1)
+    R, S = nears.shape[0], num_samples
+    sb = torch.empty(R, S + 1, dtype=torch.float32, device=nears.device)
+    eb = torch.empty_like(sb)
+    cols = 0
+    if t_rand is not None:
+        t_rand = _f32c(t_rand, "t_rand")
+        cols = t_rand.shape[-1]
+    _lib.check(_lib.lib().snerf_spaced_bins(_ptr(nears), _ptr(fars), _ptr(t_rand) if t_rand is not None else None, cols, R, S,
+                                            SPACING_KIND[kind], _ptr(sb), _ptr(eb), _stream()), "spaced_bins")
+    return sb, eb
+
+
+class _Weights(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, density, ebins):
+        R, S = density.shape
+        w = torch.empty_like(density)
+        _lib.check(_lib.lib().snerf_weights_fwd(_ptr(density), _ptr(ebins), R, S, _ptr(w), _stream()), "weights_fwd")
+        ctx.save_for_backward(density, ebins)
+        return w
+
+    @staticmethod
+    def backward(ctx, gw):
+        density, ebins = ctx.saved_tensors
+        R, S = density.shape
+        gw = gw.contiguous()
+        gd = torch.empty_like(density)
+        _lib.check(_lib.lib().snerf_weights_bwd(_ptr(density), _ptr(ebins), _ptr(gw), R, S, _ptr(gd), 0, _stream()), "weights_bwd")
+        return gd, None
+
+
+def get_weights(density, ebins):
+    """RaySamples.get_weights (NS/cameras/rays.py:127-149). density [R,S], ebins [R,S+1] -> [R,S]."""
+    return _Weights.apply(_f32c(density, "density"), _f32c(ebins, "ebins"))
+
+
+def pdf_resample(sbins_prev, nears, fars, num_samples: int, weights=None, density=None, ebins_prev=None, u=None, rand=None,
+                 anneal: float = 1.0, kind: str = "uniform", histogram_padding: float = 0.01, eps: float = 1e-5,
+                 return_inds: bool = False, return_weights: bool = False):
+    """PDFSampler (ray_samplers.py:274-369, include_original=False) with annealing (:584).
+    Exactly one of `weights` [R,Sp] or (`density`, `ebins_prev`); exactly one of u [R,S+1] (explicit),
+    rand [R,S+1]|[R,1] (training draws) or neither (eval).  Returns (sbins, ebins[, inds][, weights])."""
+    sbins_prev = _f32c(sbins_prev, "sbins_prev")
+    nears, fars = _f32c(nears, "nears").reshape(-1), _f32c(fars, "fars").reshape(-1)
+    R, Sp, S = sbins_prev.shape[0], sbins_prev.shape[1] - 1, num_samples
+    dev = sbins_prev.device
+    a = _lib.ResampleArgs()
+    keep = []
+    if density is not None:
+        density, ebins_prev = _f32c(density, "density"), _f32c(ebins_prev, "ebins_prev")
+        a.density, a.ebins_prev = density.data_ptr(), ebins_prev.data_ptr()
+        keep += [density, ebins_prev]
+    else:
+        weights = _f32c(weights.detach(), "weights")
+        a.weights_in = weights.data_ptr()
+        keep.append(weights)
+    wout = None
+    if return_weights:
+        wout = torch.empty(R, Sp, dtype=torch.float32, device=dev)
+        a.weights_out = wout.data_ptr()
+    if u is not None:
+        u = _f32c(u, "u")
+        a.u_mode, a.u_or_rand = 0, u.data_ptr()
+    elif rand is not None:
+        rand = _f32c(rand, "rand")
+        a.u_mode, a.u_or_rand, a.rand_cols = 1, rand.data_ptr(), rand.shape[-1]
+    else:
+        a.u_mode = 2
+    sb = torch.empty(R, S + 1, dtype=torch.float32, device=dev)
+    eb = torch.empty_like(sb)
+    inds = torch.empty(R, S + 1, dtype=torch.int64, device=dev) if return_inds else None
+    a.sbins_prev, a.nears, a.fars = sbins_prev.data_ptr(), nears.data_ptr(), fars.data_ptr()
+    a.sbins_out, a.ebins_out = sb.data_ptr(), eb.data_ptr()
+    a.inds_out = inds.data_ptr() if inds is not None else None
+    a.R, a.S_prev, a.S, a.kind = R, Sp, S, SPACING_KIND[kind]
+    a.anneal, a.histogram_padding, a.eps = anneal, histogram_padding, eps
+    _lib.check(_lib.lib().snerf_pdf_resample(C.byref(a), _stream()), "pdf_resample")
+    out = [sb, eb]
+    if return_inds:
+        out.append(inds)
+    if return_weights:
+        out.append(wout)
+    return tuple(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# tiny MLP
+# ----------------------------------------------------------------------------------------------
+class _MLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, params, desc, aux_col, need_gx):
+        N = x.shape[0]
+        y = torch.empty(N, desc.d_out, dtype=torch.float32, device=x.device)
+        aux = torch.empty(N, dtype=torch.float32, device=x.device) if aux_col >= 0 else None
+        _lib.check(_lib.lib().snerf_mlp_fwd(C.byref(desc), _ptr(params), _ptr(x), x.stride(0), C.c_int64(N), _ptr(y), desc.d_out,
+                                            aux_col, _ptr(aux) if aux is not None else None, _stream()), "mlp_fwd")
+        ctx.desc, ctx.aux_col, ctx.need_gx = desc, aux_col, need_gx
+        ctx.save_for_backward(x, params)
+        if aux is None:
+            return y
+        return y, aux
+
+    @staticmethod
+    def backward(ctx, gy, gaux=None):
+        x, params = ctx.saved_tensors
+        desc = ctx.desc
+        N = x.shape[0]
+        gy = gy.contiguous() if gy is not None else None
+        gaux = gaux.contiguous() if gaux is not None else None
+        gx = torch.empty(N, desc.d_in, dtype=torch.float32, device=x.device) if ctx.need_gx else None
+        gw = torch.zeros_like(params)
+        _lib.check(_lib.lib().snerf_mlp_bwd(C.byref(desc), _ptr(params), _ptr(x), x.stride(0), C.c_int64(N),
+                                            _ptr(gy) if gy is not None else None, desc.d_out, ctx.aux_col,
+                                            _ptr(gaux) if gaux is not None else None,
+                                            _ptr(gx) if gx is not None else None, desc.d_in, _ptr(gw), _stream()), "mlp_bwd")
+        return gx, gw, None, None, None
+
+
+def mlp_forward(x, params, desc: _lib.MlpDesc, aux_col: int = -1):
+    """x [N,d_in] (unit inner stride; row stride may exceed d_in), params flat -> y [N,d_out] (and exp(raw[:,aux_col]))."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("mlp: expected a float32 HIP device tensor (the HIP library is the only product path)")
+    if x.dim() != 2 or x.stride(1) != 1:
+        x = x.reshape(-1, x.shape[-1]).contiguous()
+    return _MLP.apply(x, params, desc, aux_col, x.requires_grad)

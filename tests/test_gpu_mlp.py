@@ -1,0 +1,110 @@
+"""GPU parity: fp32-MFMA tiny MLP fwd/bwd vs the CPU oracle (bias-free Linear stacks = the tcnn stand-in).
+fp32 tolerance: outputs rtol 1e-5/atol 1e-6; gradients rtol 1e-4."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+SHAPES = [  # d_in, hidden, n_hidden, d_out, out_act
+    (8, 64, 1, 1, "None"),       # K-Planes proposal sigma_net
+    (15, 64, 2, 3, "Sigmoid"),   # K-Planes color_net
+    (32, 128, 1, 16, "None"),    # sigma_net, single scale
+    (160, 128, 1, 16, "None"),   # sigma_net, k-planes preset
+    (64, 128, 1, 16, "None"),
+    (10, 16, 1, 1, "None"),      # nerfplayer-nerfacto proposal
+    (32, 64, 1, 16, "None"),     # nerfplayer mlp_base
+    (63, 64, 2, 3, "Sigmoid"),   # nerfplayer mlp_head
+]
+
+
+@pytest.mark.parametrize("d_in,hidden,n_hidden,d_out,out_act", SHAPES)
+@pytest.mark.parametrize("N", [1000, 64])
+def test_mlp_matches_oracle(d_in, hidden, n_hidden, d_out, out_act, N):
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd.tcnn_compat import Network
+
+    gen = torch.Generator().manual_seed(d_in * 7 + N)
+    net = Network(d_in, d_out, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": out_act,
+                                "n_neurons": hidden, "n_hidden_layers": n_hidden})
+    ws = [w.clone().requires_grad_(True) for w in net.linear_weights()]
+    x = (torch.rand(N, d_in, generator=gen) * 2 - 1).requires_grad_(True)
+    ref = KO.mlp(x, ws, out_act=out_act)
+    gy = torch.rand(ref.shape, generator=gen) - 0.5
+    ref.backward(gy)
+    net = net.to(DEV)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = net(xg)
+    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    y.backward(gy.to(DEV))
+    torch.testing.assert_close(xg.grad.cpu(), x.grad, rtol=1e-4, atol=1e-6)
+    got = net.linear_weights(net.params.grad.cpu())
+    for a, b in zip(got, ws):
+        torch.testing.assert_close(a, b.grad, rtol=1e-4, atol=2e-6)
+
+
+def test_mlp_exp_head_and_strided_input():
+    """sigma_net: 16 outputs = 15 geo + density_before_activation; density = trunc_exp(col 15); colour net reads
+    the first 15 columns of that [N,16] buffer in place (row stride 16)."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd.tcnn_compat import Network
+
+    gen = torch.Generator().manual_seed(9)
+    N = 777
+    cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 1}
+    sig = Network(64, 16, cfg)
+    col = Network(15, 3, {**cfg, "output_activation": "Sigmoid", "n_neurons": 64, "n_hidden_layers": 2}, seed=3)
+    ws = [w.clone().requires_grad_(True) for w in sig.linear_weights()]
+    wc = [w.clone().requires_grad_(True) for w in col.linear_weights()]
+    x = (torch.rand(N, 64, generator=gen) - 0.3) * 4
+    x[0] = 30.0  # drives the density pre-activation outside trunc_exp's [-15,15] clamp
+    x = x.requires_grad_(True)
+    h = KO.mlp(x, ws)
+    dens = KO.trunc_exp(h[:, 15:])
+    rgb = KO.mlp(h[:, :15], wc, out_act="Sigmoid")
+    gd, gr = torch.rand(N, 1, generator=gen), torch.rand(N, 3, generator=gen) - 0.5
+    (dens * gd).sum().backward(retain_graph=True)
+    (rgb * gr).sum().backward()
+    sig, col = sig.to(DEV), col.to(DEV)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    hg, dg = sig.forward_with_exp_head(xg, 15)
+    rg = col(hg[:, :15])  # strided view, no copy
+    torch.testing.assert_close(dg.cpu(), dens.detach()[:, 0], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(rg.cpu(), rgb.detach(), rtol=1e-5, atol=1e-6)
+    ((dg * gd[:, 0].to(DEV)).sum() + (rg * gr.to(DEV)).sum()).backward()
+    torch.testing.assert_close(xg.grad.cpu(), x.grad, rtol=2e-4, atol=1e-5)
+    for a, b in zip(sig.linear_weights(sig.params.grad.cpu()), ws):
+        torch.testing.assert_close(a, b.grad, rtol=2e-4, atol=1e-4 * float(b.grad.abs().max()))
+    for a, b in zip(col.linear_weights(col.params.grad.cpu()), wc):
+        torch.testing.assert_close(a, b.grad, rtol=2e-4, atol=2e-6)
+
+
+def test_mlp_full_size_linearity():
+    """Config-2 size (64*4096 samples): output is linear in the last layer's weights; gradient wrt X of sum(y)
+    is the same for every sample when hidden activations are all positive."""
+    from soccernerfs_amd.tcnn_compat import Network
+
+    N = 64 * 4096
+    net = Network(160, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128,
+                            "n_hidden_layers": 1}).to(DEV)
+    x = torch.rand(N, 160, device=DEV)
+    y1 = net(x)
+    with torch.no_grad():
+        net.params[160 * 128:] *= 2.0
+    y2 = net(x)
+    torch.testing.assert_close(y2, 2 * y1, rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        net.params.abs_()
+    xg = x.clone().requires_grad_(True)
+    net(xg).sum().backward()
+    g = xg.grad
+    torch.testing.assert_close(g, g[:1].expand_as(g), rtol=1e-5, atol=1e-6)
+
+
+def test_mlp_unsupported_shape_raises():
+    from soccernerfs_amd.tcnn_compat import Network
+
+    net = Network(8, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 48,
+                         "n_hidden_layers": 1}).to(DEV)
+    with pytest.raises(RuntimeError, match="unsupported shape"):
+        net(torch.zeros(4, 8, device=DEV))
