@@ -166,6 +166,95 @@ int snerf_mlp_fwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
 int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                   int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Compositing and ray-level losses (one wavefront per ray, S <= 320).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* RGBRenderer + AccumulationRenderer + DepthRenderer(median|expected) + MedianRGBRenderer in one pass
+ * (NS/model_components/renderers.py:58-140,197-223,226-287,290-362).
+ * bg_mode 0: per-ray colour bg[R,3] (the "random" background with the draw made an explicit input);
+ *         1: "last_sample"; 2: constant colour bg[3] ("black"/"white").
+ * training == 0 applies the eval-mode nan_to_num + clamp.  Optional outputs may be NULL.
+ * depth_expected is sum(w*steps)/(sum(w)+1e-10) WITHOUT the reference's global clip to [steps.min(), steps.max()]. */
+typedef struct {
+  const float* weights;  /* [R,S] */
+  const float* rgb;      /* [R,S,3] */
+  const float* ebins;    /* [R,S+1] */
+  const float* bg;
+  int32_t R, S, bg_mode, training;
+  float* rgb_out;        /* [R,3] */
+  float* acc_out;        /* [R] */
+  float* depth_median;   /* [R] */
+  float* depth_expected; /* [R] */
+  float* median_rgb;     /* [R,3] (the reference returns it shaped [R,1,3]) */
+  int64_t* median_index; /* [R]: searchsorted(cumsum(w), 0.5, left) clamped -- bit-exact vs the oracle */
+} snerf_render_args;
+int snerf_render_fwd(const snerf_render_args* args, snerf_stream_t stream);
+
+/* Backward of rgb_out (+ optionally accumulation) w.r.t. weights [R,S] and per-sample rgb [R,S,3] (g_rgb may be NULL).
+ * bg_mode 0 or 2 only (the training backgrounds).  accumulate_w != 0: g_weights += ... */
+int snerf_render_bwd(const float* weights, const float* rgb, const float* bg, int32_t bg_mode, const float* g_rgb_out,
+                     const float* g_acc, int32_t R, int32_t S, float* g_weights, float* g_rgb, int32_t accumulate_w,
+                     snerf_stream_t stream);
+
+/* lossfun_distortion per ray (NS/model_components/losses.py:125-136): loss_rays[R] (may be NULL) and, if g_weights != NULL,
+ * g_weights (+)= grad_scale * d loss_r / d w.  The caller supplies grad_scale = coefficient / R (mean over rays, :143). */
+int snerf_distortion(const float* weights, const float* sbins, int32_t R, int32_t S, float grad_scale, float* loss_rays,
+                     float* g_weights, int32_t accumulate, snerf_stream_t stream);
+
+/* One proposal level of interlevel_loss (losses.py:46-121): per-ray sum over nerf bins of lossfun_outer, and the gradient
+ * w.r.t. the proposal weights g_wprop[R,Sp] (= grad_scale * d sum / d wp; may be NULL).  The nerf level is detached (:111-112). */
+int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_t S, const float* p_bins, const float* w_prop, int32_t Sp,
+                     int32_t R, float grad_scale, float* loss_rays, float* g_wprop, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense per-step sweeps.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* K-Planes plane regularisers for one plane set (losses.py:356-452): accumulates the UNSCALED values into
+ * losses[3] = {space_tv, time_smoothness, sparse_transients} (caller zeroes) and, if grad != NULL, adds
+ * c_space_tv * d(space_tv) + c_time_smooth * d(time_smoothness) + c_sparse * d(sparse_transients) into grad
+ * (same layout as planes). */
+int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* grad, float c_space_tv, float c_time_smooth,
+                    float c_sparse, float* losses, snerf_stream_t stream);
+
+/* torch.optim.Adam single-tensor step (no weight decay, no amsgrad) on a flat buffer; `step` is 1-based.
+ * g is first multiplied by grad_scale (e.g. 1/world_size after an all-reduce SUM) and, if zero_grad != 0, cleared. */
+int snerf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray generation + collider.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* RayGenerator.forward -> Cameras._generate_rays_from_coords, perspective / no distortion / camera-optimiser off
+ * (NS/model_components/ray_generators.py:41-59, NS/cameras/cameras.py:505-741), optionally fused with
+ * AABBBoxCollider (NS/model_components/scene_colliders.py:59-95).  indices: int64 [R,3] = (camera, row, col). */
+typedef struct {
+  const int64_t* indices;
+  const float* fx; const float* fy; const float* cx; const float* cy; /* [M] */
+  const float* c2w;        /* [M,3,4] */
+  const float* cam_times;  /* [M] or NULL */
+  int32_t R;
+  int32_t collide;         /* 1: also fill nears/fars */
+  int32_t training;        /* collider: near_plane applies in training only */
+  float near_plane;
+  float aabb_min[3];
+  float aabb_max[3];
+  float* origins;          /* [R,3] */
+  float* dirs;             /* [R,3] */
+  float* pixel_area;       /* [R] */
+  float* dir_norm;         /* [R] */
+  float* times;            /* [R] or NULL */
+  float* nears;            /* [R] */
+  float* fars;             /* [R] */
+} snerf_raygen_args;
+int snerf_raygen(const snerf_raygen_args* args, snerf_stream_t stream);
+
+/* AABBBoxCollider alone: aabb6 = HOST pointer to {min x,y,z, max x,y,z}. */
+int snerf_aabb_collide(const float* origins, const float* dirs, int32_t R, const float* aabb6, float near_plane, int32_t training,
+                       float* nears, float* fars, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,22 @@ class MlpDesc(C.Structure):
                 ("hidden_act", C.c_int32), ("out_act", C.c_int32)]
 
 
+class RenderArgs(C.Structure):
+    _fields_ = [("weights", C.c_void_p), ("rgb", C.c_void_p), ("ebins", C.c_void_p), ("bg", C.c_void_p),
+                ("R", C.c_int32), ("S", C.c_int32), ("bg_mode", C.c_int32), ("training", C.c_int32),
+                ("rgb_out", C.c_void_p), ("acc_out", C.c_void_p), ("depth_median", C.c_void_p), ("depth_expected", C.c_void_p),
+                ("median_rgb", C.c_void_p), ("median_index", C.c_void_p)]
+
+
+class RaygenArgs(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("fx", C.c_void_p), ("fy", C.c_void_p), ("cx", C.c_void_p), ("cy", C.c_void_p),
+                ("c2w", C.c_void_p), ("cam_times", C.c_void_p),
+                ("R", C.c_int32), ("collide", C.c_int32), ("training", C.c_int32), ("near_plane", C.c_float),
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3),
+                ("origins", C.c_void_p), ("dirs", C.c_void_p), ("pixel_area", C.c_void_p), ("dir_norm", C.c_void_p),
+                ("times", C.c_void_p), ("nears", C.c_void_p), ("fars", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -72,6 +88,14 @@ def lib():
     l.snerf_last_error.restype = C.c_char_p
     l.snerf_target_arch.restype = C.c_char_p
     l.snerf_mlp_param_count.restype = C.c_int64
+    # float arguments must be declared or ctypes passes them as ints/doubles
+    F, I, L, P = C.c_float, C.c_int32, C.c_int64, C.c_void_p
+    l.snerf_distortion.argtypes = [P, P, I, I, F, P, P, I, P]
+    l.snerf_interlevel.argtypes = [P, P, I, P, P, I, I, F, P, P, P]
+    l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, P]
+    l.snerf_adam_step.argtypes = [P, P, P, P, L, F, F, F, F, I, F, I, P]
+    l.snerf_aabb_collide.argtypes = [P, P, I, P, F, I, P, P, P]
+    l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]
     if l.snerf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
     _lib = l
@@ -98,4 +122,12 @@ EXPORTS = [
     "snerf_mlp_param_count",
     "snerf_mlp_fwd",
     "snerf_mlp_bwd",
+    "snerf_render_fwd",
+    "snerf_render_bwd",
+    "snerf_distortion",
+    "snerf_interlevel",
+    "snerf_plane_reg",
+    "snerf_adam_step",
+    "snerf_raygen",
+    "snerf_aabb_collide",
 ]

@@ -1,0 +1,197 @@
+// Dense per-step sweeps: K-Planes plane regularisers (value + gradient) and fused Adam.
+//
+// Reference: NS/model_components/losses.py compute_plane_tv :356-366, compute_plane_smoothness :369-380,
+// space_tv_loss :383-406, time_smoothness_loss :409-428, sparse_transients_loss :431-452 (autograd supplies
+// the gradients there: ~10 elementwise kernels per plane, forward and backward, every step) and
+// torch.optim.Adam as configured at NS/configs/method_configs.py:546-557 (lr 1e-2, eps 1e-12).
+// Both are HBM-bound streaming passes over every parameter: float4 per lane, channel-last planes so the
+// +-1 row/column neighbours are other lanes' lines (L2 hits).
+#include "common.hpp"
+
+namespace snerf {
+
+struct RegArgs {
+  snerf_kplanes_desc d;
+  int blk_off[SNERF_MAX_SCALES][6];  // first workgroup of each plane (prefix sum), 256 float4-lanes per workgroup
+  int n_planes;                      // 6 or 3
+  const float* planes;
+  float* grad;                       // may be null (values only)
+  float c_tv, c_smooth, c_l1;        // loss coefficients folded into the gradient
+  float* losses;                     // [3] accumulated UNSCALED: space_tv, time_smoothness, sparse_transients
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float sq4(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
+
+template <int C>
+__global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
+  // locate this workgroup's plane
+  int s = 0, p = 0;
+  {
+    const int b = blockIdx.x;
+    bool found = false;
+    for (int ss = a.d.n_scales - 1; ss >= 0 && !found; --ss)
+      for (int pp = a.n_planes - 1; pp >= 0; --pp)
+        if (b >= a.blk_off[ss][pp]) { s = ss; p = pp; found = true; break; }
+  }
+  constexpr int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3};
+  constexpr int PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
+  const int ax = a.n_planes == 6 ? PA6[p] : PA3[p];
+  const int bx = a.n_planes == 6 ? PB6[p] : PB3[p];
+  const int W = a.d.res[s][ax], H = a.d.res[s][bx];
+  const bool time_plane = (a.n_planes == 6) && (bx == 3);  // planes 2,4,5: H = time
+  constexpr int C4 = C / 4;
+  const int64_t n4 = (int64_t)H * W * C4;
+  const int64_t e = (int64_t)(blockIdx.x - a.blk_off[s][p]) * 256 + threadIdx.x;
+  float l_tv = 0.f, l_sm = 0.f, l_l1 = 0.f;
+  if (e < n4) {
+    const int c4 = (int)(e % C4);
+    const int64_t hw = e / C4;
+    const int w = (int)(hw % W), h = (int)(hw / W);
+    const float* base = a.planes + a.d.off[s][p] + c4 * 4;
+    auto at = [&](int hh, int ww) { return ld4(base + ((int64_t)hh * W + ww) * C); };
+    const float4 t = at(h, w);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- total variation: w direction always; h direction only on space-only planes ----
+    const float n_w = (float)C * (float)H * (float)(W - 1);
+    if (W > 1) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (w + 1 < W) { float4 d = sub4(at(h, w + 1), t); l_tv += sq4(d) / n_w; acc = sub4(acc, d); }
+      if (w > 0) { float4 d = sub4(t, at(h, w - 1)); acc = add4(acc, d); }
+      g = add4(g, mul4(acc, 2.f * a.c_tv / n_w));
+    }
+    if (!time_plane && H > 1) {
+      const float n_h = (float)C * (float)(H - 1) * (float)W;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (h + 1 < H) { float4 d = sub4(at(h + 1, w), t); l_tv += sq4(d) / n_h; acc = sub4(acc, d); }
+      if (h > 0) { float4 d = sub4(t, at(h - 1, w)); acc = add4(acc, d); }
+      g = add4(g, mul4(acc, 2.f * a.c_tv / n_h));
+    }
+    if (time_plane) {
+      // ---- smoothness: second difference along h (= time); d2[k] = t[k+2] - 2 t[k+1] + t[k], k in [0, H-3] ----
+      if (H > 2) {
+        const float n_s = (float)C * (float)(H - 2) * (float)W;
+        auto d2 = [&](int k) {  // valid for 0 <= k <= H-3
+          float4 x0 = at(k, w), x1 = at(k + 1, w), x2 = at(k + 2, w);
+          return make_float4(x2.x - 2.f * x1.x + x0.x, x2.y - 2.f * x1.y + x0.y, x2.z - 2.f * x1.z + x0.z, x2.w - 2.f * x1.w + x0.w);
+        };
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h <= H - 3) { float4 v = d2(h); l_sm += sq4(v) / n_s; acc = add4(acc, v); }          // t[h] enters d2[h] with +1
+        if (h >= 1 && h - 1 <= H - 3) { float4 v = d2(h - 1); acc = add4(acc, mul4(v, -2.f)); }  // d2[h-1] with -2
+        if (h >= 2) { float4 v = d2(h - 2); acc = add4(acc, v); }                                 // d2[h-2] with +1
+        g = add4(g, mul4(acc, 2.f * a.c_smooth / n_s));
+      }
+      // ---- sparse transients: mean |1 - t| ----
+      const float n_a = (float)C * (float)H * (float)W;
+      l_l1 += (fabsf(1.f - t.x) + fabsf(1.f - t.y) + fabsf(1.f - t.z) + fabsf(1.f - t.w)) / n_a;
+      const float k = -a.c_l1 / n_a;
+      g = add4(g, make_float4(k * sgn(1.f - t.x), k * sgn(1.f - t.y), k * sgn(1.f - t.z), k * sgn(1.f - t.w)));
+    }
+    if (a.grad) {
+      float* gp = a.grad + a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
+      float4 old = ld4(gp);
+      *reinterpret_cast<float4*>(gp) = add4(old, g);
+    }
+  }
+  // ---- loss values: workgroup reduction, one atomic per workgroup per term ----
+  __shared__ float red[3][4];
+  l_tv = wave_sum(l_tv); l_sm = wave_sum(l_sm); l_l1 = wave_sum(l_l1);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wv] = l_tv; red[1][wv] = l_sm; red[2][wv] = l_l1; }
+  __syncthreads();
+  if (threadIdx.x < 3 && a.losses) {
+    float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    if (v != 0.f) atomicAdd(a.losses + threadIdx.x, v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam, no weight decay / amsgrad):  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps),  step_size = lr / bc1
+// Optionally zeroes g afterwards (saves a separate memset sweep) and scales g first (gradient mean over ranks).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  int64_t n, float step_size, float b1, float b2, float inv_sqrt_bc2, float eps,
+                                                  float grad_scale, int zero_grad) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+    float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gk = G[k] * grad_scale;
+      M[k] = b1 * M[k] + (1.f - b1) * gk;
+      V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+      float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
+      P[k] = P[k] - step_size * (M[k] / denom);
+    }
+    *reinterpret_cast<float4*>(p + i * 4) = pp;
+    *reinterpret_cast<float4*>(m + i * 4) = mm;
+    *reinterpret_cast<float4*>(v + i * 4) = vv;
+    if (zero_grad) *reinterpret_cast<float4*>(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // tail (n % 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    int64_t i = n4 * 4 + threadIdx.x;
+    float gk = g[i] * grad_scale;
+    float mk = b1 * m[i] + (1.f - b1) * gk;
+    float vk = b2 * v[i] + (1.f - b2) * gk * gk;
+    m[i] = mk; v[i] = vk;
+    p[i] = p[i] - step_size * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* grad, float c_space_tv, float c_time_smooth,
+                               float c_sparse, float* losses, snerf_stream_t stream) {
+  SNERF_REQUIRE(desc && planes, "plane_reg: null argument");
+  SNERF_REQUIRE(desc->n_scales >= 1 && desc->n_scales <= SNERF_MAX_SCALES, "plane_reg: n_scales=%d", desc->n_scales);
+  SNERF_REQUIRE(desc->C == 8 || desc->C == 16 || desc->C == 32, "plane_reg: C=%d unsupported", desc->C);
+  SNERF_REQUIRE(desc->n_coords == 3 || desc->n_coords == 4, "plane_reg: n_coords=%d", desc->n_coords);
+  RegArgs a = {};
+  a.d = *desc;
+  a.n_planes = desc->n_coords == 4 ? 6 : 3;
+  a.planes = planes; a.grad = grad; a.c_tv = c_space_tv; a.c_smooth = c_time_smooth; a.c_l1 = c_sparse; a.losses = losses;
+  static const int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3}, PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
+  int64_t blocks = 0;
+  for (int s = 0; s < desc->n_scales; ++s)
+    for (int p = 0; p < a.n_planes; ++p) {
+      const int ax = a.n_planes == 6 ? PA6[p] : PA3[p], bx = a.n_planes == 6 ? PB6[p] : PB3[p];
+      int64_t n4 = (int64_t)desc->res[s][ax] * desc->res[s][bx] * (desc->C / 4);
+      a.blk_off[s][p] = (int)blocks;
+      blocks += (n4 + 255) / 256;
+    }
+  SNERF_REQUIRE(blocks < (1LL << 31), "plane_reg: too many workgroups");
+  hipStream_t st = (hipStream_t)stream;
+  if (desc->C == 32) hipLaunchKernelGGL(plane_reg_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (desc->C == 16) hipLaunchKernelGGL(plane_reg_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(plane_reg_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  SNERF_LAUNCH_CHECK("plane_reg");
+  return 0;
+}
+
+extern "C" int snerf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                               int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
+  SNERF_REQUIRE(n >= 0 && step >= 1, "adam_step: n=%lld step=%d (1-based)", (long long)n, step);
+  if (n == 0) return 0;
+  SNERF_REQUIRE(p && g && m && v, "adam_step: null buffer");
+  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  int64_t n4 = (n + 3) / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2,
+                     eps, grad_scale, zero_grad);
+  SNERF_LAUNCH_CHECK("adam_step");
+  return 0;
+}

@@ -1,0 +1,122 @@
+// Ray generation (pinhole, no distortion, camera optimiser off) fused with the AABB collider.
+//
+// Reference: RayGenerator.forward (NS/model_components/ray_generators.py:41-59) ->
+// Cameras._generate_rays_from_coords (NS/cameras/cameras.py:505-741; the perspective slice :596-633,:663-670,
+// :704-741 -- ~40 small ATen kernels incl. boolean-mask scatters) and AABBBoxCollider._intersect_with_aabb
+// (NS/model_components/scene_colliders.py:59-95).  One lane per ray; the per-camera table (fx,fy,cx,cy,c2w,time)
+// is a few KB and stays in L1/L2.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace snerf {
+
+struct RaygenArgs {
+  const int64_t* indices;  // [R,3] (camera, row, col)
+  const float* fx; const float* fy; const float* cx; const float* cy;  // [M]
+  const float* c2w;        // [M,3,4]
+  const float* cam_times;  // [M] or null
+  int R;
+  float* origins; float* dirs; float* pixel_area; float* dir_norm; float* times;  // [R,3],[R,3],[R],[R],[R]
+  // collider
+  int collide; int training; float near_plane;
+  float aabb_min[3], aabb_max[3];
+  float* nears; float* fars;  // [R]
+};
+
+__device__ __forceinline__ void cam_to_world(const float* rot /*3x4 row-major*/, float x, float y, float z, float out[3], float& norm) {
+  float v[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) v[i] = (x * rot[i * 4 + 0] + y * rot[i * 4 + 1]) + z * rot[i * 4 + 2];  // sum over the last axis (cameras.py:712-714)
+  norm = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+  // normalize_with_norm (NS/cameras/camera_utils.py:240-252): norm = max(|v|, 4*eps_f64); returns x / norm and norm
+  norm = fmaxf(norm, 8.8817841970012523e-16f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) out[i] = v[i] / norm;
+}
+
+__global__ void raygen_kernel(RaygenArgs a) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.R) return;
+  const int64_t c = a.indices[(int64_t)r * 3], yi = a.indices[(int64_t)r * 3 + 1], xi = a.indices[(int64_t)r * 3 + 2];
+  const float y = (float)yi + 0.5f, x = (float)xi + 0.5f;  // image_coords = pixel index + 0.5 (cameras.py:318-319)
+  const float fx = a.fx[c], fy = a.fy[c], cx = a.cx[c], cy = a.cy[c];
+  const float* m = a.c2w + c * 12;
+  float d0[3], dx[3], dy[3], n0, nx, ny;
+  cam_to_world(m, (x - cx) / fx, -(y - cy) / fy, -1.f, d0, n0);
+  cam_to_world(m, ((x + 1.f) - cx) / fx, -(y - cy) / fy, -1.f, dx, nx);
+  cam_to_world(m, (x - cx) / fx, -((y + 1.f) - cy) / fy, -1.f, dy, ny);
+  float ax = sqrtf(((d0[0] - dx[0]) * (d0[0] - dx[0]) + (d0[1] - dx[1]) * (d0[1] - dx[1])) + (d0[2] - dx[2]) * (d0[2] - dx[2]));
+  float ay = sqrtf(((d0[0] - dy[0]) * (d0[0] - dy[0]) + (d0[1] - dy[1]) * (d0[1] - dy[1])) + (d0[2] - dy[2]) * (d0[2] - dy[2]));
+  float o[3] = {m[3], m[7], m[11]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { a.origins[(int64_t)r * 3 + k] = o[k]; a.dirs[(int64_t)r * 3 + k] = d0[k]; }
+  a.pixel_area[r] = ax * ay;
+  a.dir_norm[r] = n0;
+  if (a.times) a.times[r] = a.cam_times ? a.cam_times[c] : 0.f;
+  if (a.collide) {
+    float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float inv = 1.f / (d0[k] + 1e-6f);  // scene_colliders.py:71
+      float t1 = (a.aabb_min[k] - o[k]) * inv, t2 = (a.aabb_max[k] - o[k]) * inv;
+      tn = fmaxf(tn, fminf(t1, t2));
+      tf = fminf(tf, fmaxf(t1, t2));
+    }
+    float np = a.training ? a.near_plane : 0.f;
+    tn = fmaxf(tn, np);
+    tf = fmaxf(tf, tn + 1e-6f);
+    a.nears[r] = tn; a.fars[r] = tf;
+  }
+}
+
+__global__ void aabb_kernel(const float* __restrict__ o, const float* __restrict__ d, int R, float near_plane, int training, const float* amin3,
+                            float* __restrict__ nears, float* __restrict__ fars, float a0, float a1, float a2, float b0, float b1, float b2) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float mn[3] = {a0, a1, a2}, mx[3] = {b0, b1, b2};
+  float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float inv = 1.f / (d[(int64_t)r * 3 + k] + 1e-6f);
+    float t1 = (mn[k] - o[(int64_t)r * 3 + k]) * inv, t2 = (mx[k] - o[(int64_t)r * 3 + k]) * inv;
+    tn = fmaxf(tn, fminf(t1, t2));
+    tf = fminf(tf, fmaxf(t1, t2));
+  }
+  tn = fmaxf(tn, training ? near_plane : 0.f);
+  tf = fmaxf(tf, tn + 1e-6f);
+  nears[r] = tn; fars[r] = tf;
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_raygen(const snerf_raygen_args* p, snerf_stream_t stream) {
+  SNERF_REQUIRE(p, "raygen: null args");
+  SNERF_REQUIRE(p->R >= 0, "raygen: R=%d", p->R);
+  if (p->R == 0) return 0;
+  SNERF_REQUIRE(p->indices && p->fx && p->fy && p->cx && p->cy && p->c2w, "raygen: null camera/index buffer");
+  SNERF_REQUIRE(p->origins && p->dirs && p->pixel_area && p->dir_norm, "raygen: null output buffer");
+  SNERF_REQUIRE(!p->collide || (p->nears && p->fars), "raygen: collide set but nears/fars null");
+  RaygenArgs a;
+  a.indices = p->indices; a.fx = p->fx; a.fy = p->fy; a.cx = p->cx; a.cy = p->cy; a.c2w = p->c2w; a.cam_times = p->cam_times; a.R = p->R;
+  a.origins = p->origins; a.dirs = p->dirs; a.pixel_area = p->pixel_area; a.dir_norm = p->dir_norm; a.times = p->times;
+  a.collide = p->collide; a.training = p->training; a.near_plane = p->near_plane;
+  for (int k = 0; k < 3; ++k) { a.aabb_min[k] = p->aabb_min[k]; a.aabb_max[k] = p->aabb_max[k]; }
+  a.nears = p->nears; a.fars = p->fars;
+  hipLaunchKernelGGL(raygen_kernel, dim3(ceil_div(p->R, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SNERF_LAUNCH_CHECK("raygen");
+  return 0;
+}
+
+extern "C" int snerf_aabb_collide(const float* origins, const float* dirs, int32_t R, const float* aabb6, float near_plane, int32_t training,
+                                  float* nears, float* fars, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && aabb6, "aabb_collide: bad arguments");
+  if (R == 0) return 0;
+  SNERF_REQUIRE(origins && dirs && nears && fars, "aabb_collide: null buffer");
+  hipLaunchKernelGGL(aabb_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, origins, dirs, R, near_plane, training, nullptr, nears,
+                     fars, aabb6[0], aabb6[1], aabb6[2], aabb6[3], aabb6[4], aabb6[5]);
+  SNERF_LAUNCH_CHECK("aabb_collide");
+  return 0;
+}

@@ -1,0 +1,271 @@
+// Per-ray compositing (renderers) and the ray-level losses (distortion, interlevel), forward + backward.
+//
+// One wavefront per ray, 4 rays per workgroup, per-ray scratch in LDS.
+// Reference: NS/model_components/renderers.py (RGBRenderer :58-140, AccumulationRenderer :197-223, DepthRenderer
+// :226-287, MedianRGBRenderer :290-362) and NS/model_components/losses.py (outer :46-75, lossfun_outer :78-95,
+// interlevel_loss :106-121, lossfun_distortion :125-136).  The reference's distortion loss materialises an
+// [R,S,S] tensor (67 MB at the preset); here the S x S interaction stays in LDS/registers.
+#include "common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace snerf {
+
+constexpr int RPB = 4;
+constexpr int MAXS = 320;
+
+// ------------------------------------------------------------------------------------------------
+// render forward
+// ------------------------------------------------------------------------------------------------
+struct RenderArgs {
+  const float* weights;  // [R,S]
+  const float* rgb;      // [R,S,3]
+  const float* ebins;    // [R,S+1]
+  const float* bg;       // bg_mode 0: [R,3]; 2: [3]; 1 (last_sample): unused
+  int R, S, bg_mode, training;
+  float* rgb_out;        // [R,3]
+  float* acc_out;        // [R]
+  float* depth_median;   // [R] or null
+  float* depth_expected; // [R] or null (unclipped: sum(w*steps)/(sum(w)+1e-10))
+  float* median_rgb;     // [R,3] or null
+  int64_t* median_index; // [R] or null
+};
+
+__global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
+  __shared__ float s_w[RPB][MAXS];
+  __shared__ int s_med[RPB];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wv;
+  const bool live = ray < a.R;
+  const int r = live ? ray : a.R - 1;
+  const int S = a.S;
+  float cr = 0.f, cg = 0.f, cb = 0.f, acc = 0.f, dsum = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    float w = a.weights[(int64_t)r * S + i];
+    s_w[wv][i] = w;
+    const float* c = a.rgb + ((int64_t)r * S + i) * 3;
+    float x = c[0], y = c[1], z = c[2];
+    if (!a.training) { x = nan_to_num(x); y = nan_to_num(y); z = nan_to_num(z); }  // renderers.py:133-134
+    cr += w * x; cg += w * y; cb += w * z;
+    acc += w;
+    float e0 = a.ebins[(int64_t)r * (S + 1) + i], e1 = a.ebins[(int64_t)r * (S + 1) + i + 1];
+    dsum += w * ((e0 + e1) / 2.f);
+  }
+  cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); acc = wave_sum(acc); dsum = wave_sum(dsum);
+  __syncthreads();
+  if (lane == 0) {
+    // median: first index with cumsum(w) >= 0.5 (searchsorted left), clamped (renderers.py:264-267)
+    double run = 0.0;
+    int idx = S;
+    for (int i = 0; i < S; ++i) {
+      run = run + (double)s_w[wv][i];
+      if (idx == S && (float)run >= 0.5f) idx = i;
+    }
+    if (idx > S - 1) idx = S - 1;
+    s_med[wv] = idx;
+  }
+  __syncthreads();
+  if (lane == 0 && live) {
+    const float* last = a.rgb + ((int64_t)r * S + (S - 1)) * 3;
+    float b0, b1, b2;
+    if (a.bg_mode == 0) { b0 = a.bg[(int64_t)r * 3]; b1 = a.bg[(int64_t)r * 3 + 1]; b2 = a.bg[(int64_t)r * 3 + 2]; }
+    else if (a.bg_mode == 1) {
+      b0 = last[0]; b1 = last[1]; b2 = last[2];
+      if (!a.training) { b0 = nan_to_num(b0); b1 = nan_to_num(b1); b2 = nan_to_num(b2); }
+    } else { b0 = a.bg[0]; b1 = a.bg[1]; b2 = a.bg[2]; }
+    float o0 = cr + b0 * (1.f - acc), o1 = cg + b1 * (1.f - acc), o2 = cb + b2 * (1.f - acc);  // renderers.py:113
+    if (!a.training) { o0 = fminf(fmaxf(o0, 0.f), 1.f); o1 = fminf(fmaxf(o1, 0.f), 1.f); o2 = fminf(fmaxf(o2, 0.f), 1.f); }
+    a.rgb_out[(int64_t)r * 3] = o0; a.rgb_out[(int64_t)r * 3 + 1] = o1; a.rgb_out[(int64_t)r * 3 + 2] = o2;
+    a.acc_out[r] = acc;
+    const int m = s_med[wv];
+    if (a.median_index) a.median_index[r] = m;
+    if (a.depth_median) {
+      float e0 = a.ebins[(int64_t)r * (S + 1) + m], e1 = a.ebins[(int64_t)r * (S + 1) + m + 1];
+      a.depth_median[r] = (e0 + e1) / 2.f;
+    }
+    if (a.depth_expected) a.depth_expected[r] = dsum / (acc + 1e-10f);
+    if (a.median_rgb) {
+      const float* c = a.rgb + ((int64_t)r * S + m) * 3;
+      float x = c[0], y = c[1], z = c[2];
+      if (!a.training) {
+        x = fminf(fmaxf(nan_to_num(x), 0.f), 1.f); y = fminf(fmaxf(nan_to_num(y), 0.f), 1.f); z = fminf(fmaxf(nan_to_num(z), 0.f), 1.f);
+      }
+      a.median_rgb[(int64_t)r * 3] = x; a.median_rgb[(int64_t)r * 3 + 1] = y; a.median_rgb[(int64_t)r * 3 + 2] = z;
+    }
+  }
+}
+
+// render backward (training): rgb_out = sum_s w_s rgb_s + bg (1 - sum_s w_s); acc = sum_s w_s
+__global__ void render_bwd_kernel(const float* __restrict__ weights, const float* __restrict__ rgb, const float* __restrict__ bg, int bg_mode,
+                                  const float* __restrict__ g_rgb_out, const float* __restrict__ g_acc, int R, int S,
+                                  float* __restrict__ g_weights, float* __restrict__ g_rgb, int accumulate_w) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)R * S) return;
+  int r = (int)(gid / S);
+  float go0 = g_rgb_out[(int64_t)r * 3], go1 = g_rgb_out[(int64_t)r * 3 + 1], go2 = g_rgb_out[(int64_t)r * 3 + 2];
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  if (bg_mode == 0) { b0 = bg[(int64_t)r * 3]; b1 = bg[(int64_t)r * 3 + 1]; b2 = bg[(int64_t)r * 3 + 2]; }
+  else if (bg_mode == 2) { b0 = bg[0]; b1 = bg[1]; b2 = bg[2]; }
+  const float* c = rgb + gid * 3;
+  float w = weights[gid];
+  float gw = go0 * (c[0] - b0) + go1 * (c[1] - b1) + go2 * (c[2] - b2);
+  if (g_acc) gw += g_acc[r];
+  if (accumulate_w) g_weights[gid] += gw; else g_weights[gid] = gw;
+  if (g_rgb) { g_rgb[gid * 3] = go0 * w; g_rgb[gid * 3 + 1] = go1 * w; g_rgb[gid * 3 + 2] = go2 * w; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// distortion loss (per-ray value + gradient w.r.t. weights)
+//   L_r = sum_i w_i sum_j w_j |m_i - m_j| + (1/3) sum_i w_i^2 (t_{i+1} - t_i),  m = bin midpoints
+//   dL_r/dw_i = 2 sum_j w_j |m_i - m_j| + (2/3) w_i (t_{i+1} - t_i)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void distortion_kernel(const float* __restrict__ weights, const float* __restrict__ sbins, int R, int S,
+                                                        float grad_scale, float* __restrict__ loss_rays, float* __restrict__ g_weights,
+                                                        int accumulate) {
+  __shared__ float s_w[RPB][MAXS];
+  __shared__ float s_m[RPB][MAXS];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wv;
+  const bool live = ray < R;
+  const int r = live ? ray : R - 1;
+  for (int i = lane; i < S; i += 64) {
+    float t0 = sbins[(int64_t)r * (S + 1) + i], t1 = sbins[(int64_t)r * (S + 1) + i + 1];
+    s_w[wv][i] = weights[(int64_t)r * S + i];
+    s_m[wv][i] = (t1 + t0) / 2.f;
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float wi = s_w[wv][i], mi = s_m[wv][i];
+    float inner = 0.f;
+    for (int j = 0; j < S; ++j) inner += s_w[wv][j] * fabsf(mi - s_m[wv][j]);
+    float t0 = sbins[(int64_t)r * (S + 1) + i], t1 = sbins[(int64_t)r * (S + 1) + i + 1];
+    float dt = t1 - t0;
+    total += wi * inner + wi * wi * dt / 3.f;
+    if (g_weights && live) {
+      float g = (2.f * inner + 2.f * wi * dt / 3.f) * grad_scale;
+      if (accumulate) g_weights[(int64_t)r * S + i] += g; else g_weights[(int64_t)r * S + i] = g;
+    }
+  }
+  total = wave_sum(total);
+  if (lane == 0 && live && loss_rays) loss_rays[r] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// interlevel (proposal) loss for ONE proposal level against the (detached) nerf level:
+//   w_outer_i = cy[hi_i + 1] - cy[lo_i],  cy = [0, cumsum(wp)]
+//   lo_i = clamp(searchsorted(tp[:-1], c_i, right) - 1, 0, Sp-1),  hi_i = clamp(searchsorted(tp[1:], c_{i+1}, right), 0, Sp-1)
+//   loss_i = max(w_i - w_outer_i, 0)^2 / (w_i + 1e-7)
+// outputs per-ray sum of loss_i and d(sum)/d wp (scaled by grad_scale)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict__ c_bins, const float* __restrict__ w_nerf, int S,
+                                                        const float* __restrict__ p_bins, const float* __restrict__ w_prop, int Sp, int R,
+                                                        float grad_scale, float* __restrict__ loss_rays, float* __restrict__ g_wprop) {
+  __shared__ float s_tp[RPB][MAXS + 1];
+  __shared__ float s_cy[RPB][MAXS + 1];
+  __shared__ float s_g[RPB][MAXS];
+  __shared__ int s_lo[RPB][MAXS];
+  __shared__ int s_hi[RPB][MAXS];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wv;
+  const bool live = ray < R;
+  const int r = live ? ray : R - 1;
+  float* tp = s_tp[wv];
+  float* cy = s_cy[wv];
+  for (int i = lane; i <= Sp; i += 64) tp[i] = p_bins[(int64_t)r * (Sp + 1) + i];
+  for (int i = lane; i < Sp; i += 64) cy[i + 1] = w_prop[(int64_t)r * Sp + i];
+  __syncthreads();
+  if (lane == 0) {  // cy = [0, cumsum(wp)] (sequential, double accumulator)
+    double acc = 0.0;
+    cy[0] = 0.f;
+    for (int i = 0; i < Sp; ++i) {
+      acc = acc + (double)cy[i + 1];
+      cy[i + 1] = (float)acc;
+    }
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float c0 = c_bins[(int64_t)r * (S + 1) + i], c1 = c_bins[(int64_t)r * (S + 1) + i + 1];
+    // searchsorted(tp[0..Sp-1], c0, right)
+    int lo = 0, hi = Sp;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (tp[mid] <= c0) lo = mid + 1; else hi = mid; }
+    int ilo = lo - 1; ilo = ilo < 0 ? 0 : (ilo > Sp - 1 ? Sp - 1 : ilo);
+    // searchsorted(tp[1..Sp], c1, right)
+    lo = 0; hi = Sp;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (tp[mid + 1] <= c1) lo = mid + 1; else hi = mid; }
+    int ihi = lo; ihi = ihi < 0 ? 0 : (ihi > Sp - 1 ? Sp - 1 : ihi);
+    const float wo = cy[ihi + 1] - cy[ilo];
+    const float w = w_nerf[(int64_t)r * S + i];
+    const float d = fmaxf(w - wo, 0.f);
+    total += d * d / (w + 1.0e-7f);
+    s_lo[wv][i] = ilo; s_hi[wv][i] = ihi;
+    s_g[wv][i] = -2.f * d / (w + 1.0e-7f);  // d loss_i / d w_outer_i (0 when clipped)
+  }
+  total = wave_sum(total);
+  if (lane == 0 && live && loss_rays) loss_rays[r] = total;
+  __syncthreads();
+  if (g_wprop) {
+    for (int j = lane; j < Sp; j += 64) {
+      float acc = 0.f;
+      for (int i = 0; i < S; ++i)
+        if (s_lo[wv][i] <= j && j <= s_hi[wv][i]) acc += s_g[wv][i];
+      if (live) g_wprop[(int64_t)r * Sp + j] = acc * grad_scale;
+    }
+  }
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_render_fwd(const snerf_render_args* p, snerf_stream_t stream) {
+  SNERF_REQUIRE(p, "render_fwd: null args");
+  SNERF_REQUIRE(p->R >= 0 && p->S >= 1 && p->S <= MAXS, "render_fwd: R=%d S=%d (S <= %d)", p->R, p->S, MAXS);
+  SNERF_REQUIRE(p->bg_mode >= 0 && p->bg_mode <= 2, "render_fwd: bg_mode=%d", p->bg_mode);
+  if (p->R == 0) return 0;
+  SNERF_REQUIRE(p->weights && p->rgb && p->ebins && p->rgb_out && p->acc_out, "render_fwd: null buffer");
+  SNERF_REQUIRE(p->bg_mode == 1 || p->bg, "render_fwd: background buffer is null");
+  RenderArgs a;
+  a.weights = p->weights; a.rgb = p->rgb; a.ebins = p->ebins; a.bg = p->bg; a.R = p->R; a.S = p->S; a.bg_mode = p->bg_mode;
+  a.training = p->training; a.rgb_out = p->rgb_out; a.acc_out = p->acc_out; a.depth_median = p->depth_median;
+  a.depth_expected = p->depth_expected; a.median_rgb = p->median_rgb; a.median_index = p->median_index;
+  hipLaunchKernelGGL(render_fwd_kernel, dim3(ceil_div(p->R, RPB)), dim3(256), 0, (hipStream_t)stream, a);
+  SNERF_LAUNCH_CHECK("render_fwd");
+  return 0;
+}
+
+extern "C" int snerf_render_bwd(const float* weights, const float* rgb, const float* bg, int32_t bg_mode, const float* g_rgb_out,
+                                const float* g_acc, int32_t R, int32_t S, float* g_weights, float* g_rgb, int32_t accumulate_w,
+                                snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && S >= 1, "render_bwd: R=%d S=%d", R, S);
+  SNERF_REQUIRE(bg_mode == 0 || bg_mode == 2, "render_bwd: bg_mode=%d has no training backward", bg_mode);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(weights && rgb && bg && g_rgb_out && g_weights, "render_bwd: null buffer");
+  hipLaunchKernelGGL(render_bwd_kernel, dim3(ceil_div((int64_t)R * S, 256)), dim3(256), 0, (hipStream_t)stream, weights, rgb, bg, bg_mode,
+                     g_rgb_out, g_acc, R, S, g_weights, g_rgb, accumulate_w);
+  SNERF_LAUNCH_CHECK("render_bwd");
+  return 0;
+}
+
+extern "C" int snerf_distortion(const float* weights, const float* sbins, int32_t R, int32_t S, float grad_scale, float* loss_rays,
+                                float* g_weights, int32_t accumulate, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && S >= 1 && S <= MAXS, "distortion: R=%d S=%d (S <= %d)", R, S, MAXS);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(weights && sbins, "distortion: null buffer");
+  hipLaunchKernelGGL(distortion_kernel, dim3(ceil_div(R, RPB)), dim3(256), 0, (hipStream_t)stream, weights, sbins, R, S, grad_scale, loss_rays,
+                     g_weights, accumulate);
+  SNERF_LAUNCH_CHECK("distortion");
+  return 0;
+}
+
+extern "C" int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_t S, const float* p_bins, const float* w_prop, int32_t Sp,
+                                int32_t R, float grad_scale, float* loss_rays, float* g_wprop, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && S >= 1 && S <= MAXS && Sp >= 1 && Sp <= MAXS, "interlevel: R=%d S=%d Sp=%d", R, S, Sp);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(c_bins && w_nerf && p_bins && w_prop, "interlevel: null buffer");
+  hipLaunchKernelGGL(interlevel_kernel, dim3(ceil_div(R, RPB)), dim3(256), 0, (hipStream_t)stream, c_bins, w_nerf, S, p_bins, w_prop, Sp, R,
+                     grad_scale, loss_rays, g_wprop);
+  SNERF_LAUNCH_CHECK("interlevel");
+  return 0;
+}

@@ -217,3 +217,197 @@ def mlp_forward(x, params, desc: _lib.MlpDesc, aux_col: int = -1):
     if x.dim() != 2 or x.stride(1) != 1:
         x = x.reshape(-1, x.shape[-1]).contiguous()
     return _MLP.apply(x, params, desc, aux_col, x.requires_grad)
+
+
+# ----------------------------------------------------------------------------------------------
+# compositing + ray-level losses
+# ----------------------------------------------------------------------------------------------
+BG_MODES = {"random": 0, "last_sample": 1, "constant": 2}
+
+
+def _bg_args(background, R, dev):
+    """background: [R,3] tensor (explicit 'random' draw), 'last_sample', or a [3] tensor / 'black' / 'white'."""
+    if isinstance(background, str):
+        if background == "last_sample":
+            return 1, None
+        if background in ("black", "white"):
+            return 2, torch.full((3,), 0.0 if background == "black" else 1.0, dtype=torch.float32, device=dev)
+        raise ValueError(f"background {background!r}: pass the random colours as a tensor [R,3]")
+    bg = _f32c(background, "background")
+    if bg.dim() == 1:
+        return 2, bg
+    assert bg.shape == (R, 3)
+    return 0, bg
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, rgb, ebins, bg, bg_mode, training):
+        R, S = weights.shape
+        dev = weights.device
+        out = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        acc = torch.empty(R, dtype=torch.float32, device=dev)
+        dmed = torch.empty(R, dtype=torch.float32, device=dev)
+        dexp = torch.empty(R, dtype=torch.float32, device=dev)
+        mrgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        midx = torch.empty(R, dtype=torch.int64, device=dev)
+        a = _lib.RenderArgs()
+        a.weights, a.rgb, a.ebins = weights.data_ptr(), rgb.data_ptr(), ebins.data_ptr()
+        a.bg = bg.data_ptr() if bg is not None else None
+        a.R, a.S, a.bg_mode, a.training = R, S, bg_mode, int(training)
+        a.rgb_out, a.acc_out, a.depth_median, a.depth_expected = out.data_ptr(), acc.data_ptr(), dmed.data_ptr(), dexp.data_ptr()
+        a.median_rgb, a.median_index = mrgb.data_ptr(), midx.data_ptr()
+        _lib.check(_lib.lib().snerf_render_fwd(C.byref(a), _stream()), "render_fwd")
+        ctx.bg_mode = bg_mode
+        ctx.save_for_backward(weights, rgb, bg if bg is not None else weights.new_zeros(3))
+        ctx.mark_non_differentiable(dmed, dexp, mrgb, midx)
+        return out, acc, dmed, dexp, mrgb, midx
+
+    @staticmethod
+    def backward(ctx, g_out, g_acc, *_):
+        weights, rgb, bg = ctx.saved_tensors
+        if ctx.bg_mode == 1:
+            raise RuntimeError("render backward with 'last_sample' background is not a training configuration")
+        R, S = weights.shape
+        g_out = g_out.contiguous()
+        gw = torch.empty_like(weights)
+        grgb = torch.empty_like(rgb)
+        g_acc_p = g_acc.contiguous() if g_acc is not None else None
+        _lib.check(_lib.lib().snerf_render_bwd(_ptr(weights), _ptr(rgb), _ptr(bg), ctx.bg_mode, _ptr(g_out),
+                                               _ptr(g_acc_p) if g_acc_p is not None else None, R, S, _ptr(gw), _ptr(grgb), 0, _stream()),
+                   "render_bwd")
+        return gw, grgb, None, None, None, None
+
+
+def render(weights, rgb, ebins, background, training: bool = True):
+    """One-pass renderers (renderers.py): returns dict(rgb [R,3], accumulation [R], depth_median [R], depth_expected [R]
+    (unclipped), median_rgb [R,3], median_index [R] int64).  weights [R,S], rgb [R,S,3], ebins [R,S+1]."""
+    weights, rgb, ebins = _f32c(weights, "weights"), _f32c(rgb, "rgb"), _f32c(ebins, "ebins")
+    mode, bg = _bg_args(background, weights.shape[0], weights.device)
+    out, acc, dmed, dexp, mrgb, midx = _Render.apply(weights, rgb, ebins, bg, mode, training)
+    return {"rgb": out, "accumulation": acc, "depth_median": dmed, "depth_expected": dexp, "median_rgb": mrgb, "median_index": midx}
+
+
+class _Distortion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, sbins):
+        R, S = weights.shape
+        loss_rays = torch.empty(R, dtype=torch.float32, device=weights.device)
+        gw = torch.empty_like(weights)
+        _lib.check(_lib.lib().snerf_distortion(_ptr(weights), _ptr(sbins), R, S, 1.0 / R, _ptr(loss_rays), _ptr(gw), 0, _stream()), "distortion")
+        ctx.save_for_backward(gw)
+        return loss_rays.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gw,) = ctx.saved_tensors
+        return gw * g, None
+
+
+def distortion_loss(weights, sbins):
+    """distortion_loss (losses.py:139-144) on the nerf level: weights [R,S], sbins [R,S+1] -> scalar."""
+    return _Distortion.apply(_f32c(weights, "weights"), _f32c(sbins, "sbins"))
+
+
+class _Interlevel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w_prop, p_bins, w_nerf, c_bins):
+        R, Sp = w_prop.shape
+        S = w_nerf.shape[1]
+        loss_rays = torch.empty(R, dtype=torch.float32, device=w_prop.device)
+        g = torch.empty_like(w_prop)
+        _lib.check(_lib.lib().snerf_interlevel(_ptr(c_bins), _ptr(w_nerf), S, _ptr(p_bins), _ptr(w_prop), Sp, R, 1.0 / (R * S),
+                                               _ptr(loss_rays), _ptr(g), _stream()), "interlevel")
+        ctx.save_for_backward(g)
+        return loss_rays.sum() / (R * S)
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout, None, None, None
+
+
+def interlevel_loss(weights_list, sbins_list):
+    """interlevel_loss (losses.py:106-121): lists over levels, the last entry is the (detached) nerf level."""
+    c = _f32c(sbins_list[-1].detach(), "sbins")
+    w = _f32c(weights_list[-1].detach(), "weights")
+    total = 0.0
+    for wp, sp in zip(weights_list[:-1], sbins_list[:-1]):
+        total = total + _Interlevel.apply(_f32c(wp, "weights"), _f32c(sp.detach(), "sbins"), w, c)
+    return total
+
+
+class _PlaneReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, planes, ps: PlaneSet):
+        losses = torch.zeros(3, dtype=torch.float32, device=planes.device)
+        desc = ps.desc()
+        _lib.check(_lib.lib().snerf_plane_reg(C.byref(desc), _ptr(planes), None, 0.0, 0.0, 0.0, _ptr(losses), _stream()), "plane_reg")
+        ctx.ps = ps
+        ctx.save_for_backward(planes)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        (planes,) = ctx.saved_tensors
+        c = g.detach().cpu().tolist()  # three coefficients (host sync; the fused trainer passes them directly)
+        grad = torch.zeros_like(planes)
+        desc = ctx.ps.desc()
+        _lib.check(_lib.lib().snerf_plane_reg(C.byref(desc), _ptr(planes), _ptr(grad), c[0], c[1], c[2], None, _stream()), "plane_reg")
+        return grad, None
+
+
+def plane_regularizers(ps: PlaneSet) -> torch.Tensor:
+    """[space_tv, time_smoothness, sparse_transients] of one plane set (losses.py:383-452), differentiable."""
+    return _PlaneReg.apply(ps.planes, ps)
+
+
+def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12, grad_scale: float = 1.0, zero_grad: bool = False):
+    """In-place fused Adam on flat fp32 buffers (1-based step)."""
+    for t in (p, g, m, v):
+        _f32c(t, "adam buffer")
+    _lib.check(_lib.lib().snerf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps, step, grad_scale,
+                                          int(zero_grad), _stream()), "adam_step")
+
+
+def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_plane: float = 0.0, training: bool = True):
+    """RayGenerator.forward (+ AABBBoxCollider when aabb is given).  indices int64 [R,3]; per-camera fx,fy,cx,cy [M],
+    c2w [M,3,4], cam_times [M].  Returns dict of origins, directions, pixel_area, directions_norm, times, (nears, fars)."""
+    if not indices.is_cuda or indices.dtype != torch.int64:
+        raise RuntimeError("generate_rays: indices must be an int64 HIP device tensor")
+    indices = indices.contiguous()
+    R, dev = indices.shape[0], indices.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    out = {"origins": f(R, 3), "directions": f(R, 3), "pixel_area": f(R, 1), "directions_norm": f(R, 1), "times": f(R, 1)}
+    a = _lib.RaygenArgs()
+    a.indices = indices.data_ptr()
+    keep = [_f32c(t, "camera table") for t in (fx, fy, cx, cy, c2w)]
+    a.fx, a.fy, a.cx, a.cy, a.c2w = [t.data_ptr() for t in keep]
+    if cam_times is not None:
+        cam_times = _f32c(cam_times, "cam_times")
+        a.cam_times = cam_times.data_ptr()
+    a.R = R
+    a.origins, a.dirs, a.pixel_area, a.dir_norm, a.times = [out[k].data_ptr() for k in ("origins", "directions", "pixel_area", "directions_norm", "times")]
+    if aabb is not None:
+        ab = aabb.detach().cpu().tolist() if isinstance(aabb, torch.Tensor) else aabb
+        a.collide, a.training, a.near_plane = 1, int(training), near_plane
+        for k in range(3):
+            a.aabb_min[k], a.aabb_max[k] = ab[0][k], ab[1][k]
+        out["nears"], out["fars"] = f(R, 1), f(R, 1)
+        a.nears, a.fars = out["nears"].data_ptr(), out["fars"].data_ptr()
+    _lib.check(_lib.lib().snerf_raygen(C.byref(a), _stream()), "raygen")
+    out["camera_indices"] = indices[:, 0:1]
+    return out
+
+
+def aabb_collide(origins, directions, aabb, near_plane: float = 0.0, training: bool = True):
+    """AABBBoxCollider._intersect_with_aabb (scene_colliders.py:59-95) -> (nears [R,1], fars [R,1])."""
+    origins, directions = _f32c(origins, "origins"), _f32c(directions, "directions")
+    R = origins.shape[0]
+    nears = torch.empty(R, 1, dtype=torch.float32, device=origins.device)
+    fars = torch.empty_like(nears)
+    ab = aabb.detach().cpu().reshape(-1).tolist() if isinstance(aabb, torch.Tensor) else [v for row in aabb for v in row]
+    arr = (C.c_float * 6)(*ab)
+    _lib.check(_lib.lib().snerf_aabb_collide(_ptr(origins), _ptr(directions), R, arr, near_plane, int(training), _ptr(nears), _ptr(fars),
+                                             _stream()), "aabb_collide")
+    return nears, fars
