@@ -1,0 +1,335 @@
+"""Fused K-Planes training step: the whole hot path as one fixed sequence of libsnerf launches.
+
+What the reference does per step: Trainer.train_iteration -> VanillaPipeline.get_train_loss_dict ->
+KPlanesModel.forward/get_loss_dict -> autograd backward -> 2x Adam -> scheduler
+(NS/engine/trainer.py:383-412, NS/models/kplanes.py:349-452, NS/model_components/ray_samplers.py:559-600).
+Here the same mathematics runs as ~30 hand-written HIP kernels on one stream with every buffer preallocated,
+no autograd graph, no host synchronisation: forward, hand-derived backward (recompute instead of saving
+activations), regulariser gradients, one flat gradient buffer (a single RCCL all-reduce when world_size > 1),
+one fused Adam sweep that also clears the gradients.  `soccernerfs_amd.kplanes.KPlanesModel` is the
+nerfstudio-shaped (autograd) face of the same kernels; tests check the two against each other and the oracle.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from .plane_set import PlaneSet
+from .tcnn_compat import Network
+
+
+@dataclass
+class KPlanesTrainConfig:
+    """Values of the `k-planes` preset (NS/configs/method_configs.py:481-560) unless overridden."""
+
+    aabb_scale: float = 1.5
+    spacetime_resolution: Sequence[int] = (64, 64, 64, 100)
+    multiscale_res: Sequence[int] = (1, 2, 4, 8, 16)
+    feature_dim: int = 32
+    proposal_resolutions: Sequence[Sequence[int]] = ((128, 128, 128, 100), (256, 256, 256, 100))
+    proposal_feature_dim: int = 8
+    sigma_net_hidden_dim: int = 128
+    rgb_net_hidden_dim: int = 64
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 128)
+    num_nerf_samples_per_ray: int = 64
+    use_single_jitter: bool = False
+    near_plane: float = 0.0  # AABBBoxCollider default (kplanes.py:276-277)
+    proposal_warmup: int = 5000
+    proposal_update_every: int = 5
+    proposal_weights_anneal_max_num_iters: int = 1000
+    proposal_weights_anneal_slope: float = 10.0
+    loss_coefficients: Dict[str, float] = field(default_factory=lambda: {
+        "rgb_loss": 1.0, "interlevel_loss": 1.0, "distortion_loss": 0.001, "space_tv_loss": 0.0002,
+        "time_smoothness_loss": 0.001, "sparse_transients_loss": 0.0001, "space_tv_proposal_loss": 0.0002,
+        "time_smoothness_proposal_loss": 0.00001, "sparse_transients_proposal_loss": 0.0001})
+    # optimiser + schedule (method_configs.py:546-557)
+    lr: float = 1e-2
+    adam_eps: float = 1e-12
+    warm_up_end: int = 512
+    max_steps: int = 30000
+    lr_alpha: float = 0.0
+    seed: int = 0
+
+
+def anneal_value(step: int, max_iters: int, slope: float) -> float:
+    """set_anneal callback (NS/models/kplanes.py:326-331)."""
+    frac = min(max(step / max_iters, 0.0), 1.0)
+    return (slope * frac) / ((slope - 1) * frac + 1)
+
+
+def update_schedule(step: int, warmup: int, every: int) -> float:
+    """NS/models/kplanes.py:254-259."""
+    return min(max(every * min(max(step / warmup, 0.0), 1.0), 1.0), float(every))
+
+
+def cosine_lr_factor(step: int, warm_up_end: int, max_steps: int, alpha: float) -> float:
+    """CosineDecayScheduler (NS/engine/schedulers.py:126-141)."""
+    if step < warm_up_end:
+        return step / warm_up_end
+    progress = (step - warm_up_end) / (max_steps - warm_up_end)
+    return (math.cos(math.pi * progress) + 1.0) * 0.5 * (1 - alpha) + alpha
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class KPlanesTrainer:
+    """Owns parameters (one flat fp32 buffer), Adam state and all work buffers for a fixed ray batch size R."""
+
+    def __init__(self, cfg: KPlanesTrainConfig, num_rays: int, device="cuda:0", process_group=None):
+        self.cfg, self.R, self.dev = cfg, num_rays, torch.device(device)
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        gen = torch.Generator().manual_seed(cfg.seed)
+        a = cfg.aabb_scale
+        self.aabb = [[-a, -a, -a], [a, a, a]]
+        base = list(cfg.spacetime_resolution)
+        reso = [[r * m for r in base[:3]] + base[3:] for m in cfg.multiscale_res]
+        mlp = lambda din, dout, h, nh, act: Network(din, dout, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act,
+                                                               "n_neurons": h, "n_hidden_layers": nh}, seed=int(torch.randint(0, 2**31, (1,), generator=gen)))
+        self.field_planes = PlaneSet(cfg.feature_dim, reso, concat=True, a=0.1, b=0.5, generator=gen)
+        self.sigma_net = mlp(cfg.feature_dim * len(reso), 16, cfg.sigma_net_hidden_dim, 1, "None")
+        self.color_net = mlp(15, 3, cfg.rgb_net_hidden_dim, 2, "Sigmoid")
+        self.prop_planes = [PlaneSet(cfg.proposal_feature_dim, [list(r)], concat=False, a=0.1, b=0.15, generator=gen)
+                            for r in cfg.proposal_resolutions]
+        self.prop_nets = [mlp(cfg.proposal_feature_dim, 1, 64, 1, "None") for _ in cfg.proposal_resolutions]
+        # ---- flatten: [proposal_networks | fields], each segment 16-B aligned ----
+        self.segments = []  # (name, module, attr, offset, numel)
+        off = 0
+        for i, (pp, pn) in enumerate(zip(self.prop_planes, self.prop_nets)):
+            for name, mod, attr in ((f"prop{i}.planes", pp, "planes"), (f"prop{i}.mlp", pn, "params")):
+                n = getattr(mod, attr).numel()
+                self.segments.append((name, mod, attr, off, n))
+                off += _align4(n)
+        self.n_proposal_params = off
+        for name, mod, attr in (("field.planes", self.field_planes, "planes"), ("field.sigma", self.sigma_net, "params"),
+                                ("field.color", self.color_net, "params")):
+            n = getattr(mod, attr).numel()
+            self.segments.append((name, mod, attr, off, n))
+            off += _align4(n)
+        self.n_params = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.views, self.gviews = {}, {}
+        for name, mod, attr, o, n in self.segments:
+            self.params[o:o + n].copy_(getattr(mod, attr).detach())
+            getattr(mod, attr).data = self.params[o:o + n]  # modules now alias the flat buffer
+            self.views[name], self.gviews[name] = self.params[o:o + n], self.grads[o:o + n]
+        # ---- work buffers ----
+        R = num_rays
+        S0, S1 = cfg.num_proposal_samples_per_ray
+        S2 = cfg.num_nerf_samples_per_ray
+        self.S = (S0, S1, S2)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        self.buf = {
+            "sb": [f(R, s + 1) for s in self.S], "eb": [f(R, s + 1) for s in self.S],
+            "dens": [f(R, s) for s in self.S], "w": [f(R, s) for s in self.S], "gw": [f(R, s) for s in self.S],
+            "gdens": [f(R, s) for s in self.S],
+            "pfeat": [f(R * S0, cfg.proposal_feature_dim), f(R * S1, cfg.proposal_feature_dim)],
+            "pout": [f(R * S0, 1), f(R * S1, 1)],
+            "gpfeat": [f(R * S0, cfg.proposal_feature_dim), f(R * S1, cfg.proposal_feature_dim)],
+            "feat": f(R * S2, self.field_planes.out_dim), "gfeat": f(R * S2, self.field_planes.out_dim),
+            "h": f(R * S2, 16), "gh": torch.zeros(R * S2, 16, dtype=torch.float32, device=self.dev),
+            "rgb": f(R * S2, 3), "grgb": f(R * S2, 3),
+            "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "g_rgb_out": f(R, 3),
+            "dist_rays": f(R), "inter_rays": [f(R), f(R)],
+            "reg": torch.zeros(3, 3, dtype=torch.float32, device=self.dev),  # rows: field, prop0, prop1
+        }
+        self.step = 0                 # completed optimiser steps
+        self._steps_since_update = 0  # ProposalNetworkSampler bookkeeping (ray_samplers.py:546-557)
+        self.last = {}
+        self.lib = _lib.lib()
+        self._desc_field = self.field_planes.desc()
+        self._desc_prop = [p.desc() for p in self.prop_planes]
+
+    # -------------------------------------------------------------------------------------------
+    def _p(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def _gather(self, desc, planes, coords, N, out):
+        _lib.check(self.lib.snerf_kplanes_gather_fwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(out), self._st), "gather_fwd")
+
+    def _scatter(self, desc, planes, coords, N, gout, gplanes):
+        _lib.check(self.lib.snerf_kplanes_gather_bwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(gout), self._p(gplanes),
+                                                     self._st), "gather_bwd")
+
+    def _mlp_fwd(self, net, X, ldx, N, Y, ldy, aux_col=-1, aux=None):
+        _lib.check(self.lib.snerf_mlp_fwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(Y), ldy, aux_col,
+                                          self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
+
+    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
+        _lib.check(self.lib.snerf_mlp_bwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
+                                          self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
+                                          self._p(gX) if gX is not None else None, ldgx, self._p(self.gviews[gname]), self._st), "mlp_bwd")
+
+    def _resample(self, lvl, rand, anneal):
+        """density[lvl] -> weights[lvl] (stored) -> PDF sample level lvl+1 bins."""
+        b, a = self.buf, _lib.ResampleArgs()
+        a.density, a.ebins_prev, a.weights_out = b["dens"][lvl].data_ptr(), b["eb"][lvl].data_ptr(), b["w"][lvl].data_ptr()
+        a.sbins_prev, a.nears, a.fars = b["sb"][lvl].data_ptr(), self.rays["nears"].data_ptr(), self.rays["fars"].data_ptr()
+        if rand is None:
+            a.u_mode = 2
+        else:
+            a.u_mode, a.u_or_rand, a.rand_cols = 1, rand.data_ptr(), rand.shape[-1]
+        a.sbins_out, a.ebins_out = b["sb"][lvl + 1].data_ptr(), b["eb"][lvl + 1].data_ptr()
+        a.R, a.S_prev, a.S, a.kind = self.R, self.S[lvl], self.S[lvl + 1], 0
+        a.anneal, a.histogram_padding, a.eps = anneal, 0.01, 1e-5
+        _lib.check(self.lib.snerf_pdf_resample(C.byref(a), self._st), "pdf_resample")
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, rays: Dict[str, torch.Tensor], rng: Optional[Dict[str, torch.Tensor]], anneal: float, training: bool = True):
+        """rays: origins [R,3], directions [R,3], times [R,1] (+ nears/fars, else the AABB collider runs).
+        rng (training): t_rand [R,S0+1]|[R,1], u (list of 2 draws [R,S+1]|[R,1]), bg [R,3]."""
+        cfg, b, R = self.cfg, self.buf, self.R
+        self._st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
+        if "nears" not in rays:
+            rays = dict(rays)
+            rays["nears"], rays["fars"] = ops.aabb_collide(o, d, self.aabb, cfg.near_plane, training)
+        self.rays = rays
+        t_rand = rng["t_rand"] if training else None
+        _lib.check(self.lib.snerf_spaced_bins(self._p(rays["nears"]), self._p(rays["fars"]), self._p(t_rand) if t_rand is not None else None,
+                                              t_rand.shape[-1] if t_rand is not None else 0, R, self.S[0], 0, self._p(b["sb"][0]), self._p(b["eb"][0]),
+                                              self._st), "spaced_bins")
+        self._coords = []
+        for lvl in range(3):
+            rescale = lvl == 2  # proposal fields keep [0,1] coordinates (kplanes_field.py:440), the main field maps to [-1,1] (:283-284)
+            co = ops.coords_from_rays(o, d, t, b["eb"][lvl], self.aabb, rescale)
+            self._coords.append(co)
+            N = R * self.S[lvl]
+            if lvl < 2:
+                self._gather(self._desc_prop[lvl], self.prop_planes[lvl].planes, co, N, b["pfeat"][lvl])
+                self._mlp_fwd(self.prop_nets[lvl], b["pfeat"][lvl], cfg.proposal_feature_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
+                self._resample(lvl, rng["u"][lvl] if training else None, anneal)
+            else:
+                self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
+                self._mlp_fwd(self.sigma_net, b["feat"], self.field_planes.out_dim, N, b["h"], 16, 15, b["dens"][2])
+                self._mlp_fwd(self.color_net, b["h"], 16, N, b["rgb"], 3)
+                _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, self.S[2], self._p(b["w"][2]), self._st), "weights_fwd")
+        a = _lib.RenderArgs()
+        a.weights, a.rgb, a.ebins = b["w"][2].data_ptr(), b["rgb"].data_ptr(), b["eb"][2].data_ptr()
+        if training:
+            a.bg_mode, a.bg = 0, rng["bg"].data_ptr()
+        else:
+            a.bg_mode = 1
+        a.R, a.S, a.training = R, self.S[2], int(training)
+        a.rgb_out, a.acc_out, a.depth_median = b["rgb_out"].data_ptr(), b["acc"].data_ptr(), b["depth"].data_ptr()
+        _lib.check(self.lib.snerf_render_fwd(C.byref(a), self._st), "render_fwd")
+        return b["rgb_out"]
+
+    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool):
+        """Accumulates d(total loss)/d(params) into self.grads; fills self.last with the (scaled) loss terms."""
+        cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
+        S0, S1, S2 = self.S
+        N2 = R * S2
+        diff = b["rgb_out"] - target
+        self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
+        torch.mul(diff, 2.0 * co["rgb_loss"] / (3 * R), out=b["g_rgb_out"])
+        _lib.check(self.lib.snerf_render_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["g_rgb_out"]), None, R, S2,
+                                             self._p(b["gw"][2]), self._p(b["grgb"]), 0, self._st), "render_bwd")
+        _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, co["distortion_loss"] / R, self._p(b["dist_rays"]),
+                                             self._p(b["gw"][2]), 1, self._st), "distortion")
+        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
+                                              self._st), "weights_bwd")
+        # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
+        self._mlp_bwd(self.color_net, "field.color", b["h"], 16, N2, b["grgb"], 3, -1, None, b["gh"], 16)
+        self._mlp_bwd(self.sigma_net, "field.sigma", b["feat"], self.field_planes.out_dim, N2, b["gh"], 16, 15, b["gdens"][2], b["gfeat"],
+                      self.field_planes.out_dim)
+        self._scatter(self._desc_field, self.field_planes.planes, self._coords[2], N2, b["gfeat"], self.gviews["field.planes"])
+        # proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592)
+        for lvl, Sp in ((0, S0), (1, S1)):
+            _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
+                                                 co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
+                                                 self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
+            if proposal_grads:
+                N = R * Sp
+                _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp,
+                                                      self._p(b["gdens"][lvl]), 0, self._st), "weights_bwd")
+                self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
+                              b["gpfeat"][lvl], cfg.proposal_feature_dim)
+                self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
+        # plane regularisers: values + gradients in one sweep per plane set (kplanes.py:430-446)
+        b["reg"].zero_()
+        _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_field), self._p(self.field_planes.planes), self._p(self.gviews["field.planes"]),
+                                            co["space_tv_loss"], co["time_smoothness_loss"], co["sparse_transients_loss"], self._p(b["reg"][0]),
+                                            self._st), "plane_reg")
+        for lvl in range(2):
+            _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_prop[lvl]), self._p(self.prop_planes[lvl].planes),
+                                                self._p(self.gviews[f"prop{lvl}.planes"]), co["space_tv_proposal_loss"],
+                                                co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
+                                                self._p(b["reg"][1 + lvl]), self._st), "plane_reg")
+
+    def loss_dict(self) -> Dict[str, torch.Tensor]:
+        """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny
+        reductions, only when asked for."""
+        b, co, R = self.buf, self.cfg.loss_coefficients, self.R
+        d = dict(self.last)
+        d["distortion_loss"] = b["dist_rays"].mean() * co["distortion_loss"]
+        d["interlevel_loss"] = (b["inter_rays"][0].sum() + b["inter_rays"][1].sum()) / (R * self.S[2]) * co["interlevel_loss"]
+        reg = b["reg"]
+        d["space_tv_loss"], d["time_smoothness_loss"], d["sparse_transients_loss"] = (
+            reg[0, 0] * co["space_tv_loss"], reg[0, 1] * co["time_smoothness_loss"], reg[0, 2] * co["sparse_transients_loss"])
+        pr = reg[1] + reg[2]
+        d["space_tv_proposal_loss"], d["time_smoothness_proposal_loss"], d["sparse_transients_proposal_loss"] = (
+            pr[0] * co["space_tv_proposal_loss"], pr[1] * co["time_smoothness_proposal_loss"], pr[2] * co["sparse_transients_proposal_loss"])
+        return d
+
+    def allreduce_grads(self):
+        """One all-reduce (SUM) over the flat gradient buffer; the mean (DDP semantics, base_pipeline.py:244-246) is folded
+        into Adam's grad_scale.  RCCL when the group's backend is nccl (GPU), gloo in the CPU tests."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def optimizer_step(self):
+        """Adam(lr*cosine, eps 1e-12) over the whole flat buffer + gradient clear (Optimizers.optimizer_step_all/scheduler_step_all)."""
+        cfg = self.cfg
+        lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
+        ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps,
+                      grad_scale=1.0 / self.world, zero_grad=True)
+        self.step += 1
+
+    def random_draws(self) -> Dict[str, torch.Tensor]:
+        """The step's uniform draws (torch.rand on the current device stream), shaped as the reference's samplers draw them."""
+        R, (S0, S1, S2) = self.R, self.S
+        sj = self.cfg.use_single_jitter
+        c0, c1, c2 = (1, 1, 1) if sj else (S0 + 1, S1 + 1, S2 + 1)
+        flat = torch.rand(R * (c0 + c1 + c2 + 3), device=self.dev)
+        o = 0
+        out = []
+        for c in (c0, c1, c2, 3):
+            out.append(flat[o:o + R * c].view(R, c))
+            o += R * c
+        return {"t_rand": out[0], "u": [out[1], out[2]], "bg": out[3]}
+
+    def train_step(self, rays: Dict[str, torch.Tensor], target: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None):
+        """One full training iteration (callbacks included): returns the rendered rgb [R,3] (a work buffer)."""
+        cfg = self.cfg
+        anneal = anneal_value(self.step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope)
+        # the sampler's own step counter lags by one: it is set by the AFTER_TRAIN_ITERATION callback (kplanes.py:340-346)
+        sstep = max(self.step - 1, 0)
+        updated = self._steps_since_update > update_schedule(sstep, cfg.proposal_warmup, cfg.proposal_update_every) or sstep < 10
+        rng = rng if rng is not None else self.random_draws()
+        out = self.forward(rays, rng, anneal, training=True)
+        self.backward(target, rng, proposal_grads=updated)
+        self.allreduce_grads()
+        self.optimizer_step()
+        if updated:
+            self._steps_since_update = 0
+        self._steps_since_update += 1  # step_cb (ray_samplers.py:554-557)
+        return out
+
+    # ---- reference-layout import (parity tests / checkpoint import) ----
+    @torch.no_grad()
+    def load_oracle_params(self, P: Dict):
+        self.field_planes.load_reference([[t.to(self.dev) for t in sc] for sc in P["field_grids"]])
+        self.sigma_net.load_linear_weights([w.to(self.dev) for w in P["field_sigma"]])
+        self.color_net.load_linear_weights([w.to(self.dev) for w in P["field_color"]])
+        for i in range(len(self.prop_planes)):
+            self.prop_planes[i].load_reference([[t.to(self.dev) for t in P["prop_grids"][i]]])
+            self.prop_nets[i].load_linear_weights([w.to(self.dev) for w in P["prop_sigma"][i]])

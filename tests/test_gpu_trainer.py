@@ -1,0 +1,146 @@
+"""GPU parity: the fused K-Planes training step (soccernerfs_amd.trainer) vs the golden end-to-end vector (G11,
+captured from the reference model) and vs the CPU oracle over several optimiser steps."""
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg_from(E):
+    from soccernerfs_amd.trainer import KPlanesTrainConfig
+
+    return KPlanesTrainConfig(aabb_scale=E["aabb_scale"], spacetime_resolution=E["base_res"], multiscale_res=E["multiscale"],
+                              feature_dim=E["feat_dim"], proposal_resolutions=E["prop_res"], proposal_feature_dim=E["prop_feat"],
+                              sigma_net_hidden_dim=E["sigma_hidden"], rgb_net_hidden_dim=E["color_hidden"])
+
+
+def _name_to_view(tr, name):
+    """reference parameter name -> (flat-gradient view converted to the reference layout)."""
+    parts = name.split(".")
+    g = tr.grads
+    if parts[0] == "grids":
+        s, p = int(parts[1]), int(parts[2])
+        return tr.field_planes.to_reference(tr.gviews["field.planes"])[s][p]
+    if parts[0] == "sigma_net":
+        return tr.sigma_net.linear_weights(tr.gviews["field.sigma"])[int(parts[2])]
+    if parts[0] == "color_net":
+        return tr.color_net.linear_weights(tr.gviews["field.color"])[int(parts[2])]
+    lvl = int(parts[1])
+    if parts[2] == "grids":
+        return tr.prop_planes[lvl].to_reference(tr.gviews[f"prop{lvl}.planes"])[0][int(parts[3])]
+    return tr.prop_nets[lvl].linear_weights(tr.gviews[f"prop{lvl}.mlp"])[int(parts[4])]
+
+
+def test_fused_step_matches_reference_golden():
+    from oracle import kplanes_oracle as KO
+    from oracle.gen_golden import E2E_CFG
+    from soccernerfs_amd.trainer import KPlanesTrainer
+
+    g = load_golden("g11_model")
+    R = g["origins"].shape[0]
+    tr = KPlanesTrainer(_cfg_from(E2E_CFG), R, DEV)
+    tr.load_oracle_params(KO.make_kplanes_params(**E2E_CFG))
+    t = lambda k: g[k].to(DEV).contiguous()
+    rays = {"origins": t("origins"), "directions": t("directions"), "times": t("times")}
+    rng = {"t_rand": t("t_rand"), "u": [t("u0"), t("u1")], "bg": t("bg")}
+    rgb = tr.forward(rays, rng, float(g["anneal"]), training=True)
+    for i in range(3):
+        torch.testing.assert_close(tr.buf["sb"][i].cpu(), g[f"sbins_{i}"], rtol=0, atol=1e-5)
+        torch.testing.assert_close(tr.buf["eb"][i].cpu(), g[f"ebins_{i}"], rtol=0, atol=3e-5)
+        torch.testing.assert_close(tr.buf["w"][i].cpu(), g[f"weights_{i}"], rtol=2e-3, atol=2e-5)
+    torch.testing.assert_close(rgb.cpu(), g["rgb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(tr.buf["acc"].cpu(), g["accumulation"][:, 0], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(tr.buf["depth"].cpu(), g["depth"][:, 0], rtol=0, atol=1e-4)
+    tr.backward(t("target"), rng, proposal_grads=True)
+    ld = tr.loss_dict()
+    for k, v in ld.items():
+        torch.testing.assert_close(v.cpu(), torch.as_tensor(g["loss_" + k]), rtol=2e-3, atol=1e-9)
+    total = sum(v for v in ld.values())
+    torch.testing.assert_close(total.cpu(), torch.as_tensor(g["loss_total"]), rtol=1e-3, atol=1e-8)
+    for name in [str(n) for n in g["grad_names"]]:
+        got = _name_to_view(tr, name).cpu()
+        gabs = float(g["gabs_" + name])
+        assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= 3e-3 * gabs + 1e-9, name
+        assert abs(float(got.double().abs().sum()) - gabs) <= 3e-3 * gabs + 1e-9, name
+        probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
+        torch.testing.assert_close(probe, g["gprobe_" + name], rtol=5e-3, atol=1e-7 + 2e-3 * float(g["gprobe_" + name].abs().max()))
+
+
+def test_three_training_steps_match_oracle():
+    """Same rays, same draws, 3 Adam steps (lr warm-up included): parameters track the CPU oracle."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer, anneal_value, cosine_lr_factor
+
+    E = dict(base_res=(16, 16, 16, 4), multiscale=(1, 2), feat_dim=32, prop_res=((24, 24, 24, 4), (32, 32, 32, 4)), prop_feat=8,
+             sigma_hidden=128, color_hidden=64, aabb_scale=1.5, seed=5)
+    P = KO.make_kplanes_params(**E)
+    leaves = KO.all_param_tensors(P)
+    for x in leaves:
+        x.requires_grad_(True)
+    R = 40
+    cfg = _cfg_from(E)
+    cfg.num_proposal_samples_per_ray, cfg.num_nerf_samples_per_ray = (64, 32), 16
+    cfg.warm_up_end = 2  # make the schedule move within 3 steps
+    tr = KPlanesTrainer(cfg, R, DEV)
+    tr.load_oracle_params(P)
+    gen = torch.Generator().manual_seed(77)
+    ms = [torch.zeros_like(x) for x in leaves]
+    vs = [torch.zeros_like(x) for x in leaves]
+    for step in range(3):
+        o = (torch.rand(R, 3, generator=gen) * 2 - 1) * 1.2
+        d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)
+        times = torch.rand(R, 1, generator=gen)
+        target = torch.rand(R, 3, generator=gen)
+        rng = {"t_rand": torch.rand(R, 65, generator=gen), "u": [torch.rand(R, 33, generator=gen), torch.rand(R, 17, generator=gen)],
+               "bg": torch.rand(R, 3, generator=gen)}
+        anneal = anneal_value(step, 1000, 10.0)
+        out = KO.kplanes_forward(P, {"origins": o, "directions": d, "times": times}, rng, (64, 32), 16, anneal=anneal)
+        loss = sum(KO.kplanes_loss_dict(P, out, target).values())
+        for x in leaves:
+            x.grad = None
+        loss.backward()
+        lr = 1e-2 * cosine_lr_factor(step, 2, 30000, 0.0)
+        with torch.no_grad():
+            for x, m, v in zip(leaves, ms, vs):
+                KO.adam_step(x, x.grad if x.grad is not None else torch.zeros_like(x), m, v, step + 1, lr)
+        dv = lambda z: z.to(DEV).contiguous()
+        rgb = tr.train_step({"origins": dv(o), "directions": dv(d), "times": dv(times)}, dv(target),
+                            {"t_rand": dv(rng["t_rand"]), "u": [dv(rng["u"][0]), dv(rng["u"][1])], "bg": dv(rng["bg"])})
+        torch.testing.assert_close(rgb.cpu(), out["rgb"].detach(), rtol=2e-3, atol=5e-5)
+        torch.testing.assert_close(sum(tr.loss_dict().values()).cpu(), loss.detach(), rtol=2e-3, atol=1e-7)
+    # after step k Adam moves every touched parameter by ~lr: compare parameters (reference layout)
+    got = tr.field_planes.to_reference()
+    for s in range(2):
+        for p in range(6):
+            torch.testing.assert_close(got[s][p].cpu(), P["field_grids"][s][p].detach(), rtol=0, atol=2e-3)
+    for a, b in zip(tr.sigma_net.linear_weights(), P["field_sigma"]):
+        torch.testing.assert_close(a.cpu(), b.detach(), rtol=0, atol=2e-3)
+    for i in range(2):
+        gp = tr.prop_planes[i].to_reference()[0]
+        for p in range(6):
+            torch.testing.assert_close(gp[p].cpu(), P["prop_grids"][i][p].detach(), rtol=0, atol=2e-3)
+    assert tr.step == 3 and float(tr.grads.abs().max()) == 0.0  # Adam cleared the gradient buffer
+
+
+def test_eval_forward_matches_oracle():
+    from oracle import kplanes_oracle as KO
+    from oracle.gen_golden import E2E_CFG
+    from soccernerfs_amd.trainer import KPlanesTrainer
+
+    P = KO.make_kplanes_params(**E2E_CFG)
+    R = 50
+    gen = torch.Generator().manual_seed(3)
+    o = (torch.rand(R, 3, generator=gen) * 2 - 1) * 1.2
+    d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)
+    times = torch.rand(R, 1, generator=gen)
+    with torch.no_grad():
+        out = KO.kplanes_forward(P, {"origins": o, "directions": d, "times": times}, None, anneal=1.0, training=False)
+    tr = KPlanesTrainer(_cfg_from(E2E_CFG), R, DEV)
+    tr.load_oracle_params(P)
+    dv = lambda z: z.to(DEV).contiguous()
+    rgb = tr.forward({"origins": dv(o), "directions": dv(d), "times": dv(times)}, None, 1.0, training=False)
+    torch.testing.assert_close(rgb.cpu(), out["rgb"], rtol=2e-3, atol=1e-4)
+    torch.testing.assert_close(tr.buf["depth"].cpu(), out["depth"][:, 0], rtol=0, atol=2e-3)
