@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- train rays/s of the MI355X-native K-Planes hot path (BASELINE.json metric).
+
+One "step" = one full training iteration of the `k-planes` preset (BASELINE.json configs[1]) on a synthetic
+Broadcast-style batch of 4096 rays per GPU: pixel sampling + image gather + ray generation + AABB collider +
+3-level proposal sampling + multiscale K-Planes gather + MLPs + compositing + all losses + backward +
+plane regularisers + (N>1: one RCCL all-reduce of the flat gradient buffer) + Adam.  Inputs (image cache,
+camera tables, parameters) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant kernel
+(HIP events around its launches inside the timed region) and `cpu_baseline` (the CPU oracle -- the checker, a
+"port" of the reference's pure-PyTorch path -- timed on the host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (k-planes preset: 4096)")
+    ap.add_argument("--images", type=int, default=0, help="override the number of synthetic training images (default 19 cams x 33 frames)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr after the timed run")
+    return ap.parse_args()
+
+
+def cpu_baseline(rays_per_step=256, steps=2):
+    """The oracle's K-Planes train step (fwd + autograd bwd + Adam) at the preset's plane sizes, on the host cores."""
+    from oracle import kplanes_oracle as KO  # the checker; only timed here, never on the product path
+
+    torch.manual_seed(0)
+    n_threads = os.cpu_count() or 1
+    torch.set_num_threads(n_threads)
+    P = KO.make_kplanes_params(base_res=(64, 64, 64, 100), multiscale=(1, 2, 4, 8, 16),
+                               prop_res=((128, 128, 128, 100), (256, 256, 256, 100)))
+    leaves = KO.all_param_tensors(P)
+    for x in leaves:
+        x.requires_grad_(True)
+    ms = [torch.zeros_like(x) for x in leaves]
+    vs = [torch.zeros_like(x) for x in leaves]
+    R = rays_per_step
+    dt = 0.0
+    for step in range(steps):
+        o = (torch.rand(R, 3) * 2 - 1) * 0.9
+        d = torch.nn.functional.normalize(torch.rand(R, 3) * 2 - 1, dim=-1)
+        rays = {"origins": o, "directions": d, "times": torch.rand(R, 1)}
+        rng = {"t_rand": torch.rand(R, 257), "u": [torch.rand(R, 129), torch.rand(R, 65)], "bg": torch.rand(R, 3)}
+        target = torch.rand(R, 3)
+        t0 = time.perf_counter()
+        out = KO.kplanes_forward(P, rays, rng, anneal=KO.anneal_value(step))
+        loss = sum(KO.kplanes_loss_dict(P, out, target).values())
+        for x in leaves:
+            x.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for x, m, v in zip(leaves, ms, vs):
+                KO.adam_step(x, x.grad if x.grad is not None else torch.zeros_like(x), m, v, step + 1, 1e-2 * KO.cosine_lr_factor(step))
+        dt += time.perf_counter() - t0
+    return {"value": R * steps / dt, "unit": "rays/s", "cores": n_threads, "kind": "port",
+            "sample": f"{steps} full train steps (fwd+bwd+Adam, k-planes preset planes, fp32) of {R} rays each on the CPU oracle"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the HIP path has no fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from soccernerfs_amd import ops, synthetic
+    from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
+
+    # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
+    torch.manual_seed(20231029 + rank)
+    cfg = KPlanesTrainConfig()  # the k-planes preset
+    R = args.rays
+    trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
+
+    # ---- synthetic Broadcast-style data, resident in HBM ----
+    cams = synthetic.make_cameras(20, 960, 540)
+    times = synthetic.frame_times(100, 3)
+    train_cams = list(range(19))
+    if args.images:
+        per_cam = max(1, args.images // len(train_cams))
+        times = times[:per_cam]
+    data = synthetic.render_dataset(cams, times, train_cams, dev, chunk_rows=540)
+    images = data["images"]
+    M, H, W = images.shape[:3]
+    scale = torch.tensor([M, H, W], dtype=torch.float32, device=dev)
+
+    def one_step():
+        # uniform pixel sampler (PixelSampler.sample_method, NS/data/pixel_samplers.py:74-77) + image gather (:111-123)
+        idx = torch.floor(torch.rand(R, 3, device=dev) * scale).long()
+        target = images[idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
+        rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=trainer.aabb,
+                                 near_plane=cfg.near_plane, training=True)
+        return trainer.train_step(rays, target)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    DOMINANT = "kplanes_gather_bwd.field"
+    trainer.enable_kernel_timing([DOMINANT])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = trainer.kernel_times_ms()
+    trainer.disable_kernel_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    breakdown = None
+    if args.breakdown:
+        trainer.enable_kernel_timing(None)
+        for _ in range(20):
+            one_step()
+        breakdown = trainer.kernel_times_ms()
+        trainer.disable_kernel_timing()
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        S2 = cfg.num_nerf_samples_per_ray
+        # algorithmic bytes of ONE launch of the dominant kernel: read-modify-write of every touched texel
+        alg_bytes = R * S2 * len(cfg.multiscale_res) * 6 * 4 * cfg.feature_dim * 4 * 2
+        dom_ms = kt.get(DOMINANT, (float("nan"), 0))[0]
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        line = {
+            "metric": "train rays/sec (K-Planes Broadcast-style, whole job)", "value": R * world * args.steps / elapsed, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
+                                   "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
+                       "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
+                       "parallelism": f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "kplanes_gather_bwd_kernel<32,6> (field plane-gradient scatter)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms, "launches_timed": kt.get(DOMINANT, (0, 0))[1]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        if breakdown:
+            tot = sum(v[0] * v[1] for v in breakdown.values()) / 20
+            print(f"per-step kernel time by group (sum {tot:.3f} ms):", file=sys.stderr)
+            for k, (ms, n) in sorted(breakdown.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+                print(f"  {k:32s} {ms:8.3f} ms x {n / 20:4.1f}/step = {ms * n / 20:8.3f} ms", file=sys.stderr)
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""Synthetic "Broadcast-style" dynamic scene (the real dataset is not available offline).
+
+Geometry constants follow the reference's Broadcast-style parser defaults:
+20 pinhole cameras (19 train + 1 eval) on one side of the pitch, 1920x1080 downscaled by 2 -> 960x540,
+100 frames at 25 fps subsampled by fps_downsample (3 -> 33 frames per camera, 627 train images),
+camera translations scaled so max|t| = 1, scene_scale 1.5 => aabb [-1.5,1.5]^3, times = frame/max_frame in [0,1]
+(NS/data/dataparsers/broadcaststyle_dataparser.py:166-232,408-480).  Content is an analytic scene ray-cast on
+the GPU with torch ops: a static textured ground plane plus a "player" (two stacked spheres) and a ball on a
+parabolic arc that together cover <~1 % of the pixels, so temporal-difference (IST) maps are sparse.
+Data plumbing only -- not part of the measured hot path.
+"""
+import math
+from typing import Dict
+
+import torch
+
+
+def make_cameras(n_cams: int = 20, width: int = 960, height: int = 540, device="cpu") -> Dict[str, torch.Tensor]:
+    c2w = []
+    for i in range(n_cams):
+        ang = math.radians(-60 + 120 * i / max(n_cams - 1, 1))  # an arc along one touchline
+        pos = torch.tensor([math.sin(ang) * 1.0, -math.cos(ang) * 1.0, 0.35 + 0.15 * (i % 3)])
+        target = torch.tensor([0.15 * math.sin(3 * i), 0.1 * math.cos(2 * i), 0.0])
+        fwd = torch.nn.functional.normalize(target - pos, dim=0)
+        right = torch.nn.functional.normalize(torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0])), dim=0)
+        up = torch.linalg.cross(right, fwd)
+        c2w.append(torch.cat([torch.stack([right, up, -fwd], dim=1), pos[:, None]], dim=1))
+    c2w = torch.stack(c2w).float()
+    c2w[:, :, 3] /= c2w[:, :, 3].abs().max()  # auto-scale translations to max|t| = 1 (parser :433-438)
+    focal = 0.9 * width
+    return {"c2w": c2w.to(device), "fx": torch.full((n_cams,), focal, device=device), "fy": torch.full((n_cams,), focal, device=device),
+            "cx": torch.full((n_cams,), width / 2.0, device=device), "cy": torch.full((n_cams,), height / 2.0, device=device),
+            "width": width, "height": height}
+
+
+def frame_times(n_frames: int = 100, fps_downsample: int = 3) -> torch.Tensor:
+    """linspace(0, n-1, int(n/f)) frame ids -> time = frame / max_frame (parser :408-412,:476-479)."""
+    ids = torch.linspace(0, n_frames - 1, int(n_frames / fps_downsample)).long()
+    return ids.float() / float(n_frames - 1)
+
+
+def _sphere_hit(o, d, c, r):
+    oc = o - c
+    b = (oc * d).sum(-1)
+    disc = b * b - ((oc * oc).sum(-1) - r * r)
+    t = -b - torch.sqrt(disc.clamp_min(0))
+    return torch.where((disc > 0) & (t > 0), t, torch.full_like(t, float("inf")))
+
+
+def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
+    """Analytic colour in [0,1] for rays (o,d [N,3], unit d) at times [N]."""
+    N = o.shape[0]
+    sky = torch.stack([0.55 + 0.2 * d[:, 2], 0.7 + 0.15 * d[:, 2], 0.95 * torch.ones_like(d[:, 2])], -1).clamp(0, 1)
+    # ground plane z = -0.1: mown-stripe pitch + lines
+    tz = (-0.1 - o[:, 2]) / torch.where(d[:, 2].abs() < 1e-6, torch.full_like(d[:, 2], -1e-6), d[:, 2])
+    tg = torch.where(tz > 0, tz, torch.full_like(tz, float("inf")))
+    pg = o + d * tg.clamp(max=1e4)[:, None]
+    stripe = ((pg[:, 0] * 6).floor() % 2)
+    green = torch.stack([0.12 + 0.05 * stripe, 0.45 + 0.12 * stripe, 0.15 + 0.03 * stripe], -1)
+    line = ((pg[:, 0].abs() - 1.0).abs() < 0.01) | ((pg[:, 1].abs() - 0.65).abs() < 0.01) | (pg[:, 0].abs() < 0.008)
+    green = torch.where(line[:, None], torch.ones_like(green) * 0.92, green)
+    inside = (pg[:, 0].abs() < 1.45) & (pg[:, 1].abs() < 1.45)
+    col = torch.where((torch.isfinite(tg) & inside)[:, None], green, sky)
+    depth = torch.where(torch.isfinite(tg) & inside, tg, torch.full_like(tg, float("inf")))
+    # dynamic content
+    tt = time
+    ball_c = torch.stack([-0.6 + 1.2 * tt, 0.2 * torch.sin(6.28 * tt), -0.07 + 1.2 * tt * (1 - tt)], -1)
+    body_c = torch.stack([0.4 * torch.cos(3.14 * tt), -0.3 + 0.5 * tt, torch.full_like(tt, -0.04)], -1)
+    head_c = body_c + torch.tensor([0.0, 0.0, 0.085], device=o.device)
+    for c, r, rgb in ((ball_c, 0.03, (0.95, 0.95, 0.9)), (body_c, 0.06, (0.85, 0.1, 0.1)), (head_c, 0.03, (0.9, 0.75, 0.6))):
+        t = _sphere_hit(o, d, c, r)
+        hit = t < depth
+        n = torch.nn.functional.normalize(o + d * t.clamp(max=1e4)[:, None] - c, dim=-1)
+        lam = (n * torch.tensor([0.3, -0.4, 0.85], device=o.device)).sum(-1).clamp(0.15, 1.0)
+        sc = torch.tensor(rgb, device=o.device)[None, :] * lam[:, None]
+        col = torch.where(hit[:, None], sc, col)
+        depth = torch.where(hit, t, depth)
+    return col.clamp(0, 1)
+
+
+def render_dataset(cams: Dict[str, torch.Tensor], times: torch.Tensor, cam_ids, device, chunk_rows: int = 135) -> Dict[str, torch.Tensor]:
+    """uint8 images [M,H,W,3] on `device` for every (camera in cam_ids) x (time), plus per-image camera tables
+    (one 'camera' per image, as nerfstudio's Cameras object holds them: c2w/intrinsics repeated per frame + times)."""
+    from . import ops
+
+    H, W = cams["height"], cams["width"]
+    M = len(cam_ids) * len(times)
+    imgs = torch.empty(M, H, W, 3, dtype=torch.uint8, device=device)
+    tab = {k: [] for k in ("c2w", "fx", "fy", "cx", "cy", "times", "cam_id")}
+    m = 0
+    for c in cam_ids:
+        for t in times.tolist():
+            for k in ("c2w", "fx", "fy", "cx", "cy"):
+                tab[k].append(cams[k][c])
+            tab["times"].append(t)
+            tab["cam_id"].append(c)
+            m += 1
+    table = {k: torch.stack(v).to(device).contiguous() for k, v in tab.items() if k not in ("times", "cam_id")}
+    table["times"] = torch.tensor(tab["times"], dtype=torch.float32, device=device)
+    table["cam_id"] = torch.tensor(tab["cam_id"], dtype=torch.int64, device=device)
+    xs = torch.arange(W, device=device)
+    for m in range(M):
+        for r0 in range(0, H, chunk_rows):
+            rows = torch.arange(r0, min(r0 + chunk_rows, H), device=device)
+            yy, xx = torch.meshgrid(rows, xs, indexing="ij")
+            idx = torch.stack([torch.full_like(yy, m), yy, xx], -1).reshape(-1, 3)
+            rays = ops.generate_rays(idx, table["fx"], table["fy"], table["cx"], table["cy"], table["c2w"], table["times"])
+            col = shade(rays["origins"], rays["directions"], rays["times"][:, 0])
+            imgs[m, r0:r0 + rows.numel()] = (col.view(rows.numel(), W, 3) * 255.0 + 0.5).to(torch.uint8)
+    return {"images": imgs, **table, "width": W, "height": H}

@@ -141,6 +141,7 @@ class KPlanesTrainer:
             "dist_rays": f(R), "inter_rays": [f(R), f(R)],
             "reg": torch.zeros(3, 3, dtype=torch.float32, device=self.dev),  # rows: field, prop0, prop1
         }
+        self._timing, self._timing_all = None, False
         self.step = 0                 # completed optimiser steps
         self._steps_since_update = 0  # ProposalNetworkSampler bookkeeping (ray_samplers.py:546-557)
         self.last = {}
@@ -149,21 +150,63 @@ class KPlanesTrainer:
         self._desc_prop = [p.desc() for p in self.prop_planes]
 
     # -------------------------------------------------------------------------------------------
+    def enable_kernel_timing(self, names=None):
+        """Record HIP events (on the launch stream) around kernel groups; `names` = None times every group.
+        Read back with `kernel_times_ms()` (synchronises)."""
+        self._timing = {} if names is None else {n: [] for n in names}
+        self._timing_all = names is None
+
+    def disable_kernel_timing(self):
+        self._timing = None
+
+    def kernel_times_ms(self) -> Dict[str, Tuple[float, int]]:
+        """name -> (mean milliseconds per launch, launches)."""
+        torch.cuda.synchronize()
+        out = {}
+        for k, evs in (self._timing or {}).items():
+            if evs:
+                out[k] = (sum(a.elapsed_time(b) for a, b in evs) / len(evs), len(evs))
+        return out
+
+    class _Span:
+        def __init__(self, tr, name):
+            self.tr, self.name = tr, name
+
+        def __enter__(self):
+            t = self.tr._timing
+            self.on = t is not None and (self.tr._timing_all or self.name in t)
+            if self.on:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+        def __exit__(self, *exc):
+            if self.on:
+                b = torch.cuda.Event(enable_timing=True)
+                b.record()
+                self.tr._timing.setdefault(self.name, []).append((self.a, b))
+
+    def _span(self, name):
+        return KPlanesTrainer._Span(self, name)
+
     def _p(self, t):
         return C.c_void_p(t.data_ptr())
 
     def _gather(self, desc, planes, coords, N, out):
+      with self._span("kplanes_gather_fwd.field" if desc is self._desc_field else "kplanes_gather_fwd.prop"):
         _lib.check(self.lib.snerf_kplanes_gather_fwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(out), self._st), "gather_fwd")
 
     def _scatter(self, desc, planes, coords, N, gout, gplanes):
+      with self._span("kplanes_gather_bwd.field" if desc is self._desc_field else "kplanes_gather_bwd.prop"):
         _lib.check(self.lib.snerf_kplanes_gather_bwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(gout), self._p(gplanes),
                                                      self._st), "gather_bwd")
 
     def _mlp_fwd(self, net, X, ldx, N, Y, ldy, aux_col=-1, aux=None):
+      with self._span(f"mlp_fwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
         _lib.check(self.lib.snerf_mlp_fwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(Y), ldy, aux_col,
                                           self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
 
     def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
+      with self._span(f"mlp_bwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
         _lib.check(self.lib.snerf_mlp_bwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
                                           self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
                                           self._p(gX) if gX is not None else None, ldgx, self._p(self.gviews[gname]), self._st), "mlp_bwd")
@@ -180,7 +223,8 @@ class KPlanesTrainer:
         a.sbins_out, a.ebins_out = b["sb"][lvl + 1].data_ptr(), b["eb"][lvl + 1].data_ptr()
         a.R, a.S_prev, a.S, a.kind = self.R, self.S[lvl], self.S[lvl + 1], 0
         a.anneal, a.histogram_padding, a.eps = anneal, 0.01, 1e-5
-        _lib.check(self.lib.snerf_pdf_resample(C.byref(a), self._st), "pdf_resample")
+        with self._span("pdf_resample"):
+            _lib.check(self.lib.snerf_pdf_resample(C.byref(a), self._st), "pdf_resample")
 
     # -------------------------------------------------------------------------------------------
     def forward(self, rays: Dict[str, torch.Tensor], rng: Optional[Dict[str, torch.Tensor]], anneal: float, training: bool = True):
@@ -256,6 +300,8 @@ class KPlanesTrainer:
                 self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
         # plane regularisers: values + gradients in one sweep per plane set (kplanes.py:430-446)
         b["reg"].zero_()
+        self._reg_span = self._span("plane_reg.all")
+        self._reg_span.__enter__()
         _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_field), self._p(self.field_planes.planes), self._p(self.gviews["field.planes"]),
                                             co["space_tv_loss"], co["time_smoothness_loss"], co["sparse_transients_loss"], self._p(b["reg"][0]),
                                             self._st), "plane_reg")
@@ -264,6 +310,7 @@ class KPlanesTrainer:
                                                 self._p(self.gviews[f"prop{lvl}.planes"]), co["space_tv_proposal_loss"],
                                                 co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
                                                 self._p(b["reg"][1 + lvl]), self._st), "plane_reg")
+        self._reg_span.__exit__()
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny
@@ -290,8 +337,9 @@ class KPlanesTrainer:
         """Adam(lr*cosine, eps 1e-12) over the whole flat buffer + gradient clear (Optimizers.optimizer_step_all/scheduler_step_all)."""
         cfg = self.cfg
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
-        ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps,
-                      grad_scale=1.0 / self.world, zero_grad=True)
+        with self._span("adam_step"):
+            ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps,
+                          grad_scale=1.0 / self.world, zero_grad=True)
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:
