@@ -45,7 +45,8 @@ def cpu_baseline(rays_per_step=256, steps=2):
     from oracle import kplanes_oracle as KO  # the checker; only timed here, never on the product path
 
     torch.manual_seed(0)
-    n_threads = os.cpu_count() or 1
+    # many small ops: beyond ~16 intra-op threads torch only adds synchronisation overhead (256 threads: 2000x slower)
+    n_threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(n_threads)
     P = KO.make_kplanes_params(base_res=(64, 64, 64, 100), multiscale=(1, 2, 4, 8, 16),
                                prop_res=((128, 128, 128, 100), (256, 256, 256, 100)))
