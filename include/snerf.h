@@ -211,12 +211,13 @@ int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_t S, const 
  * Dense per-step sweeps.
  * ------------------------------------------------------------------------------------------------ */
 
-/* K-Planes plane regularisers for one plane set (losses.py:356-452): accumulates the UNSCALED values into
- * losses[3] = {space_tv, time_smoothness, sparse_transients} (caller zeroes) and, if grad != NULL, adds
+/* K-Planes plane regularisers for one plane set (losses.py:356-452): accumulates UNSCALED partial sums of
+ * {space_tv, time_smoothness, sparse_transients} into losses[n_slots][16] (columns 0..2; one 64-B line per slot so the
+ * per-workgroup adds do not serialise on one address; the caller zeroes it and sums over slots) and, if grad != NULL, adds
  * c_space_tv * d(space_tv) + c_time_smooth * d(time_smoothness) + c_sparse * d(sparse_transients) into grad
- * (same layout as planes). */
+ * (same layout as planes); overwrite != 0 STORES instead (the caller knows grad is still zero: saves the read sweep). */
 int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* grad, float c_space_tv, float c_time_smooth,
-                    float c_sparse, float* losses, snerf_stream_t stream);
+                    float c_sparse, float* losses, int32_t n_slots, int32_t overwrite, snerf_stream_t stream);
 
 /* torch.optim.Adam single-tensor step (no weight decay, no amsgrad) on a flat buffer; `step` is 1-based.
  * g is first multiplied by grad_scale (e.g. 1/world_size after an all-reduce SUM) and, if zero_grad != 0, cleared. */

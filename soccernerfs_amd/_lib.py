@@ -92,7 +92,7 @@ def lib():
     F, I, L, P = C.c_float, C.c_int32, C.c_int64, C.c_void_p
     l.snerf_distortion.argtypes = [P, P, I, I, F, P, P, I, P]
     l.snerf_interlevel.argtypes = [P, P, I, P, P, I, I, F, P, P, P]
-    l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, P]
+    l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, I, I, P]
     l.snerf_adam_step.argtypes = [P, P, P, P, L, F, F, F, F, I, F, I, P]
     l.snerf_aabb_collide.argtypes = [P, P, I, P, F, I, P, P, P]
     l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]

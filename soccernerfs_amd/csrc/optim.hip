@@ -17,7 +17,9 @@ struct RegArgs {
   const float* planes;
   float* grad;                       // may be null (values only)
   float c_tv, c_smooth, c_l1;        // loss coefficients folded into the gradient
-  float* losses;                     // [3] accumulated UNSCALED: space_tv, time_smoothness, sparse_transients
+  float* losses;                     // [n_slots][16]: per-slot partial sums (cols 0..2), UNSCALED
+  int n_slots;
+  int overwrite;                     // 1: grad = reg gradient (buffer known to be zero), 0: grad += reg gradient
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -45,13 +47,15 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   const int W = a.d.res[s][ax], H = a.d.res[s][bx];
   const bool time_plane = (a.n_planes == 6) && (bx == 3);  // planes 2,4,5: H = time
   constexpr int C4 = C / 4;
-  const int64_t n4 = (int64_t)H * W * C4;
-  const int64_t e = (int64_t)(blockIdx.x - a.blk_off[s][p]) * 256 + threadIdx.x;
+  // 32-bit index math only (64-bit div/mod is a ~100-instruction software routine on the GPU); a plane has < 2^31 float4s
+  const uint32_t n4 = (uint32_t)H * (uint32_t)W * C4;
+  const uint32_t e = (uint32_t)(blockIdx.x - a.blk_off[s][p]) * 256u + threadIdx.x;
   float l_tv = 0.f, l_sm = 0.f, l_l1 = 0.f;
   if (e < n4) {
-    const int c4 = (int)(e % C4);
-    const int64_t hw = e / C4;
-    const int w = (int)(hw % W), h = (int)(hw / W);
+    const int c4 = (int)(e % C4);       // C4 is a compile-time power of two
+    const uint32_t hw = e / C4;
+    const int h = (int)(hw / (uint32_t)W);
+    const int w = (int)(hw - (uint32_t)h * (uint32_t)W);
     const float* base = a.planes + a.d.off[s][p] + c4 * 4;
     auto at = [&](int hh, int ww) { return ld4(base + ((int64_t)hh * W + ww) * C); };
     const float4 t = at(h, w);
@@ -93,8 +97,12 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
     }
     if (a.grad) {
       float* gp = a.grad + a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
-      float4 old = ld4(gp);
-      *reinterpret_cast<float4*>(gp) = add4(old, g);
+      if (a.overwrite) {
+        *reinterpret_cast<float4*>(gp) = g;  // caller guarantees the gradient buffer is zero here: skip the read
+      } else {
+        float4 old = ld4(gp);
+        *reinterpret_cast<float4*>(gp) = add4(old, g);
+      }
     }
   }
   // ---- loss values: workgroup reduction, one atomic per workgroup per term ----
@@ -103,9 +111,11 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { red[0][wv] = l_tv; red[1][wv] = l_sm; red[2][wv] = l_l1; }
   __syncthreads();
+  // one add per workgroup per term, spread over n_slots 64-B lines: 150k workgroups adding to ONE address serialise at
+  // the memory side (measured: 1.9 ms for this kernel with a single slot, profiles/r01_kernels.md)
   if (threadIdx.x < 3 && a.losses) {
     float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-    if (v != 0.f) atomicAdd(a.losses + threadIdx.x, v);
+    if (v != 0.f) atomicAdd(a.losses + (size_t)(blockIdx.x % a.n_slots) * 16 + threadIdx.x, v);
   }
 }
 
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 using namespace snerf;
 
 extern "C" int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* grad, float c_space_tv, float c_time_smooth,
-                               float c_sparse, float* losses, snerf_stream_t stream) {
+                               float c_sparse, float* losses, int32_t n_slots, int32_t overwrite, snerf_stream_t stream) {
   SNERF_REQUIRE(desc && planes, "plane_reg: null argument");
   SNERF_REQUIRE(desc->n_scales >= 1 && desc->n_scales <= SNERF_MAX_SCALES, "plane_reg: n_scales=%d", desc->n_scales);
   SNERF_REQUIRE(desc->C == 8 || desc->C == 16 || desc->C == 32, "plane_reg: C=%d unsupported", desc->C);
@@ -160,6 +170,9 @@ extern "C" int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* plan
   a.d = *desc;
   a.n_planes = desc->n_coords == 4 ? 6 : 3;
   a.planes = planes; a.grad = grad; a.c_tv = c_space_tv; a.c_smooth = c_time_smooth; a.c_l1 = c_sparse; a.losses = losses;
+  a.overwrite = overwrite;
+  a.n_slots = n_slots;
+  SNERF_REQUIRE(!losses || n_slots >= 1, "plane_reg: n_slots=%d", n_slots);
   static const int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3}, PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
   int64_t blocks = 0;
   for (int s = 0; s < desc->n_scales; ++s)

@@ -1,0 +1,119 @@
+"""K-Planes fields with the interface of NS/fields/kplanes_field.py (KPlanesField :129-370,
+KPlanesDensityField :373-463; non-linear decoder, no appearance embedding -- the `k-planes` preset)."""
+import enum
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+from .plane_set import PlaneSet
+from .rays import Frustums, RaySamples
+from .scene_colliders import SceneBox
+from .tcnn_compat import Network
+
+
+class FieldHeadNames(enum.Enum):
+    """NS/field_components/field_heads.py:28-43 (the two heads this path emits)."""
+
+    RGB = "rgb"
+    DENSITY = "density"
+
+
+def interpolate_kplanes(pts: torch.Tensor, ms_grids: PlaneSet, concat_features: bool = None, freeze_time_planes: bool = False,
+                        freeze_space_planes: bool = False) -> torch.Tensor:
+    """interpolate_kplanes (kplanes_field.py:77-126) on a PlaneSet (which already knows concat-vs-sum)."""
+    if freeze_time_planes or freeze_space_planes:
+        raise NotImplementedError("frozen planes are not used by the k-planes preset")
+    return ops.interpolate_kplanes(pts, ms_grids)
+
+
+def _pts_from_positions(positions, times, aabb, rescale: bool):
+    p = SceneBox.get_normalized_positions(positions, aabb)
+    if rescale:
+        p = p * 2.0 - 1.0
+    t = (times * 2) - 1
+    if t.dim() == 2:
+        t = t[:, None, :]
+    return torch.cat((p, t.expand(*p.shape[:-1], 1)), dim=-1).reshape(-1, 4)
+
+
+class KPlanesField(nn.Module):
+    def __init__(self, aabb, spacetime_resolution: Sequence[int] = (256, 256, 256, 150), feat_dim: int = 16,
+                 multiscale_res: Optional[Sequence[int]] = None, concat_features_across_scales: bool = False,
+                 linear_decoder: bool = False, disable_viewing_dependent: bool = True, sigma_net_layers: int = 1,
+                 sigma_net_hidden_dim: int = 64, rgb_net_layers: int = 2, rgb_net_hidden_dim: int = 64, use_appearance_embedding: bool = False,
+                 spatial_distortion=None, **_unused) -> None:
+        super().__init__()
+        if linear_decoder or not disable_viewing_dependent or use_appearance_embedding or spatial_distortion is not None:
+            raise NotImplementedError("only the k-planes preset decoder (MLP, view-independent, bounded scene) is built")
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+        mult = list(multiscale_res or [1])
+        base = list(spacetime_resolution)
+        self.grids = PlaneSet(feat_dim, [[r * m for r in base[:3]] + base[3:] for m in mult], concat=concat_features_across_scales)
+        self.feature_dim = self.grids.out_dim
+        self.geo_feat_dim = 15
+        cfg = {"otype": "FullyFusedMLP", "activation": "ReLU"}
+        self.sigma_net = Network(self.feature_dim, self.geo_feat_dim + 1,
+                                 {**cfg, "output_activation": "None", "n_neurons": sigma_net_hidden_dim, "n_hidden_layers": sigma_net_layers})
+        self.color_net = Network(self.geo_feat_dim, 3,
+                                 {**cfg, "output_activation": "Sigmoid", "n_neurons": rgb_net_hidden_dim, "n_hidden_layers": rgb_net_layers})
+
+    def _features(self, ray_samples: RaySamples):
+        c = ray_samples._compact
+        if c is not None and c["times"] is not None:
+            return ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=True)
+        pts = _pts_from_positions(ray_samples.frustums.get_positions(), ray_samples.times, self.aabb, True)
+        return ops.interpolate_kplanes(pts, self.grids)
+
+    def get_density(self, ray_samples: RaySamples):
+        """kplanes_field.py:275-312 -> (density [R,S,1], geo features [N,15])."""
+        n_rays, n_samples = ray_samples.frustums.shape[:2]
+        h, dens = self.sigma_net.forward_with_exp_head(self._features(ray_samples), self.geo_feat_dim)
+        return dens.view(n_rays, n_samples, 1), h[:, : self.geo_feat_dim]
+
+    def get_outputs(self, ray_samples: RaySamples, density_embedding=None):
+        """kplanes_field.py:314-358."""
+        assert density_embedding is not None
+        n_rays, n_samples = ray_samples.frustums.shape[:2]
+        return self.color_net(density_embedding).view(n_rays, n_samples, 3)
+
+    def forward(self, ray_samples: RaySamples, compute_normals: bool = False, mask=None, bg_color=None):
+        density, feats = self.get_density(ray_samples)
+        return {FieldHeadNames.DENSITY: density, FieldHeadNames.RGB: self.get_outputs(ray_samples, feats)}
+
+
+class KPlanesDensityField(nn.Module):
+    def __init__(self, aabb, resolution, feature_dim, spatial_distortion=None, linear_decoder: bool = False, **_unused) -> None:
+        super().__init__()
+        if linear_decoder or spatial_distortion is not None:
+            raise NotImplementedError("only the k-planes preset proposal field is built")
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+        self.grids = PlaneSet(feature_dim, [list(resolution)], concat=False, a=0.1, b=0.15)
+        self.sigma_net = Network(feature_dim, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                                  "n_neurons": 64, "n_hidden_layers": 1})
+
+    def density_fn(self, positions, times):
+        """kplanes_field.py:410-432: positions [R,S,3] (or [N,3]), times [R,1]."""
+        shape = positions.shape[:-1]
+        if positions.dim() == 2:
+            positions, times = positions[:, None, :], times
+        pts = _pts_from_positions(positions, times, self.aabb, rescale=False)  # [0,1] coordinates: reference quirk (:440)
+        _, dens = self.sigma_net.forward_with_exp_head(ops.interpolate_kplanes(pts, self.grids), 0)
+        return dens.view(*shape, 1)
+
+    def density_from_ray_samples(self, ray_samples: RaySamples):
+        """Same values as density_fn(ray_samples.frustums.get_positions(), times) with the coordinates derived in-kernel."""
+        c = ray_samples._compact
+        n_rays, n_samples = ray_samples.frustums.shape[:2]
+        f = ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=False)
+        _, dens = self.sigma_net.forward_with_exp_head(f, 0)
+        return dens.view(n_rays, n_samples, 1)
+
+    def get_density(self, ray_samples: RaySamples):
+        if ray_samples._compact is not None:
+            return self.density_from_ray_samples(ray_samples), None
+        return self.density_fn(ray_samples.frustums.get_positions(), ray_samples.times), None
+
+    def get_outputs(self, ray_samples, density_embedding=None):
+        return {}

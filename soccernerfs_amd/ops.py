@@ -337,23 +337,26 @@ def interlevel_loss(weights_list, sbins_list):
     return total
 
 
+REG_SLOTS = 1024  # partial-sum slots of the regulariser values (one 64-B line each)
+
+
 class _PlaneReg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, planes, ps: PlaneSet):
-        losses = torch.zeros(3, dtype=torch.float32, device=planes.device)
+        parts = torch.zeros(REG_SLOTS, 16, dtype=torch.float32, device=planes.device)
         desc = ps.desc()
-        _lib.check(_lib.lib().snerf_plane_reg(C.byref(desc), _ptr(planes), None, 0.0, 0.0, 0.0, _ptr(losses), _stream()), "plane_reg")
+        _lib.check(_lib.lib().snerf_plane_reg(C.byref(desc), _ptr(planes), None, 0.0, 0.0, 0.0, _ptr(parts), REG_SLOTS, 0, _stream()), "plane_reg")
         ctx.ps = ps
         ctx.save_for_backward(planes)
-        return losses
+        return parts[:, :3].sum(0)
 
     @staticmethod
     def backward(ctx, g):
         (planes,) = ctx.saved_tensors
         c = g.detach().cpu().tolist()  # three coefficients (host sync; the fused trainer passes them directly)
-        grad = torch.zeros_like(planes)
+        grad = torch.empty_like(planes)  # overwrite mode: every element of every plane is written
         desc = ctx.ps.desc()
-        _lib.check(_lib.lib().snerf_plane_reg(C.byref(desc), _ptr(planes), _ptr(grad), c[0], c[1], c[2], None, _stream()), "plane_reg")
+        _lib.check(_lib.lib().snerf_plane_reg(C.byref(desc), _ptr(planes), _ptr(grad), c[0], c[1], c[2], None, 0, 1, _stream()), "plane_reg")
         return grad, None
 
 

@@ -139,7 +139,7 @@ class KPlanesTrainer:
             "rgb": f(R * S2, 3), "grgb": f(R * S2, 3),
             "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "g_rgb_out": f(R, 3),
             "dist_rays": f(R), "inter_rays": [f(R), f(R)],
-            "reg": torch.zeros(3, 3, dtype=torch.float32, device=self.dev),  # rows: field, prop0, prop1
+            "reg": torch.zeros(3, ops.REG_SLOTS, 16, dtype=torch.float32, device=self.dev),  # [field|prop0|prop1][slot][16]
         }
         self._timing, self._timing_all = None, False
         self.step = 0                 # completed optimiser steps
@@ -272,6 +272,20 @@ class KPlanesTrainer:
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
         S0, S1, S2 = self.S
         N2 = R * S2
+        # plane regularisers first: values + gradients in one sweep per plane set (kplanes.py:430-446).  The flat gradient
+        # buffer is still zero here (Adam cleared it), so the sweep STORES its gradient (no read) and the scatters add on top.
+        b["reg"].zero_()
+        self._reg_span = self._span("plane_reg.all")
+        self._reg_span.__enter__()
+        _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_field), self._p(self.field_planes.planes), self._p(self.gviews["field.planes"]),
+                                            co["space_tv_loss"], co["time_smoothness_loss"], co["sparse_transients_loss"], self._p(b["reg"][0]),
+                                            ops.REG_SLOTS, 1, self._st), "plane_reg")
+        for lvl in range(2):
+            _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_prop[lvl]), self._p(self.prop_planes[lvl].planes),
+                                                self._p(self.gviews[f"prop{lvl}.planes"]), co["space_tv_proposal_loss"],
+                                                co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
+                                                self._p(b["reg"][1 + lvl]), ops.REG_SLOTS, 1, self._st), "plane_reg")
+        self._reg_span.__exit__()
         diff = b["rgb_out"] - target
         self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
         torch.mul(diff, 2.0 * co["rgb_loss"] / (3 * R), out=b["g_rgb_out"])
@@ -298,19 +312,6 @@ class KPlanesTrainer:
                 self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
                               b["gpfeat"][lvl], cfg.proposal_feature_dim)
                 self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
-        # plane regularisers: values + gradients in one sweep per plane set (kplanes.py:430-446)
-        b["reg"].zero_()
-        self._reg_span = self._span("plane_reg.all")
-        self._reg_span.__enter__()
-        _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_field), self._p(self.field_planes.planes), self._p(self.gviews["field.planes"]),
-                                            co["space_tv_loss"], co["time_smoothness_loss"], co["sparse_transients_loss"], self._p(b["reg"][0]),
-                                            self._st), "plane_reg")
-        for lvl in range(2):
-            _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_prop[lvl]), self._p(self.prop_planes[lvl].planes),
-                                                self._p(self.gviews[f"prop{lvl}.planes"]), co["space_tv_proposal_loss"],
-                                                co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
-                                                self._p(b["reg"][1 + lvl]), self._st), "plane_reg")
-        self._reg_span.__exit__()
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny
@@ -319,7 +320,7 @@ class KPlanesTrainer:
         d = dict(self.last)
         d["distortion_loss"] = b["dist_rays"].mean() * co["distortion_loss"]
         d["interlevel_loss"] = (b["inter_rays"][0].sum() + b["inter_rays"][1].sum()) / (R * self.S[2]) * co["interlevel_loss"]
-        reg = b["reg"]
+        reg = b["reg"][:, :, :3].sum(1)  # [3 plane sets, 3 terms]
         d["space_tv_loss"], d["time_smoothness_loss"], d["sparse_transients_loss"] = (
             reg[0, 0] * co["space_tv_loss"], reg[0, 1] * co["time_smoothness_loss"], reg[0, 2] * co["sparse_transients_loss"])
         pr = reg[1] + reg[2]

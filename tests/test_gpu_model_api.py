@@ -1,0 +1,119 @@
+"""GPU parity of the nerfstudio-shaped plugin surface (soccernerfs_amd.kplanes.KPlanesModel and friends): the same golden
+end-to-end vector as the fused trainer (G11, captured from the reference's KPlanesModel), through Model.forward /
+get_loss_dict / autograd."""
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(E):
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd.kplanes import KPlanesModel, KPlanesModelConfig
+    from soccernerfs_amd.scene_colliders import SceneBox
+
+    cfg = KPlanesModelConfig(multiscale_res=tuple(E["multiscale"]), spacetime_resolution=tuple(E["base_res"]), feature_dim=E["feat_dim"],
+                             proposal_net_args_list=[{"feature_dim": E["prop_feat"], "resolution": list(r)} for r in E["prop_res"]],
+                             num_proposal_samples_per_ray=(256, 128), num_nerf_samples_per_ray=64, sigma_net_hidden_dim=E["sigma_hidden"],
+                             rgb_net_hidden_dim=E["color_hidden"])
+    a = E["aabb_scale"]
+    model = KPlanesModel(cfg, SceneBox(aabb=torch.tensor([[-a] * 3, [a] * 3])), num_train_data=4)
+    P = KO.make_kplanes_params(**E)
+    model.field.grids.load_reference(P["field_grids"])
+    model.field.sigma_net.load_linear_weights(P["field_sigma"])
+    model.field.color_net.load_linear_weights(P["field_color"])
+    for i, pn in enumerate(model.proposal_networks):
+        pn.grids.load_reference([P["prop_grids"][i]])
+        pn.sigma_net.load_linear_weights(P["prop_sigma"][i])
+    model = model.to(DEV)
+    model.scene_box.aabb = model.scene_box.aabb.to(DEV)
+    return model
+
+
+def test_model_forward_loss_backward_match_reference_golden():
+    from oracle.gen_golden import E2E_CFG
+    from soccernerfs_amd.rays import RayBundle
+
+    g = load_golden("g11_model")
+    model = _build(E2E_CFG)
+    model.train()
+    t = lambda k: g[k].to(DEV).contiguous()
+    draws = [t("t_rand"), t("u0"), t("u1"), t("bg")]
+
+    def rand_fn(shape, device):
+        x = draws.pop(0)
+        assert tuple(x.shape) == tuple(shape), (x.shape, shape)
+        return x
+
+    model.set_rand_fn(rand_fn)
+    for where, fn in model.get_training_callbacks():
+        if where == "before":
+            fn(300)  # the golden used anneal_value(300)
+    rb = RayBundle(origins=t("origins"), directions=t("directions"), pixel_area=torch.ones(g["origins"].shape[0], 1, device=DEV), times=t("times"))
+    out = model(rb)
+    assert not draws
+    assert set(["rgb", "accumulation", "depth", "median_rgb", "weights_list", "ray_samples_list", "prop_depth_0", "prop_depth_1"]) <= set(out)
+    assert out["median_rgb"].shape == g["median_rgb"].shape  # [R,1,3]
+    torch.testing.assert_close(out["rgb"].cpu(), g["rgb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(out["accumulation"].cpu(), g["accumulation"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(out["depth"].cpu(), g["depth"], rtol=0, atol=1e-4)
+    torch.testing.assert_close(out["prop_depth_0"].cpu(), g["prop_depth_0"], rtol=0, atol=1e-4)
+    for i in range(3):
+        torch.testing.assert_close(out["weights_list"][i][..., 0].cpu(), g[f"weights_{i}"], rtol=2e-3, atol=2e-5)
+        rs = out["ray_samples_list"][i]
+        torch.testing.assert_close(rs.spacing_starts[..., 0].cpu(), g[f"sbins_{i}"][:, :-1], rtol=0, atol=1e-5)
+        torch.testing.assert_close(rs.frustums.ends[..., 0].cpu(), g[f"ebins_{i}"][:, 1:], rtol=0, atol=3e-5)
+    ld = model.get_loss_dict(out, {"image": t("target")})
+    for k, v in ld.items():
+        torch.testing.assert_close(v.detach().cpu(), torch.as_tensor(g["loss_" + k]), rtol=2e-3, atol=1e-9)
+    total = sum(ld.values())
+    total.backward()
+    groups = model.get_param_groups()
+    assert set(groups) == {"proposal_networks", "fields"}
+    assert all(p.grad is not None for p in groups["fields"] if p.requires_grad)
+    # spot-check gradients against the golden checksums (reference parameter names)
+    fg = model.field.grids.to_reference(model.field.grids.planes.grad.cpu())
+    for s in range(2):
+        for p in range(6):
+            name = f"grids.{s}.{p}"
+            gabs = float(g["gabs_" + name])
+            assert abs(float(fg[s][p].double().abs().sum()) - gabs) <= 3e-3 * gabs + 1e-9, name
+    w0 = model.proposal_networks[0].sigma_net.linear_weights(model.proposal_networks[0].sigma_net.params.grad.cpu())
+    name = "prop.0.sigma_net.layers.0.weight"
+    assert abs(float(w0[0].double().sum()) - float(g["gsum_" + name])) <= 3e-3 * float(g["gabs_" + name]) + 1e-9
+    m = model.get_metrics_dict(out, {"image": t("target")})
+    assert "psnr" in m
+
+
+def test_density_fn_positions_path_equals_in_kernel_path():
+    """density_fns[i](positions) exactly as the reference calls it == the in-kernel coordinate path."""
+    from oracle.gen_golden import E2E_CFG
+    from soccernerfs_amd.rays import RayBundle
+
+    g = load_golden("g6_fields")
+    model = _build(E2E_CFG)
+    pos, tms = g["positions"].to(DEV), g["times"].to(DEV)
+    for i in range(2):
+        d = model.proposal_networks[i].density_fn(pos, times=tms)
+        torch.testing.assert_close(d[..., 0].cpu(), g[f"prop_density_{i}"], rtol=2e-5, atol=1e-6)
+
+
+def test_eval_image_chunked_and_ray_generator():
+    from oracle.gen_golden import E2E_CFG
+    from soccernerfs_amd.cameras import Cameras, RayGenerator
+
+    g = load_golden("g1_raygen")
+    model = _build(E2E_CFG)
+    model.eval()
+    model.config.eval_num_rays_per_chunk = 1000
+    cams = Cameras(g["c2w"].to(DEV), g["fx"].to(DEV), g["fy"].to(DEV), g["cx"].to(DEV), g["cy"].to(DEV), 96, 54, g["times"].to(DEV))
+    rg = RayGenerator(cams)
+    rb = rg(g["indices"].to(DEV))
+    torch.testing.assert_close(rb.directions.cpu(), g["directions"], rtol=1e-6, atol=2e-7)
+    img = cams.generate_rays(1)
+    out = model.get_outputs_for_camera_ray_bundle(img)
+    assert out["rgb"].shape == (54, 96, 3) and out["depth"].shape == (54, 96, 1)
+    assert float(out["rgb"].min()) >= 0.0 and float(out["rgb"].max()) <= 1.0
