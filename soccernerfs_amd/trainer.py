@@ -331,8 +331,10 @@ class KPlanesTrainer:
     def allreduce_grads(self):
         """One all-reduce (SUM) over the flat gradient buffer; the mean (DDP semantics, base_pipeline.py:244-246) is folded
         into Adam's grad_scale.  RCCL when the group's backend is nccl (GPU), gloo in the CPU tests."""
-        if self.world > 1:
-            torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        from . import dist as sdist
+
+        with self._span("allreduce_grads"):
+            self._grad_scale = sdist.allreduce_flat_(self.grads, self.pg)
 
     def optimizer_step(self):
         """Adam(lr*cosine, eps 1e-12) over the whole flat buffer + gradient clear (Optimizers.optimizer_step_all/scheduler_step_all)."""
@@ -340,7 +342,7 @@ class KPlanesTrainer:
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
         with self._span("adam_step"):
             ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps,
-                          grad_scale=1.0 / self.world, zero_grad=True)
+                          grad_scale=getattr(self, "_grad_scale", 1.0), zero_grad=True)
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:

@@ -1,0 +1,109 @@
+"""CPU, world_size 2, gloo: the N>1 path of the hot path.
+
+(1) the single collective: SUM all-reduce of a flat gradient buffer + 1/world scale == DDP's mean;
+(2) semantics: two ranks with R rays each, gradients averaged == one rank with the 2R-ray batch (every data loss is
+    a mean over rays; parameter-only regularisers are identical on every rank) -- gradients from the CPU oracle;
+(3) per-rank seeding (seed + rank) gives different rays on different ranks.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _small_params():
+    from oracle import kplanes_oracle as KO
+
+    return KO.make_kplanes_params(base_res=(8, 8, 8, 3), multiscale=(1, 2), feat_dim=32, prop_res=((12, 12, 12, 3), (16, 16, 16, 3)),
+                                  prop_feat=8, sigma_hidden=128, color_hidden=64, seed=11)
+
+
+def _batch(R, seed):
+    gen = torch.Generator().manual_seed(seed)
+    o = (torch.rand(R, 3, generator=gen) * 2 - 1) * 1.2
+    d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)
+    rays = {"origins": o, "directions": d, "times": torch.rand(R, 1, generator=gen)}
+    rng = {"t_rand": torch.rand(R, 33, generator=gen), "u": [torch.rand(R, 17, generator=gen), torch.rand(R, 9, generator=gen)],
+           "bg": torch.rand(R, 3, generator=gen)}
+    return rays, rng, torch.rand(R, 3, generator=gen)
+
+
+def _flat_grad(P, rays, rng, target):
+    from oracle import kplanes_oracle as KO
+
+    leaves = KO.all_param_tensors(P)
+    for x in leaves:
+        x.requires_grad_(True)
+        x.grad = None
+    out = KO.kplanes_forward(P, rays, rng, (32, 16), 8, anneal=0.5)
+    sum(KO.kplanes_loss_dict(P, out, target).values()).backward()
+    return torch.cat([(x.grad if x.grad is not None else torch.zeros_like(x)).reshape(-1) for x in leaves])
+
+
+def _worker(rank, world, port, R, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from soccernerfs_amd import dist as sdist
+
+    r, w, pg = sdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    rays, rng, target = _batch(R, sdist.rank_seed(100, rank))
+    g = _flat_grad(_small_params(), rays, rng, target)
+    local = g.clone()
+    scale = sdist.allreduce_flat_(g, pg)
+    assert scale == 0.5
+    t = sdist.max_over_ranks(float(rank + 1), "cpu", pg)
+    if rank == 0:
+        q.put((local, g * scale, rays["origins"], t))
+    else:
+        q.put((local, rays["origins"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_mean_equals_double_batch():
+    R = 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, R, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0 = next(x for x in got if len(x) == 4)
+    r1 = next(x for x in got if len(x) == 2)
+    local0, reduced, o0, tmax = r0
+    local1, o1 = r1
+    assert tmax == 2.0
+    assert not torch.equal(o0, o1)  # seed + rank => different rays
+    torch.testing.assert_close(reduced, (local0 + local1) / 2, rtol=1e-6, atol=1e-9)
+    # one rank, both batches concatenated
+    (ra, ga, ta), (rb, gb, tb) = _batch(R, 100), _batch(R, 101)
+    cat = lambda a, b: torch.cat([a, b], 0)
+    rays = {k: cat(ra[k], rb[k]) for k in ra}
+    rng = {"t_rand": cat(ga["t_rand"], gb["t_rand"]), "u": [cat(ga["u"][i], gb["u"][i]) for i in range(2)], "bg": cat(ga["bg"], gb["bg"])}
+    full = _flat_grad(_small_params(), rays, rng, cat(ta, tb))
+    torch.testing.assert_close(reduced, full, rtol=2e-4, atol=1e-7)
+
+
+def test_single_process_is_identity():
+    from soccernerfs_amd import dist as sdist
+
+    g = torch.arange(8.0)
+    assert sdist.allreduce_flat_(g, None) == 1.0 and torch.equal(g, torch.arange(8.0))
+    assert sdist.rank_seed(7, 3) == 10
