@@ -51,7 +51,7 @@ def _flat_grad(P, rays, rng, target):
     return torch.cat([(x.grad if x.grad is not None else torch.zeros_like(x)).reshape(-1) for x in leaves])
 
 
-def _worker(rank, world, port, R, q):
+def _worker(rank, world, port, R, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     from soccernerfs_amd import dist as sdist
@@ -65,30 +65,26 @@ def _worker(rank, world, port, R, q):
     assert scale == 0.5
     t = sdist.max_over_ranks(float(rank + 1), "cpu", pg)
     if rank == 0:
-        q.put((local, g * scale, rays["origins"], t))
+        torch.save((local, g * scale, rays["origins"], t), os.path.join(outdir, "r0.pt"))
     else:
-        q.put((local, rays["origins"]))
+        torch.save((local, rays["origins"]), os.path.join(outdir, "r1.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gradient_mean_equals_double_batch():
+def test_two_rank_gradient_mean_equals_double_batch(tmp_path):
     R = 12
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, 2, port, R, q)) for rk in range(2)]
+    procs = [ctx.Process(target=_worker, args=(rk, 2, port, R, str(tmp_path))) for rk in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=240) for _ in range(2)]
     for p in procs:
-        p.join(60)
+        p.join(240)
         assert p.exitcode == 0
-    r0 = next(x for x in got if len(x) == 4)
-    r1 = next(x for x in got if len(x) == 2)
-    local0, reduced, o0, tmax = r0
-    local1, o1 = r1
+    local0, reduced, o0, tmax = torch.load(tmp_path / "r0.pt")
+    local1, o1 = torch.load(tmp_path / "r1.pt")
     assert tmax == 2.0
     assert not torch.equal(o0, o1)  # seed + rank => different rays
     torch.testing.assert_close(reduced, (local0 + local1) / 2, rtol=1e-6, atol=1e-9)
