@@ -256,6 +256,39 @@ int snerf_raygen(const snerf_raygen_args* args, snerf_stream_t stream);
 int snerf_aabb_collide(const float* origins, const float* dirs, int32_t R, const float* aabb6, float near_plane, int32_t training,
                        float* nears, float* fars, snerf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Temporal multi-level hash grid (NeRFPlayer).  Replaces the reference's own native extension
+ * `nerfstudio_field_components_cuda` (NS/field_components/cuda/csrc/include/temporal_gridencoder.h:24-60, pybind.cu:11-13):
+ *   temporal_grid_encode_forward (inputs, temporal_row_index, embeddings, offsets, outputs, B, D, grid_C, C, L, S, H, dy_dx, gridtype, align_corners)
+ *   temporal_grid_encode_backward(grad, inputs, temporal_row_index, embeddings, offsets, grad_embeddings, B, D, grid_C, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners)
+ * dy_dx / grad_inputs (gradient w.r.t. coordinates) are not provided: xyz never requires grad on this path (camera optimiser off).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t D;             /* input dims (1..3) */
+  int32_t C;             /* level_dim: output features per level (1,2,4,8) */
+  int32_t L;             /* levels (<= 32) */
+  int32_t grid_C;        /* columns per table row = level_dim + temporal_dim */
+  int32_t H;             /* base resolution */
+  int32_t gridtype;      /* 0 = hash, 1 = tiled */
+  int32_t align_corners; /* 0 in the reference's models */
+  float S;               /* log2(per_level_scale) */
+  int32_t offsets[33];   /* row offset of each level in the table; offsets[L] = total rows */
+} snerf_tgrid_desc;
+
+/* out[B, L*C] (the layout TemporalGridEncodeFunc returns after its permute, temporal_grid.py:108).
+ * coords: mode 0 -> pts[B,D] in [0,1]; mode 1 -> derived from rays, normalised by the aabb to [0,1] (rescale ignored).
+ * Time: EITHER temporal_row_index [B/samples_per_row, 4*C] (the reference's rows: w_a, col_a, w_b, col_b per channel, as
+ * get_temporal_index builds them, temporal_grid.py:320-330) OR times [B/samples_per_row] in [0,1] (rows derived in-kernel from
+ * the closed form of the channel table).  samples_per_row: 1 = one row per sample, S = one row per ray. */
+int snerf_tgrid_encode_fwd(const snerf_tgrid_desc* desc, const float* embeddings, const snerf_coords* coords,
+                           const float* temporal_row_index, const float* times, int32_t samples_per_row, int64_t B, float* out,
+                           snerf_stream_t stream);
+/* ACCUMULATES (atomic fp32) into grad_embeddings [rows, grid_C]; the caller zeroes it when needed (the reference allocates a
+ * zeros_like(embeddings) every backward, temporal_grid.py:126). */
+int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,
+                           const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings,
+                           snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -458,6 +458,35 @@ def main():
     for pi, p in enumerate(planes):
         g8[f"reg_plane_{pi}"] = p
     save("g8_losses", **g8)
+    # ---------------- G9: temporal grid (the importable Python half of the reference) ----------------
+    print("G9 temporal grid tables")
+    from nerfstudio.field_components.temporal_grid import TemporalGridEncoder
+    g9 = {}
+    cases = {  # name: ctor kwargs (config-4 main + proposal encoders, the KAT encoder, odd shapes)
+        "main": dict(temporal_dim=64, level_dim=2, num_levels=16, log2_hashmap_size=19, base_resolution=16, desired_resolution=2048),
+        # proposal encoders as TemporalHashMLPDensityField builds them (nerfplayer_nerfacto_field.py:83-93): growth factor via exp/log
+        "prop0": dict(temporal_dim=32, level_dim=2, num_levels=5, log2_hashmap_size=17, base_resolution=16,
+                      per_level_scale=np.exp((np.log(64) - np.log(16)) / 4)),
+        "prop1": dict(temporal_dim=32, level_dim=2, num_levels=5, log2_hashmap_size=17, base_resolution=16,
+                      per_level_scale=np.exp((np.log(256) - np.log(16)) / 4)),
+        "kat": dict(temporal_dim=2, input_dim=1, num_levels=1, level_dim=1, per_level_scale=1, base_resolution=1, log2_hashmap_size=2,
+                    gridtype="tiled"),
+        "c4": dict(temporal_dim=8, level_dim=4, num_levels=3, log2_hashmap_size=10, base_resolution=4),
+        "c3": dict(temporal_dim=5, level_dim=3, num_levels=2, log2_hashmap_size=8, base_resolution=4, input_dim=2),
+    }
+    tt = torch.tensor([0.0, 0.3, 0.5, 0.999, 1.0, 0.25, 0.0163])
+    for name, kw in cases.items():
+        enc = TemporalGridEncoder(**kw)
+        g9[f"{name}_offsets"] = enc.offsets
+        g9[f"{name}_sampling_index"] = enc.sampling_index
+        g9[f"{name}_index_list"] = enc.index_list
+        g9[f"{name}_mask_a"] = enc.index_a_mask
+        g9[f"{name}_mask_b"] = enc.index_b_mask
+        g9[f"{name}_trow"] = enc.get_temporal_index(tt)
+        g9[f"{name}_per_level_scale"] = float(enc.per_level_scale)
+        g9[f"{name}_embed_shape"] = np.array(enc.embeddings.shape)
+    g9["times"] = tt
+    save("g9_tgrid", **g9)
     print("done")
 
 

@@ -71,6 +71,11 @@ class RaygenArgs(C.Structure):
                 ("times", C.c_void_p), ("nears", C.c_void_p), ("fars", C.c_void_p)]
 
 
+class TgridDesc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("C", C.c_int32), ("L", C.c_int32), ("grid_C", C.c_int32), ("H", C.c_int32), ("gridtype", C.c_int32),
+                ("align_corners", C.c_int32), ("S", C.c_float), ("offsets", C.c_int32 * 33)]
+
+
 _lib = None
 
 
@@ -130,4 +135,6 @@ EXPORTS = [
     "snerf_adam_step",
     "snerf_raygen",
     "snerf_aabb_collide",
+    "snerf_tgrid_encode_fwd",
+    "snerf_tgrid_encode_bwd",
 ]

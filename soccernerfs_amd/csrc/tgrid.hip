@@ -1,0 +1,199 @@
+// Temporal multi-level hash/tiled grid encoder (NeRFPlayer): forward gather and backward atomic scatter.
+//
+// gfx950 equivalent of the reference's only native code, NS/field_components/cuda/csrc/temporal_gridencoder.cu
+// (fast_hash :46-59, get_grid_index :62-88, kernel_grid :91-280, kernel_grid_backward :283-370) as driven by
+// NS/field_components/temporal_grid.py (TemporalGridEncodeFunc :33-156, get_temporal_index :320-330).
+//
+// Differences in design (not in results):
+//  * the reference materialises a [B, 4C] float `temporal_row_index` per SAMPLE; time is a per-ray quantity and the
+//    channel table has a closed form (oracle/tgrid_oracle.py::channel_table), so the kernel can take times[R] and derive
+//    (column, weight) per lane arithmetically -- the explicit-rows form is kept for API parity;
+//  * 2*C lanes own one (sample, level): lane = (channel, a|b column).  The <= 3 live columns of a corner row are read /
+//    atomically added by ADJACENT lanes, so a corner costs one 64-B request instead of up to three;
+//  * outputs are written [B, L*C] directly (the reference writes [L,B,C] and permutes in Python);
+//  * sample coordinates can be derived in-kernel from rays (snerf_coords mode 1), as for the K-Planes gather.
+#include "common.hpp"
+
+namespace snerf {
+
+struct TgridArgs {
+  snerf_tgrid_desc d;
+  snerf_coords c;
+  const float* emb;
+  const float* trow;   // [B/spr, 4C] or null
+  const float* times;  // [B/spr] or null (exactly one of trow/times)
+  int spr;             // samples per row of trow/times (1 = per sample; S = per ray)
+  int64_t B;
+  float* out;          // fwd: [B, L*C]
+  const float* gout;   // bwd
+  float* gemb;         // bwd
+};
+
+__device__ __forceinline__ uint32_t tg_hash(const uint32_t* pg, int D) {
+  const uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
+  uint32_t r = 0;
+  for (int i = 0; i < D; ++i) r ^= pg[i] * primes[i];
+  return r;
+}
+
+__device__ __forceinline__ uint32_t tg_row(const uint32_t* pg, int D, uint32_t hashmap_size, uint32_t resolution, int gridtype, int align) {
+  uint32_t stride = 1, index = 0;
+  for (int d = 0; d < D && stride <= hashmap_size; ++d) {
+    index += pg[d] * stride;
+    stride *= align ? resolution : (resolution + 1);
+  }
+  if (gridtype == 0 && stride > hashmap_size) index = tg_hash(pg, D);
+  return index % hashmap_size;
+}
+
+// (column, weight) of slot (ch, ab) at a time row; closed form of the reference's sampling_index table + get_temporal_index
+__device__ __forceinline__ void tg_slot_from_time(float t, int C, int n_rows, int ch, int ab, int& col, float& w) {
+  const float v = t * (float)(n_rows - 1);
+  int r = (int)v;  // floor for t >= 0
+  if (t == 1.f) r = n_rows - 1;
+  auto occ = [&](int q) { return r > q ? C + q + C * ((r - 1 - q) / C) : q; };
+  const int p = r % C;
+  if (ch == p) {
+    if (ab == 0) { col = occ(p); w = (float)(r + 1) - v; }
+    else { col = C + r; w = v - (float)r; }
+  } else {
+    col = occ(ch);
+    w = ab == 0 ? 1.f : 0.f;
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
+  const int C = a.d.C, D = a.d.D;
+  const int LPG = 2 * C;  // lanes per (sample, level)
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid / LPG;
+  const int k = (int)(gid - b * LPG);
+  const int ch = k >> 1, ab = k & 1;
+  const int level = blockIdx.y;
+  const bool live = b < a.B;
+  const int64_t bb = live ? b : a.B - 1;
+
+  // ---- coordinates in [0,1] ----
+  float x[3] = {0.f, 0.f, 0.f};
+  if (a.c.mode == 0) {
+    for (int d = 0; d < D; ++d) x[d] = a.c.pts[bb * D + d];
+  } else {
+    const int64_t r = bb / a.c.S;
+    const int s = (int)(bb - r * a.c.S);
+    const float* eb = a.c.ebins + r * (a.c.S + 1) + s;
+    const float mid = eb[0] + eb[1];
+    for (int d = 0; d < 3; ++d) {
+      float pos = a.c.origins[r * 3 + d] + (a.c.dirs[r * 3 + d] * mid) / 2.f;
+      x[d] = (pos - a.c.aabb_min[d]) / (a.c.aabb_max[d] - a.c.aabb_min[d]);
+    }
+  }
+  bool oob = false;
+  for (int d = 0; d < D; ++d) oob |= (x[d] < 0.f) || (x[d] > 1.f);  // .cu:119-124
+
+  // ---- this lane's column and temporal weight ----
+  int col;
+  float wt;
+  const int64_t trow_i = bb / a.spr;
+  if (a.trow) {
+    const float* tr = a.trow + trow_i * (4 * C) + ch * 4;
+    const float wa = tr[0];
+    if (ab == 0) { wt = wa; col = (int)__float2uint_rn(tr[1]); }
+    else { wt = (wa == 1.f) ? 0.f : tr[2]; col = (int)__float2uint_rn(tr[3]); }  // .cu:182-195: w_a == 1 => single column
+  } else {
+    tg_slot_from_time(a.times[trow_i], C, a.d.grid_C - C - 1, ch, ab, col, wt);
+  }
+
+  const uint32_t off0 = (uint32_t)a.d.offsets[level];
+  const uint32_t hashmap_size = (uint32_t)(a.d.offsets[level + 1] - a.d.offsets[level]);
+  const float scale = exp2f((float)level * a.d.S) * (float)a.d.H - 1.0f;  // .cu:146-148
+  const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+  float pos[3];
+  uint32_t pg[3];
+  for (int d = 0; d < D; ++d) {
+    pos[d] = x[d] * scale + (a.d.align_corners ? 0.0f : 0.5f);
+    float f = floorf(pos[d]);
+    pg[d] = (uint32_t)f;
+    pos[d] -= f;
+  }
+
+  float g = 0.f;
+  if (BWD) g = a.gout[bb * (a.d.L * C) + level * C + ch] * wt;
+  const bool active = live && !oob && wt != 0.f;
+  float acc = 0.f;
+  const int ncorner = 1 << D;
+  for (int idx = 0; idx < ncorner; ++idx) {
+    float w = 1.f;
+    uint32_t pl[3];
+    for (int d = 0; d < D; ++d) {
+      if ((idx & (1 << d)) == 0) { w *= 1.f - pos[d]; pl[d] = pg[d]; }
+      else { w *= pos[d]; pl[d] = pg[d] + 1; }
+    }
+    const uint32_t row = tg_row(pl, D, hashmap_size, resolution, a.d.gridtype, a.d.align_corners);
+    const size_t e = ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)col;
+    if (active) {
+      if (BWD) {
+        float v = w * g;
+        if (v != 0.f) atomicAdd(a.gemb + e, v);
+      } else {
+        acc += w * (a.emb[e] * wt);
+      }
+    }
+  }
+  if (!BWD) {
+    acc += __shfl_xor(acc, 1, 64);  // column a + column b of this channel
+    if (live && ab == 0) a.out[b * (a.d.L * C) + level * C + ch] = oob ? 0.f : acc;
+  }
+}
+
+static int validate(const snerf_tgrid_desc* d, const snerf_coords* c, const float* trow, const float* times, int spr, int64_t B) {
+  SNERF_REQUIRE(d && c, "tgrid: null descriptor");
+  SNERF_REQUIRE(d->D >= 1 && d->D <= 3, "tgrid: D=%d unsupported (1..3)", d->D);
+  SNERF_REQUIRE(d->C == 1 || d->C == 2 || d->C == 4 || d->C == 8, "tgrid: level_dim C=%d unsupported (1,2,4,8)", d->C);
+  SNERF_REQUIRE(d->L >= 1 && d->L <= 32, "tgrid: L=%d (<= 32)", d->L);
+  SNERF_REQUIRE(d->grid_C > d->C + 1, "tgrid: grid_C=%d must be level_dim + temporal_dim (temporal_dim >= 2)", d->grid_C);
+  SNERF_REQUIRE(d->gridtype == 0 || d->gridtype == 1, "tgrid: gridtype=%d", d->gridtype);
+  SNERF_REQUIRE(B >= 0 && spr >= 1, "tgrid: B=%lld samples_per_row=%d", (long long)B, spr);
+  SNERF_REQUIRE((trow != nullptr) != (times != nullptr), "tgrid: pass exactly one of temporal_row_index / times");
+  SNERF_REQUIRE(c->mode == 0 || (c->mode == 1 && d->D == 3), "tgrid: coords.mode=%d with D=%d", c->mode, d->D);
+  if (c->mode == 0) SNERF_REQUIRE(c->pts || B == 0, "tgrid: pts is null");
+  if (c->mode == 1) SNERF_REQUIRE(c->S >= 1 && B % c->S == 0 && c->origins && c->dirs && c->ebins, "tgrid: bad ray coords");
+  return 0;
+}
+
+template <bool BWD>
+static int launch(const TgridArgs& a, hipStream_t st) {
+  const int64_t threads = a.B * 2 * a.d.C;
+  dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)a.d.L);
+  hipLaunchKernelGGL(tgrid_kernel<BWD>, grid, dim3(256), 0, st, a);
+  SNERF_LAUNCH_CHECK(BWD ? "tgrid_encode_bwd" : "tgrid_encode_fwd");
+  return 0;
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_tgrid_encode_fwd(const snerf_tgrid_desc* desc, const float* embeddings, const snerf_coords* coords,
+                                      const float* temporal_row_index, const float* times, int32_t samples_per_row, int64_t B, float* out,
+                                      snerf_stream_t stream) {
+  int rc = validate(desc, coords, temporal_row_index, times, samples_per_row, B);
+  if (rc) return rc;
+  if (B == 0) return 0;
+  SNERF_REQUIRE(embeddings && out, "tgrid_encode_fwd: null buffer");
+  TgridArgs a = {};
+  a.d = *desc; a.c = *coords; a.emb = embeddings; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.out = out;
+  return launch<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,
+                                      const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings,
+                                      snerf_stream_t stream) {
+  int rc = validate(desc, coords, temporal_row_index, times, samples_per_row, B);
+  if (rc) return rc;
+  if (B == 0) return 0;
+  SNERF_REQUIRE(grad_out && grad_embeddings, "tgrid_encode_bwd: null buffer");
+  TgridArgs a = {};
+  a.d = *desc; a.c = *coords; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out; a.gemb = grad_embeddings;
+  return launch<true>(a, (hipStream_t)stream);
+}

@@ -1,0 +1,125 @@
+"""`TemporalGridEncoder` with the constructor, buffers and methods of NS/field_components/temporal_grid.py:159-376,
+running on libsnerf's gfx950 kernels (csrc/tgrid.hip) instead of the reference's CUDA extension."""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+
+def channel_table(temporal_dim: int, level_dim: int):
+    """Closed form of the table init_parameters builds (temporal_grid.py:231-308): row r blends, in channel p = r mod C,
+    the column that currently occupies position p with the entering column C + r; the other channels read their occupant."""
+    Cn, T = level_dim, temporal_dim
+    rows = max(T - 1, 1)
+    samp = torch.zeros(rows, 4 * Cn, dtype=torch.long)
+    mask_a = torch.zeros(rows, 4 * Cn, dtype=torch.bool)
+    mask_b = torch.zeros(rows, 4 * Cn, dtype=torch.bool)
+    index_list = torch.zeros(rows, 2, dtype=torch.long)
+    occ = lambda q, r: (Cn + q + Cn * ((r - 1 - q) // Cn)) if r > q else q
+    for r in range(rows):
+        p = r % Cn
+        for q in range(Cn):
+            samp[r, 4 * q], samp[r, 4 * q + 1] = 1, occ(q, r)
+        samp[r, 4 * p + 3] = Cn + r
+        mask_a[r, 4 * p], mask_b[r, 4 * p + 2] = True, True
+        index_list[r, 0], index_list[r, 1] = occ(p, r), Cn + r
+    return samp, mask_a, mask_b, index_list
+
+
+class _Encode(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, embeddings, enc, coords_keep, coords, trow, times, spr, B):
+        out = torch.empty(B, enc.output_dim, dtype=torch.float32, device=embeddings.device)
+        _lib.check(_lib.lib().snerf_tgrid_encode_fwd(C.byref(enc.desc), ops._ptr(embeddings), C.byref(coords),
+                                                     ops._ptr(trow) if trow is not None else None, ops._ptr(times) if times is not None else None,
+                                                     spr, C.c_int64(B), ops._ptr(out), ops._stream()), "tgrid_encode_fwd")
+        ctx.enc, ctx.coords, ctx.keep, ctx.trow, ctx.times, ctx.spr, ctx.B = enc, coords, coords_keep, trow, times, spr, B
+        ctx.shape = embeddings.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gemb = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().snerf_tgrid_encode_bwd(C.byref(ctx.enc.desc), C.byref(ctx.coords), ops._ptr(ctx.trow) if ctx.trow is not None else None,
+                                                     ops._ptr(ctx.times) if ctx.times is not None else None, ctx.spr, C.c_int64(ctx.B), ops._ptr(g),
+                                                     ops._ptr(gemb), ops._stream()), "tgrid_encode_bwd")
+        return gemb, None, None, None, None, None, None, None
+
+
+class TemporalGridEncoder(nn.Module):
+    def __init__(self, temporal_dim: int = 64, input_dim: int = 3, num_levels: int = 16, level_dim: int = 2, per_level_scale: float = 2.0,
+                 base_resolution: int = 16, log2_hashmap_size: int = 19, desired_resolution: Optional[float] = None, gridtype: str = "hash",
+                 align_corners: bool = False) -> None:
+        super().__init__()
+        if desired_resolution is not None:
+            per_level_scale = float(np.exp2(np.log2(float(desired_resolution) / base_resolution) / (num_levels - 1)))
+        self.temporal_dim, self.input_dim, self.num_levels, self.level_dim = temporal_dim, input_dim, num_levels, level_dim
+        self.per_level_scale, self.log2_hashmap_size, self.base_resolution = per_level_scale, log2_hashmap_size, base_resolution
+        self.output_dim = num_levels * level_dim
+        self.gridtype, self.gridtype_id, self.align_corners = gridtype, {"hash": 0, "tiled": 1}[gridtype], align_corners
+        offsets, off = [], 0
+        self.max_params = 2**log2_hashmap_size
+        for i in range(num_levels):
+            res = int(np.ceil(base_resolution * per_level_scale**i))
+            n = min(self.max_params, (res if align_corners else res + 1) ** input_dim)
+            n = int(np.ceil(n / 8) * 8)
+            offsets.append(off)
+            off += n
+        offsets.append(off)
+        self.register_buffer("offsets", torch.tensor(offsets, dtype=torch.int32))
+        self.n_params = off * level_dim
+        self.embeddings = nn.Parameter(torch.empty(off, level_dim + temporal_dim).uniform_(-1e-4, 1e-4))  # init_parameters :249-250
+        samp, ma, mb, il = channel_table(temporal_dim, level_dim)
+        self.register_buffer("sampling_index", samp)
+        self.register_buffer("index_a_mask", ma)
+        self.register_buffer("index_b_mask", mb)
+        self.register_buffer("index_list", il)  # columns (A, B) of each row: what get_temporal_tv_loss reads
+        d = _lib.TgridDesc()
+        d.D, d.C, d.L, d.grid_C, d.H = input_dim, level_dim, num_levels, level_dim + temporal_dim, base_resolution
+        d.gridtype, d.align_corners, d.S = self.gridtype_id, int(align_corners), float(np.log2(per_level_scale))
+        for i, o in enumerate(offsets):
+            d.offsets[i] = o
+        self.desc = d
+
+    def get_temporal_index(self, time: torch.Tensor) -> torch.Tensor:
+        """temporal_grid.py:320-330: time [B] -> rows [B, 4*level_dim] (w_a, col_a, w_b, col_b per channel)."""
+        n = len(self.sampling_index) - 1
+        v = time * n
+        r = v.long()
+        r[time == 1] = n
+        out = self.sampling_index[r].float()
+        out[self.index_a_mask[r]] = r + 1 - v
+        out[self.index_b_mask[r]] = v - r
+        return out
+
+    def forward(self, xyz: torch.Tensor, time: torch.Tensor, explicit_rows: bool = False) -> torch.Tensor:
+        """xyz [B, input_dim] in [0,1]; time [B,1] in [0,1] -> [B, num_levels*level_dim].  explicit_rows=True passes the
+        reference's temporal_row_index tensor to the kernel; default derives it in-kernel from `time` (same values)."""
+        xyz = ops._f32c(xyz, "xyz")
+        t = ops._f32c(time, "time").reshape(-1)
+        B = xyz.shape[0]
+        co = ops.coords_from_points(xyz)
+        if explicit_rows:
+            rows = self.get_temporal_index(t).contiguous()
+            return _Encode.apply(self.embeddings, self, (xyz, rows), co, rows, None, 1, B)
+        return _Encode.apply(self.embeddings, self, (xyz, t), co, None, t, 1, B)
+
+    def forward_rays(self, origins, directions, ray_times, ebins, aabb) -> torch.Tensor:
+        """Same encoding with sample coordinates derived in-kernel from rays (one time per ray): [R*S, L*C]."""
+        origins, directions, ebins = ops._f32c(origins, "origins"), ops._f32c(directions, "directions"), ops._f32c(ebins, "ebins")
+        t = ops._f32c(ray_times, "times").reshape(-1)
+        R, S = ebins.shape[0], ebins.shape[1] - 1
+        co = ops.coords_from_rays(origins, directions, t, ebins, aabb, rescale=False)
+        return _Encode.apply(self.embeddings, self, (origins, directions, t, ebins), co, None, t, S, R * S)
+
+    def get_temporal_tv_loss(self, row_idx: Optional[int] = None) -> torch.Tensor:
+        """temporal_grid.py:352-376: mean |emb[:, A] - emb[:, B]| for a random (or given) table row."""
+        if row_idx is None:
+            row_idx = int(torch.randint(0, len(self.index_list), [1]).item())
+        a, b = self.index_list[row_idx].tolist()
+        return (self.embeddings[:, a] - self.embeddings[:, b]).abs().mean()
