@@ -289,6 +289,26 @@ int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coo
                            const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings,
                            snerf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Ray importance sampling (IST = temporal difference).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* DynamicDataset.compute_ist (NS/data/datasets/dynamic_dataset.py:328-470): out[M,H,W] (fp16) = per-pixel max over the
+ * image's temporal neighbours of |img_i - img_j|, mean over RGB, zeroed at or below alpha (0.15 in the reference); all-ones for
+ * an image without neighbours.  images [M,H,W,3]: image_dtype 0 = uint8 (scaled by 1/255 as base_dataset.py:82 does),
+ * 1 = float32 in [0,1].  The neighbour relation (same camera id, 0.01 < |dt| <= ist_range, :426-429) is passed as CSR:
+ * nbr_off [M+1], nbr_idx [nnz] (int32, device). */
+int snerf_ist_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H, int32_t W, const int32_t* nbr_off,
+                   const int32_t* nbr_idx, float alpha, void* out_f16, snerf_stream_t stream);
+
+/* Weighted pixel draw of DynamicBasedPixelSampler.sample_method (NS/data/pixel_samplers.py:369-411): draw d takes its image from
+ * chosen_images[d / per_image] and a pixel with probability proportional to the image's weight map, by inverse-CDF on
+ * cdf[M, H*W] (fp32 inclusive prefix sums of the maps) with the uniform draw u[d].  indices [n,3] int64 = (image, row, col).
+ * (torch.multinomial draws without replacement when enough pixels are non-zero; here draws are independent -- identical
+ * distribution up to the O(per_image^2 * sum p^2) chance of a repeated pixel.) */
+int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, int32_t per_image, const float* u, int32_t n,
+                     int64_t* indices, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

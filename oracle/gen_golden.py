@@ -487,6 +487,30 @@ def main():
         g9[f"{name}_embed_shape"] = np.array(enc.embeddings.shape)
     g9["times"] = tt
     save("g9_tgrid", **g9)
+    # ---------------- G10: IST weight maps (the reference's own compute_ist on an 8-frame synthetic clip) ----------------
+    print("G10 IST maps")
+    import types
+    import cv2  # shim
+    import nerfstudio.data.datasets.dynamic_dataset as DD
+    Mc, Hc, Wc = 4, 27, 48  # 4 cameras x 8 frames
+    ids = torch.arange(Mc).repeat_interleave(8)
+    tms = torch.linspace(0, 1, 8).repeat(Mc)
+    imgs = torch.rand(Mc, 1, Hc, Wc, 3, generator=gen).expand(Mc, 8, Hc, Wc, 3).clone()  # static background per camera
+    for c in range(Mc):
+        for f in range(8):  # a moving bright blob + mild sensor noise
+            y0, x0 = 3 + f * 2, 5 + f * 4 + c
+            imgs[c, f, y0:y0 + 4, x0:x0 + 5] = torch.rand(3, generator=gen)
+    imgs = (imgs.reshape(-1, Hc, Wc, 3) + 0.02 * torch.rand(Mc * 8, Hc, Wc, 3, generator=gen)).clamp(0, 1)
+    u8 = (imgs * 255).round().to(torch.uint8)
+    imgs = u8.float() / 255.0  # what base_dataset.py:82 hands over
+    ids[-1] = 99  # a camera with a single image: no neighbour -> all-ones map
+    g10 = {"images_u8": u8, "cam_ids": ids, "cam_times": tms}
+    for rng_ in (1.0, 0.3):
+        fake = types.SimpleNamespace(ist_range=rng_, eval_dataset=False, cameras=types.SimpleNamespace(times=tms[:, None], ids=ids[:, None]),
+                                     _dataparser_outputs=None)
+        wmap = DD.DynamicDataset.compute_ist(fake, {"image": imgs, "image_idx": torch.arange(Mc * 8)}, "cpu", offline=False)
+        g10[f"ist_{str(rng_).replace('.', '_')}"] = wmap.float()
+    save("g10_ist", **g10)
     print("done")
 
 

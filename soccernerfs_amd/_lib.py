@@ -101,6 +101,7 @@ def lib():
     l.snerf_adam_step.argtypes = [P, P, P, P, L, F, F, F, F, I, F, I, P]
     l.snerf_aabb_collide.argtypes = [P, P, I, P, F, I, P, P, P]
     l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]
+    l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
     if l.snerf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
     _lib = l
@@ -137,4 +138,6 @@ EXPORTS = [
     "snerf_aabb_collide",
     "snerf_tgrid_encode_fwd",
     "snerf_tgrid_encode_bwd",
+    "snerf_ist_maps",
+    "snerf_ist_sample",
 ]

@@ -1,0 +1,93 @@
+// Ray importance sampling: IST (temporal-difference) weight maps and the device-side weighted pixel draw.
+//
+// Reference: DynamicDataset.compute_ist (NS/data/datasets/dynamic_dataset.py:328-470) -- a Python double loop over images on
+// the host -- and DynamicBasedPixelSampler.sample_method (NS/data/pixel_samplers.py:340-426) -- ~62 host iterations per
+// step of torch.multinomial + torch.nonzero (device syncs) over 518 400-element maps.  Here the maps come from one kernel
+// (one lane per pixel, neighbour list in CSR form) and the per-step draw is one kernel: inverse-CDF sampling (binary
+// search in a per-image prefix sum built once per cache refresh).
+#include "common.hpp"
+
+#include <hip/hip_fp16.h>
+
+namespace snerf {
+
+template <typename T> __device__ __forceinline__ float to_unit(T v);
+template <> __device__ __forceinline__ float to_unit<uint8_t>(uint8_t v) { return (float)v / 255.f; }  // base_dataset.py:82
+template <> __device__ __forceinline__ float to_unit<float>(float v) { return v; }
+
+// images [M,H,W,3]; nbr_off [M+1], nbr_idx [nnz]: same-camera images with 0.01 < |dt| <= ist_range (:426-429)
+template <typename T>
+__global__ void ist_kernel(const T* __restrict__ images, const int32_t* __restrict__ nbr_off, const int32_t* __restrict__ nbr_idx, int64_t HW,
+                           float alpha, __half* __restrict__ out) {
+  const int i = blockIdx.y;
+  const int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const int b = nbr_off[i], e = nbr_off[i + 1];
+  float w;
+  if (b == e) {
+    w = 1.f;  // no neighbour: uniform map (:432-434)
+  } else {
+    const T* cur = images + ((int64_t)i * HW + px) * 3;
+    const float c0 = to_unit<T>(cur[0]), c1 = to_unit<T>(cur[1]), c2 = to_unit<T>(cur[2]);
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+    for (int k = b; k < e; ++k) {
+      const T* o = images + ((int64_t)nbr_idx[k] * HW + px) * 3;
+      m0 = fmaxf(m0, fabsf(c0 - to_unit<T>(o[0])));
+      m1 = fmaxf(m1, fabsf(c1 - to_unit<T>(o[1])));
+      m2 = fmaxf(m2, fabsf(c2 - to_unit<T>(o[2])));
+    }
+    const float mean = ((m0 + m1) + m2) / 3.f;  // max_diff.mean(dim=2) (:444)
+    w = mean > alpha ? mean : 0.f;                // (:446)
+  }
+  out[(int64_t)i * HW + px] = __float2half(w);    // (:462)
+}
+
+// draws: for d in [0,n): image = chosen[d / per_image]; pick pixel with probability proportional to its weight by
+// inverting the image's inclusive prefix sum cdf[image][0..HW) at u*total.  indices [n,3] int64 = (image, row, col).
+__global__ void ist_sample_kernel(const float* __restrict__ cdf, int64_t HW, int W, const int64_t* __restrict__ chosen, int per_image,
+                                  const float* __restrict__ u, int n, int64_t* __restrict__ indices) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= n) return;
+  const int64_t img = chosen[d / per_image];
+  const float* c = cdf + img * HW;
+  const float target = u[d] * c[HW - 1];
+  int64_t lo = 0, hi = HW - 1;  // first index with c[idx] > target
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (c[mid] > target) hi = mid; else lo = mid + 1;
+  }
+  indices[(int64_t)d * 3 + 0] = img;
+  indices[(int64_t)d * 3 + 1] = lo / W;
+  indices[(int64_t)d * 3 + 2] = lo % W;
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_ist_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H, int32_t W, const int32_t* nbr_off,
+                              const int32_t* nbr_idx, float alpha, void* out_f16, snerf_stream_t stream) {
+  SNERF_REQUIRE(M >= 0 && H >= 1 && W >= 1, "ist_maps: M=%d H=%d W=%d", M, H, W);
+  SNERF_REQUIRE(image_dtype == 0 || image_dtype == 1, "ist_maps: image_dtype=%d (0 = uint8, 1 = float32)", image_dtype);
+  if (M == 0) return 0;
+  SNERF_REQUIRE(images && nbr_off && out_f16, "ist_maps: null buffer");
+  const int64_t HW = (int64_t)H * W;
+  dim3 grid((unsigned)ceil_div(HW, 256), (unsigned)M);
+  if (image_dtype == 0)
+    hipLaunchKernelGGL(ist_kernel<uint8_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)images, nbr_off, nbr_idx, HW, alpha, (__half*)out_f16);
+  else
+    hipLaunchKernelGGL(ist_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)images, nbr_off, nbr_idx, HW, alpha, (__half*)out_f16);
+  SNERF_LAUNCH_CHECK("ist_maps");
+  return 0;
+}
+
+extern "C" int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, int32_t per_image, const float* u, int32_t n,
+                                int64_t* indices, snerf_stream_t stream) {
+  SNERF_REQUIRE(n >= 0 && per_image >= 1 && H >= 1 && W >= 1, "ist_sample: n=%d per_image=%d", n, per_image);
+  if (n == 0) return 0;
+  SNERF_REQUIRE(cdf && chosen_images && u && indices, "ist_sample: null buffer");
+  hipLaunchKernelGGL(ist_sample_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, cdf, (int64_t)H * W, W, chosen_images, per_image, u, n,
+                     indices);
+  SNERF_LAUNCH_CHECK("ist_sample");
+  return 0;
+}

@@ -1,0 +1,82 @@
+"""GPU: IST maps (bit-exact vs the reference golden / oracle) and the device-side importance pixel sampler (counts exact,
+distribution statistical -- the reference's draws are RNG-specific)."""
+import pytest
+import torch
+
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("rng", ["1_0", "0_3"])
+@pytest.mark.parametrize("as_float", [False, True])
+def test_ist_maps_match_reference_golden(rng, as_float):
+    from soccernerfs_amd.pixel_samplers import compute_ist
+
+    g = load_golden("g10_ist")
+    imgs = g["images_u8"].to(DEV)
+    if as_float:
+        imgs = imgs.float() / 255.0
+    out = compute_ist(imgs, g["cam_ids"].to(DEV), g["cam_times"].to(DEV), float(rng.replace("_", ".")))
+    ref = g[f"ist_{rng}"]
+    got = out.float().cpu()
+    bad = got != ref
+    # identical except (possibly) pixels whose mean difference sits within an ulp of the 0.15 threshold
+    assert int(bad.sum()) <= 2, int(bad.sum())
+    assert out.dtype == torch.float16 and torch.all(out[-1] == 1.0)
+
+
+def test_ist_maps_larger_random_vs_oracle():
+    from oracle import ist_oracle as IO
+    from soccernerfs_amd.pixel_samplers import compute_ist
+
+    gen = torch.Generator().manual_seed(3)
+    M, H, W = 12, 33, 50
+    u8 = torch.randint(0, 256, (M, H, W, 3), generator=gen, dtype=torch.uint8)
+    u8[6:] = (u8[:6].float() * 0.9).to(torch.uint8)  # correlated pairs -> differences around the threshold
+    ids = torch.tensor([0, 0, 0, 1, 1, 1, 0, 0, 0, 1, 1, 2])
+    t = torch.tensor([0.0, 0.2, 0.4, 0.0, 0.005, 0.5, 0.6, 0.8, 1.0, 0.7, 0.9, 0.3])
+    ref = IO.compute_ist(u8.float() / 255.0, ids, t, 0.45).float()
+    got = compute_ist(u8.to(DEV), ids.to(DEV), t.to(DEV), 0.45).float().cpu()
+    assert int((got != ref).sum()) <= 3
+
+
+def test_dynamic_sampler_counts_and_distribution():
+    from soccernerfs_amd.pixel_samplers import DynamicBasedPixelSampler
+
+    torch.manual_seed(0)
+    M, H, W, R = 40, 20, 30, 4096
+    w = torch.zeros(M, H, W)
+    w[:, 5:9, 10:16] = torch.rand(M, 4, 6) + 0.2  # a small bright region per image
+    w[7] = 0.0                                    # an empty map must never be chosen
+    images = torch.randint(0, 256, (M, H, W, 3), dtype=torch.uint8)
+    batch = {"image": images.to(DEV), "image_idx": torch.arange(M, device=DEV) + 100, "ist_weights": w.to(DEV).half(), "iter_steps": 5000}
+    smp = DynamicBasedPixelSampler(R, is_pixel_ratio=0.15, iters_to_start_ist=2000)
+    num_ist = int(0.15 * R)  # 614
+    per_image = 10 * (-(-num_ist // M))  # 160
+    hits = torch.zeros(M, H, W)
+    for _ in range(30):
+        idx = smp.sample_method(R, M, H, W, batch=batch, device=DEV).cpu()
+        assert idx.shape == (R, 3) and idx.dtype == torch.int64
+        ist = idx[:num_ist]
+        assert torch.all(w[ist[:, 0], ist[:, 1], ist[:, 2]] > 0)  # every IST draw lands on a non-zero weight
+        counts = torch.bincount(ist[:, 0], minlength=M)
+        assert counts[7] == 0
+        used = counts[counts > 0]
+        assert int((used == per_image).sum()) >= len(used) - 1  # 10*ceil(num_ist/M) per chosen image, the last one clipped
+        hits.index_put_((ist[:, 0], ist[:, 1], ist[:, 2]), torch.ones(num_ist), accumulate=True)
+        rest = idx[num_ist:]
+        assert int(rest[:, 0].max()) < M and int(rest[:, 1].max()) < H and int(rest[:, 2].max()) < W
+    # within one image the empirical pixel distribution follows the weights
+    m = int(hits.sum((1, 2)).argmax())
+    p_emp = hits[m, 5:9, 10:16].flatten() / hits[m].sum()
+    p_ref = w[m, 5:9, 10:16].flatten() / w[m].sum()
+    n = float(hits[m].sum())
+    assert float(((p_emp - p_ref) ** 2 / p_ref).sum() * n) < 60.0  # chi-square, 23 dof: P(>60) ~ 4e-5
+    # before iters_to_start_ist: uniform sampling only; collate returns the reference's keys
+    batch["iter_steps"] = 10
+    out = smp.collate_image_dataset_batch(batch, R)
+    assert out["image"].shape == (R, 3) and out["image"].dtype == torch.float32 and float(out["image"].max()) <= 1.0
+    assert out["indices"].shape == (R, 3) and int(out["indices"][:, 0].min()) >= 100  # remapped through image_idx
+    assert out["ist_weights"].shape == (R,)

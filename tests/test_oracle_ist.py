@@ -1,0 +1,18 @@
+"""CPU: IST oracle vs golden maps captured from the reference's DynamicDataset.compute_ist."""
+import pytest
+import torch
+
+from oracle import ist_oracle as IO
+from tests.conftest import load_golden
+
+
+@pytest.mark.parametrize("rng", ["1_0", "0_3"])
+def test_ist_oracle_matches_reference(rng):
+    g = load_golden("g10_ist")
+    imgs = g["images_u8"].float() / 255.0
+    out = IO.compute_ist(imgs, g["cam_ids"], g["cam_times"], float(rng.replace("_", ".")))
+    assert out.dtype == torch.float16
+    assert torch.equal(out.float(), g[f"ist_{rng}"])
+    assert torch.all(out[-1] == 1.0)  # the single-image camera: uniform map
+    frac = float((out[:-1] > 0).float().mean())
+    assert 0.0 < frac < 0.2  # sparse maps: only the moving blob
