@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--images", type=int, default=0, help="override the number of synthetic training images (default 19 cams x 33 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr after the timed run")
+    ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (debug / A-B)")
+    ap.add_argument("--bwd-chunks", type=int, default=4, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
 
@@ -103,6 +105,7 @@ def main():
     cfg = KPlanesTrainConfig()  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
+    trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)

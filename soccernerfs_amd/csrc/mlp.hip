@@ -5,20 +5,21 @@
 //
 // Numerics: exact fp32 -- v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md §3),
 // so the fp32 parity bar (rtol 1e-5) against the CPU oracle holds; tcnn itself computes in fp16 (>= reference precision).
-// One 256-thread workgroup (4 waves) walks 64-sample tiles persistently: activations live in LDS (row stride = 2 mod 32
-// floats => conflict-free A-operand reads), weights (<= 112 KB per net, L2-resident) stream from global as B operands,
-// one load per k-step reused across the tile's 4 row blocks.  The backward recomputes the forward per tile (nothing but
-// X and dY ever touches HBM), keeps the weight-gradient accumulators in registers across the whole persistent loop and
-// flushes them once per workgroup with 64-B-contiguous atomics.
+//
+// Structure: persistent 256-thread workgroups (4 waves).  ALL weights of the network are staged ONCE per workgroup into
+// LDS (zero-padded, row stride = 2 mod 32 floats so both the plain and the transposed B-operand reads spread over the
+// banks); the workgroup then walks TS-sample tiles: activations live in LDS (row stride = 2 mod 32 => conflict-free
+// A-operand reads), every MFMA operand comes from LDS, nothing but X and dY ever touches HBM.  The backward recomputes the
+// forward per tile, keeps the weight-gradient accumulators in registers across the whole persistent loop and flushes
+// them once per workgroup with 64-B-contiguous atomics.  TS (64/32/16) is chosen per shape so weights + tiles fit 160 KB.
 #include "common.hpp"
 
 namespace snerf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TS = 64;   // samples per tile
-constexpr int MT = 4;    // 16-row blocks per tile
-constexpr int OUTP = 16; // padded output width (all nets here have <= 16 outputs)
+constexpr int OUTP = 16;  // padded output width (all nets here have <= 16 outputs)
+constexpr int LDS_LIMIT = 160 * 1024;
 
 struct MlpArgs {
   const float* X; int64_t N; int ldx; int d0;
@@ -33,72 +34,80 @@ struct MlpArgs {
   float* gW;
 };
 
+__host__ __device__ constexpr int ld_of(int width) { return ((width + 31) / 32) * 32 + 2; }  // = 2 mod 32
+__host__ __device__ constexpr int ldw_of(int n) { return n == OUTP ? 18 : ld_of(n); }
+
+// LDS plan (floats)
+template <int D0P, int H, int NH, int TS, bool BWD>
+struct Plan {
+  static constexpr int LD0 = ld_of(D0P), LDH = ld_of(H), LDO = ld_of(OUTP);
+  static constexpr int LW0 = ldw_of(H), LWO = ldw_of(OUTP);
+  static constexpr int W0 = 0;                             // [D0P][LW0]
+  static constexpr int W1 = W0 + D0P * LW0;                // [H][LW0] (NH == 2)
+  static constexpr int WO = W1 + (NH == 2 ? H * LW0 : 0);  // [H][LWO]
+  static constexpr int ACT0 = WO + H * LWO;                // X tile [TS][LD0]
+  static constexpr int ACT1 = ACT0 + TS * LD0;             // A1 [TS][LDH]
+  static constexpr int ACT2 = ACT1 + TS * LDH;             // A2 [TS][LDH] (NH == 2)
+  static constexpr int GZ = ACT2 + (NH == 2 ? TS * LDH : 0);  // bwd: [TS][LDH]
+  static constexpr int GZO = GZ + (BWD ? TS * LDH : 0);       // bwd: [TS][LDO]
+  static constexpr int TOTAL = GZO + (BWD ? TS * LDO : 0);
+  static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
+};
+
+template <int D0P, int H, int NH, bool BWD>
+constexpr int pick_ts() {
+  return Plan<D0P, H, NH, 64, BWD>::BYTES <= LDS_LIMIT ? 64 : (Plan<D0P, H, NH, 32, BWD>::BYTES <= LDS_LIMIT ? 32 : 16);
+}
+
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// acc[m] (m = 0..3 row blocks) += A[64 x K] (LDS, stride lda) * Wg[K x ldw] column block nt.
-// Wg row-major with `ldw` columns; rows >= Kact / cols >= Nact read as zero.
-__device__ __forceinline__ void mma_cols(const float* As, int lda, int K, const float* __restrict__ Wg, int ldw, int Kact, int Nact, int nt,
-                                         f32x4 (&acc)[MT], int lane) {
+// acc[m] (m = row blocks) += A[TS x K] (LDS, stride lda) * W[K x ..] (LDS, stride ldw), column block nt
+template <int MT>
+__device__ __forceinline__ void mma_cols(const float* As, int lda, int K, const float* Ws, int ldw, int nt, f32x4 (&acc)[MT], int lane) {
   const int lr = lane & 15, lk = lane >> 4;
-  const int col = nt * 16 + lr;
-  const bool colok = col < Nact;
+  const float* wp = Ws + lk * ldw + nt * 16 + lr;
+  const float* ap = As + lr * lda + lk;
 #pragma unroll 4
   for (int k0 = 0; k0 < K; k0 += 4) {
-    const int k = k0 + lk;
-    float b = (colok && k < Kact) ? Wg[(int64_t)k * ldw + col] : 0.f;
+    const float b = wp[k0 * ldw];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float a = As[(m * 16 + lr) * lda + k];
-      acc[m] = mfma4(a, b, acc[m]);
-    }
+    for (int m = 0; m < MT; ++m) acc[m] = mfma4(ap[m * 16 * lda + k0], b, acc[m]);
   }
 }
 
-// acc (one 16x16 block: rows mt*16.., cols nt*16..) += A[.. x K] * Wg
-__device__ __forceinline__ void mma_one(const float* As, int lda, int K, const float* __restrict__ Wg, int ldw, int Kact, int Nact, int mt, int nt,
-                                        f32x4& acc, int lane) {
+// one 16x16 block: rows mt*16.., cols nt*16..
+__device__ __forceinline__ void mma_one(const float* As, int lda, int K, const float* Ws, int ldw, int mt, int nt, f32x4& acc, int lane) {
   const int lr = lane & 15, lk = lane >> 4;
-  const int col = nt * 16 + lr;
-  const bool colok = col < Nact;
+  const float* wp = Ws + lk * ldw + nt * 16 + lr;
+  const float* ap = As + (mt * 16 + lr) * lda + lk;
 #pragma unroll 8
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const int k = k0 + lk;
-    float b = (colok && k < Kact) ? Wg[(int64_t)k * ldw + col] : 0.f;
-    float a = As[(mt * 16 + lr) * lda + k];
-    acc = mfma4(a, b, acc);
-  }
+  for (int k0 = 0; k0 < K; k0 += 4) acc = mfma4(ap[k0], wp[k0 * ldw], acc);
 }
 
-// acc[m] += G[64 x K] (LDS) * Wg^T, i.e. B[k][n] = Wg[n][k]; output column block nt indexes Wg ROWS. (dX = dZ * W^T)
-__device__ __forceinline__ void mma_cols_T(const float* Gs, int ldg, int K, const float* __restrict__ Wg, int ldw, int Kact, int Nact, int nt,
-                                           f32x4 (&acc)[MT], int lane) {
+// acc[m] += G[TS x K] (LDS) * W^T, i.e. B[k][n] = W[n][k]; output column block nt indexes W ROWS (dX = dZ * W^T)
+template <int MT>
+__device__ __forceinline__ void mma_cols_T(const float* Gs, int ldg, int K, const float* Ws, int ldw, int nt, f32x4 (&acc)[MT], int lane) {
   const int lr = lane & 15, lk = lane >> 4;
-  const int row = nt * 16 + lr;  // row of Wg = output column
-  const bool rowok = row < Nact;
+  const float* wp = Ws + (nt * 16 + lr) * ldw + lk;
+  const float* gp = Gs + lr * ldg + lk;
 #pragma unroll 4
   for (int k0 = 0; k0 < K; k0 += 4) {
-    const int k = k0 + lk;
-    float b = (rowok && k < Kact) ? Wg[(int64_t)row * ldw + k] : 0.f;
+    const float b = wp[k0];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      float a = Gs[(m * 16 + lr) * ldg + k];
-      acc[m] = mfma4(a, b, acc[m]);
-    }
+    for (int m = 0; m < MT; ++m) acc[m] = mfma4(gp[m * 16 * ldg + k0], b, acc[m]);
   }
 }
 
-// acc (16x16 block it,nt of dW) += A^T[K-block it][64 samples] * G[64][N-block nt]
+// acc (16x16 block it,nt of dW) += A^T[K-block it][TS samples] * G[TS][N-block nt]
+template <int TS>
 __device__ __forceinline__ void mma_outer(const float* As, int lda, const float* Gs, int ldg, int it, int nt, f32x4& acc, int lane) {
   const int lr = lane & 15, lk = lane >> 4;
+  const float* ap = As + lk * lda + it * 16 + lr;
+  const float* gp = Gs + lk * ldg + nt * 16 + lr;
 #pragma unroll
-  for (int s0 = 0; s0 < TS; s0 += 4) {
-    float a = As[(s0 + lk) * lda + it * 16 + lr];
-    float b = Gs[(s0 + lk) * ldg + nt * 16 + lr];
-    acc = mfma4(a, b, acc);
-  }
+  for (int s0 = 0; s0 < TS; s0 += 4) acc = mfma4(ap[s0 * lda], gp[s0 * ldg], acc);
 }
 
-// store a 16x16 accumulator block into an LDS activation tile (rows mt*16.., cols nt*16..), optional ReLU
 __device__ __forceinline__ void store_block(float* Ys, int ldy, int mt, int nt, const f32x4& acc, bool relu, int lane) {
   const int col = nt * 16 + (lane & 15);
   const int row0 = mt * 16 + (lane >> 4) * 4;
@@ -110,81 +119,115 @@ __device__ __forceinline__ void store_block(float* Ys, int ldy, int mt, int nt, 
   }
 }
 
-__device__ __forceinline__ int pad4(int x) { return (x + 3) & ~3; }
-__host__ __device__ constexpr int ld_of(int width) { return ((width + 31) / 32) * 32 + 2; }  // = 2 mod 32
-
-// Loads the X tile (rows n0.., d0 columns, zero padded to K0 columns and TS rows) into LDS.
-__device__ __forceinline__ void load_x_tile(const MlpArgs& a, int64_t n0, float* Xs, int ldxs, int K0) {
-  for (int idx = threadIdx.x; idx < TS * K0; idx += blockDim.x) {
-    int r = idx / K0, c = idx - r * K0;
-    int64_t n = n0 + r;
-    Xs[r * ldxs + c] = (n < a.N && c < a.d0) ? a.X[n * a.ldx + c] : 0.f;
+// stage one weight matrix [rows_act x cols_act] (global, row-major) into LDS [rows_pad][ldw], zero padded
+__device__ __forceinline__ void stage_weights(const float* __restrict__ Wg, int rows_act, int cols_act, float* Ws, int rows_pad, int cols_pad, int ldw) {
+  for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += blockDim.x) {
+    const int r = idx / cols_pad, c = idx - r * cols_pad;
+    Ws[r * ldw + c] = (r < rows_act && c < cols_act) ? Wg[(int64_t)r * cols_act + c] : 0.f;
   }
 }
 
-// Forward through the hidden layers for one tile; leaves A_l (post-activation) in act[l] (l = 1..NH).
-template <int D0P, int H, int NH>
-__device__ __forceinline__ void forward_hidden(const MlpArgs& a, float* const* act, const int* lds, int wave, int lane) {
-  constexpr int HT = H / 16;
-  const bool relu = a.hidden_act == 1;
+// X tile (rows n0.., d0 columns, zero padded to K0 columns / TS rows): global -> registers (issued one tile AHEAD so the
+// loads fly under the current tile's MFMAs), registers -> LDS after the tile's last reader has passed the barrier.
+template <int TS, int K0>
+struct XTile {
+  static constexpr int PER = (TS * K0 + 255) / 256;
+  float v[PER];
+  __device__ __forceinline__ void fetch(const MlpArgs& a, int64_t n0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int r = idx / K0, c = idx - r * K0;
+      const int64_t n = n0 + r;
+      v[i] = (idx < TS * K0 && n < a.N && c < a.d0) ? a.X[n * a.ldx + c] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* Xs, int ldxs) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + i * 256;
+      const int r = idx / K0, c = idx - r * K0;
+      if (idx < TS * K0) Xs[r * ldxs + c] = v[i];
+    }
+  }
+};
+
+// hidden layers of one tile; leaves A_l (post-activation) in act[l]
+template <int D0P, int H, int NH, int TS, bool BWD>
+__device__ __forceinline__ void forward_hidden(float* smem, bool relu, int wave, int lane) {
+  using P = Plan<D0P, H, NH, TS, BWD>;
+  constexpr int HT = H / 16, MT = TS / 16;
 #pragma unroll
   for (int l = 0; l < NH; ++l) {
-    const float* in = act[l];
-    float* out = act[l + 1];
+    const float* in = smem + (l == 0 ? P::ACT0 : P::ACT1);
+    float* out = smem + (l == 0 ? P::ACT1 : P::ACT2);
+    const int lda = l == 0 ? P::LD0 : P::LDH;
     const int K = l == 0 ? D0P : H;
-    const int Kact = l == 0 ? a.d0 : H;
-    const float* Wl = a.W + a.woff[l];
+    const float* Wl = smem + (l == 0 ? P::W0 : P::W1);
     if (HT >= 4) {
 #pragma unroll
       for (int j = 0; j < (HT >= 4 ? HT / 4 : 1); ++j) {
         const int nt = wave + 4 * j;
         f32x4 acc[MT] = {};
-        mma_cols(in, lds[l], K, Wl, H, Kact, H, nt, acc, lane);
+        mma_cols<MT>(in, lda, K, Wl, P::LW0, nt, acc, lane);
 #pragma unroll
-        for (int m = 0; m < MT; ++m) store_block(out, lds[l + 1], m, nt, acc[m], relu, lane);
+        for (int m = 0; m < MT; ++m) store_block(out, P::LDH, m, nt, acc[m], relu, lane);
       }
     } else {  // H == 16: one column block, waves split the row blocks
-      f32x4 acc = {};
-      mma_one(in, lds[l], K, Wl, H, Kact, H, wave, 0, acc, lane);
-      store_block(out, lds[l + 1], wave, 0, acc, relu, lane);
+      if (wave < MT) {
+        f32x4 acc = {};
+        mma_one(in, lda, K, Wl, P::LW0, wave, 0, acc, lane);
+        store_block(out, P::LDH, wave, 0, acc, relu, lane);
+      }
     }
     __syncthreads();
   }
 }
 
-template <int D0P, int H, int NH>
+template <int D0P, int H, int NH, int TS, bool BWD>
+__device__ __forceinline__ void stage_all(const MlpArgs& a, float* smem) {
+  using P = Plan<D0P, H, NH, TS, BWD>;
+  stage_weights(a.W + a.woff[0], a.d0, H, smem + P::W0, D0P, H, P::LW0);
+  if (NH == 2) stage_weights(a.W + a.woff[1], H, H, smem + P::W1, H, H, P::LW0);
+  stage_weights(a.W + a.woff[NH], H, a.dout, smem + P::WO, H, OUTP, P::LWO);
+}
+
+template <int D0P, int H, int NH, int TS>
 __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int LD0 = ld_of(D0P), LDH = ld_of(H);
-  float* act[NH + 1];
-  int lds[NH + 1];
-  act[0] = smem; lds[0] = LD0;
-  {
-    float* p = smem + TS * LD0;
-#pragma unroll
-    for (int l = 1; l <= NH; ++l) { act[l] = p; lds[l] = LDH; p += TS * LDH; }
-  }
+  using P = Plan<D0P, H, NH, TS, false>;
+  constexpr int MT = TS / 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const float* Wout = a.W + a.woff[NH];
+  stage_all<D0P, H, NH, TS, false>(a, smem);
+  const float* act_last = smem + (NH == 2 ? P::ACT2 : P::ACT1);
+  XTile<TS, D0P> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TS;
-    __syncthreads();  // previous tile's readers are done with LDS
-    load_x_tile(a, n0, act[0], LD0, D0P);
+    __syncthreads();  // weights staged / previous tile's readers done
+    xt.store(smem + P::ACT0, P::LD0);
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);  // prefetch the next tile
     __syncthreads();
-    forward_hidden<D0P, H, NH>(a, act, lds, wave, lane);
-    // output layer: wave w -> row block w
-    f32x4 acc = {};
-    mma_one(act[NH], lds[NH], H, Wout, a.dout, H, a.dout, wave, 0, acc, lane);
-    const int col = lane & 15;
-    const int64_t row0 = n0 + wave * 16 + (lane >> 4) * 4;
+    forward_hidden<D0P, H, NH, TS, false>(smem, a.hidden_act == 1, wave, lane);
+    // output layer: row block mt handled by wave mt % 4
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t n = row0 + r;
-      if (n < a.N && col < a.dout) {
-        float y = acc[r];
-        if (a.aux_out && col == a.aux_col) a.aux_out[n] = expf(y);  // trunc_exp forward (activations.py:32)
-        if (a.out_act == 1) y = 1.f / (1.f + expf(-y));
-        a.Y[n * a.ldy + col] = y;
+    for (int j = 0; j < (MT + 3) / 4; ++j) {
+      const int mt = wave + 4 * j;
+      if (mt < MT) {
+        f32x4 acc = {};
+        mma_one(act_last, P::LDH, H, smem + P::WO, P::LWO, mt, 0, acc, lane);
+        const int col = lane & 15;
+        const int64_t row0 = n0 + mt * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = row0 + r;
+          if (n < a.N && col < a.dout) {
+            float y = acc[r];
+            if (a.aux_out && col == a.aux_col) a.aux_out[n] = expf(y);  // trunc_exp forward (activations.py:32)
+            if (a.out_act == 1) y = 1.f / (1.f + expf(-y));
+            a.Y[n * a.ldy + col] = y;
+          }
+        }
       }
     }
   }
@@ -193,24 +236,22 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs a, int64_t n_tiles
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-template <int D0P, int H, int NH>
+template <int D0P, int H, int NH, int TS>
 __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) float smem[];
-  constexpr int LD0 = ld_of(D0P), LDH = ld_of(H), LDO = ld_of(OUTP);
-  constexpr int D0T = D0P / 16, HT = H / 16;
+  using P = Plan<D0P, H, NH, TS, true>;
+  constexpr int D0T = D0P / 16, HT = H / 16, MT = TS / 16;
+  constexpr int NJ = HT >= 4 ? HT / 4 : 1;  // column blocks of a hidden layer per wave
   static_assert(D0P % 16 == 0 && H % 16 == 0, "dims are padded to 16");
   static_assert(NH == 1 || HT >= 4, "two hidden layers need hidden >= 64");
-  float* act[NH + 1];
-  int lds[NH + 1];
-  act[0] = smem; lds[0] = LD0;
-  float* p = smem + TS * LD0;
-#pragma unroll
-  for (int l = 1; l <= NH; ++l) { act[l] = p; lds[l] = LDH; p += TS * LDH; }
-  float* gz = p;            // [TS][LDH] grad wrt the current hidden pre-activation
-  p += TS * LDH;
-  float* gzo = p;           // [TS][LDO] grad wrt the output pre-activation
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool relu = a.hidden_act == 1;
+  float* X = smem + P::ACT0;
+  float* A1 = smem + P::ACT1;
+  float* Alast = smem + (NH == 2 ? P::ACT2 : P::ACT1);
+  float* gz = smem + P::GZ;
+  float* gzo = smem + P::GZO;
+  stage_all<D0P, H, NH, TS, true>(a, smem);
 
   // weight-gradient accumulators, alive across the persistent loop; block t of a layer is owned by wave t % 4
   constexpr int NB0 = (D0T * HT + 3) / 4;   // layer 0: [D0P x H]
@@ -220,77 +261,79 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
   f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
 
+  XTile<TS, D0P> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TS;
     __syncthreads();
-    load_x_tile(a, n0, act[0], LD0, D0P);
+    xt.store(X, P::LD0);
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);  // prefetch the next tile
     __syncthreads();
-    forward_hidden<D0P, H, NH>(a, act, lds, wave, lane);
+    forward_hidden<D0P, H, NH, TS, true>(smem, relu, wave, lane);
     // ---- output layer forward (needed for sigmoid' / trunc_exp') and grad wrt its pre-activation ----
-    {
-      f32x4 acc = {};
-      mma_one(act[NH], lds[NH], H, a.W + a.woff[NH], a.dout, H, a.dout, wave, 0, acc, lane);
-      const int col = lane & 15;
-      const int rl0 = wave * 16 + (lane >> 4) * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t n = n0 + rl0 + r;
-        float g = 0.f;
-        if (n < a.N && col < a.dout) {
-          float y = acc[r];
-          if (a.gY) g = a.gY[n * a.ldgy + col];
-          if (a.out_act == 1) {
-            float sg = 1.f / (1.f + expf(-y));
-            g = g * sg * (1.f - sg);
+    for (int j = 0; j < (MT + 3) / 4; ++j) {
+      const int mt = wave + 4 * j;
+      if (mt < MT) {
+        f32x4 acc = {};
+        mma_one(Alast, P::LDH, H, smem + P::WO, P::LWO, mt, 0, acc, lane);
+        const int col = lane & 15;
+        const int rl0 = mt * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = n0 + rl0 + r;
+          float g = 0.f;
+          if (n < a.N && col < a.dout) {
+            float y = acc[r];
+            if (a.gY) g = a.gY[n * a.ldgy + col];
+            if (a.out_act == 1) {
+              float sg = 1.f / (1.f + expf(-y));
+              g = g * sg * (1.f - sg);
+            }
+            if (a.gaux && col == a.aux_col) g += a.gaux[n] * expf(fminf(fmaxf(y, -15.f), 15.f));  // trunc_exp backward (activations.py:38-39)
           }
-          if (a.gaux && col == a.aux_col) g += a.gaux[n] * expf(fminf(fmaxf(y, -15.f), 15.f));  // trunc_exp backward (activations.py:38-39)
+          gzo[(rl0 + r) * P::LDO + col] = g;
         }
-        gzo[(rl0 + r) * LDO + col] = g;
       }
     }
     __syncthreads();
-    // ---- dW_out += A_NH^T * gzo ;  gA_NH = gzo * W_out^T ----
+    // ---- dW_out += A_last^T * gzo ----
 #pragma unroll
     for (int j = 0; j < NBO; ++j) {
       const int it = wave + 4 * j;
-      if (it < HT) mma_outer(act[NH], lds[NH], gzo, LDO, it, 0, dWo[j], lane);
+      if (it < HT) mma_outer<TS>(Alast, P::LDH, gzo, P::LDO, it, 0, dWo[j], lane);
     }
-    // gz = (gzo * W_out^T) .* relu'(A_NH): output width H, K = 16
-    {
-      const float* Wo = a.W + a.woff[NH];
-      if (HT >= 4) {
+    // ---- gz = (gzo * W_out^T) .* relu'(A_last): output width H, K = 16 ----
+    if (HT >= 4) {
 #pragma unroll
-        for (int j = 0; j < (HT >= 4 ? HT / 4 : 1); ++j) {
-          const int nt = wave + 4 * j;
-          f32x4 acc[MT] = {};
-          mma_cols_T(gzo, LDO, OUTP, Wo, a.dout, a.dout, H, nt, acc, lane);
+      for (int j = 0; j < NJ; ++j) {
+        const int nt = wave + 4 * j;
+        f32x4 acc[MT] = {};
+        mma_cols_T<MT>(gzo, P::LDO, OUTP, smem + P::WO, P::LWO, nt, acc, lane);
+        const int col = nt * 16 + (lane & 15);
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int col = nt * 16 + (lane & 15);
-            const int row0 = m * 16 + (lane >> 4) * 4;
+        for (int m = 0; m < MT; ++m) {
+          const int row0 = m * 16 + (lane >> 4) * 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = acc[m][r];
-              if (relu && !(act[NH][(row0 + r) * LDH + col] > 0.f)) v = 0.f;
-              gz[(row0 + r) * LDH + col] = v;
-            }
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[m][r];
+            if (relu && !(Alast[(row0 + r) * P::LDH + col] > 0.f)) v = 0.f;
+            gz[(row0 + r) * P::LDH + col] = v;
           }
         }
-      } else {
-        f32x4 acc[MT] = {};
-        if (wave == 0) {
-          mma_cols_T(gzo, LDO, OUTP, Wo, a.dout, a.dout, H, 0, acc, lane);
+      }
+    } else if (wave == 0) {
+      f32x4 acc[MT] = {};
+      mma_cols_T<MT>(gzo, P::LDO, OUTP, smem + P::WO, P::LWO, 0, acc, lane);
+      const int col = lane & 15;
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int col = lane & 15;
-            const int row0 = m * 16 + (lane >> 4) * 4;
+      for (int m = 0; m < MT; ++m) {
+        const int row0 = m * 16 + (lane >> 4) * 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float v = acc[m][r];
-              if (relu && !(act[NH][(row0 + r) * LDH + col] > 0.f)) v = 0.f;
-              gz[(row0 + r) * LDH + col] = v;
-            }
-          }
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[m][r];
+          if (relu && !(Alast[(row0 + r) * P::LDH + col] > 0.f)) v = 0.f;
+          gz[(row0 + r) * P::LDH + col] = v;
         }
       }
     }
@@ -300,25 +343,24 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
 #pragma unroll
       for (int j = 0; j < NBH; ++j) {
         const int t = wave + 4 * j;
-        if (t < HT * HT) mma_outer(act[1], LDH, gz, LDH, t / HT, t % HT, dWh[j], lane);
+        if (t < HT * HT) mma_outer<TS>(A1, P::LDH, gz, P::LDH, t / HT, t % HT, dWh[j], lane);
       }
-      const float* Wh = a.W + a.woff[1];
-      f32x4 acc2[(HT >= 4 ? HT / 4 : 1)][MT] = {};
+      f32x4 acc2[NJ][MT] = {};
 #pragma unroll
-      for (int j = 0; j < (HT >= 4 ? HT / 4 : 1); ++j) mma_cols_T(gz, LDH, H, Wh, H, H, H, wave + 4 * j, acc2[j], lane);
+      for (int j = 0; j < NJ; ++j) mma_cols_T<MT>(gz, P::LDH, H, smem + P::W1, P::LW0, wave + 4 * j, acc2[j], lane);
       __syncthreads();  // everyone finished reading gz
 #pragma unroll
-      for (int j = 0; j < (HT >= 4 ? HT / 4 : 1); ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int nt = wave + 4 * j;
+        const int col = nt * 16 + (lane & 15);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const int col = nt * 16 + (lane & 15);
           const int row0 = m * 16 + (lane >> 4) * 4;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc2[j][m][r];
-            if (relu && !(act[1][(row0 + r) * LDH + col] > 0.f)) v = 0.f;
-            gz[(row0 + r) * LDH + col] = v;
+            if (relu && !(A1[(row0 + r) * P::LDH + col] > 0.f)) v = 0.f;
+            gz[(row0 + r) * P::LDH + col] = v;
           }
         }
       }
@@ -328,16 +370,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
       const int t = wave + 4 * j;
-      if (t < D0T * HT) mma_outer(act[0], LD0, gz, LDH, t / HT, t % HT, dW0[j], lane);
+      if (t < D0T * HT) mma_outer<TS>(X, P::LD0, gz, P::LDH, t / HT, t % HT, dW0[j], lane);
     }
     if (a.gX) {
-      const float* W0 = a.W + a.woff[0];
 #pragma unroll
       for (int j = 0; j < (D0T + 3) / 4; ++j) {
         const int nt = wave + 4 * j;
         if (nt < D0T) {
           f32x4 acc[MT] = {};
-          mma_cols_T(gz, LDH, H, W0, H, H, a.d0, nt, acc, lane);
+          mma_cols_T<MT>(gz, P::LDH, H, smem + P::W0, P::LW0, nt, acc, lane);
           const int col = nt * 16 + (lane & 15);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
@@ -391,24 +432,32 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
 
 template <int D0P, int H, int NH>
 static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
-  const int64_t n_tiles = (a.N + TS - 1) / TS;
-  size_t lds = (size_t)TS * (ld_of(D0P) + NH * ld_of(H)) * sizeof(float);
-  if (bwd) lds += (size_t)TS * (ld_of(H) + ld_of(OUTP)) * sizeof(float);
-  int blocks_per_cu = (int)(160 * 1024 / lds);
-  if (blocks_per_cu < 1) blocks_per_cu = 1;
-  if (blocks_per_cu > 4) blocks_per_cu = 4;
-  int64_t grid = 256 * blocks_per_cu;
-  if (grid > n_tiles) grid = n_tiles;
   if (bwd) {
-    auto k = mlp_bwd_kernel<D0P, H, NH>;
+    constexpr int TS = pick_ts<D0P, H, NH, true>();
+    using P = Plan<D0P, H, NH, TS, true>;
+    static_assert(P::BYTES <= LDS_LIMIT, "backward tile does not fit LDS");
+    const int64_t n_tiles = (a.N + TS - 1) / TS;
+    int per_cu = (int)(LDS_LIMIT / P::BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = mlp_bwd_kernel<D0P, H, NH, TS>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, a, n_tiles);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), P::BYTES, st, a, n_tiles);
   } else {
-    auto k = mlp_fwd_kernel<D0P, H, NH>;
+    constexpr int TS = pick_ts<D0P, H, NH, false>();
+    using P = Plan<D0P, H, NH, TS, false>;
+    static_assert(P::BYTES <= LDS_LIMIT, "forward tile does not fit LDS");
+    const int64_t n_tiles = (a.N + TS - 1) / TS;
+    int per_cu = (int)(LDS_LIMIT / P::BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = mlp_fwd_kernel<D0P, H, NH, TS>;
     static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, a, n_tiles);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), P::BYTES, st, a, n_tiles);
   }
   SNERF_LAUNCH_CHECK(bwd ? "mlp_bwd" : "mlp_fwd");
   return 0;
@@ -418,10 +467,10 @@ static int dispatch(const snerf_mlp_desc* d, const MlpArgs& a, bool bwd, hipStre
   const int d0p = (d->d_in + 15) / 16 * 16;
 #define CASE(D0P, H, NH) \
   if (d0p == D0P && d->hidden == H && d->n_hidden == NH) return launch<D0P, H, NH>(a, bwd, st);
-  CASE(16, 64, 1)   // K-Planes proposal sigma_net 8->64->1; nerfplayer-nerfacto proposal 10->16... (see below)
-  CASE(16, 64, 2)   // K-Planes color_net 15->64->64->3
-  CASE(32, 128, 1)  // sigma_net, 1 scale
-  CASE(64, 128, 1)  // 2 scales
+  CASE(16, 64, 1)    // K-Planes proposal sigma_net 8->64->1
+  CASE(16, 64, 2)    // K-Planes color_net 15->64->64->3
+  CASE(32, 128, 1)   // sigma_net, 1 scale
+  CASE(64, 128, 1)   // 2 scales
   CASE(96, 128, 1)
   CASE(128, 128, 1)
   CASE(160, 128, 1)  // k-planes preset: 5 scales

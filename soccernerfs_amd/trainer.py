@@ -267,41 +267,62 @@ class KPlanesTrainer:
         _lib.check(self.lib.snerf_render_fwd(C.byref(a), self._st), "render_fwd")
         return b["rgb_out"]
 
-    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool):
-        """Accumulates d(total loss)/d(params) into self.grads; fills self.last with the (scaled) loss terms."""
-        cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
-        S0, S1, S2 = self.S
-        N2 = R * S2
-        # plane regularisers first: values + gradients in one sweep per plane set (kplanes.py:430-446).  The flat gradient
-        # buffer is still zero here (Adam cleared it), so the sweep STORES its gradient (no read) and the scatters add on top.
+    # ---- stream helpers: kernels bound by different units overlap on separate HIP streams ----
+    class _On:
+        """Run the enclosed launches on `stream` (torch's current stream AND the stream handed to libsnerf)."""
+
+        def __init__(self, tr, stream):
+            self.tr, self.stream = tr, stream
+
+        def __enter__(self):
+            self.prev = self.tr._st
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+            self.tr._st = C.c_void_p(self.stream.cuda_stream)
+
+        def __exit__(self, *exc):
+            self.tr._st = self.prev
+            self.ctx.__exit__(*exc)
+
+    def _streams(self, n):
+        if not hasattr(self, "_side"):
+            self._side = []
+        while len(self._side) < n:
+            self._side.append(torch.cuda.Stream(device=self.dev))
+        return self._side[:n]
+
+    def _reg_sweep(self):
+        """Plane regularisers: values + gradients in one sweep per plane set (kplanes.py:430-446).  The flat gradient buffer
+        is still zero when this runs (Adam cleared it), so the sweep STORES its gradient and the scatters add on top."""
+        b, co = self.buf, self.cfg.loss_coefficients
         b["reg"].zero_()
-        self._reg_span = self._span("plane_reg.all")
-        self._reg_span.__enter__()
-        _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_field), self._p(self.field_planes.planes), self._p(self.gviews["field.planes"]),
-                                            co["space_tv_loss"], co["time_smoothness_loss"], co["sparse_transients_loss"], self._p(b["reg"][0]),
-                                            ops.REG_SLOTS, 1, self._st), "plane_reg")
-        for lvl in range(2):
-            _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_prop[lvl]), self._p(self.prop_planes[lvl].planes),
-                                                self._p(self.gviews[f"prop{lvl}.planes"]), co["space_tv_proposal_loss"],
-                                                co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
-                                                self._p(b["reg"][1 + lvl]), ops.REG_SLOTS, 1, self._st), "plane_reg")
-        self._reg_span.__exit__()
-        diff = b["rgb_out"] - target
-        self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
-        torch.mul(diff, 2.0 * co["rgb_loss"] / (3 * R), out=b["g_rgb_out"])
-        _lib.check(self.lib.snerf_render_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["g_rgb_out"]), None, R, S2,
-                                             self._p(b["gw"][2]), self._p(b["grgb"]), 0, self._st), "render_bwd")
-        _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, co["distortion_loss"] / R, self._p(b["dist_rays"]),
-                                             self._p(b["gw"][2]), 1, self._st), "distortion")
-        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
-                                              self._st), "weights_bwd")
+        with self._span("plane_reg.all"):
+            _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_field), self._p(self.field_planes.planes), self._p(self.gviews["field.planes"]),
+                                                co["space_tv_loss"], co["time_smoothness_loss"], co["sparse_transients_loss"], self._p(b["reg"][0]),
+                                                ops.REG_SLOTS, 1, self._st), "plane_reg")
+            for lvl in range(2):
+                _lib.check(self.lib.snerf_plane_reg(C.byref(self._desc_prop[lvl]), self._p(self.prop_planes[lvl].planes),
+                                                    self._p(self.gviews[f"prop{lvl}.planes"]), co["space_tv_proposal_loss"],
+                                                    co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
+                                                    self._p(b["reg"][1 + lvl]), ops.REG_SLOTS, 1, self._st), "plane_reg")
+
+    def _field_backward_chunk(self, r0: int, r1: int):
+        """colour-net bwd -> sigma-net bwd -> plane scatter for rays [r0, r1) of the nerf level."""
+        b, S2, F = self.buf, self.S[2], self.field_planes.out_dim
+        n0, N = r0 * S2, (r1 - r0) * S2
+        sl = lambda t: t[n0:n0 + N]
         # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
-        self._mlp_bwd(self.color_net, "field.color", b["h"], 16, N2, b["grgb"], 3, -1, None, b["gh"], 16)
-        self._mlp_bwd(self.sigma_net, "field.sigma", b["feat"], self.field_planes.out_dim, N2, b["gh"], 16, 15, b["gdens"][2], b["gfeat"],
-                      self.field_planes.out_dim)
-        self._scatter(self._desc_field, self.field_planes.planes, self._coords[2], N2, b["gfeat"], self.gviews["field.planes"])
-        # proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592)
-        for lvl, Sp in ((0, S0), (1, S1)):
+        self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
+        self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1], sl(b["gfeat"]), F)
+        rays = self.rays
+        co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
+        self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
+
+    def _proposal_backward(self, proposal_grads: bool):
+        """Proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592)."""
+        cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
+        S2 = self.S[2]
+        for lvl, Sp in ((0, self.S[0]), (1, self.S[1])):
             _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
                                                  co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
                                                  self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
@@ -312,6 +333,55 @@ class KPlanesTrainer:
                 self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
                               b["gpfeat"][lvl], cfg.proposal_feature_dim)
                 self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
+
+    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool):
+        """Accumulates d(total loss)/d(params) into self.grads (which must be zero on entry: Adam clears it); fills
+        self.last with the (scaled) loss terms.
+
+        With `self.overlap` (default) independent kernel chains run on side streams so that kernels bound by different units
+        overlap: the regulariser sweep (HBM stream), the proposal-level backward (MFMA + atomics) and the field backward split
+        into ray chunks whose MLP backward (MFMA) runs under the previous chunk's plane scatter (memory-side atomics)."""
+        cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
+        S2 = self.S[2]
+        main = torch.cuda.current_stream()
+        overlap = getattr(self, "overlap", True)
+        n_chunks = max(1, min(getattr(self, "bwd_chunks", 4), R)) if overlap else 1
+        side = self._streams(2 + min(n_chunks, 2)) if overlap else []
+        if overlap:
+            for st in side:
+                st.wait_stream(main)
+            with KPlanesTrainer._On(self, side[0]):
+                self._reg_sweep()
+            reg_done = side[0].record_event()
+            with KPlanesTrainer._On(self, side[1]):
+                side[1].wait_event(reg_done)  # proposal scatters add on top of the stored regulariser gradient
+                self._proposal_backward(proposal_grads)
+        else:
+            self._reg_sweep()
+        diff = b["rgb_out"] - target
+        self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
+        torch.mul(diff, 2.0 * co["rgb_loss"] / (3 * R), out=b["g_rgb_out"])
+        _lib.check(self.lib.snerf_render_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["g_rgb_out"]), None, R, S2,
+                                             self._p(b["gw"][2]), self._p(b["grgb"]), 0, self._st), "render_bwd")
+        _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, co["distortion_loss"] / R, self._p(b["dist_rays"]),
+                                             self._p(b["gw"][2]), 1, self._st), "distortion")
+        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
+                                              self._st), "weights_bwd")
+        if not overlap:
+            self._field_backward_chunk(0, R)
+            self._proposal_backward(proposal_grads)
+            return
+        ready = main.record_event()
+        bounds = [R * i // n_chunks for i in range(n_chunks + 1)]
+        for i in range(n_chunks):
+            st = side[2 + (i % (len(side) - 2))]
+            with KPlanesTrainer._On(self, st):
+                if i < len(side) - 2:
+                    st.wait_event(ready)
+                    st.wait_event(reg_done)
+                self._field_backward_chunk(bounds[i], bounds[i + 1])
+        for st in side:
+            main.wait_stream(st)
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny
