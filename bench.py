@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr after the timed run")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (debug / A-B)")
-    ap.add_argument("--bwd-chunks", type=int, default=4, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
+    ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
 

@@ -221,7 +221,7 @@ class KPlanesTrainer:
         else:
             a.u_mode, a.u_or_rand, a.rand_cols = 1, rand.data_ptr(), rand.shape[-1]
         a.sbins_out, a.ebins_out = b["sb"][lvl + 1].data_ptr(), b["eb"][lvl + 1].data_ptr()
-        a.R, a.S_prev, a.S, a.kind = self.R, self.S[lvl], self.S[lvl + 1], 0
+        a.R, a.S_prev, a.S, a.kind = self._fwd_rays, self.S[lvl], self.S[lvl + 1], 0
         a.anneal, a.histogram_padding, a.eps = anneal, 0.01, 1e-5
         with self._span("pdf_resample"):
             _lib.check(self.lib.snerf_pdf_resample(C.byref(a), self._st), "pdf_resample")
@@ -230,7 +230,10 @@ class KPlanesTrainer:
     def forward(self, rays: Dict[str, torch.Tensor], rng: Optional[Dict[str, torch.Tensor]], anneal: float, training: bool = True):
         """rays: origins [R,3], directions [R,3], times [R,1] (+ nears/fars, else the AABB collider runs).
         rng (training): t_rand [R,S0+1]|[R,1], u (list of 2 draws [R,S+1]|[R,1]), bg [R,3]."""
-        cfg, b, R = self.cfg, self.buf, self.R
+        cfg, b = self.cfg, self.buf
+        R = rays["origins"].shape[0]  # <= self.R: the work buffers are row-major, their first R rows are used (eval chunks)
+        assert R <= self.R and (training is False or R == self.R), "training batches must have exactly the configured number of rays"
+        self._fwd_rays = R
         self._st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
         if "nears" not in rays:
@@ -265,7 +268,7 @@ class KPlanesTrainer:
         a.R, a.S, a.training = R, self.S[2], int(training)
         a.rgb_out, a.acc_out, a.depth_median = b["rgb_out"].data_ptr(), b["acc"].data_ptr(), b["depth"].data_ptr()
         _lib.check(self.lib.snerf_render_fwd(C.byref(a), self._st), "render_fwd")
-        return b["rgb_out"]
+        return b["rgb_out"][:R]
 
     # ---- stream helpers: kernels bound by different units overlap on separate HIP streams ----
     class _On:
@@ -345,7 +348,7 @@ class KPlanesTrainer:
         S2 = self.S[2]
         main = torch.cuda.current_stream()
         overlap = getattr(self, "overlap", True)
-        n_chunks = max(1, min(getattr(self, "bwd_chunks", 4), R)) if overlap else 1
+        n_chunks = max(1, min(getattr(self, "bwd_chunks", 1), R)) if overlap else 1
         side = self._streams(2 + min(n_chunks, 2)) if overlap else []
         if overlap:
             for st in side:
