@@ -164,6 +164,12 @@ def main():
         alg_bytes = R * S2 * len(cfg.multiscale_res) * 6 * 4 * cfg.feature_dim * 4 * 2
         dom_ms = kt.get(DOMINANT, (float("nan"), 0))[0]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        # HBM traffic of that kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately; profiles/r01_pmc_*):
+        # counters cannot be read inside this process, so the committed per-launch figure for exactly this workload is quoted.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(pmc) and R == 4096 and args.rays == 4096:
+            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
         line = {
             "metric": "train rays/sec (K-Planes Broadcast-style, whole job)", "value": R * world * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -173,7 +179,7 @@ def main():
                        "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
                        "parallelism": f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "kplanes_gather_bwd_kernel<32,6> (field plane-gradient scatter)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms, "launches_timed": kt.get(DOMINANT, (0, 0))[1]},
         }
         if world == 1 and not args.no_cpu_baseline:
