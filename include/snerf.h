@@ -309,6 +309,24 @@ int snerf_ist_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H
 int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, int32_t per_image, const float* u, int32_t n,
                      int64_t* indices, snerf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Sorted plane-gradient scatter (same result as snerf_kplanes_gather_bwd, ~6x fewer atomic requests on training batches).
+ *   1. snerf_kplanes_sort_samples : counting sort of the N samples of every (scale, plane) segment by texel key
+ *      (row0 * W + x0).  Depends only on the sample coordinates -> can run on a side stream as soon as they are known.
+ *      Workspace sizes (elements, int32) from snerf_kplanes_sort_workspace: hist[hist_cells], rank[index_elems] (int32) and
+ *      sorted_rec[index_elems][4] (float: sample id bits, pixel x, pixel y, 0)  (index_elems = n_scales * n_planes * N).
+ *   2. snerf_kplanes_gradvec      : gvec[seg][N][C] = dL/d(interpolated value of plane seg) per sample (product rule).
+ *   3. snerf_kplanes_scatter_sorted: walks each segment in sorted order, applies the bilinear weights, run-length-combines
+ *      equal texel rows and ACCUMULATES into grad_planes with one 2*C-float atomic instruction per run.
+ * ------------------------------------------------------------------------------------------------ */
+int snerf_kplanes_sort_workspace(const snerf_kplanes_desc* desc, int64_t N, int64_t* hist_cells, int64_t* index_elems);
+int snerf_kplanes_sort_samples(const snerf_kplanes_desc* desc, const snerf_coords* coords, int64_t N, int32_t* hist, int32_t* rank,
+                               float* sorted_rec, snerf_stream_t stream);
+int snerf_kplanes_gradvec(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_out,
+                          float* gvec, snerf_stream_t stream);
+int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+                                 float* grad_planes, snerf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,4 +140,8 @@ EXPORTS = [
     "snerf_tgrid_encode_bwd",
     "snerf_ist_maps",
     "snerf_ist_sample",
+    "snerf_kplanes_sort_workspace",
+    "snerf_kplanes_sort_samples",
+    "snerf_kplanes_gradvec",
+    "snerf_kplanes_scatter_sorted",
 ]

@@ -32,11 +32,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(PKG, "build", os.path.basename(src) + ".o")
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
-            os.path.getmtime(src),
-            os.path.getmtime(os.path.join(CSRC, "common.hpp")),
-            os.path.getmtime(os.path.join(os.path.dirname(PKG), "include", "snerf.h")),
-        ):
+        hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(os.path.dirname(PKG), "include", "snerf.h")]
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max([os.path.getmtime(src)] + [os.path.getmtime(h) for h in hdrs]):
             continue
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         if verbose:

@@ -9,85 +9,9 @@
 // n_scales * 6 planes * 4 texels * C * 4 B.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "kplanes_common.hpp"
 
 namespace snerf {
-
-struct AxisTap {
-  int i0, i1;    // texel indices along the axis (i1 clamped for addressing)
-  float w0, w1;  // weights of i0 / i1:  (i1 - x), (x - i0); w1 forced to 0 when i0+1 is out of range
-};
-
-// ATen grid_sampler semantics for align_corners=True + padding_mode="border":
-//   x_pix = ((x + 1) / 2) * (size - 1), clipped to [0, size-1]; taps floor / floor+1.
-__device__ __forceinline__ AxisTap axis_tap(float x, int size) {
-  float fx = ((x + 1.f) / 2.f) * (float)(size - 1);
-  fx = fminf((float)(size - 1), fmaxf(fx, 0.f));
-  float f0 = floorf(fx);
-  AxisTap t;
-  t.i0 = (int)f0;
-  t.w0 = (f0 + 1.f) - fx;
-  t.w1 = fx - f0;
-  bool in = (t.i0 + 1) <= (size - 1);
-  t.i1 = in ? t.i0 + 1 : t.i0;
-  if (!in) t.w1 = 0.f;  // out-of-range corner contributes nothing (ATen within_bounds_2d)
-  return t;
-}
-
-// coordinate of sample n along x,y,z,t in grid_sample's [-1,1] convention
-template <int NP>
-__device__ __forceinline__ void load_coords(const snerf_coords& c, int64_t n, float p[4]) {
-  if (c.mode == 0) {
-    if (NP == 6) {
-      float4 v = *reinterpret_cast<const float4*>(c.pts + n * 4);
-      p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
-    } else {  // static scene: pts is [N,3]
-      p[0] = c.pts[n * 3]; p[1] = c.pts[n * 3 + 1]; p[2] = c.pts[n * 3 + 2]; p[3] = 0.f;
-    }
-  } else {
-    int64_t r = n / c.S;
-    int s = (int)(n - r * c.S);
-    const float* eb = c.ebins + r * (c.S + 1) + s;
-    float mid = eb[0] + eb[1];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float pos = c.origins[r * 3 + k] + (c.dirs[r * 3 + k] * mid) / 2.f;
-      float q = (pos - c.aabb_min[k]) / (c.aabb_max[k] - c.aabb_min[k]);
-      p[k] = c.rescale ? q * 2.f - 1.f : q;
-    }
-    p[3] = c.times[r] * 2.f - 1.f;
-  }
-}
-
-template <int NP> struct PlanePairs;
-template <> struct PlanePairs<6> {  // XY XZ XT YZ YT ZT
-  static constexpr int a[6] = {0, 0, 0, 1, 1, 2};
-  static constexpr int b[6] = {1, 2, 3, 2, 3, 3};
-};
-template <> struct PlanePairs<3> {  // static scene: XY XZ YZ
-  static constexpr int a[3] = {0, 0, 1};
-  static constexpr int b[3] = {1, 2, 2};
-};
-
-__device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
-// bilinear value of plane p for this lane's 4 channels
-template <int C>
-__device__ __forceinline__ float4 plane_sample(const float* __restrict__ base, int W, const AxisTap& tx, const AxisTap& ty, int cg) {
-  const float* r0 = base + ((int64_t)ty.i0 * W) * C + cg * 4;
-  const float* r1 = base + ((int64_t)ty.i1 * W) * C + cg * 4;
-  float4 nw = *reinterpret_cast<const float4*>(r0 + (int64_t)tx.i0 * C);
-  float4 ne = *reinterpret_cast<const float4*>(r0 + (int64_t)tx.i1 * C);
-  float4 sw = *reinterpret_cast<const float4*>(r1 + (int64_t)tx.i0 * C);
-  float4 se = *reinterpret_cast<const float4*>(r1 + (int64_t)tx.i1 * C);
-  float4 acc = f4_scale(nw, tx.w0 * ty.w0);
-  acc = f4_add(acc, f4_scale(ne, tx.w1 * ty.w0));
-  acc = f4_add(acc, f4_scale(sw, tx.w0 * ty.w1));
-  acc = f4_add(acc, f4_scale(se, tx.w1 * ty.w1));
-  return acc;
-}
 
 template <int C, int NP>
 __global__ __launch_bounds__(256) void kplanes_gather_fwd_kernel(snerf_kplanes_desc d, const float* __restrict__ planes,

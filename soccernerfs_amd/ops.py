@@ -66,6 +66,30 @@ class _KPlanesGather(torch.autograd.Function):
         return gplanes, None, None, None, None
 
 
+class SortedScatter:
+    """Workspace + driver of the sorted plane-gradient scatter (csrc/kplanes_sorted.hip) for a fixed sample count N."""
+
+    def __init__(self, ps: PlaneSet, N: int, device):
+        self.ps, self.N, self.desc = ps, N, ps.desc()
+        hc, ie = C.c_int64(0), C.c_int64(0)
+        _lib.check(_lib.lib().snerf_kplanes_sort_workspace(C.byref(self.desc), C.c_int64(N), C.byref(hc), C.byref(ie)), "sort_workspace")
+        self.hist = torch.empty(hc.value, dtype=torch.int32, device=device)
+        self.rank = torch.empty(ie.value, dtype=torch.int32, device=device)
+        self.sorted_rec = torch.empty(ie.value, 4, dtype=torch.float32, device=device)  # {sample id bits, pixel x, pixel y, 0}
+        self.gvec = torch.empty(ie.value * ps.C, dtype=torch.float32, device=device)
+
+    def sort(self, coords: _lib.Coords, stream=None):
+        _lib.check(_lib.lib().snerf_kplanes_sort_samples(C.byref(self.desc), C.byref(coords), C.c_int64(self.N), _ptr(self.hist), _ptr(self.rank),
+                                                         _ptr(self.sorted_rec), stream if stream is not None else _stream()), "sort_samples")
+
+    def scatter(self, planes, coords: _lib.Coords, gout, gplanes, stream=None):
+        st = stream if stream is not None else _stream()
+        _lib.check(_lib.lib().snerf_kplanes_gradvec(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gout), _ptr(self.gvec), st),
+                   "gradvec")
+        _lib.check(_lib.lib().snerf_kplanes_scatter_sorted(C.byref(self.desc), C.c_int64(self.N), _ptr(self.gvec), _ptr(self.sorted_rec), _ptr(gplanes), st),
+                   "scatter_sorted")
+
+
 def interpolate_kplanes(pts: torch.Tensor, plane_set: PlaneSet) -> torch.Tensor:
     """Drop-in for interpolate_kplanes(pts, ms_grids, concat_features, ...) (NS/fields/kplanes_field.py:77-126).
     pts [N,4] in [-1,1]; returns [N, C*n_scales] (concat) or [N, C]."""

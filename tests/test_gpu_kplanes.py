@@ -138,3 +138,47 @@ def test_gather_empty_and_errors():
     bad.C = 12
     with pytest.raises(RuntimeError, match="unsupported"):
         ops.interpolate_kplanes(torch.zeros(4, 4, device=dev), bad)
+
+
+@pytest.mark.parametrize("C,ms,concat,N", [(32, (1, 2, 4), True, 3001), (8, (1,), False, 5000), (32, (1, 2, 4, 8, 16), True, 64 * 512)])
+def test_sorted_scatter_equals_direct_scatter_and_oracle(C, ms, concat, N):
+    """The sorted variant (counting sort by texel key + run-length combining) gives the same plane gradients as the
+    sample-major scatter (and, for the small cases, as the oracle's autograd)."""
+    import ctypes as Ct
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    dev = _dev()
+    gen = torch.Generator().manual_seed(21)
+    base = (11, 9, 7, 5) if N < 20000 else (64, 64, 64, 100)
+    ps = PlaneSet(C, [[r * m for r in base[:3]] + [base[3]] for m in ms], concat=concat, generator=gen)
+    with torch.no_grad():
+        ps.planes.copy_(torch.rand(ps.numel, generator=gen) + 0.2)
+    ref_grids = [[t.clone().requires_grad_(True) for t in sc] for sc in ps.to_reference()]
+    ps = ps.to(dev)
+    pts = torch.rand(N, 4, generator=gen) * 2.2 - 1.1
+    pts[: N // 3, 3] = 0.25  # many samples share a time row, as rays of one image do
+    pts[: N // 8] = pts[0]   # heavy duplicates: long equal-key runs
+    gout = torch.rand(N, ps.out_dim, generator=gen) - 0.5
+    ptsd, goutd = pts.to(dev), gout.to(dev)
+    co = ops.coords_from_points(ptsd)
+    direct = torch.zeros_like(ps.planes)
+    desc = ps.desc()
+    _lib.check(_lib.lib().snerf_kplanes_gather_bwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(goutd), ops._ptr(direct),
+                                                   ops._stream()))
+    ss = ops.SortedScatter(ps, N, dev)
+    ss.sort(co)
+    # the permutation of every segment is a permutation of 0..N-1, ordered by key
+    sn = ss.sorted_rec[:, 0].contiguous().view(torch.int32).view(-1, N)
+    assert torch.equal(torch.sort(sn, dim=1).values, torch.arange(N, device=dev, dtype=torch.int32).expand_as(sn))
+    got = torch.zeros_like(ps.planes)
+    ss.scatter(ps.planes, co, goutd, got)
+    torch.testing.assert_close(got, direct, rtol=1e-4, atol=1e-5)
+    if N < 20000:
+        ref = KO.interpolate_kplanes(pts, ref_grids, concat)
+        ref.backward(gout)
+        g = ps.to_reference(got.cpu())
+        for s in range(len(ms)):
+            for p in range(6):
+                torch.testing.assert_close(g[s][p], ref_grids[s][p].grad, rtol=1e-4, atol=1e-5)
