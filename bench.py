@@ -134,8 +134,10 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    DOMINANT = "kplanes_gather_bwd.field"
-    trainer.enable_kernel_timing([DOMINANT])
+    # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
+    CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
+            "kplanes_gather_fwd.field"]
+    trainer.enable_kernel_timing(CAND)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -160,16 +162,31 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         S2 = cfg.num_nerf_samples_per_ray
-        # algorithmic bytes of ONE launch of the dominant kernel: read-modify-write of every touched texel
-        alg_bytes = R * S2 * len(cfg.multiscale_res) * 6 * 4 * cfg.feature_dim * 4 * 2
-        dom_ms = kt.get(DOMINANT, (float("nan"), 0))[0]
+        # algorithmic bytes / flops of ONE launch (SURVEY.md §8d conventions: 4 texels per bilinear tap, no cache credit)
+        gather = R * S2 * len(cfg.multiscale_res) * 6 * 4 * cfg.feature_dim * 4  # every texel of every tap, once
+        F = cfg.feature_dim * len(cfg.multiscale_res)
+        alg = {
+            "adam_step": ("hbm", 32 * trainer.n_params, "adam_kernel: p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
+            "adam_planes.field": ("hbm", 32 * trainer.field_planes.numel,
+                                  "plane_reg_kernel<32,true> (Adam + K-Planes regularisers fused, field planes): p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
+            "kplanes_scatter_sorted.field": ("hbm", 2 * gather, "scatter_sorted_kernel<32,6>: read-modify-write of every touched texel"),
+            "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
+            "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),
+            "kplanes_gather_fwd.field": ("hbm", gather, "kplanes_gather_fwd_kernel<32,6>: texel reads"),
+            "mlp_bwd.160x128x1": ("mfma", 3 * 2 * R * S2 * (F * cfg.sigma_net_hidden_dim + cfg.sigma_net_hidden_dim * 16), "mlp_bwd_kernel<160,128,1>: 3x forward flops (fp32 MFMA)"),
+        }
+        timed = {k: v for k, v in kt.items() if k in alg}
+        DOMINANT = max(timed, key=lambda k: timed[k][0] * timed[k][1])
+        bound, alg_bytes, kdesc = alg[DOMINANT]
+        dom_ms = timed[DOMINANT][0]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        peak = HBM_PEAK_GBS if bound == "hbm" else 157300.0  # fp32 MFMA peak, GFLOP/s
         # HBM traffic of that kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately; profiles/r01_pmc_*):
         # counters cannot be read inside this process, so the committed per-launch figure for exactly this workload is quoted.
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc) and R == 4096 and args.rays == 4096:
-            traffic = json.load(open(pmc)).get("traffic_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(DOMINANT, {}).get("traffic_bytes_per_launch")
         line = {
             "metric": "train rays/sec (K-Planes Broadcast-style, whole job)", "value": R * world * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -178,9 +195,10 @@ def main():
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
                        "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
                        "parallelism": f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "kplanes_gather_bwd_kernel<32,6> (field plane-gradient scatter)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dom_ms, "launches_timed": kt.get(DOMINANT, (0, 0))[1]},
+            "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic, "algorithmic_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
+                         "launches_timed": timed[DOMINANT][1],
+                         "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -220,9 +220,18 @@ int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* 
                     float c_sparse, float* losses, int32_t n_slots, int32_t overwrite, snerf_stream_t stream);
 
 /* torch.optim.Adam single-tensor step (no weight decay, no amsgrad) on a flat buffer; `step` is 1-based.
- * g is first multiplied by grad_scale (e.g. 1/world_size after an all-reduce SUM) and, if zero_grad != 0, cleared. */
-int snerf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+ * g is first multiplied by grad_scale (e.g. 1/world_size after an all-reduce SUM) and, if zero_grad != 0, cleared.
+ * The new parameters go to p_out (may equal p: in place). */
+int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+
+/* Adam over one K-Planes plane set with the plane regularisers (snerf_plane_reg) fused in: the regulariser gradient is
+ * formed from the +-1/+-2 neighbours of the OLD parameters inside the optimiser sweep and never touches HBM; g holds the
+ * data-term gradient only.  Parameters must ping-pong: p_in (old, read with neighbours) != p_out (new).  All pointers address
+ * the plane set's segment (same layout as `planes`).  losses / n_slots as in snerf_plane_reg (may be NULL). */
+int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
+                           float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
+                           float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray generation + collider.

@@ -19,6 +19,11 @@ struct RegArgs {
   float c_tv, c_smooth, c_l1;        // loss coefficients folded into the gradient
   float* losses;                     // [n_slots][16]: per-slot partial sums (cols 0..2), UNSCALED
   int n_slots;
+  // fused Adam (adam_planes_kernel): the regulariser gradient never touches HBM; parameters ping-pong p_in -> p_out because the
+  // sweep reads +-1/+-2 neighbours of the OLD parameters
+  float* p_out; float* m; float* v;
+  float step_size, b1, b2, inv_sqrt_bc2, eps, grad_scale;
+  int zero_grad;
   int overwrite;                     // 1: grad = reg gradient (buffer known to be zero), 0: grad += reg gradient
 };
 
@@ -29,7 +34,7 @@ __device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a
 __device__ __forceinline__ float sq4(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
 
-template <int C>
+template <int C, bool ADAM>
 __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   // locate this workgroup's plane
   int s = 0, p = 0;
@@ -95,7 +100,22 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
       const float k = -a.c_l1 / n_a;
       g = add4(g, make_float4(k * sgn(1.f - t.x), k * sgn(1.f - t.y), k * sgn(1.f - t.z), k * sgn(1.f - t.w)));
     }
-    if (a.grad) {
+    if (ADAM) {
+      const int64_t o = a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
+      float4 gg = ld4(a.grad + o), mm = ld4(a.m + o), vv = ld4(a.v + o), pp = t;
+      float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* RG = &g.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gk = G[k] * a.grad_scale + RG[k];
+        M[k] = a.b1 * M[k] + (1.f - a.b1) * gk;
+        V[k] = a.b2 * V[k] + (1.f - a.b2) * gk * gk;
+        P[k] = P[k] - a.step_size * (M[k] / (sqrtf(V[k]) * a.inv_sqrt_bc2 + a.eps));
+      }
+      *reinterpret_cast<float4*>(a.p_out + o) = pp;
+      *reinterpret_cast<float4*>(a.m + o) = mm;
+      *reinterpret_cast<float4*>(a.v + o) = vv;
+      if (a.zero_grad) *reinterpret_cast<float4*>(a.grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (a.grad) {
       float* gp = a.grad + a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
       if (a.overwrite) {
         *reinterpret_cast<float4*>(gp) = g;  // caller guarantees the gradient buffer is zero here: skip the read
@@ -124,7 +144,7 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
 //   p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps),  step_size = lr / bc1
 // Optionally zeroes g afterwards (saves a separate memset sweep) and scales g first (gradient mean over ranks).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+__global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                   int64_t n, float step_size, float b1, float b2, float inv_sqrt_bc2, float eps,
                                                   float grad_scale, int zero_grad) {
   const int64_t n4 = n / 4;
@@ -139,7 +159,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
       float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
       P[k] = P[k] - step_size * (M[k] / denom);
     }
-    *reinterpret_cast<float4*>(p + i * 4) = pp;
+    *reinterpret_cast<float4*>(p_out + i * 4) = pp;
     *reinterpret_cast<float4*>(m + i * 4) = mm;
     *reinterpret_cast<float4*>(v + i * 4) = vv;
     if (zero_grad) *reinterpret_cast<float4*>(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     float mk = b1 * m[i] + (1.f - b1) * gk;
     float vk = b2 * v[i] + (1.f - b2) * gk * gk;
     m[i] = mk; v[i] = vk;
-    p[i] = p[i] - step_size * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
+    p_out[i] = p[i] - step_size * (mk / (sqrtf(vk) * inv_sqrt_bc2 + eps));
     if (zero_grad) g[i] = 0.f;
   }
 }
@@ -184,26 +204,64 @@ extern "C" int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* plan
     }
   SNERF_REQUIRE(blocks < (1LL << 31), "plane_reg: too many workgroups");
   hipStream_t st = (hipStream_t)stream;
-  if (desc->C == 32) hipLaunchKernelGGL(plane_reg_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else if (desc->C == 16) hipLaunchKernelGGL(plane_reg_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(plane_reg_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  if (desc->C == 32) hipLaunchKernelGGL((plane_reg_kernel<32, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (desc->C == 16) hipLaunchKernelGGL((plane_reg_kernel<16, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((plane_reg_kernel<8, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   SNERF_LAUNCH_CHECK("plane_reg");
   return 0;
 }
 
-extern "C" int snerf_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+static void adam_consts(float lr, float beta1, float beta2, int step, float& step_size, float& inv_sqrt_bc2) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  step_size = (float)((double)lr / bc1);
+  inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
+
+extern "C" int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
+                                      float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
+                                      float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
+  SNERF_REQUIRE(desc && p_in && p_out && g && m && v, "adam_planes_step: null argument");
+  SNERF_REQUIRE(p_in != p_out, "adam_planes_step: parameters must ping-pong (p_in != p_out): the regulariser reads neighbours of the old values");
+  SNERF_REQUIRE(desc->n_scales >= 1 && desc->n_scales <= SNERF_MAX_SCALES, "adam_planes_step: n_scales=%d", desc->n_scales);
+  SNERF_REQUIRE(desc->C == 8 || desc->C == 16 || desc->C == 32, "adam_planes_step: C=%d unsupported", desc->C);
+  SNERF_REQUIRE(desc->n_coords == 3 || desc->n_coords == 4, "adam_planes_step: n_coords=%d", desc->n_coords);
+  SNERF_REQUIRE(step >= 1 && (!losses || n_slots >= 1), "adam_planes_step: step=%d n_slots=%d", step, n_slots);
+  RegArgs a = {};
+  a.d = *desc;
+  a.n_planes = desc->n_coords == 4 ? 6 : 3;
+  a.planes = p_in; a.grad = g; a.c_tv = c_space_tv; a.c_smooth = c_time_smooth; a.c_l1 = c_sparse; a.losses = losses; a.n_slots = n_slots;
+  a.p_out = p_out; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+  adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
+  static const int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3}, PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
+  int64_t blocks = 0;
+  for (int s = 0; s < desc->n_scales; ++s)
+    for (int p = 0; p < a.n_planes; ++p) {
+      const int ax = a.n_planes == 6 ? PA6[p] : PA3[p], bx = a.n_planes == 6 ? PB6[p] : PB3[p];
+      int64_t n4 = (int64_t)desc->res[s][ax] * desc->res[s][bx] * (desc->C / 4);
+      a.blk_off[s][p] = (int)blocks;
+      blocks += (n4 + 255) / 256;
+    }
+  SNERF_REQUIRE(blocks < (1LL << 31), "adam_planes_step: too many workgroups");
+  hipStream_t st = (hipStream_t)stream;
+  if (desc->C == 32) hipLaunchKernelGGL((plane_reg_kernel<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else if (desc->C == 16) hipLaunchKernelGGL((plane_reg_kernel<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((plane_reg_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  SNERF_LAUNCH_CHECK("adam_planes_step");
+  return 0;
+}
+
+extern "C" int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                                int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
   SNERF_REQUIRE(n >= 0 && step >= 1, "adam_step: n=%lld step=%d (1-based)", (long long)n, step);
   if (n == 0) return 0;
-  SNERF_REQUIRE(p && g && m && v, "adam_step: null buffer");
-  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1);
-  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  SNERF_REQUIRE(p && p_out && g && m && v, "adam_step: null buffer");
+  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)p_out | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
+  float step_size, inv_sqrt_bc2;
+  adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
   int64_t n4 = (n + 3) / 4;
   int64_t blocks = (n4 + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2,
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, p_out, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2,
                      eps, grad_scale, zero_grad);
   SNERF_LAUNCH_CHECK("adam_step");
   return 0;

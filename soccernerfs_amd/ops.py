@@ -389,12 +389,22 @@ def plane_regularizers(ps: PlaneSet) -> torch.Tensor:
     return _PlaneReg.apply(ps.planes, ps)
 
 
-def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12, grad_scale: float = 1.0, zero_grad: bool = False):
-    """In-place fused Adam on flat fp32 buffers (1-based step)."""
+def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12, grad_scale: float = 1.0, zero_grad: bool = False,
+              p_out=None):
+    """Fused Adam on flat fp32 buffers (1-based step); in place unless p_out is given."""
     for t in (p, g, m, v):
         _f32c(t, "adam buffer")
-    _lib.check(_lib.lib().snerf_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps, step, grad_scale,
-                                          int(zero_grad), _stream()), "adam_step")
+    _lib.check(_lib.lib().snerf_adam_step(_ptr(p), _ptr(p if p_out is None else p_out), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps,
+                                          step, grad_scale, int(zero_grad), _stream()), "adam_step")
+
+
+def adam_planes_step(ps: PlaneSet, p_in, p_out, g, m, v, coefs, losses, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12,
+                     grad_scale: float = 1.0, zero_grad: bool = True):
+    """Adam over one plane set with the plane regularisers fused in (ping-pong p_in -> p_out). coefs = (space_tv, time_smooth, sparse)."""
+    desc = ps.desc()
+    _lib.check(_lib.lib().snerf_adam_planes_step(C.byref(desc), _ptr(p_in), _ptr(p_out), _ptr(g), _ptr(m), _ptr(v), coefs[0], coefs[1], coefs[2],
+                                                 _ptr(losses) if losses is not None else None, REG_SLOTS if losses is not None else 0, lr, betas[0],
+                                                 betas[1], eps, step, grad_scale, int(zero_grad), _stream()), "adam_planes_step")
 
 
 def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_plane: float = 0.0, training: bool = True):

@@ -116,11 +116,14 @@ class KPlanesTrainer:
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
-        self.views, self.gviews = {}, {}
+        self.views, self.gviews, self.mviews, self.vviews = {}, {}, {}, {}
         for name, mod, attr, o, n in self.segments:
             self.params[o:o + n].copy_(getattr(mod, attr).detach())
-            getattr(mod, attr).data = self.params[o:o + n]  # modules now alias the flat buffer
-            self.views[name], self.gviews[name] = self.params[o:o + n], self.grads[o:o + n]
+            self.gviews[name], self.mviews[name], self.vviews[name] = self.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n]
+        self._repoint(self.params)
+        # the regulariser-fused optimiser sweep reads neighbours of the OLD parameters: parameters ping-pong between two buffers
+        self.fuse_reg_into_adam = True
+        self._params_alt = torch.empty_like(self.params)
         # ---- work buffers ----
         R = num_rays
         S0, S1 = cfg.num_proposal_samples_per_ray
@@ -153,6 +156,13 @@ class KPlanesTrainer:
         self.lib = _lib.lib()
         self._desc_field = self.field_planes.desc()
         self._desc_prop = [p.desc() for p in self.prop_planes]
+
+    def _repoint(self, flat: torch.Tensor):
+        """Make `flat` the live parameter buffer: module parameters and self.views alias its segments."""
+        self.params = flat
+        for name, mod, attr, o, n in self.segments:
+            getattr(mod, attr).data = flat[o:o + n]
+            self.views[name] = flat[o:o + n]
 
     # -------------------------------------------------------------------------------------------
     def enable_kernel_timing(self, names=None):
@@ -335,8 +345,13 @@ class KPlanesTrainer:
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
         if self.sorted_scatter and self._sort_done is not None and r0 == 0 and r1 == self.R:
             torch.cuda.current_stream().wait_event(self._sort_done)
-            with self._span("kplanes_gather_bwd.field"):
-                self._ss.scatter(self.field_planes.planes, co, b["gfeat"], self.gviews["field.planes"], self._st)
+            ss = self._ss
+            with self._span("kplanes_gradvec.field"):
+                _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
+                                                          self._p(b["gfeat"]), self._p(ss.gvec), self._st), "gradvec")
+            with self._span("kplanes_scatter_sorted.field"):
+                _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                                                                 self._p(self.gviews["field.planes"]), self._st), "scatter_sorted")
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
 
@@ -356,7 +371,7 @@ class KPlanesTrainer:
                               b["gpfeat"][lvl], cfg.proposal_feature_dim)
                 self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
 
-    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool):
+    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True):
         """Accumulates d(total loss)/d(params) into self.grads (which must be zero on entry: Adam clears it); fills
         self.last with the (scaled) loss terms.
 
@@ -372,13 +387,14 @@ class KPlanesTrainer:
         if overlap:
             for st in side:
                 st.wait_stream(main)
-            with KPlanesTrainer._On(self, side[0]):
-                self._reg_sweep()
+            if include_reg:
+                with KPlanesTrainer._On(self, side[0]):
+                    self._reg_sweep()
             reg_done = side[0].record_event()
             with KPlanesTrainer._On(self, side[1]):
                 side[1].wait_event(reg_done)  # proposal scatters add on top of the stored regulariser gradient
                 self._proposal_backward(proposal_grads)
-        else:
+        elif include_reg:
             self._reg_sweep()
         diff = b["rgb_out"] - target
         self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
@@ -428,13 +444,40 @@ class KPlanesTrainer:
         with self._span("allreduce_grads"):
             self._grad_scale = sdist.allreduce_flat_(self.grads, self.pg)
 
-    def optimizer_step(self):
+    def optimizer_step(self, fused_reg: bool = False):
         """Adam(lr*cosine, eps 1e-12) over the whole flat buffer + gradient clear (Optimizers.optimizer_step_all/scheduler_step_all)."""
-        cfg = self.cfg
+        cfg, co = self.cfg, self.cfg.loss_coefficients
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
-        with self._span("adam_step"):
-            ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps,
-                          grad_scale=getattr(self, "_grad_scale", 1.0), zero_grad=True)
+        gs = getattr(self, "_grad_scale", 1.0)
+        if not fused_reg:
+            with self._span("adam_step"):
+                ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=True)
+            self.step += 1
+            return
+        # regularisers fused into the sweep: plane sets go through snerf_adam_planes_step (values land in buf["reg"]), the MLP
+        # segments through the plain kernel; everything writes the OTHER parameter buffer, which then becomes live
+        new = self._params_alt
+        self.buf["reg"].zero_()
+        off = {name: (o, n) for name, _, _, o, n in self.segments}
+        sl = lambda t, name: t[off[name][0]:off[name][0] + off[name][1]]
+        sets = [("field.planes", self.field_planes, ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss"), 0)]
+        sets += [(f"prop{i}.planes", self.prop_planes[i], ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
+                                                           "sparse_transients_proposal_loss"), 1 + i) for i in range(2)]
+        for name, ps, keys, row in sets:
+            with self._span("adam_planes." + name.split(".")[0]):
+                ops.adam_planes_step(ps, sl(self.params, name), sl(new, name), self.gviews[name], self.mviews[name], self.vviews[name],
+                                     tuple(co[k] for k in keys), self.buf["reg"][row], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs)
+        with self._span("adam_step.mlps"):
+            # MLP segments: prop0.mlp, prop1.mlp and the adjacent field.sigma + field.color
+            o0, n0 = off["field.sigma"]
+            o1, n1 = off["field.color"]
+            ranges = [off["prop0.mlp"], off["prop1.mlp"], (o0, o1 + n1 - o0)]
+            for o, n in ranges:
+                n4 = (n + 3) // 4 * 4
+                ops.adam_step(self.params[o:o + n4], self.grads[o:o + n4], self.exp_avg[o:o + n4], self.exp_avg_sq[o:o + n4], self.step + 1, lr,
+                              eps=cfg.adam_eps, grad_scale=gs, zero_grad=True, p_out=new[o:o + n4])
+        self._params_alt = self.params
+        self._repoint(new)
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:
@@ -459,9 +502,10 @@ class KPlanesTrainer:
         updated = self._steps_since_update > update_schedule(sstep, cfg.proposal_warmup, cfg.proposal_update_every) or sstep < 10
         rng = rng if rng is not None else self.random_draws()
         out = self.forward(rays, rng, anneal, training=True)
-        self.backward(target, rng, proposal_grads=updated)
+        fuse = self.fuse_reg_into_adam
+        self.backward(target, rng, proposal_grads=updated, include_reg=not fuse)
         self.allreduce_grads()
-        self.optimizer_step()
+        self.optimizer_step(fused_reg=fuse)
         if updated:
             self._steps_since_update = 0
         self._steps_since_update += 1  # step_cb (ray_samplers.py:554-557)
