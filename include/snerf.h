@@ -320,11 +320,12 @@ int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chos
 
 /* ------------------------------------------------------------------------------------------------
  * Sorted plane-gradient scatter (same result as snerf_kplanes_gather_bwd, ~6x fewer atomic requests on training batches).
- *   1. snerf_kplanes_sort_samples : counting sort of the N samples of every (scale, plane) segment by texel key
- *      (row0 * W + x0).  Depends only on the sample coordinates -> can run on a side stream as soon as they are known.
- *      Workspace sizes (elements, int32) from snerf_kplanes_sort_workspace: hist[hist_cells], rank[index_elems] (int32) and
- *      sorted_rec[index_elems][4] (float: sample id bits, pixel x, pixel y, 0)  (index_elems = n_scales * n_planes * N).
- *   2. snerf_kplanes_gradvec      : gvec[seg][N][C] = dL/d(interpolated value of plane seg) per sample (product rule).
+ *   1. snerf_kplanes_sort_samples : counting sort of the N samples, once per PLANE, by the Z-order (Morton) code of their texel
+ *      at the finest scale -- one order serves every scale, because a coarser texel is a (nearly) aligned block of fine ones.
+ *      Depends only on the sample coordinates -> can run on a side stream as soon as they are known.
+ *      Workspace sizes (elements) from snerf_kplanes_sort_workspace: hist[hist_cells], rank[index_elems] (int32) and
+ *      sorted_rec[index_elems][4] (float: sample id bits, the two normalised plane coordinates, 0)  (index_elems = n_planes * N).
+ *   2. snerf_kplanes_gradvec      : gvec[scale*n_planes+plane][N][C] = dL/d(interpolated value of that plane) per sample.
  *   3. snerf_kplanes_scatter_sorted: walks each segment in sorted order, applies the bilinear weights, run-length-combines
  *      equal texel rows and ACCUMULATES into grad_planes with one 2*C-float atomic instruction per run.
  * ------------------------------------------------------------------------------------------------ */

@@ -7,12 +7,16 @@
 // texels, and coarse spatial planes a few thousand.  Sorting the samples of every (scale, plane) segment by texel key
 // makes equal keys adjacent, so run-length combining removes ~85 % of the requests.
 //
-// Pipeline (all segments of a plane set at once; seg = scale * NP + plane, every segment has exactly N entries):
-//   K1 rank    : one lane per sample: key = cell(seg) + row0 * W + x0;  rank = atomicAdd(&hist[key], 1)   (int atomics)
+// ONE sort per plane serves every scale: the key is the Z-order (Morton) code of the sample's texel at the FINEST scale, so
+// the samples of any coarser texel (a ~power-of-two block of fine texels) are (almost always) contiguous too.
+//
+// Pipeline (NP plane segments, each with exactly N entries):
+//   K1 rank    : one lane per (sample, plane): key = cell(plane) + morton(x0, row0 at the finest scale);
+//                rank = atomicAdd(&hist[key], 1)   (int atomics)
 //   K2 scan    : exclusive prefix sum of hist (3 small kernels)
-//   K3 reorder : sorted_rec[scan[key] + rank] = {n, fx, fy} (sample id + its pixel coordinates on that plane) -- a counting
-//                sort; positions depend only on the sample coordinates, so K1-K3 run on a side stream under the forward /
-//                MLP backward, and pass B never has to touch the ray buffers again
+//   K3 reorder : sorted_rec[scan[key] + rank] = {n, coord_a, coord_b} (sample id + its two normalised coordinates on that
+//                plane) -- a counting sort; positions depend only on the sample coordinates, so K1-K3 run on a side stream
+//                under the forward / MLP backward, and pass B never has to touch the ray buffers again
 //   A  gradvec : sample-major, float4 per lane (like the forward gather): g_q = dL/d(interp of plane q) -> gvec[seg][n][C]
 //   B  scatter : per segment, lane groups of 2*C lanes (x-corner, channel) walk RUN consecutive SORTED entries, multiply by
 //                the bilinear weights, run-length-combine per row and flush with one 256-B atomic instruction per run.
@@ -23,9 +27,24 @@
 namespace snerf {
 
 struct SegTable {
-  int n_seg;
-  int cell_off[SNERF_MAX_SCALES * 6 + 1];  // first histogram cell of each segment; [n_seg] = total cells
+  int n_planes;
+  int cell_off[7];  // first histogram cell of each plane; [n_planes] = total cells
+  int fine[4];      // sort-grid resolution of each axis = its finest resolution over the scales
+  int fine_rm[4];   // finer sort grid for the minor axis of row-major (time) planes: several samples share a (time row, texel)
+                    // there, and only a (near-)true sort by x keeps every scale's texel index monotone inside a row
+  int row_major[6]; // 1: key = i0_b * fine_rm[a] + i0_a(fine_rm) (time planes: the time row is exact at every scale); 0: Morton(i0_a, i0_b)
 };
+
+// Morton interleave of two 16-bit integers (x -> even bits, y -> odd bits)
+__device__ __forceinline__ uint32_t part1by1(uint32_t v) {
+  v &= 0x0000ffffu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__device__ __forceinline__ uint32_t morton2(uint32_t x, uint32_t y) { return part1by1(x) | (part1by1(y) << 1); }
 
 template <int NP>
 __device__ __forceinline__ void seg_axes(int q, int& a, int& b) {
@@ -53,33 +72,28 @@ __device__ __forceinline__ AxisTap tap_from_pix(float fx, int size) {
 }
 
 template <int NP, bool REORDER>
-__global__ __launch_bounds__(256) void sort_keys_kernel(snerf_kplanes_desc d, snerf_coords c, SegTable st, int64_t N, int32_t* __restrict__ hist,
+__global__ __launch_bounds__(256) void sort_keys_kernel(snerf_coords c, SegTable st, int64_t N, int32_t* __restrict__ hist,
                                                        int32_t* __restrict__ rank, const int32_t* __restrict__ scan, float4* __restrict__ sorted_rec) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float p[4];
   load_coords<NP>(c, n, p);
-  {
-    const int s = blockIdx.y;  // one lane per (sample, scale): 5x the lanes in flight for the (latency-bound) returning atomics
-    int i0[4];
-    float px[4];
+  int i0[4], i0f[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      px[k] = axis_pix(p[k], d.res[s][k] > 0 ? d.res[s][k] : 1);
-      i0[k] = (int)floorf(px[k]);
-    }
+  for (int k = 0; k < 4; ++k) {
+    i0[k] = (int)floorf(axis_pix(p[k], st.fine[k] > 0 ? st.fine[k] : 1));
+    i0f[k] = (int)floorf(axis_pix(p[k], st.fine_rm[k] > 0 ? st.fine_rm[k] : 1));
+  }
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      constexpr auto& A = PlanePairs<NP>::a;
-      constexpr auto& B = PlanePairs<NP>::b;
-      const int seg = s * NP + q;
-      const int key = st.cell_off[seg] + i0[B[q]] * d.res[s][A[q]] + i0[A[q]];
-      if (!REORDER) {
-        rank[(int64_t)seg * N + n] = atomicAdd(hist + key, 1);
-      } else {
-        // sorted record: sample id + its pixel coordinates on this plane, so pass B never touches the ray buffers
-        sorted_rec[scan[key] + rank[(int64_t)seg * N + n]] = make_float4(__int_as_float((int)n), px[A[q]], px[B[q]], 0.f);
-      }
+  for (int q = 0; q < NP; ++q) {
+    constexpr auto& A = PlanePairs<NP>::a;
+    constexpr auto& B = PlanePairs<NP>::b;
+    const int key = st.cell_off[q] + (st.row_major[q] ? i0[B[q]] * st.fine_rm[A[q]] + i0f[A[q]] : (int)morton2((uint32_t)i0[A[q]], (uint32_t)i0[B[q]]));
+    if (!REORDER) {
+      rank[(int64_t)q * N + n] = atomicAdd(hist + key, 1);
+    } else {
+      // sorted record: sample id + its two normalised coordinates on this plane, so pass B never touches the ray buffers
+      sorted_rec[scan[key] + rank[(int64_t)q * N + n]] = make_float4(__int_as_float((int)n), p[A[q]], p[B[q]], 0.f);
     }
   }
 }
@@ -197,11 +211,59 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
   int a, b;
   seg_axes<NP>(q, a, b);
   const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
-  const float4* rec = sorted_rec + (int64_t)seg * N + i0;
+  const float4* rec = sorted_rec + (int64_t)q * N + i0;  // the plane's order is shared by all scales
   const float* gv = gvec + (int64_t)seg * N * C + ch;
   float* gbase = gplanes + d.off[s][q] + li;
   int pend_key[2] = {-1, -1};
   float pend_val[2] = {0.f, 0.f};
+  if (LPS == 64) {
+    // The per-entry work (two bilinear taps, keys) is the same for all 64 lanes: do it LANE-PARALLEL for 64 entries at a time
+    // (lane l handles entry base + l), then walk the 64 entries in order broadcasting the precomputed values with
+    // v_readlane -- ~3x fewer vector instructions per entry than recomputing the taps in every lane.
+    const int lane = threadIdx.x & 63;
+    for (int base = 0; base < cnt; base += 64) {
+      const int e = base + lane;
+      const float4 r = rec[e < cnt ? e : cnt - 1];
+      const AxisTap tx = axis_tap(r.y, W);
+      const AxisTap ty = axis_tap(r.z, H);
+      const int nn = __float_as_int(r.x);
+      const int k0 = ty.i0 * W + tx.i0, k1 = ty.i1 * W + tx.i0;
+      const float wxa = tx.w0, wxb = tx.w1, wya = ty.w0, wyb = ty.w1;
+      const int m = (cnt - base) < 64 ? (cnt - base) : 64;
+      for (int u0 = 0; u0 < m; u0 += UNROLL) {
+        float g[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          const int uu = (u0 + u) < m ? (u0 + u) : (m - 1);
+          g[u] = gv[(int64_t)__builtin_amdgcn_readlane(nn, uu) * C];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          const int uu = u0 + u;
+          if (uu < m) {
+            const float wx0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wxa), uu));
+            const float wx1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wxb), uu));
+            const float wx = half ? wx1 : wx0;
+            const float gx = g[u] * wx;
+            const int key[2] = {__builtin_amdgcn_readlane(k0, uu), __builtin_amdgcn_readlane(k1, uu)};
+            const float wy[2] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(wya), uu)),
+                                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wyb), uu))};
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+              const float val = gx * wy[rr];
+              if (key[rr] != pend_key[rr]) {
+                if (pend_val[rr] != 0.f) atomicAdd(gbase + (int64_t)pend_key[rr] * C, pend_val[rr]);
+                pend_key[rr] = key[rr];
+                pend_val[rr] = val;
+              } else {
+                pend_val[rr] += val;
+              }
+            }
+          }
+        }
+      }
+    }
+  } else
   for (int i = 0; i < cnt; i += UNROLL) {
     float4 r[UNROLL];
     float g[UNROLL];
@@ -212,8 +274,8 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if (i + u < cnt) {
-        const AxisTap tx = tap_from_pix(r[u].y, W);
-        const AxisTap ty = tap_from_pix(r[u].z, H);
+        const AxisTap tx = axis_tap(r[u].y, W);
+        const AxisTap ty = axis_tap(r[u].z, H);
         const float gx = g[u] * (half ? tx.w1 : tx.w0);
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -238,16 +300,36 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
 static int build_segs(const snerf_kplanes_desc* d, SegTable& st) {
   const int NP = d->n_coords == 4 ? 6 : 3;
   static const int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3}, PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
-  st.n_seg = d->n_scales * NP;
-  int64_t off = 0;
-  for (int s = 0; s < d->n_scales; ++s)
-    for (int q = 0; q < NP; ++q) {
-      const int a = NP == 6 ? PA6[q] : PA3[q], b = NP == 6 ? PB6[q] : PB3[q];
-      st.cell_off[s * NP + q] = (int)off;
-      off += (int64_t)d->res[s][a] * d->res[s][b];
+  st.n_planes = NP;
+  for (int k = 0; k < 4; ++k) {
+    int fine = 1, coarse = 1 << 30;
+    for (int s = 0; s < d->n_scales; ++s) {
+      const int r = d->res[s][k] > 0 ? d->res[s][k] : 1;
+      fine = r > fine ? r : fine;
+      coarse = r < coarse ? r : coarse;
     }
-  SNERF_REQUIRE(off < (1LL << 31), "kplanes_sort: too many plane cells (%lld)", (long long)off);
-  st.cell_off[st.n_seg] = (int)off;
+    (void)coarse;
+    st.fine[k] = fine;  // measured: aligning the sort grid to the coarsest scale, or a finer grid for the time planes, does not pay
+    SNERF_REQUIRE(st.fine[k] <= 32768, "kplanes_sort: resolution %d too large for the Morton key", st.fine[k]);
+    st.fine_rm[k] = fine;
+  }
+  int64_t off = 0;
+  for (int q = 0; q < NP; ++q) {
+    const int a = NP == 6 ? PA6[q] : PA3[q], b = NP == 6 ? PB6[q] : PB3[q];
+    st.cell_off[q] = (int)off;
+    // planes whose row axis is time: time is not multiscale, so (time row, fine x) row-major keeps every scale's runs whole
+    st.row_major[q] = (NP == 6 && b == 3) ? 1 : 0;
+    if (st.row_major[q]) {
+      off += (int64_t)st.fine_rm[a] * st.fine[b];
+    } else {
+      const int m = st.fine[a] > st.fine[b] ? st.fine[a] : st.fine[b];
+      int bits = 0;
+      while ((1 << bits) < m) ++bits;
+      off += (int64_t)1 << (2 * bits);  // Morton codes of a (2^bits)^2 square
+    }
+  }
+  SNERF_REQUIRE(off < (1LL << 30), "kplanes_sort: too many Morton cells (%lld)", (long long)off);
+  st.cell_off[NP] = (int)off;
   return 0;
 }
 
@@ -271,8 +353,8 @@ extern "C" int snerf_kplanes_sort_workspace(const snerf_kplanes_desc* desc, int6
   int rc = build_segs(desc, st);
   if (rc) return rc;
   // hist: cells + room for the scan's block sums (one per 1024 cells, +1024 slack)
-  *hist_cells = (int64_t)st.cell_off[st.n_seg] + ((int64_t)st.cell_off[st.n_seg] + 1023) / 1024 + 1024;
-  *index_elems = (int64_t)st.n_seg * N;
+  *hist_cells = (int64_t)st.cell_off[st.n_planes] + ((int64_t)st.cell_off[st.n_planes] + 1023) / 1024 + 1024;
+  *index_elems = (int64_t)st.n_planes * N;
   return 0;
 }
 
@@ -287,19 +369,19 @@ extern "C" int snerf_kplanes_sort_samples(const snerf_kplanes_desc* desc, const 
   rc = build_segs(desc, st);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t cells = st.cell_off[st.n_seg];
+  const int64_t cells = st.cell_off[st.n_planes];
   const int nb = (int)((cells + 1023) / 1024);
   int32_t* block_sums = hist + cells;
   rc = check_hip(hipMemsetAsync(hist, 0, (size_t)cells * sizeof(int32_t), s), "kplanes_sort memset");
   if (rc) return rc;
-  const dim3 gs((unsigned)ceil_div(N, 256), (unsigned)desc->n_scales);
-  if (desc->n_coords == 4) hipLaunchKernelGGL((sort_keys_kernel<6, false>), gs, dim3(256), 0, s, *desc, *coords, st, N, hist, rank, nullptr, nullptr);
-  else hipLaunchKernelGGL((sort_keys_kernel<3, false>), gs, dim3(256), 0, s, *desc, *coords, st, N, hist, rank, nullptr, nullptr);
+  const dim3 gs((unsigned)ceil_div(N, 256));
+  if (desc->n_coords == 4) hipLaunchKernelGGL((sort_keys_kernel<6, false>), gs, dim3(256), 0, s, *coords, st, N, hist, rank, nullptr, nullptr);
+  else hipLaunchKernelGGL((sort_keys_kernel<3, false>), gs, dim3(256), 0, s, *coords, st, N, hist, rank, nullptr, nullptr);
   hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, s, hist, cells, block_sums);
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, block_sums, nb);
   hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, s, hist, cells, block_sums);
-  if (desc->n_coords == 4) hipLaunchKernelGGL((sort_keys_kernel<6, true>), gs, dim3(256), 0, s, *desc, *coords, st, N, nullptr, rank, hist, sorted_n);
-  else hipLaunchKernelGGL((sort_keys_kernel<3, true>), gs, dim3(256), 0, s, *desc, *coords, st, N, nullptr, rank, hist, sorted_n);
+  if (desc->n_coords == 4) hipLaunchKernelGGL((sort_keys_kernel<6, true>), gs, dim3(256), 0, s, *coords, st, N, nullptr, rank, hist, sorted_n);
+  else hipLaunchKernelGGL((sort_keys_kernel<3, true>), gs, dim3(256), 0, s, *coords, st, N, nullptr, rank, hist, sorted_n);
   SNERF_LAUNCH_CHECK("kplanes_sort_samples");
   return 0;
 }

@@ -76,7 +76,7 @@ class SortedScatter:
         self.hist = torch.empty(hc.value, dtype=torch.int32, device=device)
         self.rank = torch.empty(ie.value, dtype=torch.int32, device=device)
         self.sorted_rec = torch.empty(ie.value, 4, dtype=torch.float32, device=device)  # {sample id bits, pixel x, pixel y, 0}
-        self.gvec = torch.empty(ie.value * ps.C, dtype=torch.float32, device=device)
+        self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=torch.float32, device=device)  # [scale*planes+plane][N][C]
 
     def sort(self, coords: _lib.Coords, stream=None):
         _lib.check(_lib.lib().snerf_kplanes_sort_samples(C.byref(self.desc), C.byref(coords), C.c_int64(self.N), _ptr(self.hist), _ptr(self.rank),

@@ -169,7 +169,7 @@ def test_sorted_scatter_equals_direct_scatter_and_oracle(C, ms, concat, N):
                                                    ops._stream()))
     ss = ops.SortedScatter(ps, N, dev)
     ss.sort(co)
-    # the permutation of every segment is a permutation of 0..N-1, ordered by key
+    # the order of every plane is a permutation of 0..N-1
     sn = ss.sorted_rec[:, 0].contiguous().view(torch.int32).view(-1, N)
     assert torch.equal(torch.sort(sn, dim=1).values, torch.arange(N, device=dev, dtype=torch.int32).expand_as(sn))
     got = torch.zeros_like(ps.planes)

@@ -1,0 +1,39 @@
+"""Flush counts of the sorted scatter on a real training batch (dev tool)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soccernerfs_amd import ops, synthetic
+from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
+
+dev = torch.device("cuda:0"); torch.manual_seed(0)
+cfg = KPlanesTrainConfig(); R = 4096
+tr = KPlanesTrainer(cfg, R, dev)
+cams = synthetic.make_cameras(20, 960, 540); times = synthetic.frame_times(100, 3)[:4]
+data = synthetic.render_dataset(cams, times, list(range(19)), dev, chunk_rows=540)
+M, H, W = data["images"].shape[:3]; scale = torch.tensor([M, H, W], dtype=torch.float32, device=dev)
+def step():
+    idx = torch.floor(torch.rand(R, 3, device=dev) * scale).long()
+    target = data["images"][idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
+    rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=tr.aabb, near_plane=0.0, training=True)
+    tr.train_step(rays, target)
+for _ in range(30): step()
+torch.cuda.synchronize()
+N = R * 64
+rec = tr._ss.sorted_rec.view(6, N, 4)
+pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+tot = 0
+for si, m in enumerate((1, 2, 4, 8, 16)):
+    res = [64 * m, 64 * m, 64 * m, 100]
+    line = f"scale {m:2d}:"
+    for q, (a, b) in enumerate(pairs):
+        xa, xb = rec[q, :, 1], rec[q, :, 2]
+        pa = (((xa + 1) / 2) * (res[a] - 1)).clamp(0, res[a] - 1).floor().long()
+        pb = (((xb + 1) / 2) * (res[b] - 1)).clamp(0, res[b] - 1).floor().long()
+        key = pb * res[a] + pa
+        chg = (key[1:] != key[:-1])
+        starts = torch.zeros(N, dtype=torch.bool, device=dev); starts[::64] = True
+        fl = int((chg | starts[1:]).sum()) + 1
+        uniq = torch.unique(key).numel()
+        tot += fl
+        line += f" {fl/N:5.3f}/{uniq/N:5.3f}"
+    print(line + "   (flushes per entry in sorted order with 64-entry chunks / distinct keys per entry)")
+print(f"total row-0 flushes {tot/1e6:.2f} M of {30*N/1e6:.2f} M entries")
