@@ -54,6 +54,12 @@ struct Plan {
   static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
 };
 
+// waves per workgroup: the 128-wide nets leave room for only ONE workgroup per CU (weights + tiles ~150 KB of LDS), so they run
+// 8 waves (2 per SIMD) to overlap one wave's LDS / barrier waits with the other's MFMAs (measured: 55 % of wave cycles were waits
+// at 1 wave per SIMD, MFMA pipe 29 % busy -- profiles/r01_kernels.md); the 64-wide nets fit 2+ workgroups per CU with 4 waves.
+template <int H>
+constexpr int waves_of() { return H >= 128 ? 8 : 4; }
+
 template <int D0P, int H, int NH, bool BWD>
 constexpr int pick_ts() {
   return Plan<D0P, H, NH, 64, BWD>::BYTES <= LDS_LIMIT ? 64 : (Plan<D0P, H, NH, 32, BWD>::BYTES <= LDS_LIMIT ? 32 : 16);
@@ -129,14 +135,14 @@ __device__ __forceinline__ void stage_weights(const float* __restrict__ Wg, int 
 
 // X tile (rows n0.., d0 columns, zero padded to K0 columns / TS rows): global -> registers (issued one tile AHEAD so the
 // loads fly under the current tile's MFMAs), registers -> LDS after the tile's last reader has passed the barrier.
-template <int TS, int K0>
+template <int TS, int K0, int NT>
 struct XTile {
-  static constexpr int PER = (TS * K0 + 255) / 256;
+  static constexpr int PER = (TS * K0 + NT - 1) / NT;
   float v[PER];
   __device__ __forceinline__ void fetch(const MlpArgs& a, int64_t n0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int idx = threadIdx.x + i * 256;
+      const int idx = threadIdx.x + i * NT;
       const int r = idx / K0, c = idx - r * K0;
       const int64_t n = n0 + r;
       v[i] = (idx < TS * K0 && n < a.N && c < a.d0) ? a.X[n * a.ldx + c] : 0.f;
@@ -145,7 +151,7 @@ struct XTile {
   __device__ __forceinline__ void store(float* Xs, int ldxs) const {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int idx = threadIdx.x + i * 256;
+      const int idx = threadIdx.x + i * NT;
       const int r = idx / K0, c = idx - r * K0;
       if (idx < TS * K0) Xs[r * ldxs + c] = v[i];
     }
@@ -156,7 +162,7 @@ struct XTile {
 template <int D0P, int H, int NH, int TS, bool BWD>
 __device__ __forceinline__ void forward_hidden(float* smem, bool relu, int wave, int lane) {
   using P = Plan<D0P, H, NH, TS, BWD>;
-  constexpr int HT = H / 16, MT = TS / 16;
+  constexpr int HT = H / 16, MT = TS / 16, NW = waves_of<H>();
 #pragma unroll
   for (int l = 0; l < NH; ++l) {
     const float* in = smem + (l == 0 ? P::ACT0 : P::ACT1);
@@ -166,8 +172,8 @@ __device__ __forceinline__ void forward_hidden(float* smem, bool relu, int wave,
     const float* Wl = smem + (l == 0 ? P::W0 : P::W1);
     if (HT >= 4) {
 #pragma unroll
-      for (int j = 0; j < (HT >= 4 ? HT / 4 : 1); ++j) {
-        const int nt = wave + 4 * j;
+      for (int j = 0; j < (HT >= NW ? HT / NW : 1); ++j) {
+        const int nt = wave + NW * j;
         f32x4 acc[MT] = {};
         mma_cols<MT>(in, lda, K, Wl, P::LW0, nt, acc, lane);
 #pragma unroll
@@ -193,14 +199,14 @@ __device__ __forceinline__ void stage_all(const MlpArgs& a, float* smem) {
 }
 
 template <int D0P, int H, int NH, int TS>
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs a, int64_t n_tiles) {
+__global__ __launch_bounds__(waves_of<H>() * 64) void mlp_fwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) float smem[];
   using P = Plan<D0P, H, NH, TS, false>;
-  constexpr int MT = TS / 16;
+  constexpr int MT = TS / 16, NW = waves_of<H>();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   stage_all<D0P, H, NH, TS, false>(a, smem);
   const float* act_last = smem + (NH == 2 ? P::ACT2 : P::ACT1);
-  XTile<TS, D0P> xt;
+  XTile<TS, D0P, NW * 64> xt;
   xt.fetch(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TS;
@@ -209,10 +215,10 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs a, int64_t n_tiles
     if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);  // prefetch the next tile
     __syncthreads();
     forward_hidden<D0P, H, NH, TS, false>(smem, a.hidden_act == 1, wave, lane);
-    // output layer: row block mt handled by wave mt % 4
+    // output layer: row block mt handled by wave mt % NW
 #pragma unroll
-    for (int j = 0; j < (MT + 3) / 4; ++j) {
-      const int mt = wave + 4 * j;
+    for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
+      const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc = {};
         mma_one(act_last, P::LDH, H, smem + P::WO, P::LWO, mt, 0, acc, lane);
@@ -237,11 +243,11 @@ __global__ __launch_bounds__(256) void mlp_fwd_kernel(MlpArgs a, int64_t n_tiles
 // backward
 // ---------------------------------------------------------------------------------------------
 template <int D0P, int H, int NH, int TS>
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
+__global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) float smem[];
   using P = Plan<D0P, H, NH, TS, true>;
-  constexpr int D0T = D0P / 16, HT = H / 16, MT = TS / 16;
-  constexpr int NJ = HT >= 4 ? HT / 4 : 1;  // column blocks of a hidden layer per wave
+  constexpr int D0T = D0P / 16, HT = H / 16, MT = TS / 16, NW = waves_of<H>();
+  constexpr int NJ = HT >= NW ? HT / NW : 1;  // column blocks of a hidden layer per wave
   static_assert(D0P % 16 == 0 && H % 16 == 0, "dims are padded to 16");
   static_assert(NH == 1 || HT >= 4, "two hidden layers need hidden >= 64");
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -253,15 +259,15 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
   float* gzo = smem + P::GZO;
   stage_all<D0P, H, NH, TS, true>(a, smem);
 
-  // weight-gradient accumulators, alive across the persistent loop; block t of a layer is owned by wave t % 4
-  constexpr int NB0 = (D0T * HT + 3) / 4;   // layer 0: [D0P x H]
-  constexpr int NBH = (HT * HT + 3) / 4;    // hidden->hidden (NH == 2)
-  constexpr int NBO = (HT + 3) / 4;         // output: [H x 16]
+  // weight-gradient accumulators, alive across the persistent loop; block t of a layer is owned by wave t % NW
+  constexpr int NB0 = (D0T * HT + NW - 1) / NW;   // layer 0: [D0P x H]
+  constexpr int NBH = (HT * HT + NW - 1) / NW;    // hidden->hidden (NH == 2)
+  constexpr int NBO = (HT + NW - 1) / NW;         // output: [H x 16]
   f32x4 dW0[NB0] = {};
   f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
 
-  XTile<TS, D0P> xt;
+  XTile<TS, D0P, NW * 64> xt;
   xt.fetch(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TS;
@@ -272,8 +278,8 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     forward_hidden<D0P, H, NH, TS, true>(smem, relu, wave, lane);
     // ---- output layer forward (needed for sigmoid' / trunc_exp') and grad wrt its pre-activation ----
 #pragma unroll
-    for (int j = 0; j < (MT + 3) / 4; ++j) {
-      const int mt = wave + 4 * j;
+    for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
+      const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc = {};
         mma_one(Alast, P::LDH, H, smem + P::WO, P::LWO, mt, 0, acc, lane);
@@ -300,14 +306,14 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     // ---- dW_out += A_last^T * gzo ----
 #pragma unroll
     for (int j = 0; j < NBO; ++j) {
-      const int it = wave + 4 * j;
+      const int it = wave + NW * j;
       if (it < HT) mma_outer<TS>(Alast, P::LDH, gzo, P::LDO, it, 0, dWo[j], lane);
     }
     // ---- gz = (gzo * W_out^T) .* relu'(A_last): output width H, K = 16 ----
     if (HT >= 4) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int nt = wave + 4 * j;
+        const int nt = wave + NW * j;
         f32x4 acc[MT] = {};
         mma_cols_T<MT>(gzo, P::LDO, OUTP, smem + P::WO, P::LWO, nt, acc, lane);
         const int col = nt * 16 + (lane & 15);
@@ -342,16 +348,16 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     if (NH == 2) {
 #pragma unroll
       for (int j = 0; j < NBH; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wave + NW * j;
         if (t < HT * HT) mma_outer<TS>(A1, P::LDH, gz, P::LDH, t / HT, t % HT, dWh[j], lane);
       }
       f32x4 acc2[NJ][MT] = {};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) mma_cols_T<MT>(gz, P::LDH, H, smem + P::W1, P::LW0, wave + 4 * j, acc2[j], lane);
+      for (int j = 0; j < NJ; ++j) mma_cols_T<MT>(gz, P::LDH, H, smem + P::W1, P::LW0, wave + NW * j, acc2[j], lane);
       __syncthreads();  // everyone finished reading gz
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int nt = wave + 4 * j;
+        const int nt = wave + NW * j;
         const int col = nt * 16 + (lane & 15);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -369,13 +375,13 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     // ---- first layer: dW_0 += X^T * gz ; gX = gz * W_0^T ----
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
-      const int t = wave + 4 * j;
+      const int t = wave + NW * j;
       if (t < D0T * HT) mma_outer<TS>(X, P::LD0, gz, P::LDH, t / HT, t % HT, dW0[j], lane);
     }
     if (a.gX) {
 #pragma unroll
-      for (int j = 0; j < (D0T + 3) / 4; ++j) {
-        const int nt = wave + 4 * j;
+      for (int j = 0; j < (D0T + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
         if (nt < D0T) {
           f32x4 acc[MT] = {};
           mma_cols_T<MT>(gz, P::LDH, H, smem + P::W0, P::LW0, nt, acc, lane);
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     const int cl = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
-      const int t = wave + 4 * j;
+      const int t = wave + NW * j;
       if (t < D0T * HT) {
         const int it = t / HT, nt = t % HT;
 #pragma unroll
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     if (NH == 2) {
 #pragma unroll
       for (int j = 0; j < NBH; ++j) {
-        const int t = wave + 4 * j;
+        const int t = wave + NW * j;
         if (t < HT * HT) {
           const int it = t / HT, nt = t % HT;
 #pragma unroll
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(MlpArgs a, int64_t n_tiles
     }
 #pragma unroll
     for (int j = 0; j < NBO; ++j) {
-      const int it = wave + 4 * j;
+      const int it = wave + NW * j;
       if (it < HT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -444,7 +450,7 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     auto k = mlp_bwd_kernel<D0P, H, NH, TS>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), P::BYTES, st, a, n_tiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_of<H>() * 64), P::BYTES, st, a, n_tiles);
   } else {
     constexpr int TS = pick_ts<D0P, H, NH, false>();
     using P = Plan<D0P, H, NH, TS, false>;
@@ -457,7 +463,7 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     auto k = mlp_fwd_kernel<D0P, H, NH, TS>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), P::BYTES, st, a, n_tiles);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_of<H>() * 64), P::BYTES, st, a, n_tiles);
   }
   SNERF_LAUNCH_CHECK(bwd ? "mlp_bwd" : "mlp_fwd");
   return 0;
