@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr after the timed run")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (debug / A-B)")
+    ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
@@ -106,6 +107,8 @@ def main():
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
+    if args.no_shard:
+        trainer.shard_optimizer = False
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)
@@ -167,7 +170,7 @@ def main():
         F = cfg.feature_dim * len(cfg.multiscale_res)
         alg = {
             "adam_step": ("hbm", 32 * trainer.n_params, "adam_kernel: p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
-            "adam_planes.field": ("hbm", 32 * trainer.field_planes.numel,
+            "adam_planes.field": ("hbm", 32 * (trainer._field_seg[2] // world if trainer._sharded() else trainer.field_planes.numel),
                                   "plane_reg_kernel<32,true> (Adam + K-Planes regularisers fused, field planes): p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
             "kplanes_scatter_sorted.field": ("hbm", 2 * gather, "scatter_sorted_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
@@ -185,7 +188,7 @@ def main():
         # counters cannot be read inside this process, so the committed per-launch figure for exactly this workload is quoted.
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc) and R == 4096 and args.rays == 4096:
+        if os.path.exists(pmc) and R == 4096 and world == 1:
             traffic = json.load(open(pmc)).get(DOMINANT, {}).get("traffic_bytes_per_launch")
         line = {
             "metric": "train rays/sec (K-Planes Broadcast-style, whole job)", "value": R * world * args.steps / elapsed, "unit": "rays/s",
@@ -194,7 +197,10 @@ def main():
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
                        "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
-                       "parallelism": f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step" if world > 1 else "single GPU"},
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"ray-sharded x{world}; field-plane gradients: RCCL reduce-scatter -> Adam on a 1/{world} shard -> all-gather of the new "
+                           "planes (= one all-reduce's bytes), small segments: all-reduce" if trainer._sharded() else
+                           f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step")},
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "algorithmic_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "launches_timed": timed[DOMINANT][1],

@@ -233,6 +233,15 @@ int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, fl
                            float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
                            float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
 
+/* Same, restricted to the floats [range_lo, range_hi) of the segment (both multiples of 4): the optimiser shard of one rank when
+ * the gradient is reduce-scattered instead of all-reduced (DDP + ZeroRedundancyOptimizer semantics; the reference's DDP wrapper
+ * is NS/pipelines/base_pipeline.py:244-246).  p_in must hold the WHOLE old segment (neighbours across the shard edge are read);
+ * only the range of p_out, g, m, v is touched; the loss partials cover the range only. */
+int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
+                                 float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
+                                 float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, int64_t range_lo, int64_t range_hi,
+                                 snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Ray generation + collider.
  * ------------------------------------------------------------------------------------------------ */

@@ -100,6 +100,7 @@ def lib():
     l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, I, I, P]
     l.snerf_adam_step.argtypes = [P, P, P, P, P, L, F, F, F, F, I, F, I, P]
     l.snerf_adam_planes_step.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, P]
+    l.snerf_adam_planes_step_range.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, L, L, P]
     l.snerf_aabb_collide.argtypes = [P, P, I, P, F, I, P, P, P]
     l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
@@ -136,6 +137,7 @@ EXPORTS = [
     "snerf_plane_reg",
     "snerf_adam_step",
     "snerf_adam_planes_step",
+    "snerf_adam_planes_step_range",
     "snerf_raygen",
     "snerf_aabb_collide",
     "snerf_tgrid_encode_fwd",

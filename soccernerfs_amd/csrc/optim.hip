@@ -25,6 +25,9 @@ struct RegArgs {
   float step_size, b1, b2, inv_sqrt_bc2, eps, grad_scale;
   int zero_grad;
   int overwrite;                     // 1: grad = reg gradient (buffer known to be zero), 0: grad += reg gradient
+  // optimiser sharding (one rank updates floats [range_lo, range_hi) of the segment): the grid starts at workgroup blk_base
+  int blk_base;
+  int64_t range_lo, range_hi;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -38,8 +41,9 @@ template <int C, bool ADAM>
 __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   // locate this workgroup's plane
   int s = 0, p = 0;
+  const int blk = (int)blockIdx.x + a.blk_base;
   {
-    const int b = blockIdx.x;
+    const int b = blk;
     bool found = false;
     for (int ss = a.d.n_scales - 1; ss >= 0 && !found; --ss)
       for (int pp = a.n_planes - 1; pp >= 0; --pp)
@@ -54,9 +58,10 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   constexpr int C4 = C / 4;
   // 32-bit index math only (64-bit div/mod is a ~100-instruction software routine on the GPU); a plane has < 2^31 float4s
   const uint32_t n4 = (uint32_t)H * (uint32_t)W * C4;
-  const uint32_t e = (uint32_t)(blockIdx.x - a.blk_off[s][p]) * 256u + threadIdx.x;
+  const uint32_t e = (uint32_t)(blk - a.blk_off[s][p]) * 256u + threadIdx.x;
   float l_tv = 0.f, l_sm = 0.f, l_l1 = 0.f;
-  if (e < n4) {
+  const int64_t o_lane = a.d.off[s][p] + (int64_t)e * 4;  // this lane's float4 inside the segment
+  if (e < n4 && o_lane >= a.range_lo && o_lane < a.range_hi) {
     const int c4 = (int)(e % C4);       // C4 is a compile-time power of two
     const uint32_t hw = e / C4;
     const int h = (int)(hw / (uint32_t)W);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   // the memory side (measured: 1.9 ms for this kernel with a single slot, profiles/r01_kernels.md)
   if (threadIdx.x < 3 && a.losses) {
     float v = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-    if (v != 0.f) atomicAdd(a.losses + (size_t)(blockIdx.x % a.n_slots) * 16 + threadIdx.x, v);
+    if (v != 0.f) atomicAdd(a.losses + (size_t)(blk % a.n_slots) * 16 + threadIdx.x, v);
   }
 }
 
@@ -203,6 +208,7 @@ extern "C" int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* plan
       blocks += (n4 + 255) / 256;
     }
   SNERF_REQUIRE(blocks < (1LL << 31), "plane_reg: too many workgroups");
+  a.blk_base = 0; a.range_lo = 0; a.range_hi = INT64_MAX;
   hipStream_t st = (hipStream_t)stream;
   if (desc->C == 32) hipLaunchKernelGGL((plane_reg_kernel<32, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
   else if (desc->C == 16) hipLaunchKernelGGL((plane_reg_kernel<16, false>), dim3((unsigned)blocks), dim3(256), 0, st, a);
@@ -217,37 +223,58 @@ static void adam_consts(float lr, float beta1, float beta2, int step, float& ste
   inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
 }
 
-extern "C" int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
-                                      float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
-                                      float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
+extern "C" int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
+                                            float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
+                                            float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, int64_t range_lo,
+                                            int64_t range_hi, snerf_stream_t stream) {
   SNERF_REQUIRE(desc && p_in && p_out && g && m && v, "adam_planes_step: null argument");
   SNERF_REQUIRE(p_in != p_out, "adam_planes_step: parameters must ping-pong (p_in != p_out): the regulariser reads neighbours of the old values");
   SNERF_REQUIRE(desc->n_scales >= 1 && desc->n_scales <= SNERF_MAX_SCALES, "adam_planes_step: n_scales=%d", desc->n_scales);
   SNERF_REQUIRE(desc->C == 8 || desc->C == 16 || desc->C == 32, "adam_planes_step: C=%d unsupported", desc->C);
   SNERF_REQUIRE(desc->n_coords == 3 || desc->n_coords == 4, "adam_planes_step: n_coords=%d", desc->n_coords);
   SNERF_REQUIRE(step >= 1 && (!losses || n_slots >= 1), "adam_planes_step: step=%d n_slots=%d", step, n_slots);
+  SNERF_REQUIRE(range_lo >= 0 && (range_lo & 3) == 0 && (range_hi & 3) == 0, "adam_planes_step: range [%lld, %lld) must be float4-aligned",
+                (long long)range_lo, (long long)range_hi);
   RegArgs a = {};
   a.d = *desc;
   a.n_planes = desc->n_coords == 4 ? 6 : 3;
   a.planes = p_in; a.grad = g; a.c_tv = c_space_tv; a.c_smooth = c_time_smooth; a.c_l1 = c_sparse; a.losses = losses; a.n_slots = n_slots;
   a.p_out = p_out; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+  a.range_lo = range_lo; a.range_hi = range_hi;
   adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
   static const int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3}, PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
-  int64_t blocks = 0;
+  int64_t blocks = 0, b_lo = INT64_MAX, b_hi = -1;  // workgroups [b_lo, b_hi] hold every float4 of the range (memory order == grid order)
   for (int s = 0; s < desc->n_scales; ++s)
     for (int p = 0; p < a.n_planes; ++p) {
       const int ax = a.n_planes == 6 ? PA6[p] : PA3[p], bx = a.n_planes == 6 ? PB6[p] : PB3[p];
-      int64_t n4 = (int64_t)desc->res[s][ax] * desc->res[s][bx] * (desc->C / 4);
+      const int64_t n4 = (int64_t)desc->res[s][ax] * desc->res[s][bx] * (desc->C / 4);
       a.blk_off[s][p] = (int)blocks;
+      const int64_t lo = range_lo > desc->off[s][p] ? range_lo - desc->off[s][p] : 0;                 // floats, relative to the plane
+      const int64_t hi = (range_hi < desc->off[s][p] + n4 * 4 ? range_hi : desc->off[s][p] + n4 * 4) - desc->off[s][p];
+      if (hi > lo) {
+        const int64_t first = blocks + lo / 1024, last = blocks + (hi - 1) / 1024;
+        b_lo = first < b_lo ? first : b_lo;
+        b_hi = last > b_hi ? last : b_hi;
+      }
       blocks += (n4 + 255) / 256;
     }
   SNERF_REQUIRE(blocks < (1LL << 31), "adam_planes_step: too many workgroups");
+  if (b_hi < b_lo) return 0;  // the range holds none of this set's parameters
+  a.blk_base = (int)b_lo;
+  const unsigned grid = (unsigned)(b_hi - b_lo + 1);
   hipStream_t st = (hipStream_t)stream;
-  if (desc->C == 32) hipLaunchKernelGGL((plane_reg_kernel<32, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else if (desc->C == 16) hipLaunchKernelGGL((plane_reg_kernel<16, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((plane_reg_kernel<8, true>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  if (desc->C == 32) hipLaunchKernelGGL((plane_reg_kernel<32, true>), dim3(grid), dim3(256), 0, st, a);
+  else if (desc->C == 16) hipLaunchKernelGGL((plane_reg_kernel<16, true>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((plane_reg_kernel<8, true>), dim3(grid), dim3(256), 0, st, a);
   SNERF_LAUNCH_CHECK("adam_planes_step");
   return 0;
+}
+
+extern "C" int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
+                                      float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
+                                      float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
+  return snerf_adam_planes_step_range(desc, p_in, p_out, g, m, v, c_space_tv, c_time_smooth, c_sparse, losses, n_slots, lr, beta1, beta2, eps, step,
+                                      grad_scale, zero_grad, 0, INT64_MAX & ~(int64_t)3, stream);
 }
 
 extern "C" int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

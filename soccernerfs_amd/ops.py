@@ -399,12 +399,15 @@ def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps: float =
 
 
 def adam_planes_step(ps: PlaneSet, p_in, p_out, g, m, v, coefs, losses, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12,
-                     grad_scale: float = 1.0, zero_grad: bool = True):
-    """Adam over one plane set with the plane regularisers fused in (ping-pong p_in -> p_out). coefs = (space_tv, time_smooth, sparse)."""
+                     grad_scale: float = 1.0, zero_grad: bool = True, shard_range=None):
+    """Adam over one plane set with the plane regularisers fused in (ping-pong p_in -> p_out). coefs = (space_tv, time_smooth, sparse).
+    shard_range = (lo, hi): update only floats [lo, hi) of the segment (this rank's optimiser shard); all tensors are whole segments."""
     desc = ps.desc()
-    _lib.check(_lib.lib().snerf_adam_planes_step(C.byref(desc), _ptr(p_in), _ptr(p_out), _ptr(g), _ptr(m), _ptr(v), coefs[0], coefs[1], coefs[2],
-                                                 _ptr(losses) if losses is not None else None, REG_SLOTS if losses is not None else 0, lr, betas[0],
-                                                 betas[1], eps, step, grad_scale, int(zero_grad), _stream()), "adam_planes_step")
+    lo, hi = (0, ps.numel + 3 & ~3) if shard_range is None else shard_range
+    _lib.check(_lib.lib().snerf_adam_planes_step_range(C.byref(desc), _ptr(p_in), _ptr(p_out), _ptr(g), _ptr(m), _ptr(v), coefs[0], coefs[1], coefs[2],
+                                                       _ptr(losses) if losses is not None else None, REG_SLOTS if losses is not None else 0, lr,
+                                                       betas[0], betas[1], eps, step, grad_scale, int(zero_grad), int(lo), int(hi), _stream()),
+               "adam_planes_step")
 
 
 def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_plane: float = 0.0, training: bool = True):

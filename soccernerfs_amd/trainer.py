@@ -84,6 +84,10 @@ class KPlanesTrainer:
         self.cfg, self.R, self.dev = cfg, num_rays, torch.device(device)
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        # world > 1: reduce-scatter + sharded Adam + all-gather for the field planes instead of one all-reduce (see dist.py)
+        self.shard_optimizer = self.world > 1
+        self._rs_work = self._ar_work = self._ag_work = self._reg_work = None
         gen = torch.Generator().manual_seed(cfg.seed)
         a = cfg.aabb_scale
         self.aabb = [[-a, -a, -a], [a, a, a]]
@@ -110,7 +114,13 @@ class KPlanesTrainer:
                                 ("field.color", self.color_net, "params")):
             n = getattr(mod, attr).numel()
             self.segments.append((name, mod, attr, off, n))
-            off += _align4(n)
+            if name == "field.planes":
+                # padded so that the segment splits into `world` equal float4-aligned optimiser shards; the pad stays zero
+                q = 4 * self.world
+                self._field_seg = (off, n, (n + q - 1) // q * q)
+                off += self._field_seg[2]
+            else:
+                off += _align4(n)
         self.n_params = off
         self.params = torch.zeros(off, dtype=torch.float32, device=self.dev)
         self.grads = torch.zeros_like(self.params)
@@ -123,7 +133,11 @@ class KPlanesTrainer:
         self._repoint(self.params)
         # the regulariser-fused optimiser sweep reads neighbours of the OLD parameters: parameters ping-pong between two buffers
         self.fuse_reg_into_adam = True
-        self._params_alt = torch.empty_like(self.params)
+        self._params_alt = torch.zeros_like(self.params)
+        if self.world > 1:
+            shard = self._field_seg[2] // self.world
+            self._g_shard = torch.zeros(shard, dtype=torch.float32, device=self.dev)  # reduce-scatter output
+            self._p_shard = torch.zeros(shard, dtype=torch.float32, device=self.dev)  # all-gather input
         # ---- work buffers ----
         R = num_rays
         S0, S1 = cfg.num_proposal_samples_per_ray
@@ -270,6 +284,7 @@ class KPlanesTrainer:
                 self._mlp_fwd(self.prop_nets[lvl], b["pfeat"][lvl], cfg.proposal_feature_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
+                self._wait_params()
                 self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
                 if training and self.sorted_scatter and R == self.R:
                     # sort the nerf-level samples per (scale, plane) on a side stream.  Started AFTER the (memory-bound) gather so
@@ -382,7 +397,9 @@ class KPlanesTrainer:
         S2 = self.S[2]
         main = torch.cuda.current_stream()
         overlap = getattr(self, "overlap", True)
-        n_chunks = max(1, min(getattr(self, "bwd_chunks", 1), R)) if overlap else 1
+        sharded = self._sharded()  # the field-plane gradient leaves for the reduce-scatter as soon as it is complete, and the
+        #                            proposal backward runs AFTER it, under the collective
+        n_chunks = max(1, min(getattr(self, "bwd_chunks", 1), R)) if overlap and not sharded else 1
         side = self._streams(2 + min(n_chunks, 2))[:2 + min(n_chunks, 2)] if overlap else []
         if overlap:
             for st in side:
@@ -391,9 +408,10 @@ class KPlanesTrainer:
                 with KPlanesTrainer._On(self, side[0]):
                     self._reg_sweep()
             reg_done = side[0].record_event()
-            with KPlanesTrainer._On(self, side[1]):
-                side[1].wait_event(reg_done)  # proposal scatters add on top of the stored regulariser gradient
-                self._proposal_backward(proposal_grads)
+            if not sharded:
+                with KPlanesTrainer._On(self, side[1]):
+                    side[1].wait_event(reg_done)  # proposal scatters add on top of the stored regulariser gradient
+                    self._proposal_backward(proposal_grads)
         elif include_reg:
             self._reg_sweep()
         diff = b["rgb_out"] - target
@@ -407,6 +425,8 @@ class KPlanesTrainer:
                                               self._st), "weights_bwd")
         if not overlap:
             self._field_backward_chunk(0, R)
+            if sharded:
+                self._start_field_grad_exchange()
             self._proposal_backward(proposal_grads)
             return
         ready = main.record_event()
@@ -418,6 +438,14 @@ class KPlanesTrainer:
                     st.wait_event(ready)
                     st.wait_event(reg_done)
                 self._field_backward_chunk(bounds[i], bounds[i + 1])
+                if sharded:
+                    self._start_field_grad_exchange()
+        if sharded:
+            field_done = side[2].record_event()
+            with KPlanesTrainer._On(self, side[1]):
+                side[1].wait_event(field_done)
+                side[1].wait_event(reg_done)
+                self._proposal_backward(proposal_grads)
         for st in side:
             main.wait_stream(st)
 
@@ -425,6 +453,8 @@ class KPlanesTrainer:
         """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny
         reductions, only when asked for."""
         b, co, R = self.buf, self.cfg.loss_coefficients, self.R
+        if self._reg_work is not None:
+            self._reg_work.wait()  # sharded optimiser: the field planes' regulariser values are summed across ranks asynchronously
         d = dict(self.last)
         d["distortion_loss"] = b["dist_rays"].mean() * co["distortion_loss"]
         d["interlevel_loss"] = (b["inter_rays"][0].sum() + b["inter_rays"][1].sum()) / (R * self.S[2]) * co["interlevel_loss"]
@@ -435,6 +465,83 @@ class KPlanesTrainer:
         d["space_tv_proposal_loss"], d["time_smoothness_proposal_loss"], d["sparse_transients_proposal_loss"] = (
             pr[0] * co["space_tv_proposal_loss"], pr[1] * co["time_smoothness_proposal_loss"], pr[2] * co["sparse_transients_proposal_loss"])
         return d
+
+    # ---- world > 1: reduce-scatter -> sharded Adam -> all-gather for the field planes (dist.py) ----
+    def _sharded(self) -> bool:
+        return self.world > 1 and self.shard_optimizer and self.fuse_reg_into_adam
+
+    def _wait_params(self):
+        """The current stream waits for the all-gather of the previous step's new field planes (no host block)."""
+        if self._ag_work is not None:
+            self._ag_work.wait()
+            self._ag_work = None
+
+    def _start_field_grad_exchange(self):
+        """Called on the stream that produced the field-plane gradient, right after the scatter: reduce-scatter(SUM) of the padded
+        segment into this rank's shard buffer, asynchronous on RCCL's stream."""
+        from . import dist as sdist
+
+        o, _, npad = self._field_seg
+        with self._span("reduce_scatter.field"):
+            self._rs_work = sdist.reduce_scatter_sum(self._g_shard, self.grads[o:o + npad], self.pg, async_op=True)
+
+    def _sharded_optimizer_step(self):
+        """After backward() (all side streams joined): all-reduce of the small segments, Adam + regularisers on this rank's shard
+        of the field planes, all-gather of the new planes (left in flight: forward() waits for it before the field gather)."""
+        from . import dist as sdist
+
+        cfg, co = self.cfg, self.cfg.loss_coefficients
+        lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
+        gs = 1.0 / self.world
+        off = {name: (o, n) for name, _, _, o, n in self.segments}
+        o, n, npad = self._field_seg
+        shard = npad // self.world
+        lo = self.rank * shard
+        hi = min(lo + shard, _align4(n))
+        new = self._params_alt
+        # small segments: [prop0 planes | prop0 mlp | prop1 planes | prop1 mlp] before the field planes, [sigma | color] after them
+        with self._span("allreduce_grads"):
+            small = [self.grads[:o], self.grads[o + npad:]]
+            self._ar_work = [sdist.all_reduce_sum_(t, self.pg, async_op=True) for t in small if t.numel()]
+        if self._reg_work is not None:
+            self._reg_work.wait()  # last step's regulariser-value reduction still reads buf["reg"]
+        self.buf["reg"].zero_()
+        self._rs_work.wait()
+        self.grads[o + lo:o + lo + shard].copy_(self._g_shard)
+        with self._span("adam_planes.field"):
+            if hi > lo:
+                ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
+                                     self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
+                                     self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=False, shard_range=(lo, hi))
+        self._p_shard.copy_(new[o + lo:o + lo + shard])
+        with self._span("all_gather.field"):
+            self._ag_work = sdist.all_gather_shards(new[o:o + npad], self._p_shard, self.pg, async_op=True)
+        for w in self._ar_work:
+            w.wait()
+        for i in range(2):
+            name, ps = f"prop{i}.planes", self.prop_planes[i]
+            with self._span(f"adam_planes.prop{i}"):
+                ops.adam_planes_step(ps, self.views[name], new[off[name][0]:off[name][0] + off[name][1]], self.gviews[name], self.mviews[name],
+                                     self.vviews[name], tuple(co[k] for k in ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
+                                                                              "sparse_transients_proposal_loss")),
+                                     self.buf["reg"][1 + i], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs)
+        self._adam_mlps(new, off, lr, gs)
+        self.grads[o:o + npad].zero_()  # the shard kernel leaves the gradient alone: clear the whole segment for the next step
+        # regulariser VALUES of the field planes are per-shard partial sums: add them up across ranks (logging only)
+        self._reg_work = sdist.all_reduce_sum_(self.buf["reg"][0], self.pg, async_op=True)
+        self._params_alt = self.params
+        self._repoint(new)
+        self.step += 1
+
+    def _adam_mlps(self, new, off, lr, gs):
+        with self._span("adam_step.mlps"):
+            # MLP segments: prop0.mlp, prop1.mlp and the adjacent field.sigma + field.color
+            o0, n0 = off["field.sigma"]
+            o1, n1 = off["field.color"]
+            for o, n in (off["prop0.mlp"], off["prop1.mlp"], (o0, o1 + n1 - o0)):
+                n4 = (n + 3) // 4 * 4
+                ops.adam_step(self.params[o:o + n4], self.grads[o:o + n4], self.exp_avg[o:o + n4], self.exp_avg_sq[o:o + n4], self.step + 1, lr,
+                              eps=self.cfg.adam_eps, grad_scale=gs, zero_grad=True, p_out=new[o:o + n4])
 
     def allreduce_grads(self):
         """One all-reduce (SUM) over the flat gradient buffer; the mean (DDP semantics, base_pipeline.py:244-246) is folded
@@ -467,15 +574,7 @@ class KPlanesTrainer:
             with self._span("adam_planes." + name.split(".")[0]):
                 ops.adam_planes_step(ps, sl(self.params, name), sl(new, name), self.gviews[name], self.mviews[name], self.vviews[name],
                                      tuple(co[k] for k in keys), self.buf["reg"][row], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs)
-        with self._span("adam_step.mlps"):
-            # MLP segments: prop0.mlp, prop1.mlp and the adjacent field.sigma + field.color
-            o0, n0 = off["field.sigma"]
-            o1, n1 = off["field.color"]
-            ranges = [off["prop0.mlp"], off["prop1.mlp"], (o0, o1 + n1 - o0)]
-            for o, n in ranges:
-                n4 = (n + 3) // 4 * 4
-                ops.adam_step(self.params[o:o + n4], self.grads[o:o + n4], self.exp_avg[o:o + n4], self.exp_avg_sq[o:o + n4], self.step + 1, lr,
-                              eps=cfg.adam_eps, grad_scale=gs, zero_grad=True, p_out=new[o:o + n4])
+        self._adam_mlps(new, off, lr, gs)
         self._params_alt = self.params
         self._repoint(new)
         self.step += 1
@@ -504,8 +603,11 @@ class KPlanesTrainer:
         out = self.forward(rays, rng, anneal, training=True)
         fuse = self.fuse_reg_into_adam
         self.backward(target, rng, proposal_grads=updated, include_reg=not fuse)
-        self.allreduce_grads()
-        self.optimizer_step(fused_reg=fuse)
+        if self._sharded():
+            self._sharded_optimizer_step()
+        else:
+            self.allreduce_grads()
+            self.optimizer_step(fused_reg=fuse)
         if updated:
             self._steps_since_update = 0
         self._steps_since_update += 1  # step_cb (ray_samplers.py:554-557)

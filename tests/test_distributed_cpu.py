@@ -97,6 +97,44 @@ def test_two_rank_gradient_mean_equals_double_batch(tmp_path):
     torch.testing.assert_close(reduced, full, rtol=2e-4, atol=1e-7)
 
 
+def _shard_worker(rank, world, port, outdir):
+    """Reduce-scatter -> 'optimiser' on the shard -> all-gather must equal all-reduce -> optimiser on everything (dist.py)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from soccernerfs_amd import dist as sdist
+
+    _, _, pg = sdist.init_from_env(backend="gloo")
+    n = 4 * world * 37
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1) + rank
+    p = torch.linspace(-1, 1, n)
+    shard = torch.empty(n // world)
+    sdist.reduce_scatter_sum(shard, g, pg, async_op=True).wait()
+    lo = rank * (n // world)
+    new_shard = p[lo:lo + n // world] - 0.1 * shard / world  # an SGD step stands in for Adam
+    full = torch.empty(n)
+    sdist.all_gather_shards(full, new_shard.contiguous(), pg, async_op=True).wait()
+    ref_g = g.clone()
+    sdist.all_reduce_sum_(ref_g, pg, async_op=True).wait()
+    torch.save((full, p - 0.1 * ref_g / world), os.path.join(outdir, f"s{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_reduce_scatter_shard_all_gather_equals_all_reduce(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(rk, 2, port, str(tmp_path))) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    (f0, r0), (f1, r1) = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    assert torch.equal(f0, f1) and torch.equal(r0, r1)
+    torch.testing.assert_close(f0, r0, rtol=0, atol=0)
+
+
 def test_single_process_is_identity():
     from soccernerfs_amd import dist as sdist
 
