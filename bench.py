@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr after the timed run")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (debug / A-B)")
+    ap.add_argument("--start-step", type=int, default=0, help="pretend this many optimiser steps are done: >= 5000 gives the steady-state "
+                    "schedule (proposal networks updated every 5th step, kplanes.py:254-259) instead of the every-step schedule of early training")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
@@ -109,6 +111,7 @@ def main():
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
     if args.no_shard:
         trainer.shard_optimizer = False
+    trainer.step = args.start_step
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)
@@ -196,6 +199,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
+                       "schedule": "early training: proposal networks updated every step" if args.start_step < 10 else
+                                   f"from optimiser step {args.start_step} (proposal networks updated every {cfg.proposal_update_every}th step past step {cfg.proposal_warmup})",
                        "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
                        "parallelism": "single GPU" if world == 1 else (
                            f"ray-sharded x{world}; field-plane gradients: RCCL reduce-scatter -> Adam on a 1/{world} shard -> all-gather of the new "

@@ -164,6 +164,11 @@ class KPlanesTrainer:
         self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev)
         self._ss.desc = self.field_planes.desc()
         self._sort_done = None
+        # sorted scatter for the proposal planes too (opt-in; measured SLOWER at the preset: the planes are small enough that their
+        # atomics are served by L2 -- 0.5 M of 19 M requests reach memory -- while sorting 1.5 M samples x 6 planes costs ~0.6 ms)
+        self.sorted_scatter_proposals = False
+        self._ss_prop = None
+        self._sort_done_prop = [None, None]
         self.step = 0                 # completed optimiser steps
         self._steps_since_update = 0  # ProposalNetworkSampler bookkeeping (ray_samplers.py:546-557)
         self.last = {}
@@ -281,6 +286,16 @@ class KPlanesTrainer:
             N = R * self.S[lvl]
             if lvl < 2:
                 self._gather(self._desc_prop[lvl], self.prop_planes[lvl].planes, co, N, b["pfeat"][lvl])
+                self._sort_done_prop[lvl] = None
+                if training and self.sorted_scatter_proposals and R == self.R:
+                    if self._ss_prop is None:
+                        self._ss_prop = [ops.SortedScatter(self.prop_planes[l], R * self.S[l], self.dev) for l in range(2)]
+                    main = torch.cuda.current_stream()
+                    st = self._stream("sort")
+                    st.wait_stream(main)
+                    with KPlanesTrainer._On(self, st), self._span("kplanes_sort.prop"):
+                        self._ss_prop[lvl].sort(co, self._st)
+                    self._sort_done_prop[lvl] = st.record_event()
                 self._mlp_fwd(self.prop_nets[lvl], b["pfeat"][lvl], cfg.proposal_feature_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
@@ -290,7 +305,7 @@ class KPlanesTrainer:
                     # sort the nerf-level samples per (scale, plane) on a side stream.  Started AFTER the (memory-bound) gather so
                     # that it runs under the MFMA-bound MLP forward / backward that follow on the main stream.
                     main = torch.cuda.current_stream()
-                    (st,) = self._streams(5)[4:5]
+                    st = self._stream("sort")
                     st.wait_stream(main)
                     with KPlanesTrainer._On(self, st), self._span("kplanes_sort"):
                         self._ss.sort(co, self._st)
@@ -326,12 +341,14 @@ class KPlanesTrainer:
             self.tr._st = self.prev
             self.ctx.__exit__(*exc)
 
-    def _streams(self, n):
+    def _stream(self, role: str):
+        """Side stream by role, created on first use (so the common path holds main + "sort" + "prop" only: HIP multiplexes
+        streams onto GPU_MAX_HW_QUEUES = 4 hardware queues and chains sharing a queue do not overlap)."""
         if not hasattr(self, "_side"):
-            self._side = []
-        while len(self._side) < n:
-            self._side.append(torch.cuda.Stream(device=self.dev))
-        return self._side[:n]
+            self._side = {}
+        if role not in self._side:
+            self._side[role] = torch.cuda.Stream(device=self.dev)
+        return self._side[role]
 
     def _reg_sweep(self):
         """Plane regularisers: values + gradients in one sweep per plane set (kplanes.py:430-446).  The flat gradient buffer
@@ -384,7 +401,18 @@ class KPlanesTrainer:
                                                       self._p(b["gdens"][lvl]), 0, self._st), "weights_bwd")
                 self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
                               b["gpfeat"][lvl], cfg.proposal_feature_dim)
-                self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
+                if self.sorted_scatter_proposals and self._sort_done_prop[lvl] is not None:
+                    torch.cuda.current_stream().wait_event(self._sort_done_prop[lvl])
+                    ss = self._ss_prop[lvl]
+                    with self._span("kplanes_gradvec.prop"):
+                        _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.prop_planes[lvl].planes), C.byref(self._coords[lvl]),
+                                                                  C.c_int64(N), self._p(b["gpfeat"][lvl]), self._p(ss.gvec), self._st), "gradvec")
+                    with self._span("kplanes_scatter_sorted.prop"):
+                        _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                                                                         self._p(self.gviews[f"prop{lvl}.planes"]), self._st), "scatter_sorted")
+                else:
+                    self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl],
+                                  self.gviews[f"prop{lvl}.planes"])
 
     def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True):
         """Accumulates d(total loss)/d(params) into self.grads (which must be zero on entry: Adam clears it); fills
@@ -400,20 +428,30 @@ class KPlanesTrainer:
         sharded = self._sharded()  # the field-plane gradient leaves for the reduce-scatter as soon as it is complete, and the
         #                            proposal backward runs AFTER it, under the collective
         n_chunks = max(1, min(getattr(self, "bwd_chunks", 1), R)) if overlap and not sharded else 1
-        side = self._streams(2 + min(n_chunks, 2))[:2 + min(n_chunks, 2)] if overlap else []
-        if overlap:
-            for st in side:
+        joins = []
+        reg_done = None
+        if include_reg:
+            if overlap:
+                st = self._stream("reg")
                 st.wait_stream(main)
-            if include_reg:
-                with KPlanesTrainer._On(self, side[0]):
+                with KPlanesTrainer._On(self, st):
                     self._reg_sweep()
-            reg_done = side[0].record_event()
-            if not sharded:
-                with KPlanesTrainer._On(self, side[1]):
-                    side[1].wait_event(reg_done)  # proposal scatters add on top of the stored regulariser gradient
-                    self._proposal_backward(proposal_grads)
-        elif include_reg:
-            self._reg_sweep()
+                reg_done = st.record_event()  # every scatter adds on top of the STORED regulariser gradient
+                joins.append(st)
+            else:
+                self._reg_sweep()
+
+        def proposal_chain(after=None):
+            st = self._stream("prop")
+            st.wait_stream(main) if after is None else st.wait_event(after)
+            if reg_done is not None:
+                st.wait_event(reg_done)
+            with KPlanesTrainer._On(self, st):
+                self._proposal_backward(proposal_grads)
+            joins.append(st)
+
+        if overlap and not sharded:
+            proposal_chain()
         diff = b["rgb_out"] - target
         self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
         torch.mul(diff, 2.0 * co["rgb_loss"] / (3 * R), out=b["g_rgb_out"])
@@ -423,30 +461,30 @@ class KPlanesTrainer:
                                              self._p(b["gw"][2]), 1, self._st), "distortion")
         _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
                                               self._st), "weights_bwd")
-        if not overlap:
+        if reg_done is not None:
+            main.wait_event(reg_done)
+        if n_chunks == 1:
+            # the field chain stays on the caller's stream: every extra stream is one more HIP stream competing for the (four)
+            # hardware queues, and two chains that land on one queue serialise (seen in the rocprofv3 timeline, profiles/r01_kernels.md)
             self._field_backward_chunk(0, R)
             if sharded:
                 self._start_field_grad_exchange()
-            self._proposal_backward(proposal_grads)
-            return
-        ready = main.record_event()
-        bounds = [R * i // n_chunks for i in range(n_chunks + 1)]
-        for i in range(n_chunks):
-            st = side[2 + (i % (len(side) - 2))]
-            with KPlanesTrainer._On(self, st):
-                if i < len(side) - 2:
-                    st.wait_event(ready)
-                    st.wait_event(reg_done)
-                self._field_backward_chunk(bounds[i], bounds[i + 1])
-                if sharded:
-                    self._start_field_grad_exchange()
-        if sharded:
-            field_done = side[2].record_event()
-            with KPlanesTrainer._On(self, side[1]):
-                side[1].wait_event(field_done)
-                side[1].wait_event(reg_done)
+                if overlap:
+                    proposal_chain(after=main.record_event())
+            if not overlap:
                 self._proposal_backward(proposal_grads)
-        for st in side:
+        else:
+            ready = main.record_event()
+            bounds = [R * i // n_chunks for i in range(n_chunks + 1)]
+            chunk_streams = [self._stream("chunk0"), self._stream("chunk1")]
+            for i in range(n_chunks):
+                st = chunk_streams[i % 2]
+                if i < 2:
+                    st.wait_event(ready)
+                    joins.append(st)
+                with KPlanesTrainer._On(self, st):
+                    self._field_backward_chunk(bounds[i], bounds[i + 1])
+        for st in joins:
             main.wait_stream(st)
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
