@@ -345,6 +345,10 @@ int snerf_kplanes_gradvec(const snerf_kplanes_desc* desc, const float* planes, c
                           float* gvec, snerf_stream_t stream);
 int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
                                  float* grad_planes, snerf_stream_t stream);
+/* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
+ * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
+int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+                                        float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,7 @@ EXPORTS = [
     "snerf_adam_step",
     "snerf_adam_planes_step",
     "snerf_adam_planes_step_range",
+    "snerf_kplanes_scatter_sorted_scales",
     "snerf_raygen",
     "snerf_aabb_collide",
     "snerf_tgrid_encode_fwd",

@@ -195,16 +195,18 @@ __global__ __launch_bounds__(256) void gradvec_kernel(snerf_kplanes_desc d, cons
 template <int C, int NP>
 __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
                                                             const float4* __restrict__ sorted_rec, float* __restrict__ gplanes, int run,
-                                                            int64_t groups_per_seg) {
+                                                            int64_t groups_per_seg, int seg_begin) {
   constexpr int LPS = 2 * C;
-  constexpr int UNROLL = 4;
+  constexpr int UNROLL = 8;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t group = gid / LPS;
+  // LPS == 64: one lane group = one wave, so the group index (and everything derived from it) is wave-uniform; readfirstlane
+  // lets the compiler keep it in SGPRs and branch scalar
+  const int64_t group = LPS == 64 ? (int64_t)blockIdx.x * (blockDim.x / 64) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : gid / LPS;
   const int li = (int)(gid % LPS);
   const int half = li / C, ch = li % C;
-  const int seg = (int)(group / groups_per_seg);
+  const int seg = seg_begin + (int)(group / groups_per_seg);
   if (seg >= d.n_scales * NP) return;
-  const int64_t i0 = (group - (int64_t)seg * groups_per_seg) * run;
+  const int64_t i0 = (group - (int64_t)(seg - seg_begin) * groups_per_seg) * run;
   if (i0 >= N) return;
   const int cnt = (int)((N - i0) < run ? (N - i0) : run);
   const int s = seg / NP, q = seg % NP;
@@ -296,6 +298,12 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
   for (int rr = 0; rr < 2; ++rr)
     if (pend_val[rr] != 0.f) atomicAdd(gbase + (int64_t)pend_key[rr] * C, pend_val[rr]);
 }
+
+// Measured and dropped (profiles/r01_kernels.md): a per-wave LDS texel cache behind the register stage (64 direct-mapped texel
+// rows, tags in lanes) halves the atomic requests (8.4 M -> 4.5 M) but is no faster: with ds_add_f32 each LDS instruction costs
+// ~146 cycles (6x slower end to end), with read-add-write the LDS round trip per flush sits on the wave's critical path
+// (0.88-0.93 ms vs 0.80-0.86 ms).  Ablation of this kernel: 0.28 ms without gvec loads and atomics, 0.36 ms without atomics,
+// 0.86 ms complete -- the in-loop atomics are what it waits for.
 
 static int build_segs(const snerf_kplanes_desc* d, SegTable& st) {
   const int NP = d->n_coords == 4 ? 6 : 3;
@@ -393,12 +401,16 @@ static int launch_gradvec(const snerf_kplanes_desc* d, const float* planes, cons
   return 0;
 }
 template <int C, int NP>
-static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const float* gvec, const float4* sorted_n, float* gp, hipStream_t st) {
-  static const int run = [] { const char* e = getenv("SNERF_SORTED_RUN"); int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();
+static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const float* gvec, const float4* sorted_n, float* gp, int scale_begin,
+                                 int scale_end, hipStream_t st) {
+  static const int run = [] { const char* e = getenv("SNERF_SORTED_RUN"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
   const int64_t groups_per_seg = (N + run - 1) / run;
-  const int64_t threads = groups_per_seg * d->n_scales * NP * (2 * C);
-  hipLaunchKernelGGL((scatter_sorted_kernel<C, NP>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, *d, N, gvec, sorted_n, gp, run,
-                     groups_per_seg);
+  // the kernel stops at segment n_scales * NP: hand it a descriptor that ends at scale_end
+  snerf_kplanes_desc dd = *d;
+  dd.n_scales = scale_end;
+  const int64_t threads = groups_per_seg * (scale_end - scale_begin) * NP * (2 * C);
+  hipLaunchKernelGGL((scatter_sorted_kernel<C, NP>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, dd, N, gvec, sorted_n, gp, run,
+                     groups_per_seg, scale_begin * NP);
   SNERF_LAUNCH_CHECK("kplanes_scatter_sorted");
   return 0;
 }
@@ -425,12 +437,20 @@ extern "C" int snerf_kplanes_gradvec(const snerf_kplanes_desc* desc, const float
   DISPATCH2(launch_gradvec, desc, planes, coords, N, grad_out, gvec, (hipStream_t)stream);
 }
 
-extern "C" int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
-                                            float* grad_planes, snerf_stream_t stream) {
+extern "C" int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+                                                   float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
   snerf_coords dummy = {};
   int rc = check_desc(desc, &dummy, N);
   if (rc) return rc;
-  if (N == 0) return 0;
+  SNERF_REQUIRE(scale_begin >= 0 && scale_begin <= scale_end && scale_end <= desc->n_scales, "kplanes_scatter_sorted: scales [%d, %d) of %d",
+                scale_begin, scale_end, desc->n_scales);
+  if (N == 0 || scale_begin == scale_end) return 0;
   SNERF_REQUIRE(gvec && sorted_rec && grad_planes, "kplanes_scatter_sorted: null buffer");
-  DISPATCH2(launch_scatter_sorted, desc, N, gvec, reinterpret_cast<const float4*>(sorted_rec), grad_planes, (hipStream_t)stream);
+  DISPATCH2(launch_scatter_sorted, desc, N, gvec, reinterpret_cast<const float4*>(sorted_rec), grad_planes, scale_begin, scale_end, (hipStream_t)stream);
+}
+
+extern "C" int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+                                            float* grad_planes, snerf_stream_t stream) {
+  SNERF_REQUIRE(desc, "kplanes_scatter_sorted: null descriptor");
+  return snerf_kplanes_scatter_sorted_scales(desc, N, gvec, sorted_rec, grad_planes, 0, desc->n_scales, stream);
 }

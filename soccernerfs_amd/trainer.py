@@ -87,6 +87,13 @@ class KPlanesTrainer:
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         # world > 1: reduce-scatter + sharded Adam + all-gather for the field planes instead of one all-reduce (see dist.py)
         self.shard_optimizer = self.world > 1
+        # Two optional overlaps of the field planes' optimiser sweep, both measured at +1-2 % only (the sweep saturates HBM and slows
+        # whatever runs beside it) and therefore off: async_field_adam runs it on its own stream under the NEXT step's pixel draw /
+        # ray generation / proposal levels (forward() joins it before the field gather, synchronize() joins it for outside readers);
+        # adam_under_scatter sweeps the finest scale while the coarser scales are still being scattered.
+        self.async_field_adam = False
+        self.adam_under_scatter = False
+        self._field_adam_done = None
         self._rs_work = self._ar_work = self._ag_work = self._reg_work = None
         gen = torch.Generator().manual_seed(cfg.seed)
         a = cfg.aabb_scale
@@ -381,9 +388,18 @@ class KPlanesTrainer:
             with self._span("kplanes_gradvec.field"):
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
                                                           self._p(b["gfeat"]), self._p(ss.gvec), self._st), "gradvec")
+            ns = len(self.cfg.multiscale_res)
+            early = getattr(self, "_pipeline_adam", False) and ns > 1
             with self._span("kplanes_scatter_sorted.field"):
-                _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), self._p(ss.sorted_rec),
-                                                                 self._p(self.gviews["field.planes"]), self._st), "scatter_sorted")
+                # finest scale first: it holds ~3/4 of the plane parameters, so its optimiser sweep (HBM-bound) can start on a side
+                # stream while the other scales are still being scattered (atomic-bound)
+                if early:
+                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                                                                            self._p(self.gviews["field.planes"]), ns - 1, ns, self._st), "scatter_sorted")
+                    self._adam_field_range(self._finest_offset(), None, side=True)
+                _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                                                                        self._p(self.gviews["field.planes"]), 0, ns - 1 if early else ns, self._st),
+                           "scatter_sorted")
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
 
@@ -493,6 +509,8 @@ class KPlanesTrainer:
         b, co, R = self.buf, self.cfg.loss_coefficients, self.R
         if self._reg_work is not None:
             self._reg_work.wait()  # sharded optimiser: the field planes' regulariser values are summed across ranks asynchronously
+        if getattr(self, "_field_adam_done", None) is not None:
+            torch.cuda.current_stream().wait_event(self._field_adam_done)  # the regulariser values come out of the (async) optimiser sweep
         d = dict(self.last)
         d["distortion_loss"] = b["dist_rays"].mean() * co["distortion_loss"]
         d["interlevel_loss"] = (b["inter_rays"][0].sum() + b["inter_rays"][1].sum()) / (R * self.S[2]) * co["interlevel_loss"]
@@ -509,10 +527,20 @@ class KPlanesTrainer:
         return self.world > 1 and self.shard_optimizer and self.fuse_reg_into_adam
 
     def _wait_params(self):
-        """The current stream waits for the all-gather of the previous step's new field planes (no host block)."""
+        """The current stream waits until the field planes of the last optimiser step are complete: the all-gather (sharded
+        multi-GPU) or the sweep on the "adam" stream (async_field_adam).  No host block."""
         if self._ag_work is not None:
             self._ag_work.wait()
             self._ag_work = None
+        ev = getattr(self, "_field_adam_done", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._field_adam_done = None
+
+    def synchronize(self):
+        """Join every stream the trainer uses; call before reading parameters / Adam state from outside a train step."""
+        self._wait_params()
+        torch.cuda.synchronize(self.dev)
 
     def _start_field_grad_exchange(self):
         """Called on the stream that produced the field-plane gradient, right after the scatter: reduce-scatter(SUM) of the padded
@@ -581,6 +609,33 @@ class KPlanesTrainer:
                 ops.adam_step(self.params[o:o + n4], self.grads[o:o + n4], self.exp_avg[o:o + n4], self.exp_avg_sq[o:o + n4], self.step + 1, lr,
                               eps=self.cfg.adam_eps, grad_scale=gs, zero_grad=True, p_out=new[o:o + n4])
 
+    def _finest_offset(self) -> int:
+        """First float of the finest scale's planes inside the field-plane segment (planes are laid out scale-major)."""
+        return int(self._desc_field.off[len(self.cfg.multiscale_res) - 1][0])
+
+    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool):
+        """Fused Adam + regularisers over floats [lo, hi) of the field planes, old -> other half of the ping-pong pair.  side=True:
+        on the "adam" stream, ordered after everything issued so far on the current stream (the scatter of those planes)."""
+        cfg, co = self.cfg, self.cfg.loss_coefficients
+        lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
+        n4 = _align4(self.field_planes.numel)
+        rng_ = (lo, n4 if hi is None else hi)
+        o, n = next((o, n) for name, _, _, o, n in self.segments if name == "field.planes")
+        args = (self.field_planes, self.params[o:o + n], self._params_alt[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
+                self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
+                self.buf["reg"][0], self.step + 1, lr)
+        kw = dict(eps=cfg.adam_eps, grad_scale=getattr(self, "_grad_scale", 1.0), zero_grad=True, shard_range=rng_)
+        if not side:
+            with self._span("adam_planes.field"):
+                ops.adam_planes_step(*args, **kw)
+            return
+        cur = torch.cuda.current_stream()
+        st = self._stream("adam")
+        st.wait_stream(cur)
+        with KPlanesTrainer._On(self, st), self._span("adam_planes.field"):
+            ops.adam_planes_step(*args, **kw)
+        self._early_adam_hi = lo  # optimizer_step still owes [0, lo)
+
     def allreduce_grads(self):
         """One all-reduce (SUM) over the flat gradient buffer; the mean (DDP semantics, base_pipeline.py:244-246) is folded
         into Adam's grad_scale.  RCCL when the group's backend is nccl (GPU), gloo in the CPU tests."""
@@ -602,12 +657,26 @@ class KPlanesTrainer:
         # regularisers fused into the sweep: plane sets go through snerf_adam_planes_step (values land in buf["reg"]), the MLP
         # segments through the plain kernel; everything writes the OTHER parameter buffer, which then becomes live
         new = self._params_alt
-        self.buf["reg"].zero_()
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         sl = lambda t, name: t[off[name][0]:off[name][0] + off[name][1]]
-        sets = [("field.planes", self.field_planes, ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss"), 0)]
-        sets += [(f"prop{i}.planes", self.prop_planes[i], ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
-                                                           "sparse_transients_proposal_loss"), 1 + i) for i in range(2)]
+        early_hi = getattr(self, "_early_adam_hi", None)
+        self._early_adam_hi = None
+        async_field = getattr(self, "async_field_adam", False) and getattr(self, "overlap", True)
+        if early_hi is None:
+            if not getattr(self, "_reg_zeroed", False):
+                self.buf["reg"].zero_()
+            # async: the big sweep goes to the "adam" stream and is NOT joined here -- the next step's pixel draw, ray generation and
+            # proposal levels (which read only the small segments updated below) run under it; forward() joins before the field gather
+            self._adam_field_range(0, None, side=async_field)
+            self._early_adam_hi = None
+            if async_field:
+                self._field_adam_done = self._stream("adam").record_event()
+        else:  # the finest scale is already being swept on the "adam" stream (train_step pipelining): the coarser scales remain
+            self._adam_field_range(0, early_hi, side=False)
+            torch.cuda.current_stream().wait_stream(self._stream("adam"))
+        self._reg_zeroed = False
+        sets = [(f"prop{i}.planes", self.prop_planes[i], ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
+                                                          "sparse_transients_proposal_loss"), 1 + i) for i in range(2)]
         for name, ps, keys, row in sets:
             with self._span("adam_planes." + name.split(".")[0]):
                 ops.adam_planes_step(ps, sl(self.params, name), sl(new, name), self.gviews[name], self.mviews[name], self.vviews[name],
@@ -640,7 +709,15 @@ class KPlanesTrainer:
         rng = rng if rng is not None else self.random_draws()
         out = self.forward(rays, rng, anneal, training=True)
         fuse = self.fuse_reg_into_adam
+        # single GPU: no gradient exchange between scatter and optimiser, so the optimiser sweep of the finest scale overlaps the scatter
+        # of the coarser ones
+        self._pipeline_adam = (fuse and self.world == 1 and not self._sharded() and self.sorted_scatter and getattr(self, "overlap", True)
+                               and getattr(self, "adam_under_scatter", False))
+        if self._pipeline_adam:
+            self.buf["reg"].zero_()
+            self._reg_zeroed = True
         self.backward(target, rng, proposal_grads=updated, include_reg=not fuse)
+        self._pipeline_adam = False
         if self._sharded():
             self._sharded_optimizer_step()
         else:

@@ -110,8 +110,7 @@ def _worker_main():
     for k in range(n_steps):
         rays, target, rng = _batch(R, rank, k)
         tr.train_step(rays, target, rng)
-    tr._wait_params()
-    torch.cuda.synchronize()
+    tr.synchronize()
     reg = tr.loss_dict()
     torch.save({"segments": {name: tr.views[name].cpu() for name in tr.views}, "m": {name: tr.mviews[name].cpu() for name in tr.mviews},
                 "gmax": float(tr.grads.abs().max()), "space_tv": float(reg["space_tv_loss"]), "step": tr.step},
@@ -187,8 +186,7 @@ def test_sharded_step_through_rccl_world_size_one():
         tr._p_shard = torch.zeros(shard, device=DEV)
         for k in range(n_steps):
             tr.train_step(*_batch(R, 0, k)[:2], _batch(R, 0, k)[2])
-        tr._wait_params()
-        torch.cuda.synchronize()
+        tr.synchronize()
         got = {n: v.clone() for n, v in tr.views.items()}
         tv = float(tr.loss_dict()["space_tv_loss"])
     finally:
@@ -196,7 +194,7 @@ def test_sharded_step_through_rccl_world_size_one():
     ref = KPlanesTrainer(_small_cfg(), R, DEV)
     for k in range(n_steps):
         ref.train_step(*_batch(R, 0, k)[:2], _batch(R, 0, k)[2])
-    torch.cuda.synchronize()
+    ref.synchronize()
     for name in ref.views:
         bad = ((got[name] - ref.views[name]).abs() > 2e-4).float().mean()
         assert float(bad) < 2e-3, (name, float(bad))

@@ -37,3 +37,26 @@ for si, m in enumerate((1, 2, 4, 8, 16)):
         line += f" {fl/N:5.3f}/{uniq/N:5.3f}"
     print(line + "   (flushes per entry in sorted order with 64-entry chunks / distinct keys per entry)")
 print(f"total row-0 flushes {tot/1e6:.2f} M of {30*N/1e6:.2f} M entries")
+
+# ---- what an LDS texel cache per chunk of sorted entries could save: distinct (chunk, texel) pairs vs today's texel-row flushes ----
+print("texel-row updates per entry: today's run-length flushes (x2 texels x2 rows) vs distinct texels per chunk of K sorted entries")
+for K in (64, 256, 1024):
+    tot_now, tot_distinct = 0, 0
+    for si, m in enumerate((1, 2, 4, 8, 16)):
+        res = [64 * m, 64 * m, 64 * m, 100]
+        for q, (a, b) in enumerate(pairs):
+            xa, xb = rec[q, :, 1], rec[q, :, 2]
+            pa = (((xa + 1) / 2) * (res[a] - 1)).clamp(0, res[a] - 1).floor().long()
+            pb = (((xb + 1) / 2) * (res[b] - 1)).clamp(0, res[b] - 1).floor().long()
+            pa1, pb1 = (pa + 1).clamp(max=res[a] - 1), (pb + 1).clamp(max=res[b] - 1)
+            chunk = torch.arange(N, device=dev) // K
+            keys = torch.cat([(chunk * res[b] + y) * res[a] + x for x in (pa, pa1) for y in (pb, pb1)])
+            tot_distinct += torch.unique(keys).numel()
+            if K == 64:
+                key = pb * res[a] + pa
+                chg = (key[1:] != key[:-1])
+                starts = torch.zeros(N, dtype=torch.bool, device=dev); starts[::64] = True
+                tot_now += (int((chg | starts[1:]).sum()) + 1) * 4
+    if K == 64:
+        print(f"  today: {tot_now / 1e6:.2f} M texel-row flushes")
+    print(f"  chunk {K:5d}: {tot_distinct / 1e6:.2f} M distinct (chunk, texel) rows")
