@@ -67,40 +67,83 @@ constexpr int pick_ts() {
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// The MFMA helpers below read their operands in GROUPS of G k-steps, the next group's LDS reads issued before the current
+// group's MFMAs (register double buffer).  Written the obvious way -- read a, read b, mfma -- the compiler emits
+// ds_read / s_waitcnt lgkmcnt(0) / v_mfma per k-step: every MFMA waits a full LDS round trip and the matrix pipe sat 23 % busy
+// (rocprofv3: SQ_VALU_MFMA_BUSY_CYCLES vs kernel time, profiles/r01_kernels.md).
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) f(i);
+}
+
 // acc[m] (m = row blocks) += A[TS x K] (LDS, stride lda) * W[K x ..] (LDS, stride ldw), column block nt
-template <int MT>
-__device__ __forceinline__ void mma_cols(const float* As, int lda, int K, const float* Ws, int ldw, int nt, f32x4 (&acc)[MT], int lane) {
+template <int MT, int K>
+__device__ __forceinline__ void mma_cols(const float* As, int lda, const float* Ws, int ldw, int nt, f32x4 (&acc)[MT], int lane) {
+  constexpr int KS = K / 4, G = KS % 8 == 0 ? 8 : 4, NG = KS / G;
+  static_assert(KS % G == 0, "K must be a multiple of 16");
   const int lr = lane & 15, lk = lane >> 4;
   const float* wp = Ws + lk * ldw + nt * 16 + lr;
   const float* ap = As + lr * lda + lk;
-#pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const float b = wp[k0 * ldw];
+  float bq[2][G], aq[2][G][MT];
+  auto load = [&](int g, int buf) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = mfma4(ap[m * 16 * lda + k0], b, acc[m]);
+    for (int i = 0; i < G; ++i) {
+      const int k0 = (g * G + i) * 4;
+      bq[buf][i] = wp[k0 * ldw];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aq[buf][i][m] = ap[m * 16 * lda + k0];
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next group's reads ABOVE this group's MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma4(aq[g & 1][i][m], bq[g & 1][i], acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // one 16x16 block: rows mt*16.., cols nt*16..
-__device__ __forceinline__ void mma_one(const float* As, int lda, int K, const float* Ws, int ldw, int mt, int nt, f32x4& acc, int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  const float* wp = Ws + lk * ldw + nt * 16 + lr;
-  const float* ap = As + (mt * 16 + lr) * lda + lk;
-#pragma unroll 8
-  for (int k0 = 0; k0 < K; k0 += 4) acc = mfma4(ap[k0], wp[k0 * ldw], acc);
+template <int K>
+__device__ __forceinline__ void mma_one(const float* As, int lda, const float* Ws, int ldw, int mt, int nt, f32x4& acc, int lane) {
+  f32x4 a1[1] = {acc};
+  mma_cols<1, K>(As + mt * 16 * lda, lda, Ws, ldw, nt, a1, lane);
+  acc = a1[0];
 }
 
 // acc[m] += G[TS x K] (LDS) * W^T, i.e. B[k][n] = W[n][k]; output column block nt indexes W ROWS (dX = dZ * W^T)
-template <int MT>
-__device__ __forceinline__ void mma_cols_T(const float* Gs, int ldg, int K, const float* Ws, int ldw, int nt, f32x4 (&acc)[MT], int lane) {
+template <int MT, int K>
+__device__ __forceinline__ void mma_cols_T(const float* Gs, int ldg, const float* Ws, int ldw, int nt, f32x4 (&acc)[MT], int lane) {
+  constexpr int KS = K / 4, G = KS % 8 == 0 ? 8 : 4, NG = KS / G;
+  static_assert(KS % G == 0, "K must be a multiple of 16");
   const int lr = lane & 15, lk = lane >> 4;
   const float* wp = Ws + (nt * 16 + lr) * ldw + lk;
   const float* gp = Gs + lr * ldg + lk;
-#pragma unroll 4
-  for (int k0 = 0; k0 < K; k0 += 4) {
-    const float b = wp[k0];
+  float bq[2][G], aq[2][G][MT];
+  auto load = [&](int g, int buf) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = mfma4(gp[m * 16 * ldg + k0], b, acc[m]);
+    for (int i = 0; i < G; ++i) {
+      const int k0 = (g * G + i) * 4;
+      bq[buf][i] = wp[k0];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aq[buf][i][m] = gp[m * 16 * ldg + k0];
+    }
+  };
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next group's reads ABOVE this group's MFMAs (the scheduler sinks them otherwise)
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma4(aq[g & 1][i][m], bq[g & 1][i], acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -110,8 +153,12 @@ __device__ __forceinline__ void mma_outer(const float* As, int lda, const float*
   const int lr = lane & 15, lk = lane >> 4;
   const float* ap = As + lk * lda + it * 16 + lr;
   const float* gp = Gs + lk * ldg + nt * 16 + lr;
+  float aq[TS / 4], gq[TS / 4];
 #pragma unroll
-  for (int s0 = 0; s0 < TS; s0 += 4) acc = mfma4(ap[s0 * lda], gp[s0 * ldg], acc);
+  for (int i = 0; i < TS / 4; ++i) { aq[i] = ap[i * 4 * lda]; gq[i] = gp[i * 4 * ldg]; }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < TS / 4; ++i) acc = mfma4(aq[i], gq[i], acc);
 }
 
 __device__ __forceinline__ void store_block(float* Ys, int ldy, int mt, int nt, const f32x4& acc, bool relu, int lane) {
@@ -175,14 +222,14 @@ __device__ __forceinline__ void forward_hidden(float* smem, bool relu, int wave,
       for (int j = 0; j < (HT >= NW ? HT / NW : 1); ++j) {
         const int nt = wave + NW * j;
         f32x4 acc[MT] = {};
-        mma_cols<MT>(in, lda, K, Wl, P::LW0, nt, acc, lane);
+        if (l == 0) mma_cols<MT, D0P>(in, lda, Wl, P::LW0, nt, acc, lane); else mma_cols<MT, H>(in, lda, Wl, P::LW0, nt, acc, lane);
 #pragma unroll
         for (int m = 0; m < MT; ++m) store_block(out, P::LDH, m, nt, acc[m], relu, lane);
       }
     } else {  // H == 16: one column block, waves split the row blocks
       if (wave < MT) {
         f32x4 acc = {};
-        mma_one(in, lda, K, Wl, P::LW0, wave, 0, acc, lane);
+        if (l == 0) mma_one<D0P>(in, lda, Wl, P::LW0, wave, 0, acc, lane); else mma_one<H>(in, lda, Wl, P::LW0, wave, 0, acc, lane);
         store_block(out, P::LDH, wave, 0, acc, relu, lane);
       }
     }
@@ -221,7 +268,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_fwd_kernel(MlpArgs a, 
       const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc = {};
-        mma_one(act_last, P::LDH, H, smem + P::WO, P::LWO, mt, 0, acc, lane);
+        mma_one<H>(act_last, P::LDH, smem + P::WO, P::LWO, mt, 0, acc, lane);
         const int col = lane & 15;
         const int64_t row0 = n0 + mt * 16 + (lane >> 4) * 4;
 #pragma unroll
@@ -282,7 +329,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
       const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc = {};
-        mma_one(Alast, P::LDH, H, smem + P::WO, P::LWO, mt, 0, acc, lane);
+        mma_one<H>(Alast, P::LDH, smem + P::WO, P::LWO, mt, 0, acc, lane);
         const int col = lane & 15;
         const int rl0 = mt * 16 + (lane >> 4) * 4;
 #pragma unroll
@@ -315,7 +362,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
       for (int j = 0; j < NJ; ++j) {
         const int nt = wave + NW * j;
         f32x4 acc[MT] = {};
-        mma_cols_T<MT>(gzo, P::LDO, OUTP, smem + P::WO, P::LWO, nt, acc, lane);
+        mma_cols_T<MT, OUTP>(gzo, P::LDO, smem + P::WO, P::LWO, nt, acc, lane);
         const int col = nt * 16 + (lane & 15);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -330,7 +377,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
       }
     } else if (wave == 0) {
       f32x4 acc[MT] = {};
-      mma_cols_T<MT>(gzo, P::LDO, OUTP, smem + P::WO, P::LWO, 0, acc, lane);
+      mma_cols_T<MT, OUTP>(gzo, P::LDO, smem + P::WO, P::LWO, 0, acc, lane);
       const int col = lane & 15;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -353,7 +400,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
       }
       f32x4 acc2[NJ][MT] = {};
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) mma_cols_T<MT>(gz, P::LDH, H, smem + P::W1, P::LW0, wave + NW * j, acc2[j], lane);
+      for (int j = 0; j < NJ; ++j) mma_cols_T<MT, H>(gz, P::LDH, smem + P::W1, P::LW0, wave + NW * j, acc2[j], lane);
       __syncthreads();  // everyone finished reading gz
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -384,7 +431,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
         const int nt = wave + NW * j;
         if (nt < D0T) {
           f32x4 acc[MT] = {};
-          mma_cols_T<MT>(gz, P::LDH, H, smem + P::W0, P::LW0, nt, acc, lane);
+          mma_cols_T<MT, H>(gz, P::LDH, smem + P::W0, P::LW0, nt, acc, lane);
           const int col = nt * 16 + (lane & 15);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
