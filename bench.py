@@ -185,7 +185,12 @@ def main():
             "mlp_bwd.160x128x1": ("mfma", 3 * 2 * R * S2 * (F * cfg.sigma_net_hidden_dim + cfg.sigma_net_hidden_dim * 16), "mlp_bwd_kernel<160,128,1>: 3x forward flops (fp32 MFMA)"),
         }
         timed = {k: v for k, v in kt.items() if k in alg}
-        DOMINANT = max(timed, key=lambda k: timed[k][0] * timed[k][1])
+        per_step = lambda k: timed[k][0] * timed[k][1]
+        DOMINANT = max(timed, key=per_step)
+        # the optimiser sweep and the sorted scatter are within a few % of each other: on a near-tie report the sweep, whose
+        # algorithmic bytes are exact (PMC traffic = 1.01x) -- the scatter's SURVEY-convention bytes ignore run-length combining
+        if "adam_planes.field" in timed and per_step("adam_planes.field") >= 0.9 * per_step(DOMINANT):
+            DOMINANT = "adam_planes.field"
         bound, alg_bytes, kdesc = alg[DOMINANT]
         dom_ms = timed[DOMINANT][0]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
@@ -202,7 +207,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
-                       "schedule": "early training: proposal networks updated every step" if args.start_step < 10 else
+                       "schedule": "early training: proposal networks updated every 2nd step (every step for the first 10)" if args.start_step < 10 else
                                    f"from optimiser step {args.start_step} (proposal networks updated every {cfg.proposal_update_every}th step past step {cfg.proposal_warmup})",
                        "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
                        "parallelism": "single GPU" if world == 1 else (
@@ -212,7 +217,9 @@ def main():
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "algorithmic_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "launches_timed": timed[DOMINANT][1],
-                         "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT}},
+                         "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT},
+                         "other_kernels_frac": {k: round(alg[k][1] / (v[0] * 1e-3) / 1e9 / (HBM_PEAK_GBS if alg[k][0] == "hbm" else 157300.0), 3)
+                                                for k, v in timed.items() if k != DOMINANT}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -1,0 +1,63 @@
+#!/bin/bash
+# Run on the GPU box from the repo root: bench line, rocprofv3 kernel stats and the three PMC passes for the judged profiles.
+# usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>_*)
+set -u
+TAG=${1:-r01}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --no-cpu-baseline --start-step 6000 > $OUT/${TAG}_bench_steady.json 2>> $OUT/${TAG}_bench.err
+python bench.py --no-cpu-baseline --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+for C in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --images 38 > /dev/null 2>&1
+done
+cd $ROOT
+python - <<PY
+import csv, glob, collections, json
+tag = "$TAG"
+out = "gpurun_out"
+# kernel stats
+f = glob.glob(f"{out}/{tag}_stats/**/*kernel_stats.csv", recursive=True)
+if f:
+    rows = list(csv.reader(open(f[0])))
+    with open(f"{out}/{tag}_kernel_stats.csv", "w") as g:
+        g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline\n")
+        csv.writer(g).writerows(rows[:45])
+# pmc
+acc = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum"):
+    f = glob.glob(f"{out}/{tag}_pmc_{c}/**/*counter_collection.csv", recursive=True)
+    if not f:
+        continue
+    tmp = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == c:
+            tmp[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+    for k, v in tmp.items():
+        acc[k][c] = sum(v) / len(v)
+with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
+    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --images 38  (one counter per pass)\n")
+    g.write("# mean per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE reads 1/2 of a coalesced stream -> traffic = 2*FETCH + WRITE)\n")
+    g.write("kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,TCC_EA0_ATOMIC_requests,traffic_bytes\n")
+    for k, v in sorted(acc.items(), key=lambda kv: -(2 * kv[1].get("FETCH_SIZE", 0) + kv[1].get("WRITE_SIZE", 0))):
+        if "snerf" not in k:
+            continue
+        tr = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
+        g.write(f'"{k}",{v.get("FETCH_SIZE", 0):.1f},{v.get("WRITE_SIZE", 0):.1f},{v.get("TCC_EA0_ATOMIC_sum", 0):.1f},{tr:.0f}\n')
+names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_sorted_kernel<32, 6>",
+         "kplanes_gradvec.field": "snerf::gradvec_kernel<32, 6>", "kplanes_gather_fwd.field": "snerf::kplanes_gather_fwd_kernel<32, 6>",
+         "mlp_bwd.160x128x1": "snerf::mlp_bwd_kernel<160, 128, 1, 32>"}
+tj = {"_note": "traffic_bytes_per_launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->B) from separate rocprofv3 --pmc passes, k-planes preset, 4096 rays "
+               f"(profiles/{tag}_pmc_counters.csv)"}
+for span, k in names.items():
+    if k in acc:
+        v = acc[k]
+        tj[span] = {"kernel": k, "traffic_bytes_per_launch": (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024,
+                    "atomic_requests": v.get("TCC_EA0_ATOMIC_sum", 0)}
+json.dump(tj, open(f"{out}/{tag}_pmc_traffic.json", "w"), indent=1)
+PY
+rm -rf $OUT/${TAG}_stats $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE $OUT/${TAG}_pmc_TCC_EA0_ATOMIC_sum
+ls -la $OUT | grep $TAG
