@@ -31,6 +31,15 @@ struct RegArgs {
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ldnt4(const float* p) {
+  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void stnt4(float* p, float4 v) {
+  nt_f4 w = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(w, reinterpret_cast<nt_f4*>(p));
+}
 __device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
@@ -107,7 +116,9 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
     }
     if (ADAM) {
       const int64_t o = a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
-      float4 gg = ld4(a.grad + o), mm = ld4(a.m + o), vv = ld4(a.v + o), pp = t;
+      // g, m, v are touched exactly once per step: stream them past the caches (nontemporal) so that L2 keeps the parameter lines
+      // the neighbouring lanes re-read for the regulariser stencil
+      float4 gg = ldnt4(a.grad + o), mm = ldnt4(a.m + o), vv = ldnt4(a.v + o), pp = t;
       float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* RG = &g.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -116,10 +127,10 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
         V[k] = a.b2 * V[k] + (1.f - a.b2) * gk * gk;
         P[k] = P[k] - a.step_size * (M[k] / (sqrtf(V[k]) * a.inv_sqrt_bc2 + a.eps));
       }
-      *reinterpret_cast<float4*>(a.p_out + o) = pp;
-      *reinterpret_cast<float4*>(a.m + o) = mm;
-      *reinterpret_cast<float4*>(a.v + o) = vv;
-      if (a.zero_grad) *reinterpret_cast<float4*>(a.grad + o) = make_float4(0.f, 0.f, 0.f, 0.f);
+      stnt4(a.p_out + o, pp);
+      stnt4(a.m + o, mm);
+      stnt4(a.v + o, vv);
+      if (a.zero_grad) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
     } else if (a.grad) {
       float* gp = a.grad + a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
       if (a.overwrite) {
