@@ -126,12 +126,10 @@ def main():
     data = synthetic.render_dataset(cams, times, train_cams, dev, chunk_rows=540)
     images = data["images"]
     M, H, W = images.shape[:3]
-    scale = torch.tensor([M, H, W], dtype=torch.float32, device=dev)
 
     def one_step():
         # uniform pixel sampler (PixelSampler.sample_method, NS/data/pixel_samplers.py:74-77) + image gather (:111-123)
-        idx = torch.floor(torch.rand(R, 3, device=dev) * scale).long()
-        target = images[idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
+        idx, target = ops.sample_pixels_uniform(torch.rand(R, 3, device=dev), M, H, W, images)
         rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=trainer.aabb,
                                  near_plane=cfg.near_plane, training=True)
         return trainer.train_step(rays, target)

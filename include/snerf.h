@@ -197,6 +197,12 @@ int snerf_render_bwd(const float* weights, const float* rgb, const float* bg, in
                      const float* g_acc, int32_t R, int32_t S, float* g_weights, float* g_rgb, int32_t accumulate_w,
                      snerf_stream_t stream);
 
+/* snerf_render_bwd with the image loss folded in (MSELoss, NS/models/kplanes.py:291,418): g_rgb_out = go_scale * (rgb_out - target)
+ * is formed inside the kernel (go_scale = 2 * coefficient / (3 R) for the mean over R x 3 elements); sqerr_rays[R] (may be NULL)
+ * receives sum_c (rgb_out - target)^2 so that the loss VALUE is one small reduction when somebody asks for it. */
+int snerf_render_mse_bwd(const float* weights, const float* rgb, const float* bg, int32_t bg_mode, const float* rgb_out, const float* target,
+                         float go_scale, int32_t R, int32_t S, float* g_weights, float* g_rgb, float* sqerr_rays, snerf_stream_t stream);
+
 /* lossfun_distortion per ray (NS/model_components/losses.py:125-136): loss_rays[R] (may be NULL) and, if g_weights != NULL,
  * g_weights (+)= grad_scale * d loss_r / d w.  The caller supplies grad_scale = coefficient / R (mean over rays, :143). */
 int snerf_distortion(const float* weights, const float* sbins, int32_t R, int32_t S, float grad_scale, float* loss_rays,
@@ -269,6 +275,12 @@ typedef struct {
   float* fars;             /* [R] */
 } snerf_raygen_args;
 int snerf_raygen(const snerf_raygen_args* args, snerf_stream_t stream);
+
+/* PixelSampler.sample_method (NS/data/pixel_samplers.py:74-77): indices[R,3] = floor(u[R,3] * (M,H,W)) as int64 (image, row, col), fused
+ * with collate_image_dataset_batch's gather (:111-123): target[R,3] = images[c,y,x,:] / 255 for a resident uint8 image cache
+ * [M,H,W,3] (images may be NULL: indices only). */
+int snerf_sample_pixels_uniform(const float* u, int32_t R, int32_t M, int32_t H, int32_t W, const uint8_t* images, int64_t* indices,
+                                float* target, snerf_stream_t stream);
 
 /* AABBBoxCollider alone: aabb6 = HOST pointer to {min x,y,z, max x,y,z}. */
 int snerf_aabb_collide(const float* origins, const float* dirs, int32_t R, const float* aabb6, float near_plane, int32_t training,

@@ -70,6 +70,24 @@ __global__ void raygen_kernel(RaygenArgs a) {
   }
 }
 
+// PixelSampler.sample_method (NS/data/pixel_samplers.py:74-77: floor(rand(R,3) * [M,H,W]).long()) fused with the image gather of
+// collate_image_dataset_batch (:111-123): one lane per ray instead of seven elementwise / index launches
+__global__ void sample_pixels_kernel(const float* __restrict__ u, int R, int M, int H, int W, const uint8_t* __restrict__ images,
+                                     int64_t* __restrict__ indices, float* __restrict__ target) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  // rand < 1 so the products stay below M, H, W except for the fp32 rounding of u * n at u -> 1: clamp like an index would fault otherwise
+  int64_t c = (int64_t)floorf(u[(int64_t)r * 3] * (float)M), y = (int64_t)floorf(u[(int64_t)r * 3 + 1] * (float)H),
+          x = (int64_t)floorf(u[(int64_t)r * 3 + 2] * (float)W);
+  c = c < M ? c : M - 1; y = y < H ? y : H - 1; x = x < W ? x : W - 1;
+  indices[(int64_t)r * 3] = c; indices[(int64_t)r * 3 + 1] = y; indices[(int64_t)r * 3 + 2] = x;
+  if (images) {
+    const uint8_t* px = images + (((int64_t)c * H + y) * W + x) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) target[(int64_t)r * 3 + k] = (float)px[k] / 255.0f;  // uint8 -> float32 / 255 (NS/data/datasets/base_dataset.py:82)
+  }
+}
+
 __global__ void aabb_kernel(const float* __restrict__ o, const float* __restrict__ d, int R, float near_plane, int training, const float* amin3,
                             float* __restrict__ nears, float* __restrict__ fars, float a0, float a1, float a2, float b0, float b1, float b2) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -107,6 +125,16 @@ extern "C" int snerf_raygen(const snerf_raygen_args* p, snerf_stream_t stream) {
   a.nears = p->nears; a.fars = p->fars;
   hipLaunchKernelGGL(raygen_kernel, dim3(ceil_div(p->R, 256)), dim3(256), 0, (hipStream_t)stream, a);
   SNERF_LAUNCH_CHECK("raygen");
+  return 0;
+}
+
+extern "C" int snerf_sample_pixels_uniform(const float* u, int32_t R, int32_t M, int32_t H, int32_t W, const uint8_t* images, int64_t* indices,
+                                           float* target, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && M >= 1 && H >= 1 && W >= 1, "sample_pixels_uniform: R=%d M=%d H=%d W=%d", R, M, H, W);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(u && indices && (!images || target), "sample_pixels_uniform: null buffer");
+  hipLaunchKernelGGL(sample_pixels_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, u, R, M, H, W, images, indices, target);
+  SNERF_LAUNCH_CHECK("sample_pixels_uniform");
   return 0;
 }
 

@@ -114,6 +114,27 @@ __global__ void render_bwd_kernel(const float* __restrict__ weights, const float
   if (g_rgb) { g_rgb[gid * 3] = go0 * w; g_rgb[gid * 3 + 1] = go1 * w; g_rgb[gid * 3 + 2] = go2 * w; }
 }
 
+// render backward with the MSE image loss folded in: g_rgb_out = go_scale * (rgb_out - target) is formed per lane instead of by four
+// elementwise launches (sub, square-mean, scale); sqerr_rays[r] = sum_c (rgb_out - target)^2 for the (lazy) loss value
+__global__ void render_mse_bwd_kernel(const float* __restrict__ weights, const float* __restrict__ rgb, const float* __restrict__ bg, int bg_mode,
+                                      const float* __restrict__ rgb_out, const float* __restrict__ target, float go_scale, int R, int S,
+                                      float* __restrict__ g_weights, float* __restrict__ g_rgb, float* __restrict__ sqerr_rays) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (int64_t)R * S) return;
+  int r = (int)(gid / S);
+  const float d0 = rgb_out[(int64_t)r * 3] - target[(int64_t)r * 3], d1 = rgb_out[(int64_t)r * 3 + 1] - target[(int64_t)r * 3 + 1],
+              d2 = rgb_out[(int64_t)r * 3 + 2] - target[(int64_t)r * 3 + 2];
+  if (sqerr_rays && gid == (int64_t)r * S) sqerr_rays[r] = (d0 * d0 + d1 * d1) + d2 * d2;
+  const float go0 = d0 * go_scale, go1 = d1 * go_scale, go2 = d2 * go_scale;
+  float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  if (bg_mode == 0) { b0 = bg[(int64_t)r * 3]; b1 = bg[(int64_t)r * 3 + 1]; b2 = bg[(int64_t)r * 3 + 2]; }
+  else if (bg_mode == 2) { b0 = bg[0]; b1 = bg[1]; b2 = bg[2]; }
+  const float* c = rgb + gid * 3;
+  const float w = weights[gid];
+  g_weights[gid] = go0 * (c[0] - b0) + go1 * (c[1] - b1) + go2 * (c[2] - b2);
+  if (g_rgb) { g_rgb[gid * 3] = go0 * w; g_rgb[gid * 3 + 1] = go1 * w; g_rgb[gid * 3 + 2] = go2 * w; }
+}
+
 // ------------------------------------------------------------------------------------------------
 // distortion loss (per-ray value + gradient w.r.t. weights)
 //   L_r = sum_i w_i sum_j w_j |m_i - m_j| + (1/3) sum_i w_i^2 (t_{i+1} - t_i),  m = bin midpoints
@@ -245,6 +266,19 @@ extern "C" int snerf_render_bwd(const float* weights, const float* rgb, const fl
   hipLaunchKernelGGL(render_bwd_kernel, dim3(ceil_div((int64_t)R * S, 256)), dim3(256), 0, (hipStream_t)stream, weights, rgb, bg, bg_mode,
                      g_rgb_out, g_acc, R, S, g_weights, g_rgb, accumulate_w);
   SNERF_LAUNCH_CHECK("render_bwd");
+  return 0;
+}
+
+extern "C" int snerf_render_mse_bwd(const float* weights, const float* rgb, const float* bg, int32_t bg_mode, const float* rgb_out,
+                                    const float* target, float go_scale, int32_t R, int32_t S, float* g_weights, float* g_rgb, float* sqerr_rays,
+                                    snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && S >= 1, "render_mse_bwd: R=%d S=%d", R, S);
+  SNERF_REQUIRE(bg_mode == 0 || bg_mode == 2, "render_mse_bwd: bg_mode %d has no training backward", bg_mode);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(weights && rgb && bg && rgb_out && target && g_weights, "render_mse_bwd: null buffer");
+  hipLaunchKernelGGL(render_mse_bwd_kernel, dim3(ceil_div((int64_t)R * S, 256)), dim3(256), 0, (hipStream_t)stream, weights, rgb, bg, bg_mode,
+                     rgb_out, target, go_scale, R, S, g_weights, g_rgb, sqerr_rays);
+  SNERF_LAUNCH_CHECK("render_mse_bwd");
   return 0;
 }
 

@@ -2,6 +2,8 @@
 on caller-allocated torch tensors (device memory plumbing only -- the kernels are in csrc/)."""
 import ctypes as C
 
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -438,6 +440,22 @@ def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_
     _lib.check(_lib.lib().snerf_raygen(C.byref(a), _stream()), "raygen")
     out["camera_indices"] = indices[:, 0:1]
     return out
+
+
+def sample_pixels_uniform(u: torch.Tensor, num_images: int, height: int, width: int, images: Optional[torch.Tensor] = None):
+    """PixelSampler.sample_method's uniform draw (pixel_samplers.py:74-77) from u = rand(R,3), fused with the image gather of
+    collate_image_dataset_batch (:111-123) when the uint8 image cache [M,H,W,3] is given.  Returns (indices int64 [R,3], target fp32 [R,3] | None)."""
+    u = _f32c(u, "u")
+    R = u.shape[0]
+    idx = torch.empty(R, 3, dtype=torch.int64, device=u.device)
+    target = None
+    if images is not None:
+        if not images.is_cuda or images.dtype != torch.uint8 or not images.is_contiguous() or tuple(images.shape) != (num_images, height, width, 3):
+            raise RuntimeError("sample_pixels_uniform: images must be a contiguous uint8 HIP tensor [M,H,W,3]")
+        target = torch.empty(R, 3, dtype=torch.float32, device=u.device)
+    _lib.check(_lib.lib().snerf_sample_pixels_uniform(_ptr(u), R, num_images, height, width, _ptr(images) if images is not None else None, _ptr(idx),
+                                                      _ptr(target) if target is not None else None, _stream()), "sample_pixels_uniform")
+    return idx, target
 
 
 def aabb_collide(origins, directions, aabb, near_plane: float = 0.0, training: bool = True):

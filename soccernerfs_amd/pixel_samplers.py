@@ -48,8 +48,8 @@ class PixelSampler:
     def sample_method(self, batch_size: int, num_images: int, image_height: int, image_width: int, mask=None, batch=None, device="cuda"):
         if mask is not None:
             raise NotImplementedError("masked sampling is not used by the soccer datasets")
-        scale = torch.tensor([num_images, image_height, image_width], device=device)
-        return torch.floor(torch.rand((batch_size, 3), device=device) * scale).long()  # :74-77
+        # :74-77 floor(rand(R,3) * [M,H,W]).long(), one kernel
+        return ops.sample_pixels_uniform(torch.rand((batch_size, 3), device=device), num_images, image_height, image_width)[0]
 
     def collate_image_dataset_batch(self, batch: Dict, num_rays_per_batch: int, keep_full_image: bool = False):
         """:81-128: batch["image"] [M,H,W,3] (uint8 or float), batch["image_idx"] [M]."""

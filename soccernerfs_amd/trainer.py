@@ -162,7 +162,7 @@ class KPlanesTrainer:
             "h": f(R * S2, 16), "gh": torch.zeros(R * S2, 16, dtype=torch.float32, device=self.dev),
             "rgb": f(R * S2, 3), "grgb": f(R * S2, 3),
             "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "g_rgb_out": f(R, 3),
-            "dist_rays": f(R), "inter_rays": [f(R), f(R)],
+            "dist_rays": f(R), "inter_rays": [f(R), f(R)], "sqerr": torch.zeros(R, dtype=torch.float32, device=self.dev),
             "reg": torch.zeros(3, ops.REG_SLOTS, 16, dtype=torch.float32, device=self.dev),  # [field|prop0|prop1][slot][16]
         }
         self._timing, self._timing_all = None, False
@@ -468,11 +468,12 @@ class KPlanesTrainer:
 
         if overlap and not sharded:
             proposal_chain()
-        diff = b["rgb_out"] - target
-        self.last = {"rgb_loss": (diff * diff).mean() * co["rgb_loss"]}  # MSELoss (kplanes.py:418)
-        torch.mul(diff, 2.0 * co["rgb_loss"] / (3 * R), out=b["g_rgb_out"])
-        _lib.check(self.lib.snerf_render_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["g_rgb_out"]), None, R, S2,
-                                             self._p(b["gw"][2]), self._p(b["grgb"]), 0, self._st), "render_bwd")
+        # MSELoss (kplanes.py:418) folded into the render backward: g_rgb_out = 2 c / (3R) * (rgb_out - target); value lazily from sqerr
+        target = target if target.is_contiguous() else target.contiguous()
+        self.last = {}
+        _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
+                                                 2.0 * co["rgb_loss"] / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]),
+                                                 self._st), "render_mse_bwd")
         _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, co["distortion_loss"] / R, self._p(b["dist_rays"]),
                                              self._p(b["gw"][2]), 1, self._st), "distortion")
         _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
@@ -512,6 +513,7 @@ class KPlanesTrainer:
         if getattr(self, "_field_adam_done", None) is not None:
             torch.cuda.current_stream().wait_event(self._field_adam_done)  # the regulariser values come out of the (async) optimiser sweep
         d = dict(self.last)
+        d["rgb_loss"] = b["sqerr"].sum() / (3 * R) * co["rgb_loss"]
         d["distortion_loss"] = b["dist_rays"].mean() * co["distortion_loss"]
         d["interlevel_loss"] = (b["inter_rays"][0].sum() + b["inter_rays"][1].sum()) / (R * self.S[2]) * co["interlevel_loss"]
         reg = b["reg"][:, :, :3].sum(1)  # [3 plane sets, 3 terms]

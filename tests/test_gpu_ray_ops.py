@@ -134,3 +134,23 @@ def test_ray_ops_argument_errors():
         ops.spaced_bins(nears, nears + 1, 8, torch.zeros(4, 5, device=DEV))
     with pytest.raises(RuntimeError, match="S"):
         ops.get_weights(torch.zeros(2, 400, device=DEV), torch.zeros(2, 401, device=DEV))
+
+
+def test_sample_pixels_uniform_matches_torch_expression():
+    """PixelSampler.sample_method (pixel_samplers.py:74-77) + the image gather of collate_image_dataset_batch (:111-123), fused."""
+    from soccernerfs_amd import ops
+
+    gen = torch.Generator().manual_seed(8)
+    M, H, W, R = 7, 33, 50, 5000
+    u = torch.rand(R, 3, generator=gen)
+    u[0], u[1] = 0.0, 1.0 - 2.0**-24  # both ends of [0, 1)
+    images = torch.randint(0, 256, (M, H, W, 3), generator=gen, dtype=torch.uint8)
+    want = torch.floor(u * torch.tensor([M, H, W])).long()
+    want_t = images[want[:, 0], want[:, 1], want[:, 2]].float() / 255.0
+    idx, tgt = ops.sample_pixels_uniform(u.to("cuda:0"), M, H, W, images.to("cuda:0"))
+    assert idx.dtype == torch.int64 and torch.equal(idx.cpu(), want)
+    assert torch.equal(tgt.cpu(), want_t)
+    idx2, none = ops.sample_pixels_uniform(u.to("cuda:0"), M, H, W)
+    assert none is None and torch.equal(idx2, idx)
+    with pytest.raises(RuntimeError):
+        ops.sample_pixels_uniform(u.to("cuda:0"), M, H, W, images.to("cuda:0").float())

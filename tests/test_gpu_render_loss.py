@@ -151,3 +151,28 @@ def test_raygen_and_collider_golden():
     n, f = ops.aabb_collide(out["origins"], out["directions"], c["aabb"], 0.05, True)
     close(out["nears"], n, rtol=0, atol=0)
     close(out["fars"], f, rtol=0, atol=0)
+
+
+def test_render_mse_bwd_equals_render_bwd_of_mse_gradient():
+    """snerf_render_mse_bwd == snerf_render_bwd fed with 2c/(3R) (rgb_out - target), plus the per-ray squared error."""
+    import ctypes as C
+    from soccernerfs_amd import _lib, ops
+
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(12)
+    R, S, coef = 77, 48, 0.7
+    w = torch.rand(R, S, generator=gen).to(dev)
+    rgb = torch.rand(R, S, 3, generator=gen).to(dev)
+    bg = torch.rand(R, 3, generator=gen).to(dev)
+    out = torch.rand(R, 3, generator=gen).to(dev)
+    target = torch.rand(R, 3, generator=gen).to(dev)
+    go = (out - target) * (2 * coef / (3 * R))
+    gw_ref, grgb_ref = torch.empty_like(w), torch.empty_like(rgb)
+    L, p = _lib.lib(), ops._ptr
+    _lib.check(L.snerf_render_bwd(p(w), p(rgb), p(bg), 0, p(go), None, R, S, p(gw_ref), p(grgb_ref), 0, ops._stream()))
+    gw, grgb, sq = torch.empty_like(w), torch.empty_like(rgb), torch.empty(R, device=dev)
+    _lib.check(L.snerf_render_mse_bwd(p(w), p(rgb), p(bg), 0, p(out), p(target), 2 * coef / (3 * R), R, S, p(gw), p(grgb), p(sq), ops._stream()))
+    torch.testing.assert_close(gw, gw_ref, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(grgb, grgb_ref, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(sq, ((out - target) ** 2).sum(-1), rtol=1e-6, atol=0)
+    torch.testing.assert_close(sq.sum() / (3 * R) * coef, torch.nn.functional.mse_loss(out, target) * coef, rtol=1e-5, atol=0)
