@@ -31,24 +31,43 @@ def channel_table(temporal_dim: int, level_dim: int):
 
 
 class _Encode(torch.autograd.Function):
+    """Encoder forward/backward.  Optionally carries the temporal-TV term of the same table (columns tv_a, tv_b) as a second output,
+    so that the table receives ONE gradient tensor per step: as separate autograd nodes the two column slices cost two dense
+    zero-filled [rows, 66] tensors plus the adds that merge them with the scatter gradient (2.9 ms of a 12 ms step on the 1.54 GB
+    table, profiles/r01_kernels.md)."""
+
     @staticmethod
-    def forward(ctx, embeddings, enc, coords_keep, coords, trow, times, spr, B):
+    def forward(ctx, embeddings, enc, coords_keep, coords, trow, times, spr, B, tv_a, tv_b):
         out = torch.empty(B, enc.output_dim, dtype=torch.float32, device=embeddings.device)
         _lib.check(_lib.lib().snerf_tgrid_encode_fwd(C.byref(enc.desc), ops._ptr(embeddings), C.byref(coords),
                                                      ops._ptr(trow) if trow is not None else None, ops._ptr(times) if times is not None else None,
                                                      spr, C.c_int64(B), ops._ptr(out), ops._stream()), "tgrid_encode_fwd")
         ctx.enc, ctx.coords, ctx.keep, ctx.trow, ctx.times, ctx.spr, ctx.B = enc, coords, coords_keep, trow, times, spr, B
-        ctx.shape = embeddings.shape
-        return out
+        ctx.shape, ctx.tv = embeddings.shape, None
+        if tv_a is None:
+            return out, None
+        diff = embeddings[:, tv_a] - embeddings[:, tv_b]
+        ctx.tv = (tv_a, tv_b, torch.sign(diff))
+        return out, diff.abs().mean()
 
     @staticmethod
-    def backward(ctx, g):
-        g = g.contiguous()
-        gemb = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        _lib.check(_lib.lib().snerf_tgrid_encode_bwd(C.byref(ctx.enc.desc), C.byref(ctx.coords), ops._ptr(ctx.trow) if ctx.trow is not None else None,
-                                                     ops._ptr(ctx.times) if ctx.times is not None else None, ctx.spr, C.c_int64(ctx.B), ops._ptr(g),
-                                                     ops._ptr(gemb), ops._stream()), "tgrid_encode_bwd")
-        return gemb, None, None, None, None, None, None, None
+    def backward(ctx, g, g_tv):
+        enc = ctx.enc
+        acc = enc.embeddings.grad if getattr(enc, "accumulate_into_grad", False) else None
+        gemb = acc if acc is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=enc.embeddings.device)
+        if g is not None:
+            g = g.contiguous()
+            _lib.check(_lib.lib().snerf_tgrid_encode_bwd(C.byref(enc.desc), C.byref(ctx.coords), ops._ptr(ctx.trow) if ctx.trow is not None else None,
+                                                         ops._ptr(ctx.times) if ctx.times is not None else None, ctx.spr, C.c_int64(ctx.B), ops._ptr(g),
+                                                         ops._ptr(gemb), ops._stream()), "tgrid_encode_bwd")
+        if g_tv is not None and ctx.tv is not None:
+            a, b, sgn = ctx.tv
+            sgn = sgn * (g_tv / ctx.shape[0])
+            gemb[:, a] += sgn
+            gemb[:, b] -= sgn
+        # accumulate_into_grad (set by optimizers.FusedAdam): the scatter went straight into the persistent, optimiser-cleared
+        # .grad buffer; returning None keeps autograd from allocating / adding a second dense tensor
+        return (None if acc is not None else gemb), None, None, None, None, None, None, None, None, None
 
 
 class TemporalGridEncoder(nn.Module):
@@ -79,6 +98,10 @@ class TemporalGridEncoder(nn.Module):
         self.register_buffer("index_a_mask", ma)
         self.register_buffer("index_b_mask", mb)
         self.register_buffer("index_list", il)  # columns (A, B) of each row: what get_temporal_tv_loss reads
+        self._index_list_host = il.tolist()
+        self.fuse_tv, self._tv_cached = True, None
+        self.tv_row_override = None  # parity hook: fixed table row instead of the random draw
+        self.accumulate_into_grad = False
         d = _lib.TgridDesc()
         d.D, d.C, d.L, d.grid_C, d.H = input_dim, level_dim, num_levels, level_dim + temporal_dim, base_resolution
         d.gridtype, d.align_corners, d.S = self.gridtype_id, int(align_corners), float(np.log2(per_level_scale))
@@ -104,10 +127,14 @@ class TemporalGridEncoder(nn.Module):
         t = ops._f32c(time, "time").reshape(-1)
         B = xyz.shape[0]
         co = ops.coords_from_points(xyz)
+        tv_a, tv_b = self._draw_tv_columns()
         if explicit_rows:
             rows = self.get_temporal_index(t).contiguous()
-            return _Encode.apply(self.embeddings, self, (xyz, rows), co, rows, None, 1, B)
-        return _Encode.apply(self.embeddings, self, (xyz, t), co, None, t, 1, B)
+            out, tv = _Encode.apply(self.embeddings, self, (xyz, rows), co, rows, None, 1, B, tv_a, tv_b)
+        else:
+            out, tv = _Encode.apply(self.embeddings, self, (xyz, t), co, None, t, 1, B, tv_a, tv_b)
+        self._tv_cached = tv
+        return out
 
     def forward_rays(self, origins, directions, ray_times, ebins, aabb) -> torch.Tensor:
         """Same encoding with sample coordinates derived in-kernel from rays (one time per ray): [R*S, L*C]."""
@@ -115,10 +142,24 @@ class TemporalGridEncoder(nn.Module):
         t = ops._f32c(ray_times, "times").reshape(-1)
         R, S = ebins.shape[0], ebins.shape[1] - 1
         co = ops.coords_from_rays(origins, directions, t, ebins, aabb, rescale=False)
-        return _Encode.apply(self.embeddings, self, (origins, directions, t, ebins), co, None, t, S, R * S)
+        tv_a, tv_b = self._draw_tv_columns()
+        out, tv = _Encode.apply(self.embeddings, self, (origins, directions, t, ebins), co, None, t, S, R * S, tv_a, tv_b)
+        self._tv_cached = tv
+        return out
+
+    def _draw_tv_columns(self):
+        """Training forward: draw the table row get_temporal_tv_loss would draw (temporal_grid.py:371-373) so that the TV term rides on
+        the encoder's autograd node; its value is handed out by the next get_temporal_tv_loss() call."""
+        if not (self.fuse_tv and self.training and torch.is_grad_enabled() and self.embeddings.requires_grad):
+            return None, None
+        row = self.tv_row_override if self.tv_row_override is not None else int(torch.randint(0, len(self.index_list), [1]).item())
+        return tuple(self._index_list_host[row])
 
     def get_temporal_tv_loss(self, row_idx: Optional[int] = None) -> torch.Tensor:
         """temporal_grid.py:352-376: mean |emb[:, A] - emb[:, B]| for a random (or given) table row."""
+        if row_idx is None and getattr(self, "_tv_cached", None) is not None:
+            tv, self._tv_cached = self._tv_cached, None
+            return tv
         if row_idx is None:
             row_idx = int(torch.randint(0, len(self.index_list), [1]).item())
         a, b = self.index_list[row_idx].tolist()

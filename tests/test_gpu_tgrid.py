@@ -170,3 +170,55 @@ def test_nerfplayer_model_trains():
         losses.append(float(ld["rgb_loss"]))
     assert out["depth"].shape == (R, 1) and out["rgb"].shape == (R, 3)
     assert losses[-1] < losses[0], losses
+
+
+def test_fused_tv_and_fused_adam_match_torch_adam():
+    """The temporal-TV term riding on the encoder's autograd node + optimizers.FusedAdam (gradient scattered straight into the
+    persistent .grad, cleared by the optimiser sweep) reproduce separate TV autograd + torch.optim.Adam over three steps."""
+    import copy
+    from soccernerfs_amd.optimizers import FusedAdam
+    from soccernerfs_amd.rays import RayBundle
+
+    base = _make_model().to(DEV).train()
+    base.scene_box.aabb = base.scene_box.aabb.to(DEV)
+    models = [base, copy.deepcopy(base)]
+    encs = [[m.field.mlp_base] + [p.encoding for p in m.proposal_networks] for m in models]
+    for e in encs[0]:
+        e.fuse_tv = False
+    models[0].tv_row_fn = lambda enc: 3
+    for e in encs[1]:
+        e.tv_row_override = 3
+    plist = lambda m: [p for g in m.get_param_groups().values() for p in g if p.requires_grad]
+    opts = [torch.optim.Adam(plist(models[0]), lr=1e-2, eps=1e-15), FusedAdam(plist(models[1]), lr=1e-2, eps=1e-15, encoders=encs[1])]
+    gen = torch.Generator().manual_seed(5)
+    R = 64
+    for step in range(3):
+        o = ((torch.rand(R, 3, generator=gen) * 2 - 1) * 0.3).to(DEV)
+        d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1).to(DEV)
+        cams = torch.randint(0, 5, (R, 1), generator=gen).to(DEV)
+        times = torch.rand(R, 1, generator=gen).to(DEV)
+        target = torch.rand(R, 3, generator=gen).to(DEV)
+        losses = []
+        for m, opt in zip(models, opts):
+            torch.manual_seed(100 + step)  # same sampler jitter / background colours in both models
+            for where, fn in m.get_training_callbacks():
+                if where == "before":
+                    fn(step)
+            out = m(RayBundle(origins=o, directions=d, pixel_area=torch.ones(R, 1, device=DEV), camera_indices=cams, times=times))
+            ld = m.get_loss_dict(out, {"image": target}, m.get_metrics_dict(out, {"image": target}))
+            loss = sum(ld.values())
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            for where, fn in m.get_training_callbacks():
+                if where == "after":
+                    fn(step)
+            losses.append({k: float(v.detach()) for k, v in ld.items()})
+        for k in losses[0]:
+            assert abs(losses[0][k] - losses[1][k]) <= 1e-4 * abs(losses[0][k]) + 1e-9, (step, k, losses)
+    for (n0, p0), (n1, p1) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        if p0.numel():
+            bad = ((p0 - p1).abs() > 2e-4).float().mean()  # Adam's first steps move by ~lr*sign(g): rounding-noise gradients may flip
+            assert float(bad) < 2e-3, (n0, float(bad))
+    for e in encs[1]:
+        assert float(e.embeddings.grad.abs().max()) == 0.0  # cleared by the optimiser sweep
