@@ -319,6 +319,15 @@ int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coo
                            const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings,
                            snerf_stream_t stream);
 
+/* TemporalGridEncoder.get_temporal_tv_loss (NS/field_components/temporal_grid.py:352-376): mean over table rows of
+ * |E[r, col_a] - E[r, col_b]|.  fwd ADDS per-workgroup partial sums of |.| into partial[n_slots][16] (col 0; caller zeroes, then
+ * value = sum / rows); bwd ADDS g_tv[0] * sign(.) / rows into grad_embeddings[:, col_a] and subtracts it from [:, col_b]
+ * (g_tv: device scalar, the upstream gradient of the loss value). */
+int snerf_tgrid_tv_fwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float* partial, int32_t n_slots,
+                       snerf_stream_t stream);
+int snerf_tgrid_tv_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* g_tv,
+                       float* grad_embeddings, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Ray importance sampling (IST = temporal difference).
  * ------------------------------------------------------------------------------------------------ */

@@ -163,9 +163,12 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
 __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                   int64_t n, float step_size, float b1, float b2, float inv_sqrt_bc2, float eps,
                                                   float grad_scale, int zero_grad) {
+  // one float4 per lane, every buffer streamed past the caches once (nontemporal): as plane_reg_kernel's Adam path, which reaches
+  // 6.1 TB/s against 4.6 TB/s for a 4096-workgroup grid-stride loop with cached accesses
   const int64_t n4 = n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 pp = ldnt4(p + i * 4), gg = ldnt4(g + i * 4), mm = ldnt4(m + i * 4), vv = ldnt4(v + i * 4);
     float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -175,10 +178,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
       float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
       P[k] = P[k] - step_size * (M[k] / denom);
     }
-    *reinterpret_cast<float4*>(p_out + i * 4) = pp;
-    *reinterpret_cast<float4*>(m + i * 4) = mm;
-    *reinterpret_cast<float4*>(v + i * 4) = vv;
-    if (zero_grad) *reinterpret_cast<float4*>(g + i * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    stnt4(p_out + i * 4, pp);
+    stnt4(m + i * 4, mm);
+    stnt4(v + i * 4, vv);
+    if (zero_grad) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
   }
   // tail (n % 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -298,7 +301,7 @@ extern "C" int snerf_adam_step(const float* p, float* p_out, float* g, float* m,
   adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
   int64_t n4 = (n + 3) / 4;
   int64_t blocks = (n4 + 255) / 256;
-  if (blocks > 256 * 16) blocks = 256 * 16;
+  SNERF_REQUIRE(blocks < (1LL << 31), "adam_step: n=%lld too large for one launch", (long long)n);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, p_out, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2,
                      eps, grad_scale, zero_grad);
   SNERF_LAUNCH_CHECK("adam_step");

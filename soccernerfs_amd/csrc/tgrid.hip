@@ -174,6 +174,50 @@ static int launch(const TgridArgs& a, hipStream_t st) {
 
 using namespace snerf;
 
+// ---- temporal TV term (TemporalGridEncoder.get_temporal_tv_loss, temporal_grid.py:352-376): mean_r |E[r, a] - E[r, b]| ----
+// One lane per table row; both columns of a row sit in the same 264-B row, so a pass reads one or two sectors per row.
+namespace snerf {
+__global__ __launch_bounds__(256) void tgrid_tv_fwd_kernel(const float* __restrict__ E, int64_t rows, int grid_C, int a, int b, float* __restrict__ partial,
+                                                          int n_slots) {
+  float acc = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x)
+    acc += fabsf(E[r * grid_C + a] - E[r * grid_C + b]);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(partial + (blockIdx.x % n_slots) * 16, acc);
+}
+__global__ __launch_bounds__(256) void tgrid_tv_bwd_kernel(const float* __restrict__ E, int64_t rows, int grid_C, int a, int b, const float* __restrict__ g_tv,
+                                                          float* __restrict__ gE) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float d = E[r * grid_C + a] - E[r * grid_C + b];
+  const float s = ((d > 0.f) - (d < 0.f)) * (g_tv[0] / (float)rows);  // d|x|/dx = sign(x) (0 at 0, as torch.abs), mean over rows
+  if (s != 0.f) { gE[r * grid_C + a] += s; gE[r * grid_C + b] -= s; }
+}
+}  // namespace snerf
+
+extern "C" int snerf_tgrid_tv_fwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float* partial, int32_t n_slots,
+                                  snerf_stream_t stream) {
+  SNERF_REQUIRE(rows >= 1 && grid_C >= 1 && col_a >= 0 && col_a < grid_C && col_b >= 0 && col_b < grid_C && n_slots >= 1,
+                "tgrid_tv_fwd: rows=%lld grid_C=%d cols=(%d,%d) n_slots=%d", (long long)rows, grid_C, col_a, col_b, n_slots);
+  SNERF_REQUIRE(embeddings && partial, "tgrid_tv_fwd: null buffer");
+  const int64_t blocks = (rows + 255) / 256;
+  hipLaunchKernelGGL(snerf::tgrid_tv_fwd_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, embeddings, rows, grid_C,
+                     col_a, col_b, partial, n_slots);
+  SNERF_LAUNCH_CHECK("tgrid_tv_fwd");
+  return 0;
+}
+
+extern "C" int snerf_tgrid_tv_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* g_tv,
+                                  float* grad_embeddings, snerf_stream_t stream) {
+  SNERF_REQUIRE(rows >= 1 && grid_C >= 1 && col_a >= 0 && col_a < grid_C && col_b >= 0 && col_b < grid_C && col_a != col_b,
+                "tgrid_tv_bwd: rows=%lld grid_C=%d cols=(%d,%d)", (long long)rows, grid_C, col_a, col_b);
+  SNERF_REQUIRE(embeddings && g_tv && grad_embeddings, "tgrid_tv_bwd: null buffer");
+  hipLaunchKernelGGL(snerf::tgrid_tv_bwd_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, embeddings, rows, grid_C, col_a, col_b,
+                     g_tv, grad_embeddings);
+  SNERF_LAUNCH_CHECK("tgrid_tv_bwd");
+  return 0;
+}
+
 extern "C" int snerf_tgrid_encode_fwd(const snerf_tgrid_desc* desc, const float* embeddings, const snerf_coords* coords,
                                       const float* temporal_row_index, const float* times, int32_t samples_per_row, int64_t B, float* out,
                                       snerf_stream_t stream) {

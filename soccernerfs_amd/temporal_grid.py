@@ -46,9 +46,12 @@ class _Encode(torch.autograd.Function):
         ctx.shape, ctx.tv = embeddings.shape, None
         if tv_a is None:
             return out, None
-        diff = embeddings[:, tv_a] - embeddings[:, tv_b]
-        ctx.tv = (tv_a, tv_b, torch.sign(diff))
-        return out, diff.abs().mean()
+        part = torch.zeros(64, 16, dtype=torch.float32, device=embeddings.device)
+        _lib.check(_lib.lib().snerf_tgrid_tv_fwd(ops._ptr(embeddings), C.c_int64(embeddings.shape[0]), embeddings.shape[1], tv_a, tv_b, ops._ptr(part), 64,
+                                                 ops._stream()), "tgrid_tv_fwd")
+        ctx.tv = (tv_a, tv_b)
+        ctx.save_for_backward(embeddings)
+        return out, part[:, 0].sum() / embeddings.shape[0]
 
     @staticmethod
     def backward(ctx, g, g_tv):
@@ -61,10 +64,10 @@ class _Encode(torch.autograd.Function):
                                                          ops._ptr(ctx.times) if ctx.times is not None else None, ctx.spr, C.c_int64(ctx.B), ops._ptr(g),
                                                          ops._ptr(gemb), ops._stream()), "tgrid_encode_bwd")
         if g_tv is not None and ctx.tv is not None:
-            a, b, sgn = ctx.tv
-            sgn = sgn * (g_tv / ctx.shape[0])
-            gemb[:, a] += sgn
-            gemb[:, b] -= sgn
+            (emb,) = ctx.saved_tensors
+            gt = g_tv.detach().reshape(1).float().contiguous()
+            _lib.check(_lib.lib().snerf_tgrid_tv_bwd(ops._ptr(emb), C.c_int64(ctx.shape[0]), ctx.shape[1], ctx.tv[0], ctx.tv[1], ops._ptr(gt), ops._ptr(gemb),
+                                                     ops._stream()), "tgrid_tv_bwd")
         # accumulate_into_grad (set by optimizers.FusedAdam): the scatter went straight into the persistent, optimiser-cleared
         # .grad buffer; returning None keeps autograd from allocating / adding a second dense tensor
         return (None if acc is not None else gemb), None, None, None, None, None, None, None, None, None
