@@ -60,6 +60,19 @@ __global__ __launch_bounds__(256) void kplanes_gather_fwd_kernel(snerf_kplanes_d
 // (v1 of this kernel used float4-per-lane atomics at a 16-B lane stride: quarter-full requests, 12.8 ms at
 // config-2 size vs. 0.5 ms for the forward -- profiles/r01_kernels.md.)
 // ---------------------------------------------------------------------------------------------
+// value of lane (l ^ C): the other x-corner's partial sum.  __shfl_xor compiles to ds_bpermute_b32 (an LDS-crossbar access with a
+// per-lane address; SQ_LDS_BANK_CONFLICT showed it 87 % conflicted here); the fixed patterns have cheaper forms
+template <int C>
+__device__ __forceinline__ float xor_lanes(float x) {
+  if (C == 8) {  // rotate by 8 inside each row of 16 lanes: DPP row_ror:8, no LDS involved
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
+  } else if (C == 16) {  // swap the two 16-lane halves of each 32: ds_swizzle bit mode, xor mask 0x10 (no memory access, no per-lane address)
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(x), 0x401f));
+  } else {
+    return __shfl_xor(x, C, 64);
+  }
+}
+
 template <int C, int NP>
 __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_desc d, const float* __restrict__ planes,
                                                                 snerf_coords c, int64_t N, const float* __restrict__ gout,
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
         float a = base[((int64_t)ty.i0 * W + xi) * C];
         float b = base[((int64_t)ty.i1 * W + xi) * C];
         float part = wx[q] * (ty.w0 * a + ty.w1 * b);
-        v[q] = part + __shfl_xor(part, C, 64);
+        v[q] = part + xor_lanes<C>(part);
       }
       const float g = gout[n * out_w + (d.concat ? s * C : 0) + ch];
       float suf[NP + 1];
