@@ -216,6 +216,8 @@ def main():
                          "frac": achieved / peak, "traffic": traffic, "algorithmic_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "launches_timed": timed[DOMINANT][1],
                          "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT},
+                         "other_kernels_note": "fractions below use SURVEY 8d algorithmic bytes (4 texels per bilinear tap, no cache credit): a value "
+                                               "above 1 means caches / run-length combining removed traffic, not that a peak was exceeded",
                          "other_kernels_frac": {k: round(alg[k][1] / (v[0] * 1e-3) / 1e9 / (HBM_PEAK_GBS if alg[k][0] == "hbm" else 157300.0), 3)
                                                 for k, v in timed.items() if k != DOMINANT}},
         }
