@@ -302,8 +302,9 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
 // Measured and dropped (profiles/r01_kernels.md): a per-wave LDS texel cache behind the register stage (64 direct-mapped texel
 // rows, tags in lanes) halves the atomic requests (8.4 M -> 4.5 M) but is no faster: with ds_add_f32 each LDS instruction costs
 // ~146 cycles (6x slower end to end), with read-add-write the LDS round trip per flush sits on the wave's critical path
-// (0.88-0.93 ms vs 0.80-0.86 ms).  Ablation of this kernel: 0.28 ms without gvec loads and atomics, 0.36 ms without atomics,
-// 0.86 ms complete -- the in-loop atomics are what it waits for.
+// (0.88-0.93 ms vs 0.80-0.86 ms); deferring the add/write to the next flush so that the read has time to land: 1.09 ms.
+// Ablation of this kernel: 0.28 ms without gvec loads and atomics, 0.36 ms without atomics, 0.81-0.86 ms complete -- the in-loop
+// atomics are what it waits for, and the time follows neither the request count nor the prefetch depth nor the VALU count.
 
 static int build_segs(const snerf_kplanes_desc* d, SegTable& st) {
   const int NP = d->n_coords == 4 ? 6 : 3;
