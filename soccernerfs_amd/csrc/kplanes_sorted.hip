@@ -28,7 +28,11 @@ namespace snerf {
 
 struct SegTable {
   int n_planes;
-  int cell_off[7];  // first histogram cell of each plane; [n_planes] = total cells
+  int per_scale;    // 1: every (scale, plane) segment has its own order, keyed by that scale's own texel -> runs == cells exactly
+  int n_segs;       // n_planes (shared order) or n_scales * n_planes (per-scale)
+  int n_scales;
+  int res[SNERF_MAX_SCALES][4];
+  int cell_off[SNERF_MAX_SCALES * 6 + 1];  // first histogram cell of each segment; [n_segs] = total cells
   int fine[4];      // sort-grid resolution of each axis = its finest resolution over the scales
   int fine_rm[4];   // finer sort grid for the minor axis of row-major (time) planes: several samples share a (time row, texel)
                     // there, and only a (near-)true sort by x keeps every scale's texel index monotone inside a row
@@ -78,6 +82,26 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(snerf_coords c, SegTable
   if (n >= N) return;
   float p[4];
   load_coords<NP>(c, n, p);
+  constexpr auto& A = PlanePairs<NP>::a;
+  constexpr auto& B = PlanePairs<NP>::b;
+  if (st.per_scale) {
+    for (int s = 0; s < st.n_scales; ++s) {
+      int i0[4], rs[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        rs[k] = st.res[s][k] > 0 ? st.res[s][k] : 1;
+        i0[k] = (int)floorf(axis_pix(p[k], rs[k]));  // == axis_tap(p, res).i0: the run key pass B compares
+      }
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int seg = s * NP + q;
+        const int key = st.cell_off[seg] + (st.row_major[q] ? i0[B[q]] * rs[A[q]] + i0[A[q]] : (int)morton2((uint32_t)i0[A[q]], (uint32_t)i0[B[q]]));
+        if (!REORDER) rank[(int64_t)seg * N + n] = atomicAdd(hist + key, 1);
+        else sorted_rec[scan[key] + rank[(int64_t)seg * N + n]] = make_float4(__int_as_float((int)n), p[A[q]], p[B[q]], 0.f);
+      }
+    }
+    return;
+  }
   int i0[4], i0f[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -86,8 +110,6 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(snerf_coords c, SegTable
   }
 #pragma unroll
   for (int q = 0; q < NP; ++q) {
-    constexpr auto& A = PlanePairs<NP>::a;
-    constexpr auto& B = PlanePairs<NP>::b;
     const int key = st.cell_off[q] + (st.row_major[q] ? i0[B[q]] * st.fine_rm[A[q]] + i0f[A[q]] : (int)morton2((uint32_t)i0[A[q]], (uint32_t)i0[B[q]]));
     if (!REORDER) {
       rank[(int64_t)q * N + n] = atomicAdd(hist + key, 1);
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(256) void gradvec_kernel(snerf_kplanes_desc d, cons
 template <int C, int NP>
 __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
                                                             const float4* __restrict__ sorted_rec, float* __restrict__ gplanes, int run,
-                                                            int64_t groups_per_seg, int seg_begin) {
+                                                            int64_t groups_per_seg, int seg_begin, int per_scale) {
   constexpr int LPS = 2 * C;
   constexpr int UNROLL = 8;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -213,7 +235,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
   int a, b;
   seg_axes<NP>(q, a, b);
   const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
-  const float4* rec = sorted_rec + (int64_t)q * N + i0;  // the plane's order is shared by all scales
+  const float4* rec = sorted_rec + (int64_t)(per_scale ? seg : q) * N + i0;  // the plane's order is shared by all scales unless per_scale
   const float* gv = gvec + (int64_t)seg * N * C + ch;
   float* gbase = gplanes + d.off[s][q] + li;
   int pend_key[2] = {-1, -1};
@@ -299,6 +321,172 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
     if (pend_val[rr] != 0.f) atomicAdd(gbase + (int64_t)pend_key[rr] * C, pend_val[rr]);
 }
 
+// ---- pass B, C = 32: chunk-local regrouping by THIS scale's texel key, run-length combining, x-carry ----
+// The shared Z-order of the finest scale keeps a chunk of 256 consecutive entries spatially compact at every scale, but the
+// `res-1` scaling of align_corners=True does not nest coarse texel edges in fine ones, so a coarse cell's samples arrive in
+// several runs (2.0 M flushes for 0.93 M distinct cells; a separate global sort per scale brings pass B from 0.81 to 0.53 ms but
+// costs 0.5 ms more sorting).  Here every wave re-sorts ITS 256 entries by the segment's own key (row * W + x0) with an in-register
+// bitonic network (36 rounds, ~550 instructions, no memory traffic) and walks them in that order: equal keys are adjacent, and
+// inside a row x0 ascends, so for x-adjacent cells the shared texel (x0+1 of one cell = x0 of the next) is CARRIED in registers
+// from half 1 to half 0 instead of being flushed twice.  What bounds this pass is the number of lane-level atomic operations
+// (profiles/r01_kernels.md); regrouping + carry cut them by more than half.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+  if (J >= 32) return (uint32_t)__shfl_xor((int)v, J, 64);
+  return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (J << 10) | 0x1f);  // bit mode: lane ^ J inside each group of 32
+}
+
+template <int K, int J>
+__device__ __forceinline__ void bitonic_round(uint32_t (&w)[4], int lane) {
+  if (J >= 64) {  // partner is another register of the same lane
+    constexpr int JR = J / 64;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if ((r & JR) == 0) {
+        const bool up = (((r * 64) & K) == 0);  // K >= 128 here: direction depends on the register index only
+        const uint32_t a = w[r], b = w[r | JR];
+        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+        w[r] = up ? lo : hi;
+        w[r | JR] = up ? hi : lo;
+      }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const uint32_t other = lane_xor<J>(w[r]);
+      const int e = r * 64 + lane;
+      const bool up = (e & K) == 0, lower = (lane & J) == 0;
+      const uint32_t lo = w[r] < other ? w[r] : other, hi = w[r] < other ? other : w[r];
+      w[r] = (lower == up) ? lo : hi;
+    }
+  }
+}
+
+template <int K, int J>
+struct BitonicJ {
+  static __device__ __forceinline__ void run(uint32_t (&w)[4], int lane) {
+    bitonic_round<K, J>(w, lane);
+    BitonicJ<K, J / 2>::run(w, lane);
+  }
+};
+template <int K>
+struct BitonicJ<K, 0> {
+  static __device__ __forceinline__ void run(uint32_t (&)[4], int) {}
+};
+template <int K>
+struct BitonicK {
+  static __device__ __forceinline__ void run(uint32_t (&w)[4], int lane) {
+    BitonicK<K / 2>::run(w, lane);
+    BitonicJ<K, K / 2>::run(w, lane);
+  }
+};
+template <>
+struct BitonicK<1> {
+  static __device__ __forceinline__ void run(uint32_t (&)[4], int) {}
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
+                                                             const float4* __restrict__ sorted_rec, float* __restrict__ gplanes,
+                                                             int64_t groups_per_seg, int seg_begin, int per_scale) {
+  constexpr int C = 32, CH = 256, UNROLL = 8;
+  // per wave, per entry (in WALK order) 8 dwords: {gvec row offset (elements), x0 | y0 << 16, -, -, wx0*wy0, wx0*wy1, wx1*wy0, wx1*wy1}.
+  // Everything per-entry is prepared lane-parallel (4 entries per lane) so that the walk -- one entry per wave instruction -- costs
+  // ~10 VALU instructions per entry: the first version of this kernel spent ~60 and was VALU-issue bound (0.79 ms with 43 % fewer
+  // atomic instructions than the plain run-length kernel's 0.81 ms).
+  __shared__ __align__(16) uint32_t s_rec[4][CH * 8];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int half = lane >> 5, ch = lane & 31;
+  const int64_t group = (int64_t)blockIdx.x * 4 + wave;
+  const int seg = seg_begin + (int)(group / groups_per_seg);
+  if (seg >= d.n_scales * NP) return;
+  const int64_t i0 = (group - (int64_t)(seg - seg_begin) * groups_per_seg) * CH;
+  if (i0 >= N) return;
+  const int cnt = (int)((N - i0) < CH ? (N - i0) : CH);
+  const int s = seg / NP, q = seg % NP;
+  int a, b;
+  seg_axes<NP>(q, a, b);
+  const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
+  const float4* rec = sorted_rec + (int64_t)(per_scale ? seg : q) * N + i0;
+  const float* gseg = gvec + (int64_t)seg * N * C;  // wave-uniform base; rows are addressed with 32-bit element offsets
+  float* gch = gplanes + d.off[s][q] + ch;
+  uint32_t* R = s_rec[wave];
+  const bool sortable = (int64_t)W * H <= (1 << 23);  // key << 8 | index must fit 31 bits (the launcher guarantees N * C < 2^31)
+
+  // 1. sort words: (row * W + x0) << 8 | entry, entry e = r * 64 + lane
+  uint32_t word[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    word[r] = 0xffffffffu;
+    if (e < cnt) {
+      const float4 rc = rec[e];
+      const int x0 = (int)floorf(axis_pix(rc.y, W)), y0 = (int)floorf(axis_pix(rc.z, H));  // == axis_tap(.).i0
+      word[r] = sortable ? (((uint32_t)(y0 * W + x0) << 8) | (uint32_t)e) : (uint32_t)e;
+    }
+  }
+  // 2. in-wave bitonic sort (ascending; 0xffffffff pads go last).  Not sortable (> 2^23 texels): the words are already ascending.
+  if (sortable) BitonicK<CH>::run(word, lane);
+  // 3. walk records, written at their position in the sorted order; positions >= cnt get a null record (zero weights)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    uint4 hd = make_uint4(0u, 0xffffffffu, 0u, 0u);
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < cnt) {
+      const float4 rc = rec[word[r] & 255u];
+      const AxisTap tx = axis_tap(rc.y, W);
+      const AxisTap ty = axis_tap(rc.z, H);
+      hd.x = (uint32_t)__float_as_int(rc.x) * (uint32_t)C;
+      hd.y = (uint32_t)tx.i0 | ((uint32_t)ty.i0 << 16);
+      wt = make_float4(tx.w0 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w0, tx.w1 * ty.w1);  // a clamped second tap has weight 0
+    }
+    *reinterpret_cast<uint4*>(R + e * 8) = hd;
+    *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
+  }
+  // 4. the walk.  pend[rr]: run of row Y = y0 + rr whose half-0 texel column is pX; lane = (x-corner, channel).  A row or column
+  //    beyond the border only ever accumulates zeros and is never flushed (guards on pval != 0).
+  int pX[2] = {-2, -2}, pY[2] = {-2, -2};
+  float pval[2] = {0.f, 0.f};
+  const uint32_t* Rl = R + 4 + half * 2;  // this lane's weight pair of an entry
+  for (int e0 = 0; e0 < cnt; e0 += UNROLL) {
+    uint2 hd[UNROLL];
+    float2 wt[UNROLL];
+    float g[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      hd[u] = *reinterpret_cast<const uint2*>(R + (e0 + u) * 8);       // wave-uniform address: LDS broadcast
+      wt[u] = *reinterpret_cast<const float2*>(Rl + (e0 + u) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) g[u] = gseg[hd[u].x + ch];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd[u].y);
+      const int X0 = (int)(packed & 0xffffu), Y0 = (int)(packed >> 16);
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int Y = Y0 + rr;
+        const float val = g[u] * (rr ? wt[u].y : wt[u].x);
+        if (X0 == pX[rr] && Y == pY[rr]) {
+          pval[rr] += val;
+        } else if (Y == pY[rr] && X0 == pX[rr] + 1) {
+          // x-adjacent cell of the same row: texel pX is complete (flush it, 32 lanes), texel pX + 1 carries over from half 1 to half 0
+          if (half == 0 && pval[rr] != 0.f) atomicAdd(gch + ((int64_t)Y * W + pX[rr]) * C, pval[rr]);
+          const float moved = __shfl_xor(pval[rr], 32, 64);
+          pval[rr] = (half == 0 ? moved : 0.f) + val;
+          pX[rr] = X0;
+        } else {
+          if (pval[rr] != 0.f) atomicAdd(gch + ((int64_t)pY[rr] * W + pX[rr] + half) * C, pval[rr]);
+          pX[rr] = X0; pY[rr] = Y; pval[rr] = val;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr)
+    if (pval[rr] != 0.f) atomicAdd(gch + ((int64_t)pY[rr] * W + pX[rr] + half) * C, pval[rr]);
+}
+
 // Measured and dropped (profiles/r01_kernels.md): a per-wave LDS texel cache behind the register stage (64 direct-mapped texel
 // rows, tags in lanes) halves the atomic requests (8.4 M -> 4.5 M) but is no faster: with ds_add_f32 each LDS instruction costs
 // ~146 cycles (6x slower end to end), with read-add-write the LDS round trip per flush sits on the wave's critical path
@@ -322,7 +510,35 @@ static int build_segs(const snerf_kplanes_desc* d, SegTable& st) {
     SNERF_REQUIRE(st.fine[k] <= 32768, "kplanes_sort: resolution %d too large for the Morton key", st.fine[k]);
     st.fine_rm[k] = fine;
   }
+  static const int per_scale = [] { const char* e = getenv("SNERF_SORT_PER_SCALE"); return e ? atoi(e) : 0; }();
+  st.per_scale = per_scale && d->n_scales > 1;
+  st.n_scales = d->n_scales;
+  for (int s = 0; s < d->n_scales; ++s)
+    for (int k = 0; k < 4; ++k) st.res[s][k] = d->res[s][k];
   int64_t off = 0;
+  if (st.per_scale) {
+    st.n_segs = d->n_scales * NP;
+    for (int s = 0; s < d->n_scales; ++s)
+      for (int q = 0; q < NP; ++q) {
+        const int a = NP == 6 ? PA6[q] : PA3[q], b = NP == 6 ? PB6[q] : PB3[q];
+        const int ra = d->res[s][a] > 0 ? d->res[s][a] : 1, rb = d->res[s][b] > 0 ? d->res[s][b] : 1;
+        SNERF_REQUIRE(ra <= 32768 && rb <= 32768, "kplanes_sort: resolution too large for the Morton key");
+        st.cell_off[s * NP + q] = (int)off;
+        st.row_major[q] = (NP == 6 && b == 3) ? 1 : 0;
+        if (st.row_major[q]) {
+          off += (int64_t)ra * rb;
+        } else {
+          const int m = ra > rb ? ra : rb;
+          int bits = 0;
+          while ((1 << bits) < m) ++bits;
+          off += (int64_t)1 << (2 * bits);
+        }
+      }
+    SNERF_REQUIRE(off < (1LL << 30), "kplanes_sort: too many Morton cells (%lld)", (long long)off);
+    st.cell_off[st.n_segs] = (int)off;
+    return 0;
+  }
+  st.n_segs = NP;
   for (int q = 0; q < NP; ++q) {
     const int a = NP == 6 ? PA6[q] : PA3[q], b = NP == 6 ? PB6[q] : PB3[q];
     st.cell_off[q] = (int)off;
@@ -362,8 +578,8 @@ extern "C" int snerf_kplanes_sort_workspace(const snerf_kplanes_desc* desc, int6
   int rc = build_segs(desc, st);
   if (rc) return rc;
   // hist: cells + room for the scan's block sums (one per 1024 cells, +1024 slack)
-  *hist_cells = (int64_t)st.cell_off[st.n_planes] + ((int64_t)st.cell_off[st.n_planes] + 1023) / 1024 + 1024;
-  *index_elems = (int64_t)st.n_planes * N;
+  *hist_cells = (int64_t)st.cell_off[st.n_segs] + ((int64_t)st.cell_off[st.n_segs] + 1023) / 1024 + 1024;
+  *index_elems = (int64_t)st.n_segs * N;
   return 0;
 }
 
@@ -378,7 +594,7 @@ extern "C" int snerf_kplanes_sort_samples(const snerf_kplanes_desc* desc, const 
   rc = build_segs(desc, st);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int64_t cells = st.cell_off[st.n_planes];
+  const int64_t cells = st.cell_off[st.n_segs];
   const int nb = (int)((cells + 1023) / 1024);
   int32_t* block_sums = hist + cells;
   rc = check_hip(hipMemsetAsync(hist, 0, (size_t)cells * sizeof(int32_t), s), "kplanes_sort memset");
@@ -409,9 +625,20 @@ static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const f
   // the kernel stops at segment n_scales * NP: hand it a descriptor that ends at scale_end
   snerf_kplanes_desc dd = *d;
   dd.n_scales = scale_end;
+  SegTable stb;
+  int rc = build_segs(d, stb);
+  if (rc) return rc;
+  static const int grouped = [] { const char* e = getenv("SNERF_SCATTER_GROUPED"); return e ? atoi(e) : 1; }();
+  if (C == 32 && grouped && N * C < (1LL << 31)) {  // 32-bit gvec row offsets inside the kernel
+    const int64_t gps = (N + 255) / 256;
+    hipLaunchKernelGGL((scatter_grouped_kernel<NP>), dim3((unsigned)ceil_div(gps * (scale_end - scale_begin) * NP, 4)), dim3(256), 0, st, dd, N, gvec,
+                       sorted_n, gp, gps, scale_begin * NP, stb.per_scale);
+    SNERF_LAUNCH_CHECK("kplanes_scatter_grouped");
+    return 0;
+  }
   const int64_t threads = groups_per_seg * (scale_end - scale_begin) * NP * (2 * C);
   hipLaunchKernelGGL((scatter_sorted_kernel<C, NP>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, dd, N, gvec, sorted_n, gp, run,
-                     groups_per_seg, scale_begin * NP);
+                     groups_per_seg, scale_begin * NP, stb.per_scale);
   SNERF_LAUNCH_CHECK("kplanes_scatter_sorted");
   return 0;
 }
