@@ -388,7 +388,7 @@ template <int NP>
 __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
                                                              const float4* __restrict__ sorted_rec, float* __restrict__ gplanes,
                                                              int64_t groups_per_seg, int seg_begin, int per_scale) {
-  constexpr int C = 32, CH = 256, UNROLL = 8;
+  constexpr int C = 32, CH = 256, UNROLL = 16;
   // per wave, per entry (in WALK order) 8 dwords: {gvec row offset (elements), x0 | y0 << 16, -, -, wx0*wy0, wx0*wy1, wx1*wy0, wx1*wy1}.
   // Everything per-entry is prepared lane-parallel (4 entries per lane) so that the walk -- one entry per wave instruction -- costs
   // ~10 VALU instructions per entry: the first version of this kernel spent ~60 and was VALU-issue bound (0.79 ms with 43 % fewer
@@ -443,48 +443,48 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
     *reinterpret_cast<uint4*>(R + e * 8) = hd;
     *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
   }
-  // 4. the walk.  pend[rr]: run of row Y = y0 + rr whose half-0 texel column is pX; lane = (x-corner, channel).  A row or column
-  //    beyond the border only ever accumulates zeros and is never flushed (guards on pval != 0).
-  int pX[2] = {-2, -2}, pY[2] = {-2, -2};
-  float pval[2] = {0.f, 0.f};
+  // 4. the walk.  One pending cell (x0 | y0 << 16 = ppk) with two accumulators per lane: rows y0 and y0 + 1; lane = (x-corner, channel).
+  //    A row or column beyond the border only ever accumulates zeros and is never flushed (guards on != 0).
+  uint32_t ppk = 0xfffffff0u;  // matches no record, nor record - 1
+  float p0 = 0.f, p1 = 0.f;
   const uint32_t* Rl = R + 4 + half * 2;  // this lane's weight pair of an entry
+  const int64_t rowC = (int64_t)W * C;
   for (int e0 = 0; e0 < cnt; e0 += UNROLL) {
-    uint2 hd[UNROLL];
-    float2 wt[UNROLL];
+    // UNROLL gvec rows in flight per wave (the pass streams 1 GB of them: with 8 in flight it was latency-bound, 0.61 vs 0.56 ms at 16);
+    // the small per-entry fields are re-read from LDS when the entry is processed, so only g[] stays in registers
     float g[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      hd[u] = *reinterpret_cast<const uint2*>(R + (e0 + u) * 8);       // wave-uniform address: LDS broadcast
-      wt[u] = *reinterpret_cast<const float2*>(Rl + (e0 + u) * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) g[u] = gseg[hd[u].x + ch];
+    for (int u = 0; u < UNROLL; ++u) g[u] = gseg[R[(e0 + u) * 8] + ch];  // wave-uniform LDS address: broadcast
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd[u].y);
-      const int X0 = (int)(packed & 0xffffu), Y0 = (int)(packed >> 16);
-#pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int Y = Y0 + rr;
-        const float val = g[u] * (rr ? wt[u].y : wt[u].x);
-        if (X0 == pX[rr] && Y == pY[rr]) {
-          pval[rr] += val;
-        } else if (Y == pY[rr] && X0 == pX[rr] + 1) {
-          // x-adjacent cell of the same row: texel pX is complete (flush it, 32 lanes), texel pX + 1 carries over from half 1 to half 0
-          if (half == 0 && pval[rr] != 0.f) atomicAdd(gch + ((int64_t)Y * W + pX[rr]) * C, pval[rr]);
-          const float moved = __shfl_xor(pval[rr], 32, 64);
-          pval[rr] = (half == 0 ? moved : 0.f) + val;
-          pX[rr] = X0;
-        } else {
-          if (pval[rr] != 0.f) atomicAdd(gch + ((int64_t)pY[rr] * W + pX[rr] + half) * C, pval[rr]);
-          pX[rr] = X0; pY[rr] = Y; pval[rr] = val;
-        }
+      const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 1]);
+      const float2 wt = *reinterpret_cast<const float2*>(Rl + (e0 + u) * 8);
+      const float v0 = g[u] * wt.x, v1 = g[u] * wt.y;
+      if (packed == ppk) {
+        p0 += v0; p1 += v1;
+      } else if (packed == ppk + 1u) {
+        // x-adjacent cell of the same row pair: texel column pX is complete (flush it, 32 lanes), column pX + 1 carries over from
+        // half 1 to half 0
+        float* dst = gch + ((int64_t)(ppk >> 16) * W + (ppk & 0xffffu)) * C;
+        if (half == 0 && p0 != 0.f) atomicAdd(dst, p0);
+        if (half == 0 && p1 != 0.f) atomicAdd(dst + rowC, p1);
+        const float m0 = __shfl_xor(p0, 32, 64), m1 = __shfl_xor(p1, 32, 64);
+        p0 = (half == 0 ? m0 : 0.f) + v0;
+        p1 = (half == 0 ? m1 : 0.f) + v1;
+        ppk = packed;
+      } else {
+        float* dst = gch + ((int64_t)(ppk >> 16) * W + (ppk & 0xffffu) + half) * C;
+        if (p0 != 0.f) atomicAdd(dst, p0);
+        if (p1 != 0.f) atomicAdd(dst + rowC, p1);
+        ppk = packed; p0 = v0; p1 = v1;
       }
     }
   }
-#pragma unroll
-  for (int rr = 0; rr < 2; ++rr)
-    if (pval[rr] != 0.f) atomicAdd(gch + ((int64_t)pY[rr] * W + pX[rr] + half) * C, pval[rr]);
+  {
+    float* dst = gch + ((int64_t)(ppk >> 16) * W + (ppk & 0xffffu) + half) * C;
+    if (p0 != 0.f) atomicAdd(dst, p0);
+    if (p1 != 0.f) atomicAdd(dst + rowC, p1);
+  }
 }
 
 // Measured and dropped (profiles/r01_kernels.md): a per-wave LDS texel cache behind the register stage (64 direct-mapped texel
