@@ -286,6 +286,98 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_fwd_kernel(MlpArgs a, 
   }
 }
 
+// Forward, one hidden layer, H / 16 == number of waves: wave w always computes hidden units 16w .. 16w+15, so ITS B operand of
+// layer 0 (D0P / 4 k-steps x one float per lane) is loop-invariant -- it lives in registers for the whole persistent loop and W0
+// never enters LDS.  That removes a third of the LDS reads and 83 KB of the 130 KB the sigma net needed, so two workgroups
+// (16 waves) share a CU instead of one and barrier stalls of one overlap MFMAs of the other.
+template <int D0P, int H, int TS>
+struct PlanWreg {
+  static constexpr int LD0 = ld_of(D0P), LDH = ld_of(H), LWO = ldw_of(OUTP);
+  static constexpr int WO = 0;                   // [H][LWO]
+  static constexpr int ACT0 = WO + H * LWO;      // X tile [TS][LD0]
+  static constexpr int ACT1 = ACT0 + TS * LD0;   // A1 [TS][LDH]
+  static constexpr int TOTAL = ACT1 + TS * LDH;
+  static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
+};
+
+template <int MT, int K>
+__device__ __forceinline__ void mma_cols_breg(const float* As, int lda, const float (&breg)[K / 4], f32x4 (&acc)[MT], int lane) {
+  constexpr int KS = K / 4, G = KS % 8 == 0 ? 8 : 4, NG = KS / G;
+  const int lr = lane & 15, lk = lane >> 4;
+  const float* ap = As + lr * lda + lk;
+  float aq[2][G][MT];
+  auto load = [&](int g, int buf) {
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) aq[buf][i][m] = ap[m * 16 * lda + (g * G + i) * 4];
+  };
+  load(0, 0);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = mfma4(aq[g & 1][i][m], breg[g * G + i], acc[m]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int D0P, int H, int TS>
+__global__ __launch_bounds__(H / 16 * 64) void mlp_fwd_wreg_kernel(MlpArgs a, int64_t n_tiles) {
+  extern __shared__ __align__(16) float smem[];
+  using P = PlanWreg<D0P, H, TS>;
+  constexpr int MT = TS / 16, NW = H / 16, KS = D0P / 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  float breg[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) {
+    const int k = 4 * i + lk;
+    breg[i] = k < a.d0 ? a.W[a.woff[0] + (int64_t)k * H + wave * 16 + lr] : 0.f;
+  }
+  stage_weights(a.W + a.woff[1], H, a.dout, smem + P::WO, H, OUTP, P::LWO);
+  const bool relu = a.hidden_act == 1;
+  XTile<TS, D0P, NW * 64> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();  // WO staged / previous tile's readers done
+    xt.store(smem + P::ACT0, P::LD0);
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);  // prefetch the next tile
+    __syncthreads();
+    {
+      f32x4 acc[MT] = {};
+      mma_cols_breg<MT, D0P>(smem + P::ACT0, P::LD0, breg, acc, lane);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) store_block(smem + P::ACT1, P::LDH, m, wave, acc[m], relu, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
+      const int mt = wave + NW * j;
+      if (mt < MT) {
+        f32x4 acc = {};
+        mma_one<H>(smem + P::ACT1, P::LDH, smem + P::WO, P::LWO, mt, 0, acc, lane);
+        const int col = lane & 15;
+        const int64_t row0 = n0 + mt * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = row0 + r;
+          if (n < a.N && col < a.dout) {
+            float y = acc[r];
+            if (a.aux_out && col == a.aux_col) a.aux_out[n] = expf(y);  // trunc_exp forward (activations.py:32)
+            if (a.out_act == 1) y = 1.f / (1.f + expf(-y));
+            a.Y[n * a.ldy + col] = y;
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
@@ -483,6 +575,11 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
   }
 }
 
+static bool wreg_enabled() {
+  static const bool on = [] { const char* e = getenv("SNERF_MLP_WREG"); return e ? atoi(e) != 0 : true; }();
+  return on;
+}
+
 template <int D0P, int H, int NH>
 static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
   if (bwd) {
@@ -498,6 +595,19 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_of<H>() * 64), P::BYTES, st, a, n_tiles);
+  } else if (NH == 1 && H / 16 == waves_of<H>() && wreg_enabled()) {
+    constexpr int TS = H >= 128 ? 16 : 64;
+    using P = PlanWreg<D0P, H, TS>;
+    const int64_t n_tiles = (a.N + TS - 1) / TS;
+    int per_cu = (int)(LDS_LIMIT / P::BYTES);
+    const int by_regs = H >= 128 ? 2 : 4;  // 8-wave workgroups holding D0P/4 weight registers per lane: two per CU
+    per_cu = per_cu < 1 ? 1 : (per_cu > by_regs ? by_regs : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = mlp_fwd_wreg_kernel<D0P, H, TS>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(H / 16 * 64), P::BYTES, st, a, n_tiles);
   } else {
     constexpr int TS = pick_ts<D0P, H, NH, false>();
     using P = Plan<D0P, H, NH, TS, false>;
