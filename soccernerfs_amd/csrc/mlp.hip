@@ -62,6 +62,9 @@ constexpr int waves_of() { return H >= 128 ? 8 : 4; }
 
 template <int D0P, int H, int NH, bool BWD>
 constexpr int pick_ts() {
+  // 4-wave workgroups (H < 128): a tile size that lets at least two workgroups share a CU -- one wave per SIMD cannot hide its own
+  // LDS / barrier waits (color_net backward: 90 KB at TS = 64 -> one workgroup per CU; 58 KB at TS = 32 -> two)
+  if (H < 128 && Plan<D0P, H, NH, 64, BWD>::BYTES > LDS_LIMIT / 2 && Plan<D0P, H, NH, 32, BWD>::BYTES <= LDS_LIMIT / 2) return 32;
   return Plan<D0P, H, NH, 64, BWD>::BYTES <= LDS_LIMIT ? 64 : (Plan<D0P, H, NH, 32, BWD>::BYTES <= LDS_LIMIT ? 32 : 16);
 }
 
