@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
       float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* RG = &g.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float gk = G[k] * a.grad_scale + RG[k];
+        float gk = G[k] * a.grad_scale + RG[k];
+        if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;  // a non-finite gradient element is dropped, never written into m / v / p
         M[k] = a.b1 * M[k] + (1.f - a.b1) * gk;
         V[k] = a.b2 * V[k] + (1.f - a.b2) * gk * gk;
         P[k] = P[k] - a.step_size * (M[k] / (sqrtf(V[k]) * a.inv_sqrt_bc2 + a.eps));
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float gk = G[k] * grad_scale;
+      if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;  // a non-finite gradient element is dropped, never written into m / v / p
       M[k] = b1 * M[k] + (1.f - b1) * gk;
       V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
       float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = n4 * 4 + threadIdx.x;
     float gk = g[i] * grad_scale;
+    if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;
     float mk = b1 * m[i] + (1.f - b1) * gk;
     float vk = b2 * v[i] + (1.f - b2) * gk * gk;
     m[i] = mk; v[i] = vk;

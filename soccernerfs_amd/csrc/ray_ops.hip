@@ -241,7 +241,10 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
       bool fin = (wraw == wraw) && fabsf(wraw) != INFINITY;
       Tk[k] = T; ek[k] = e;
       gwterm[k] = fin ? g * wraw : 0.f;
-      if (!fin) Tk[k] = 0.f;
+      // a non-finite weight (density = exp(x) overflowed to inf on a zero-width bin: 0 * inf) passes no gradient, as nan_to_num
+      // does -- and must not leave a NaN factor behind: 0 * NaN is NaN (seen once in ~20 k training steps: one NaN here reaches
+      // every parameter through the sigma net and the TV stencil within a few steps)
+      if (!fin) { Tk[k] = 0.f; ek[k] = 0.f; }
     }
   }
   __syncthreads();
@@ -268,6 +271,7 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
       float e0 = ebins[(int64_t)r * (S + 1) + i], e1 = ebins[(int64_t)r * (S + 1) + i + 1];
       float gdd = g * Tk[k] * ek[k] - aux[i];
       float out = gdd * (e1 - e0);
+      if (!(fabsf(out) <= 3.402823466e+38f)) out = 0.f;  // inf * 0 / NaN: no gradient (the reference's GradScaler would skip such a step)
       if (accumulate) gdens[(int64_t)r * S + i] += out; else gdens[(int64_t)r * S + i] = out;
     }
   }

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--eval-every", type=int, default=10000)
     ap.add_argument("--out", default="gpurun_out/psnr.json")
     ap.add_argument("--seed", type=int, default=20231029)
+    ap.add_argument("--check-finite", type=int, default=0, help="every N steps: stop at the first non-finite parameter / Adam state and say where")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(args.seed)
@@ -80,6 +81,17 @@ def main():
         rays = ops.generate_rays(idx, train["fx"], train["fy"], train["cx"], train["cy"], train["c2w"], train["times"], aabb=trainer.aabb,
                                  near_plane=cfg.near_plane, training=True)
         trainer.train_step(rays, target)
+        if args.check_finite and step % args.check_finite == args.check_finite - 1:
+            trainer.synchronize()
+            bad = [(name, what) for name, _, _, o, n in trainer.segments for what, buf in (("param", trainer.params), ("exp_avg", trainer.exp_avg),
+                   ("exp_avg_sq", trainer.exp_avg_sq), ("grad", trainer.grads)) if not bool(torch.isfinite(buf[o:o + n]).all())]
+            if bad:
+                print(f"non-finite values first seen at step {step + 1}: {bad}", flush=True)
+                for name, _, _, o, n in trainer.segments:
+                    p_ = trainer.params[o:o + n]
+                    fin = p_[torch.isfinite(p_)]
+                    print(f"  {name}: non-finite params {int((~torch.isfinite(p_)).sum())} of {n}, max |p| {float(fin.abs().max()) if fin.numel() else float('nan'):.3e}")
+                return
         if step % 500 == 499:
             torch.cuda.synchronize()
             dt = time.time() - t1
