@@ -92,6 +92,12 @@ def main():
     if world != args.gpus and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (the HIP path has no fallback)"
+    # test hooks (tests/test_gpu_sharded.py): exercise the multi-rank code path of this script on a ONE-GPU box -- every rank on
+    # device 0, collectives through gloo (staged via host memory by dist.py).  Never set by the driver.
+    one_device = os.environ.get("SNERF_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("SNERF_BENCH_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -99,7 +105,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
         pg = dist.group.WORLD
 
     from soccernerfs_amd import ops, synthetic
@@ -154,7 +163,7 @@ def main():
     kt = trainer.kernel_times_ms()
     trainer.disable_kernel_timing()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
