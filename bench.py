@@ -230,6 +230,16 @@ def main():
                          "other_kernels_frac": {k: round(alg[k][1] / (v[0] * 1e-3) / 1e9 / (HBM_PEAK_GBS if alg[k][0] == "hbm" else 157300.0), 3)
                                                 for k, v in timed.items() if k != DOMINANT}},
         }
+        # second half of BASELINE.json's metric (PSNR@30k): not re-measured here (a 30 k-step run takes minutes) -- the committed result of
+        # tools/train_psnr.py on this workload is quoted with its source
+        psnr_file = os.path.join(ROOT, "profiles", "r01_psnr_30k.json")
+        if os.path.exists(psnr_file):
+            try:
+                ev = json.load(open(psnr_file))["evals"][-1]
+                line["psnr_30k"] = {"held_out_camera_db": round(ev["psnr_heldout_mean"], 2), "train_views_db": round(ev["psnr_train_views_mean"], 2),
+                                    "step": ev["step"], "source": "profiles/r01_psnr_30k.json (tools/train_psnr.py, same preset and synthetic scene)"}
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         if breakdown:
