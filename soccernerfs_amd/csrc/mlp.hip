@@ -6,12 +6,16 @@
 // Numerics: exact fp32 -- v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain (cdna_hip_programming.md §3),
 // so the fp32 parity bar (rtol 1e-5) against the CPU oracle holds; tcnn itself computes in fp16 (>= reference precision).
 //
-// Structure: persistent 256-thread workgroups (4 waves).  ALL weights of the network are staged ONCE per workgroup into
-// LDS (zero-padded, row stride = 2 mod 32 floats so both the plain and the transposed B-operand reads spread over the
-// banks); the workgroup then walks TS-sample tiles: activations live in LDS (row stride = 2 mod 32 => conflict-free
-// A-operand reads), every MFMA operand comes from LDS, nothing but X and dY ever touches HBM.  The backward recomputes the
-// forward per tile, keeps the weight-gradient accumulators in registers across the whole persistent loop and flushes
-// them once per workgroup with 64-B-contiguous atomics.  TS (64/32/16) is chosen per shape so weights + tiles fit 160 KB.
+// Structure: persistent workgroups (4 waves for the 64-wide nets, 8 for the 128-wide ones) walk TS-sample tiles; activations
+// live in LDS (row stride = 2 mod 32 floats => conflict-free A-operand reads), every MFMA operand is read in groups of 8 k-steps
+// one group ahead of the MFMAs that consume it, nothing but X and dY ever touches HBM.
+//   forward, one hidden layer (mlp_fwd_wreg_kernel): each wave owns 16 hidden units, its layer-0 B operand stays in registers for
+//     the whole loop; only the 16-wide output weights are in LDS; two workgroups per CU.
+//   forward with two hidden layers / backward: all weights staged ONCE per workgroup into LDS (zero-padded, row stride = 2 mod 32
+//     so both the plain and the transposed B-operand reads spread over the banks).  The backward recomputes the forward per tile,
+//     keeps the weight-gradient accumulators in registers across the whole persistent loop and flushes them once per workgroup
+//     with 64-B-contiguous atomics.  TS (64/32/16) is chosen per shape so that weights + tiles fit and, for 4-wave workgroups,
+//     two of them share a CU.
 #include "common.hpp"
 
 namespace snerf {
