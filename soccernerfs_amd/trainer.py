@@ -430,7 +430,8 @@ class KPlanesTrainer:
                     self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl],
                                   self.gviews[f"prop{lvl}.planes"])
 
-    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True):
+    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True,
+                 defer_prop_join: bool = False):
         """Accumulates d(total loss)/d(params) into self.grads (which must be zero on entry: Adam clears it); fills
         self.last with the (scaled) loss terms.
 
@@ -501,13 +502,26 @@ class KPlanesTrainer:
                     joins.append(st)
                 with KPlanesTrainer._On(self, st):
                     self._field_backward_chunk(bounds[i], bounds[i + 1])
+        # defer_prop_join (train_step, single GPU): the proposal chain may still be running when this returns -- nothing before the
+        # proposal planes' own optimiser kernels needs its gradients, so its tail runs under the field planes' sweep instead of in
+        # front of it; _join_prop() is the barrier
+        self._prop_pending = None
         for st in joins:
-            main.wait_stream(st)
+            if defer_prop_join and not sharded and st is self._side.get("prop"):
+                self._prop_pending = st
+            else:
+                main.wait_stream(st)
+
+    def _join_prop(self):
+        if getattr(self, "_prop_pending", None) is not None:
+            torch.cuda.current_stream().wait_stream(self._prop_pending)
+            self._prop_pending = None
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny
         reductions, only when asked for."""
         b, co, R = self.buf, self.cfg.loss_coefficients, self.R
+        self._join_prop()
         if self._reg_work is not None:
             self._reg_work.wait()  # sharded optimiser: the field planes' regulariser values are summed across ranks asynchronously
         if getattr(self, "_field_adam_done", None) is not None:
@@ -541,6 +555,7 @@ class KPlanesTrainer:
 
     def synchronize(self):
         """Join every stream the trainer uses; call before reading parameters / Adam state from outside a train step."""
+        self._join_prop()
         self._wait_params()
         torch.cuda.synchronize(self.dev)
 
@@ -643,6 +658,8 @@ class KPlanesTrainer:
         into Adam's grad_scale.  RCCL when the group's backend is nccl (GPU), gloo in the CPU tests."""
         from . import dist as sdist
 
+        if self.world > 1:
+            self._join_prop()
         with self._span("allreduce_grads"):
             self._grad_scale = sdist.allreduce_flat_(self.grads, self.pg)
 
@@ -652,6 +669,7 @@ class KPlanesTrainer:
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
         gs = getattr(self, "_grad_scale", 1.0)
         if not fused_reg:
+            self._join_prop()
             with self._span("adam_step"):
                 ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=True)
             self.step += 1
@@ -677,6 +695,7 @@ class KPlanesTrainer:
             self._adam_field_range(0, early_hi, side=False)
             torch.cuda.current_stream().wait_stream(self._stream("adam"))
         self._reg_zeroed = False
+        self._join_prop()  # the proposal gradients are needed from here on
         sets = [(f"prop{i}.planes", self.prop_planes[i], ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
                                                           "sparse_transients_proposal_loss"), 1 + i) for i in range(2)]
         for name, ps, keys, row in sets:
@@ -718,7 +737,7 @@ class KPlanesTrainer:
         if self._pipeline_adam:
             self.buf["reg"].zero_()
             self._reg_zeroed = True
-        self.backward(target, rng, proposal_grads=updated, include_reg=not fuse)
+        self.backward(target, rng, proposal_grads=updated, include_reg=not fuse, defer_prop_join=fuse and self.world == 1)
         self._pipeline_adam = False
         if self._sharded():
             self._sharded_optimizer_step()
