@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--start-step", type=int, default=0, help="pretend this many optimiser steps are done: >= 5000 gives the steady-state "
                     "schedule (proposal networks updated every 5th step, kplanes.py:254-259) instead of the every-step schedule of early training")
     ap.add_argument("--adam-under-scatter", action="store_true", help="A-B: sweep the finest scale's planes while the coarser scales are scattered")
-    ap.add_argument("--async-adam", action="store_true", help="A-B: field-plane optimiser sweep on its own stream, under the next step's proposal levels")
+    ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
@@ -123,7 +123,7 @@ def main():
     if args.no_shard:
         trainer.shard_optimizer = False
     trainer.step = args.start_step
-    trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, args.async_adam
+    trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)

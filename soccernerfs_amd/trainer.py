@@ -87,11 +87,12 @@ class KPlanesTrainer:
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         # world > 1: reduce-scatter + sharded Adam + all-gather for the field planes instead of one all-reduce (see dist.py)
         self.shard_optimizer = self.world > 1
-        # Two optional overlaps of the field planes' optimiser sweep, both measured at +1-2 % only (the sweep saturates HBM and slows
-        # whatever runs beside it) and therefore off: async_field_adam runs it on its own stream under the NEXT step's pixel draw /
-        # ray generation / proposal levels (forward() joins it before the field gather, synchronize() joins it for outside readers);
-        # adam_under_scatter sweeps the finest scale while the coarser scales are still being scattered.
-        self.async_field_adam = False
+        # async_field_adam: the field planes' optimiser sweep runs on its own stream under the NEXT step's pixel draw / ray generation /
+        # proposal levels (which read only the small segments); forward() joins it before the field gather, loss_dict() and
+        # synchronize() join it for outside readers -- call synchronize() before reading parameters / Adam state / gradients from
+        # outside a train step.  +3-5 % (bench.py --sync-adam for A-B).  adam_under_scatter (sweep the finest scale while the coarser
+        # scales are still being scattered) measured +1 % and stays off.
+        self.async_field_adam = True
         self.adam_under_scatter = False
         self._field_adam_done = None
         self._rs_work = self._ar_work = self._ag_work = self._reg_work = None
