@@ -82,3 +82,12 @@ def test_oob_and_interpolation_properties():
     # constant table => constant output (interpolation weights sum to 1 in space and time)
     out2 = TO.encode(x[2:], TO.temporal_index(t[2:], tab), torch.full_like(emb, 0.7), offs, 1.0, 4, 0, 2)
     torch.testing.assert_close(out2, torch.full_like(out2, 0.7), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("log2", [8, 17, 19])
+def test_fast_hash_matches_reference_hash_encoding_on_random_corners(log2):
+    """G9b (oracle/gen_golden_hash.py): the reference's importable pure-torch hash on 512 random corners == fast_hash mod 2^k."""
+    g = load_golden("g9b_hash")
+    pos, want = g[f"pos_{log2}"].long(), g[f"hash_{log2}"].long()
+    got = TO.fast_hash(pos) % (1 << log2)
+    assert torch.equal(got, want)
