@@ -222,3 +222,76 @@ def test_fused_tv_and_fused_adam_match_torch_adam():
             assert float(bad) < 2e-3, (n0, float(bad))
     for e in encs[1]:
         assert float(e.embeddings.grad.abs().max()) == 0.0  # cleared by the optimiser sweep
+
+
+def test_nerfplayer_model_matches_reference_golden():
+    """G12 (oracle/gen_golden_nerfplayer.py): the reference's own NerfplayerNerfactoModel, run on the CPU with explicit random draws
+    -- outputs, sample bins, every loss term and per-tensor gradient checksums."""
+    from tests.conftest import load_golden
+    from soccernerfs_amd.nerfplayer_nerfacto import NerfplayerNerfactoModel, NerfplayerNerfactoModelConfig
+    from soccernerfs_amd.rays import RayBundle
+    from soccernerfs_amd.scene_colliders import SceneBox
+
+    g = load_golden("g12_nerfplayer")
+    cfg = NerfplayerNerfactoModelConfig(
+        num_levels=4, features_per_level=2, log2_hashmap_size=10, temporal_dim=8,
+        proposal_net_args_list=[{"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 32},
+                                {"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 64}],
+        num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8)
+    model = NerfplayerNerfactoModel(cfg, SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3])), num_train_data=int(g["num_images"]))
+    P = lambda name: g["param_" + name]
+    with torch.no_grad():
+        model.field.embedding_appearance.weight.copy_(P("field.embedding_appearance.embedding.weight"))
+        model.field.mlp_base.embeddings.copy_(P("field.mlp_base.embeddings"))
+        model.field.mlp_base_decode.load_linear_weights([P(f"field.mlp_base_decode.layers.{i}.weight") for i in range(2)])
+        model.field.mlp_head.load_linear_weights([P(f"field.mlp_head.layers.{i}.weight") for i in range(3)])
+        for k, pn in enumerate(model.proposal_networks):
+            pn.encoding.embeddings.copy_(P(f"proposal_networks.{k}.encoding.embeddings"))
+            pn.linear.load_linear_weights([P(f"proposal_networks.{k}.linear.layers.{i}.weight") for i in range(2)])
+    model = model.to(DEV).train()
+    model.scene_box.aabb = model.scene_box.aabb.to(DEV)
+    t = lambda k: g[k].to(DEV).contiguous()
+    draws = [t("t_rand"), t("u0"), t("u1"), t("bg")]
+    model.set_rand_fn(lambda shape, device=None: draws.pop(0))
+    model.tv_row_fn = lambda enc: int(g["tv_row"])
+    for e in [model.field.mlp_base] + [p.encoding for p in model.proposal_networks]:
+        e.fuse_tv = False
+    model.proposal_sampler.set_anneal(float(g["anneal"]))
+    R = int(g["R"])
+    rb = RayBundle(origins=t("origins"), directions=t("directions"), pixel_area=torch.ones(R, 1, device=DEV), camera_indices=t("cams"), times=t("times"))
+    out = model(rb)
+    assert not draws
+    for i in range(3):
+        torch.testing.assert_close(out["ray_samples_list"][i]._compact["ebins"].cpu(), g[f"ebins_{i}"], rtol=0, atol=3e-5)
+        torch.testing.assert_close(out["weights_list"][i][..., 0].cpu() if out["weights_list"][i].dim() == 3 else out["weights_list"][i].cpu(),
+                                   g[f"weights_{i}"], rtol=2e-3, atol=2e-5)
+    torch.testing.assert_close(out["rgb"].cpu(), g["rgb"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(out["accumulation"].cpu(), g["accumulation"], rtol=1e-3, atol=2e-5)
+    torch.testing.assert_close(out["depth"].cpu(), g["depth"], rtol=1e-3, atol=1e-4)
+    for i in range(2):
+        torch.testing.assert_close(out[f"prop_depth_{i}"].cpu(), g[f"prop_depth_{i}"], rtol=1e-3, atol=1e-4)
+    target = t("target")
+    md = model.get_metrics_dict(out, {"image": target})
+    ld = model.get_loss_dict(out, {"image": target}, md)
+    torch.testing.assert_close(md["distortion"].detach().cpu(), torch.as_tensor(g["distortion"]), rtol=2e-3, atol=1e-9)
+    assert set(ld) == {"rgb_loss", "interlevel_loss", "distortion_loss", "temporal_tv_loss"}
+    for k, v in ld.items():
+        torch.testing.assert_close(v.detach().cpu(), torch.as_tensor(g["loss_" + k]), rtol=2e-3, atol=1e-9)
+    sum(ld.values()).backward()
+    mine = {"field.embedding_appearance.embedding.weight": model.field.embedding_appearance.weight.grad,
+            "field.mlp_base.embeddings": model.field.mlp_base.embeddings.grad}
+    for i, w in enumerate(model.field.mlp_base_decode.linear_weights(model.field.mlp_base_decode.params.grad)):
+        mine[f"field.mlp_base_decode.layers.{i}.weight"] = w
+    for i, w in enumerate(model.field.mlp_head.linear_weights(model.field.mlp_head.params.grad)):
+        mine[f"field.mlp_head.layers.{i}.weight"] = w
+    for k, pn in enumerate(model.proposal_networks):
+        mine[f"proposal_networks.{k}.encoding.embeddings"] = pn.encoding.embeddings.grad
+        for i, w in enumerate(pn.linear.linear_weights(pn.linear.params.grad)):
+            mine[f"proposal_networks.{k}.linear.layers.{i}.weight"] = w
+    for name in [str(n) for n in g["param_names"]]:
+        got = mine[name].cpu()
+        gabs = float(g["gabs_" + name])
+        assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= 3e-3 * gabs + 1e-9, name
+        assert abs(float(got.double().abs().sum()) - gabs) <= 3e-3 * gabs + 1e-9, name
+        probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
+        torch.testing.assert_close(probe, g["gprobe_" + name], rtol=5e-3, atol=1e-7 + 2e-3 * float(g["gprobe_" + name].abs().max()))

@@ -91,3 +91,44 @@ def test_fast_hash_matches_reference_hash_encoding_on_random_corners(log2):
     pos, want = g[f"pos_{log2}"].long(), g[f"hash_{log2}"].long()
     got = TO.fast_hash(pos) % (1 << log2)
     assert torch.equal(got, want)
+
+
+def _g12_enc(g, prefix, temporal_dim, num_levels, log2, max_res=None):
+    """Encoder description dict of oracle.tgrid_oracle.encode for one of G12's tables."""
+    if max_res is None:  # main field: desired_resolution 2048 * scene scale 1 (nerfplayer_nerfacto_field.py:250-262)
+        scale = TO.resolve_scale(num_levels, 16, 2.0, 2048)
+    else:
+        scale = float(np.exp((np.log(max_res) - np.log(16)) / (num_levels - 1)))
+    offsets = TO.level_offsets(num_levels, 16, scale, log2)
+    assert offsets[-1] == g["param_" + prefix + ".embeddings"].shape[0]
+    return {"offsets": offsets, "log2_scale": float(np.log2(scale)), "base_res": 16, "gridtype": 0, "level_dim": 2,
+            "table": TO.channel_table(temporal_dim, 2)}
+
+
+def test_oracle_fields_reproduce_reference_model_golden():
+    """G12 (the reference's NerfplayerNerfactoModel run on the CPU): from the stored sample bins, the oracle's proposal density field
+    and main field give the reference's weights at every level and its composited rgb."""
+    from oracle import kplanes_oracle as KO
+
+    g = load_golden("g12_nerfplayer")
+    o, d, times = g["origins"], g["directions"], g["times"]
+    aabb = torch.tensor([[-1.0] * 3, [1.0] * 3])
+    lin = lambda prefix, n: [g[f"param_{prefix}.layers.{i}.weight"] for i in range(n)]
+    for lvl in range(2):
+        eb = g[f"ebins_{lvl}"]
+        pos = o[:, None, :] + d[:, None, :] * ((eb[:, :-1] + eb[:, 1:]) / 2)[..., None]
+        enc = _g12_enc(g, f"proposal_networks.{lvl}.encoding", 4, 3, 9, max_res=(32, 64)[lvl])
+        dens = TO.density_field_forward(pos, times, aabb, enc, g[f"param_proposal_networks.{lvl}.encoding.embeddings"], lin(f"proposal_networks.{lvl}.linear", 2))
+        w = KO.get_weights(eb[:, 1:] - eb[:, :-1], dens)
+        torch.testing.assert_close(w, g[f"weights_{lvl}"], rtol=1e-4, atol=1e-6)
+    eb = g["ebins_2"]
+    pos = o[:, None, :] + d[:, None, :] * ((eb[:, :-1] + eb[:, 1:]) / 2)[..., None]
+    enc = _g12_enc(g, "field.mlp_base", 8, 4, 10)
+    app = g["param_field.embedding_appearance.embedding.weight"][g["cams"][:, 0].long()]
+    dens, rgb = TO.main_field_forward(pos, d, times, aabb, enc, g["param_field.mlp_base.embeddings"], lin("field.mlp_base_decode", 2),
+                                      lin("field.mlp_head", 3), app)
+    w = KO.get_weights(eb[:, 1:] - eb[:, :-1], dens)
+    torch.testing.assert_close(w, g["weights_2"], rtol=1e-4, atol=1e-6)
+    comp = (w[..., None] * rgb).sum(1) + g["bg"] * (1 - w.sum(1, keepdim=True))
+    torch.testing.assert_close(comp, g["rgb"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(w.sum(1, keepdim=True), g["accumulation"], rtol=1e-4, atol=1e-6)
