@@ -327,6 +327,9 @@ int snerf_tgrid_tv_fwd(const float* embeddings, int64_t rows, int32_t grid_C, in
                        snerf_stream_t stream);
 int snerf_tgrid_tv_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* g_tv,
                        float* grad_embeddings, snerf_stream_t stream);
+/* Both in one pass, for callers that know the upstream gradient g_tv (the loss weight) before the value (the fused trainer). */
+int snerf_tgrid_tv_fwd_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
+                           int32_t n_slots, float* grad_embeddings, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray importance sampling (IST = temporal difference).

@@ -107,6 +107,7 @@ def lib():
     l.snerf_sample_pixels_uniform.argtypes = [P, I, I, I, I, P, P, P, P]
     l.snerf_tgrid_tv_fwd.argtypes = [P, L, I, I, I, P, I, P]
     l.snerf_tgrid_tv_bwd.argtypes = [P, L, I, I, I, P, P, P]
+    l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
     if l.snerf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
@@ -145,6 +146,7 @@ EXPORTS = [
     "snerf_render_mse_bwd",
     "snerf_tgrid_tv_fwd",
     "snerf_tgrid_tv_bwd",
+    "snerf_tgrid_tv_fwd_bwd",
     "snerf_sample_pixels_uniform",
     "snerf_kplanes_scatter_sorted_scales",
     "snerf_raygen",

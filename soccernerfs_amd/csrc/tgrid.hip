@@ -193,7 +193,32 @@ __global__ __launch_bounds__(256) void tgrid_tv_bwd_kernel(const float* __restri
   const float s = ((d > 0.f) - (d < 0.f)) * (g_tv[0] / (float)rows);  // d|x|/dx = sign(x) (0 at 0, as torch.abs), mean over rows
   if (s != 0.f) { gE[r * grid_C + a] += s; gE[r * grid_C + b] -= s; }
 }
+// value and gradient in one pass over the two columns (the fused trainer knows the upstream gradient -- the loss weight -- up front)
+__global__ __launch_bounds__(256) void tgrid_tv_fwd_bwd_kernel(const float* __restrict__ E, int64_t rows, int grid_C, int a, int b, float g_over_rows,
+                                                              float* __restrict__ partial, int n_slots, float* __restrict__ gE) {
+  float acc = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const float d = E[r * grid_C + a] - E[r * grid_C + b];
+    acc += fabsf(d);
+    const float s = ((d > 0.f) - (d < 0.f)) * g_over_rows;
+    if (s != 0.f) { gE[r * grid_C + a] += s; gE[r * grid_C + b] -= s; }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(partial + (blockIdx.x % n_slots) * 16, acc);
+}
 }  // namespace snerf
+
+extern "C" int snerf_tgrid_tv_fwd_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
+                                      int32_t n_slots, float* grad_embeddings, snerf_stream_t stream) {
+  SNERF_REQUIRE(rows >= 1 && grid_C >= 1 && col_a >= 0 && col_a < grid_C && col_b >= 0 && col_b < grid_C && col_a != col_b && n_slots >= 1,
+                "tgrid_tv_fwd_bwd: rows=%lld grid_C=%d cols=(%d,%d) n_slots=%d", (long long)rows, grid_C, col_a, col_b, n_slots);
+  SNERF_REQUIRE(embeddings && partial && grad_embeddings, "tgrid_tv_fwd_bwd: null buffer");
+  const int64_t blocks = (rows + 255) / 256;
+  hipLaunchKernelGGL(snerf::tgrid_tv_fwd_bwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, embeddings, rows,
+                     grid_C, col_a, col_b, g_tv / (float)rows, partial, n_slots, grad_embeddings);
+  SNERF_LAUNCH_CHECK("tgrid_tv_fwd_bwd");
+  return 0;
+}
 
 extern "C" int snerf_tgrid_tv_fwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float* partial, int32_t n_slots,
                                   snerf_stream_t stream) {

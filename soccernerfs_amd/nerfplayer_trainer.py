@@ -1,0 +1,258 @@
+"""Fused training step of the reference's NeRFPlayer-nerfacto model (config 4) on libsnerf: one flat parameter / gradient / Adam
+buffer, preallocated work buffers, no autograd graph, no allocation and no host synchronisation inside a step.
+
+What the reference does per step: Trainer.train_iteration -> NerfplayerNerfactoModel.get_outputs / get_metrics_dict / get_loss_dict
+(NS/models/nerfplayer_nerfacto.py:206-318) -> autograd backward -> 2x Adam (NS/configs/method_configs.py:648-657: lr 1e-2,
+eps 1e-12, cosine schedule with 512 warm-up steps) -> callbacks (proposal-weight annealing, proposal update schedule:
+NS/models/nerfacto.py:235-264).  Same mathematics here, in this order:
+
+  collider (AABB) -> piecewise sampler (single jitter) -> [temporal hash grid -> 10->16->1 MLP -> trunc_exp -> weights -> PDF] x2
+  -> main grid (16 levels) -> 32->64->16 MLP (density = trunc_exp(col 0)) -> [SH4(dir) | 15 geo features | appearance(cam)] ->
+  63->64->64->3 sigmoid MLP -> weights -> rgb / accumulation / expected depth -> MSE + interlevel + 1e-3 distortion + temporal TV x3
+  -> gradients of all of it -> one Adam sweep (gradient cleared in the sweep) with the TV gradient added just before it.
+
+The nerfstudio-shaped autograd model (nerfplayer_nerfacto.py, pinned against the reference by golden G12) is the checker of this file:
+tests/test_gpu_nerfplayer_trainer.py compares losses and every gradient tensor on identical draws."""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
+from .sh import sh4_from_unit_dirs
+from .tcnn_compat import Network
+from .temporal_grid import TemporalGridEncoder
+from .trainer import anneal_value, cosine_lr_factor
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class NerfplayerTrainer:
+    def __init__(self, cfg: NerfplayerNerfactoModelConfig, num_rays: int, num_images: int, aabb_scale: float = 1.0, device="cuda:0",
+                 lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0):
+        if not cfg.disable_scene_contraction or cfg.use_same_proposal_network or cfg.num_proposal_iterations != 2:
+            raise NotImplementedError("NerfplayerTrainer covers the nerfplayer-nerfacto preset (AABB collider, two proposal networks)")
+        self.cfg, self.R, self.dev = cfg, num_rays, torch.device(device)
+        self.lr, self.adam_eps, self.warm_up_end, self.max_steps = lr, adam_eps, warm_up_end, max_steps
+        a = aabb_scale
+        self.aabb = [[-a, -a, -a], [a, a, a]]
+        torch.manual_seed(seed)
+        mlp = lambda din, dout, h, nh, act: Network(din, dout, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act,
+                                                               "n_neurons": h, "n_hidden_layers": nh})
+        # ---- modules exactly as the fields build them (nerfplayer_nerfacto_field.py:83-104, 238-311) ----
+        self.prop_enc: List[TemporalGridEncoder] = []
+        self.prop_mlp: List[Network] = []
+        for args in cfg.proposal_net_args_list[:2]:
+            L, H = args.get("num_levels", 8), args.get("hidden_dim", 64)
+            growth = float(np.exp((np.log(args.get("max_res", 1024)) - np.log(16)) / (L - 1)))
+            self.prop_enc.append(TemporalGridEncoder(input_dim=3, temporal_dim=args.get("temporal_dim", 64), num_levels=L, level_dim=2,
+                                                     per_level_scale=growth, base_resolution=16, log2_hashmap_size=args.get("log2_hashmap_size", 18)))
+            self.prop_mlp.append(mlp(2 * L, 1, H, 1, "None"))
+        self.enc = TemporalGridEncoder(input_dim=3, temporal_dim=cfg.temporal_dim, num_levels=cfg.num_levels, level_dim=cfg.features_per_level,
+                                       log2_hashmap_size=cfg.log2_hashmap_size, desired_resolution=1024 * 2.0 * a)
+        self.decode = mlp(cfg.num_levels * cfg.features_per_level, 16, 64, 1, "None")
+        self.head = mlp(16 + 15 + 32, 3, 64, 2, "Sigmoid")
+        self.appearance = torch.nn.Embedding(num_images, 32)
+        # ---- one flat buffer ----
+        self.segments = []  # (name, tensor-owner, attr, offset, numel)
+        off = 0
+        for i in range(2):
+            for name, mod, attr in ((f"prop{i}.table", self.prop_enc[i], "embeddings"), (f"prop{i}.mlp", self.prop_mlp[i], "params")):
+                n = getattr(mod, attr).numel()
+                self.segments.append((name, mod, attr, off, n))
+                off += _align4(n)
+        for name, mod, attr in (("field.table", self.enc, "embeddings"), ("field.decode", self.decode, "params"), ("field.head", self.head, "params"),
+                                ("field.appearance", self.appearance, "weight")):
+            n = getattr(mod, attr).numel()
+            self.segments.append((name, mod, attr, off, n))
+            off += _align4(n)
+        self.n_params = off
+        self.params = torch.zeros(off, dtype=torch.float32, device=self.dev)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.views, self.gviews = {}, {}
+        for name, mod, attr, o, n in self.segments:
+            p = getattr(mod, attr)
+            self.params[o:o + n].copy_(p.detach().reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)  # the module's parameter aliases its segment
+            self.views[name] = p.data
+            self.gviews[name] = self.grads[o:o + n].view(p.shape)
+        # ---- work buffers ----
+        R = num_rays
+        S0, S1 = cfg.num_proposal_samples_per_ray
+        S2 = cfg.num_nerf_samples_per_ray
+        self.S = (S0, S1, S2)
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.dev)
+        self.buf = {
+            "sb": [f(R, s + 1) for s in self.S], "eb": [f(R, s + 1) for s in self.S],
+            "dens": [f(R, s) for s in self.S], "w": [f(R, s) for s in self.S], "gw": [f(R, s) for s in self.S], "gdens": [f(R, s) for s in self.S],
+            "pfeat": [f(R * S0, self.prop_enc[0].output_dim), f(R * S1, self.prop_enc[1].output_dim)],
+            "pout": [f(R * S0, 1), f(R * S1, 1)],
+            "gpfeat": [f(R * S0, self.prop_enc[0].output_dim), f(R * S1, self.prop_enc[1].output_dim)],
+            "feat": f(R * S2, self.enc.output_dim), "gfeat": f(R * S2, self.enc.output_dim),
+            "h": f(R * S2, 16), "gh": z(R * S2, 16),
+            "hx": z(R * S2, 64), "ghx": f(R * S2, 64),           # head input [SH 16 | geo 15 | appearance 32 | pad], and its gradient
+            "rgb": f(R * S2, 3), "grgb": f(R * S2, 3),
+            "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "sqerr": z(R), "dist_rays": f(R), "inter_rays": [f(R), f(R)],
+            "tv": z(3, 64, 16),
+        }
+        self.lib = _lib.lib()
+        self.step = 0
+        self._steps_since_update = 0
+        self.tv_rows: Optional[List[int]] = None  # parity hook: fixed table rows [field, prop0, prop1] instead of the random draw
+        self._tv_cols = [(0, 1)] * 3
+
+    # ---- helpers ----
+    def _p(self, t):
+        return C.c_void_p(t.data_ptr())
+
+    def _tgrid_fwd(self, enc, table, co, times, S, N, out):
+        _lib.check(self.lib.snerf_tgrid_encode_fwd(C.byref(enc.desc), self._p(table), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(out),
+                                                   self._st), "tgrid_fwd")
+
+    def _tgrid_bwd(self, enc, co, times, S, N, gout, gtable):
+        _lib.check(self.lib.snerf_tgrid_encode_bwd(C.byref(enc.desc), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(gout), self._p(gtable),
+                                                   self._st), "tgrid_bwd")
+
+    def _mlp_fwd(self, net, X, ldx, N, Y, ldy, aux_col=-1, aux=None):
+        _lib.check(self.lib.snerf_mlp_fwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(Y), ldy, aux_col,
+                                          self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
+
+    def _mlp_bwd(self, net, gW, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
+        _lib.check(self.lib.snerf_mlp_bwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(gY) if gY is not None else None,
+                                          ldgy, aux_col, self._p(gaux) if gaux is not None else None, self._p(gX) if gX is not None else None, ldgx,
+                                          self._p(gW), self._st), "mlp_bwd")
+
+    def _resample(self, lvl, rand, anneal):
+        b, a = self.buf, _lib.ResampleArgs()
+        a.density, a.ebins_prev, a.weights_out = b["dens"][lvl].data_ptr(), b["eb"][lvl].data_ptr(), b["w"][lvl].data_ptr()
+        a.sbins_prev, a.nears, a.fars = b["sb"][lvl].data_ptr(), self.rays["nears"].data_ptr(), self.rays["fars"].data_ptr()
+        a.u_mode, a.u_or_rand, a.rand_cols = 1, rand.data_ptr(), rand.shape[-1]
+        a.sbins_out, a.ebins_out = b["sb"][lvl + 1].data_ptr(), b["eb"][lvl + 1].data_ptr()
+        a.R, a.S_prev, a.S, a.kind = self.R, self.S[lvl], self.S[lvl + 1], 1  # spacing = UniformLinDispPiecewise (ray_samplers.py:242-243)
+        a.anneal, a.histogram_padding, a.eps = anneal, 0.01, 1e-5
+        _lib.check(self.lib.snerf_pdf_resample(C.byref(a), self._st), "pdf_resample")
+
+    # ---- forward ----
+    def forward(self, rays: Dict[str, torch.Tensor], cams: torch.Tensor, rng: Dict[str, torch.Tensor], anneal: float):
+        """rays: origins [R,3], directions [R,3] (unit), times [R,1]; cams int64 [R]; rng: t_rand [R,1], u [2 x [R,1]], bg [R,3]."""
+        cfg, b, R = self.cfg, self.buf, self.R
+        self._st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
+        rays = dict(rays)
+        rays["nears"], rays["fars"] = ops.aabb_collide(o, d, self.aabb, 0.0, True)  # AABBBoxCollider(scene_box): near_plane 0
+        self.rays, self.cams = rays, cams
+        _lib.check(self.lib.snerf_spaced_bins(self._p(rays["nears"]), self._p(rays["fars"]), self._p(rng["t_rand"]), rng["t_rand"].shape[-1], R,
+                                              self.S[0], 1, self._p(b["sb"][0]), self._p(b["eb"][0]), self._st), "spaced_bins")
+        self._coords = []
+        for lvl in range(3):
+            co = ops.coords_from_rays(o, d, t, b["eb"][lvl], self.aabb, False)
+            self._coords.append(co)
+            S, N = self.S[lvl], R * self.S[lvl]
+            if lvl < 2:
+                enc, net = self.prop_enc[lvl], self.prop_mlp[lvl]
+                self._tgrid_fwd(enc, enc.embeddings, co, t, S, N, b["pfeat"][lvl])
+                self._mlp_fwd(net, b["pfeat"][lvl], enc.output_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
+                self._resample(lvl, rng["u"][lvl], anneal)
+            else:
+                self._tgrid_fwd(self.enc, self.enc.embeddings, co, t, S, N, b["feat"])
+                self._mlp_fwd(self.decode, b["feat"], self.enc.output_dim, N, b["h"], 16, 0, b["dens"][2])
+                hx = b["hx"].view(R, S, 64)
+                hx[:, :, 0:16] = sh4_from_unit_dirs(d)[:, None, :]
+                hx[:, :, 16:31] = b["h"].view(R, S, 16)[:, :, 1:16]
+                hx[:, :, 31:63] = self.appearance.weight[cams][:, None, :]
+                self._mlp_fwd(self.head, b["hx"], 64, N, b["rgb"], 3)
+                _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, S, self._p(b["w"][2]), self._st), "weights_fwd")
+        a = _lib.RenderArgs()
+        a.weights, a.rgb, a.ebins = b["w"][2].data_ptr(), b["rgb"].data_ptr(), b["eb"][2].data_ptr()
+        a.bg_mode, a.bg = 0, rng["bg"].data_ptr()
+        a.R, a.S, a.training = R, self.S[2], 1
+        a.rgb_out, a.acc_out, a.depth_expected = b["rgb_out"].data_ptr(), b["acc"].data_ptr(), b["depth"].data_ptr()
+        _lib.check(self.lib.snerf_render_fwd(C.byref(a), self._st), "render_fwd")
+        return b["rgb_out"]
+
+    # ---- backward ----
+    def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool):
+        cfg, b, R = self.cfg, self.buf, self.R
+        S2, N2 = self.S[2], R * self.S[2]
+        t = self.rays["times"].reshape(-1)
+        target = target if target.is_contiguous() else target.contiguous()
+        _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
+                                                 2.0 / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]), self._st), "render_mse_bwd")
+        _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, cfg.distortion_loss_mult / R, self._p(b["dist_rays"]),
+                                             self._p(b["gw"][2]), 1, self._st), "distortion")
+        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
+                                              self._st), "weights_bwd")
+        # colour head: gX = [dSH (unused) | d geo | d appearance | pad]
+        self._mlp_bwd(self.head, self.gviews["field.head"], b["hx"], 64, N2, b["grgb"], 3, -1, None, b["ghx"], 64)
+        ghx = b["ghx"].view(R, S2, 64)
+        b["gh"].view(R, S2, 16)[:, :, 1:16] = ghx[:, :, 16:31]  # column 0 (density) enters through gaux below
+        self.gviews["field.appearance"].index_add_(0, self.cams, ghx[:, :, 31:63].sum(1))
+        self._mlp_bwd(self.decode, self.gviews["field.decode"], b["feat"], self.enc.output_dim, N2, b["gh"], 16, 0, b["gdens"][2], b["gfeat"],
+                      self.enc.output_dim)
+        self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])
+        # proposal supervision (interlevel loss, losses.py:106-121)
+        for lvl in range(2):
+            Sp, Np = self.S[lvl], R * self.S[lvl]
+            _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
+                                                 cfg.interlevel_loss_mult / (R * S2), self._p(b["inter_rays"][lvl]),
+                                                 self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
+            if proposal_grads:
+                enc, net = self.prop_enc[lvl], self.prop_mlp[lvl]
+                _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp, self._p(b["gdens"][lvl]),
+                                                      0, self._st), "weights_bwd")
+                self._mlp_bwd(net, self.gviews[f"prop{lvl}.mlp"], b["pfeat"][lvl], enc.output_dim, Np, None, 1, 0, b["gdens"][lvl], b["gpfeat"][lvl],
+                              enc.output_dim)
+                self._tgrid_bwd(enc, self._coords[lvl], t, Sp, Np, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.table"])
+        # temporal TV of the three tables (temporal_grid.py:352-376; nerfplayer_nerfacto.py:311-316): value + gradient
+        if cfg.temporal_tv_weight > 0:
+            b["tv"].zero_()
+            for k, (enc, name) in enumerate(((self.enc, "field.table"), (self.prop_enc[0], "prop0.table"), (self.prop_enc[1], "prop1.table"))):
+                row = self.tv_rows[k] if self.tv_rows is not None else int(torch.randint(0, len(enc._index_list_host), [1]).item())
+                ca, cb = enc._index_list_host[row]
+                self._tv_cols[k] = (ca, cb)
+                rows_, gc = enc.embeddings.shape
+                _lib.check(self.lib.snerf_tgrid_tv_fwd_bwd(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, float(cfg.temporal_tv_weight),
+                                                           self._p(b["tv"][k]), 64, self._p(self.gviews[name]), self._st), "tv_fwd_bwd")
+
+    def loss_dict(self) -> Dict[str, torch.Tensor]:
+        b, cfg, R = self.buf, self.cfg, self.R
+        d = {"rgb_loss": b["sqerr"].sum() / (3 * R),
+             "interlevel_loss": (b["inter_rays"][0].sum() + b["inter_rays"][1].sum()) / (R * self.S[2]) * cfg.interlevel_loss_mult,
+             "distortion_loss": b["dist_rays"].mean() * cfg.distortion_loss_mult}
+        if cfg.temporal_tv_weight > 0:
+            rows = [e.embeddings.shape[0] for e in (self.enc, self.prop_enc[0], self.prop_enc[1])]
+            d["temporal_tv_loss"] = sum(b["tv"][k, :, 0].sum() / rows[k] for k in range(3)) * cfg.temporal_tv_weight
+        return d
+
+    def optimizer_step(self):
+        lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+        ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
+        self.step += 1
+
+    def random_draws(self) -> Dict[str, torch.Tensor]:
+        R = self.R
+        flat = torch.rand(R * 6, device=self.dev)  # single jitter: one draw per ray and level (nerfplayer_nerfacto.py:99) + background
+        return {"t_rand": flat[:R].view(R, 1), "u": [flat[R:2 * R].view(R, 1), flat[2 * R:3 * R].view(R, 1)], "bg": flat[3 * R:].view(R, 3)}
+
+    def train_step(self, rays: Dict[str, torch.Tensor], cams: torch.Tensor, target: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None):
+        cfg = self.cfg
+        anneal = anneal_value(self.step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope) \
+            if cfg.use_proposal_weight_anneal else 1.0
+        sstep = max(self.step - 1, 0)  # the sampler's counter is set by the AFTER_TRAIN_ITERATION callback (nerfacto.py:249-263)
+        sched = float(np.clip(np.interp(sstep, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1, cfg.proposal_update_every))
+        updated = self._steps_since_update > sched or sstep < 10
+        rng = rng if rng is not None else self.random_draws()
+        out = self.forward(rays, cams, rng, anneal)
+        self.backward(target, rng, proposal_grads=updated)
+        self.optimizer_step()
+        if updated:
+            self._steps_since_update = 0
+        self._steps_since_update += 1
+        return out

@@ -1,0 +1,102 @@
+"""GPU: the fused NeRFPlayer-nerfacto trainer (soccernerfs_amd.nerfplayer_trainer) against the nerfstudio-shaped autograd model on the same
+HIP kernels -- which is itself pinned against the reference's own model by golden G12 (tests/test_gpu_tgrid.py)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg():
+    from soccernerfs_amd.nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
+
+    return NerfplayerNerfactoModelConfig(
+        num_levels=6, log2_hashmap_size=12, temporal_dim=16,
+        proposal_net_args_list=[{"hidden_dim": 16, "temporal_dim": 8, "log2_hashmap_size": 10, "num_levels": 4, "max_res": 32},
+                                {"hidden_dim": 16, "temporal_dim": 8, "log2_hashmap_size": 10, "num_levels": 4, "max_res": 64}],
+        num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=16)
+
+
+def _batch(R, n_img, seed):
+    gen = torch.Generator().manual_seed(seed)
+    o = ((torch.rand(R, 3, generator=gen) * 2 - 1) * 0.3).to(DEV)
+    d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1).to(DEV)
+    times = torch.rand(R, 1, generator=gen).to(DEV)
+    cams = torch.randint(0, n_img, (R,), generator=gen).to(DEV)
+    target = torch.rand(R, 3, generator=gen).to(DEV)
+    rng = {"t_rand": torch.rand(R, 1, generator=gen).to(DEV), "u": [torch.rand(R, 1, generator=gen).to(DEV), torch.rand(R, 1, generator=gen).to(DEV)],
+           "bg": torch.rand(R, 3, generator=gen).to(DEV)}
+    return {"origins": o, "directions": d, "times": times}, cams, target, rng
+
+
+def test_fused_step_equals_autograd_model():
+    from soccernerfs_amd.nerfplayer_nerfacto import NerfplayerNerfactoModel
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+    from soccernerfs_amd.rays import RayBundle
+    from soccernerfs_amd.scene_colliders import SceneBox
+
+    R, n_img = 96, 7
+    cfg = _cfg()
+    tr = NerfplayerTrainer(cfg, R, n_img, aabb_scale=1.0, device=DEV, seed=3)
+    with torch.no_grad():  # O(1) tables: the 1e-4 init gives a featureless field
+        for name in ("field.table", "prop0.table", "prop1.table"):
+            tr.views[name].uniform_(-1.0, 1.0)
+    model = NerfplayerNerfactoModel(cfg, SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3])), num_train_data=n_img).to(DEV).train()
+    model.scene_box.aabb = model.scene_box.aabb.to(DEV)
+    pairs = {"field.table": model.field.mlp_base.embeddings, "field.decode": model.field.mlp_base_decode.params, "field.head": model.field.mlp_head.params,
+             "field.appearance": model.field.embedding_appearance.weight}
+    for i, pn in enumerate(model.proposal_networks):
+        pairs[f"prop{i}.table"], pairs[f"prop{i}.mlp"] = pn.encoding.embeddings, pn.linear.params
+    with torch.no_grad():
+        for name, p in pairs.items():
+            p.copy_(tr.views[name].view(p.shape))
+    rays, cams, target, rng = _batch(R, n_img, 11)
+    anneal, rows = 0.4, [2, 1, 3]
+    # ---- autograd model ----
+    draws = [rng["t_rand"], rng["u"][0], rng["u"][1], rng["bg"]]
+    model.set_rand_fn(lambda shape, device=None: draws.pop(0))
+    encs = [model.field.mlp_base] + [p.encoding for p in model.proposal_networks]
+    for e in encs:
+        e.fuse_tv = False
+    model.tv_row_fn = lambda enc: rows[[id(e) for e in encs].index(id(enc))]
+    model.proposal_sampler.set_anneal(anneal)
+    out = model(RayBundle(origins=rays["origins"], directions=rays["directions"], pixel_area=torch.ones(R, 1, device=DEV), camera_indices=cams[:, None],
+                          times=rays["times"]))
+    ld = model.get_loss_dict(out, {"image": target}, model.get_metrics_dict(out, {"image": target}))
+    sum(ld.values()).backward()
+    # ---- fused trainer ----
+    tr.tv_rows = rows
+    rgb = tr.forward(rays, cams, rng, anneal)
+    tr.backward(target, rng, proposal_grads=True)
+    torch.testing.assert_close(rgb, out["rgb"].detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(tr.buf["acc"], out["accumulation"].detach()[:, 0], rtol=1e-4, atol=1e-6)
+    for i in range(3):
+        torch.testing.assert_close(tr.buf["eb"][i], out["ray_samples_list"][i]._compact["ebins"], rtol=0, atol=1e-6)
+    mine = tr.loss_dict()
+    assert set(mine) == set(ld)
+    for k in ld:
+        torch.testing.assert_close(mine[k], ld[k].detach(), rtol=1e-4, atol=1e-9)
+    for name, p in pairs.items():
+        g_ref = p.grad.reshape(-1)
+        g = tr.gviews[name].reshape(-1)
+        scale = float(g_ref.abs().max())
+        assert scale > 0, name
+        torch.testing.assert_close(g, g_ref, rtol=1e-3, atol=1e-5 * scale, msg=lambda m: f"{name}: {m}")
+
+
+def test_fused_training_reduces_loss_and_keeps_parameters_finite():
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R, n_img = 256, 5
+    tr = NerfplayerTrainer(_cfg(), R, n_img, device=DEV, warm_up_end=1, seed=1)
+    with torch.no_grad():
+        for name in ("field.table", "prop0.table", "prop1.table"):
+            tr.views[name].uniform_(-0.5, 0.5)
+    rays, cams, target, rng = _batch(R, n_img, 5)
+    target = target * 0.5
+    losses = []
+    for _ in range(12):
+        tr.train_step(rays, cams, target, rng)
+        losses.append(float(tr.loss_dict()["rgb_loss"]))
+    assert tr.step == 12 and losses[-1] < losses[1], losses
+    assert bool(torch.isfinite(tr.params).all()) and float(tr.grads.abs().max()) == 0.0

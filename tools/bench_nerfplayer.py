@@ -13,10 +13,35 @@ ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--optim", default="snerf", choices=["snerf", "fused", "foreach", "single"])
 ap.add_argument("--no-fuse-tv", action="store_true")
+ap.add_argument("--fused", action="store_true", help="soccernerfs_amd.nerfplayer_trainer.NerfplayerTrainer instead of the autograd model")
 ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+if args.fused:
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R = args.rays
+    tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 36 * 100, device=dev)
+    tr.step = 600  # past the learning-rate warm-up
+
+    def fstep():
+        o = (torch.rand(R, 3, device=dev) * 2 - 1) * 0.6
+        d = torch.nn.functional.normalize(torch.rand(R, 3, device=dev) * 2 - 1, dim=-1)
+        tr.train_step({"origins": o, "directions": d, "times": torch.rand(R, 1, device=dev)}, torch.randint(0, 3600, (R,), device=dev),
+                      torch.rand(R, 3, device=dev))
+
+    for _ in range(args.warmup):
+        fstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fstep()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"config": "nerfplayer-nerfacto preset (fused trainer)", "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
+                      "rays_per_s": R * args.steps / dt}))
+    sys.exit(0)
 model = NerfplayerNerfactoModel(NerfplayerNerfactoModelConfig(), SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3])), num_train_data=36 * 100).to(dev).train()
 model.scene_box.aabb = model.scene_box.aabb.to(dev)
 params = [p for g in model.get_param_groups().values() for p in g if p.requires_grad]
