@@ -1,5 +1,7 @@
 """Fused training step of the reference's NeRFPlayer-nerfacto model (config 4) on libsnerf: one flat parameter / gradient / Adam
-buffer, preallocated work buffers, no autograd graph, no allocation and no host synchronisation inside a step.
+buffer, preallocated per-sample work buffers, no autograd graph and no host synchronisation inside a step (the only tensors created
+per step are three per-RAY temporaries -- SH of the directions, the gathered appearance rows and their summed gradient -- from
+torch's caching allocator).
 
 What the reference does per step: Trainer.train_iteration -> NerfplayerNerfactoModel.get_outputs / get_metrics_dict / get_loss_dict
 (NS/models/nerfplayer_nerfacto.py:206-318) -> autograd backward -> 2x Adam (NS/configs/method_configs.py:648-657: lr 1e-2,
