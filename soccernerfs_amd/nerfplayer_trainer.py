@@ -135,22 +135,30 @@ class NerfplayerTrainer:
         b, a = self.buf, _lib.ResampleArgs()
         a.density, a.ebins_prev, a.weights_out = b["dens"][lvl].data_ptr(), b["eb"][lvl].data_ptr(), b["w"][lvl].data_ptr()
         a.sbins_prev, a.nears, a.fars = b["sb"][lvl].data_ptr(), self.rays["nears"].data_ptr(), self.rays["fars"].data_ptr()
-        a.u_mode, a.u_or_rand, a.rand_cols = 1, rand.data_ptr(), rand.shape[-1]
+        if rand is None:
+            a.u_mode = 2
+        else:
+            a.u_mode, a.u_or_rand, a.rand_cols = 1, rand.data_ptr(), rand.shape[-1]
         a.sbins_out, a.ebins_out = b["sb"][lvl + 1].data_ptr(), b["eb"][lvl + 1].data_ptr()
         a.R, a.S_prev, a.S, a.kind = self.R, self.S[lvl], self.S[lvl + 1], 1  # spacing = UniformLinDispPiecewise (ray_samplers.py:242-243)
         a.anneal, a.histogram_padding, a.eps = anneal, 0.01, 1e-5
         _lib.check(self.lib.snerf_pdf_resample(C.byref(a), self._st), "pdf_resample")
 
     # ---- forward ----
-    def forward(self, rays: Dict[str, torch.Tensor], cams: torch.Tensor, rng: Dict[str, torch.Tensor], anneal: float):
-        """rays: origins [R,3], directions [R,3] (unit), times [R,1]; cams int64 [R]; rng: t_rand [R,1], u [2 x [R,1]], bg [R,3]."""
+    def forward(self, rays: Dict[str, torch.Tensor], cams: Optional[torch.Tensor], rng: Dict[str, torch.Tensor], anneal: float, training: bool = True):
+        """rays: origins [R,3], directions [R,3] (unit), times [R,1]; cams int64 [R]; rng: t_rand [R,1], u [2 x [R,1]], bg [R,3].
+        training=False (exactly R rays): no jitter, deterministic PDF samples, average / zero appearance embedding
+        (nerfplayer_nerfacto_field.py:362-372), eval-mode compositing; rng needs only bg (the "random" background is drawn in eval too,
+        renderers.py:102-104)."""
         cfg, b, R = self.cfg, self.buf, self.R
         self._st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
         rays = dict(rays)
-        rays["nears"], rays["fars"] = ops.aabb_collide(o, d, self.aabb, 0.0, True)  # AABBBoxCollider(scene_box): near_plane 0
+        rays["nears"], rays["fars"] = ops.aabb_collide(o, d, self.aabb, 0.0, training)  # AABBBoxCollider(scene_box): near_plane 0
         self.rays, self.cams = rays, cams
-        _lib.check(self.lib.snerf_spaced_bins(self._p(rays["nears"]), self._p(rays["fars"]), self._p(rng["t_rand"]), rng["t_rand"].shape[-1], R,
+        t_rand = rng["t_rand"] if training else None
+        _lib.check(self.lib.snerf_spaced_bins(self._p(rays["nears"]), self._p(rays["fars"]), self._p(t_rand) if t_rand is not None else None,
+                                              t_rand.shape[-1] if t_rand is not None else 0, R,
                                               self.S[0], 1, self._p(b["sb"][0]), self._p(b["eb"][0]), self._st), "spaced_bins")
         self._coords = []
         for lvl in range(3):
@@ -161,20 +169,25 @@ class NerfplayerTrainer:
                 enc, net = self.prop_enc[lvl], self.prop_mlp[lvl]
                 self._tgrid_fwd(enc, enc.embeddings, co, t, S, N, b["pfeat"][lvl])
                 self._mlp_fwd(net, b["pfeat"][lvl], enc.output_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
-                self._resample(lvl, rng["u"][lvl], anneal)
+                self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
                 self._tgrid_fwd(self.enc, self.enc.embeddings, co, t, S, N, b["feat"])
                 self._mlp_fwd(self.decode, b["feat"], self.enc.output_dim, N, b["h"], 16, 0, b["dens"][2])
                 hx = b["hx"].view(R, S, 64)
                 hx[:, :, 0:16] = sh4_from_unit_dirs(d)[:, None, :]
                 hx[:, :, 16:31] = b["h"].view(R, S, 16)[:, :, 1:16]
-                hx[:, :, 31:63] = self.appearance.weight[cams][:, None, :]
+                if training:
+                    hx[:, :, 31:63] = self.appearance.weight[cams][:, None, :]
+                elif cfg.use_average_appearance_embedding:
+                    hx[:, :, 31:63] = self.appearance.weight.mean(0)[None, None, :]
+                else:
+                    hx[:, :, 31:63] = 0.0
                 self._mlp_fwd(self.head, b["hx"], 64, N, b["rgb"], 3)
                 _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, S, self._p(b["w"][2]), self._st), "weights_fwd")
         a = _lib.RenderArgs()
         a.weights, a.rgb, a.ebins = b["w"][2].data_ptr(), b["rgb"].data_ptr(), b["eb"][2].data_ptr()
         a.bg_mode, a.bg = 0, rng["bg"].data_ptr()
-        a.R, a.S, a.training = R, self.S[2], 1
+        a.R, a.S, a.training = R, self.S[2], int(training)
         a.rgb_out, a.acc_out, a.depth_expected = b["rgb_out"].data_ptr(), b["acc"].data_ptr(), b["depth"].data_ptr()
         _lib.check(self.lib.snerf_render_fwd(C.byref(a), self._st), "render_fwd")
         return b["rgb_out"]

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""PSNR@N-iterations run of the nerfplayer-nerfacto preset with the fused trainer on the synthetic multi-view clip (stadium-style split:
+30 training cameras + 6 held out, every frame; NS/data/dataparsers/stadiumwide_dataparser.py:94-112), uniform pixels, then full-image
+renders of held-out cameras in eval mode.  Convergence check of soccernerfs_amd.nerfplayer_trainer, not the bench line.
+
+    python tools/train_psnr_nerfplayer.py --steps 30000 --out gpurun_out/psnr_nerfplayer.json
+"""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soccernerfs_amd import ops, synthetic
+from soccernerfs_amd.nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
+from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+from soccernerfs_amd.trainer import anneal_value
+
+
+@torch.no_grad()
+def eval_psnr(tr, data, n_images, anneal):
+    imgs = data["images"]; M, H, W = imgs.shape[:3]; R = tr.R
+    ys, xs = torch.meshgrid(torch.arange(H, device=imgs.device), torch.arange(W, device=imgs.device), indexing="ij")
+    out_ps = []
+    for m in torch.linspace(0, M - 1, n_images).long().tolist():
+        idx = torch.stack([torch.full_like(ys, m), ys, xs], -1).reshape(-1, 3)
+        n = idx.shape[0] // R * R  # whole chunks of R rays (the trainer's buffers have a fixed batch size)
+        out = torch.empty(n, 3, device=imgs.device)
+        for i in range(0, n, R):
+            rays = ops.generate_rays(idx[i:i + R].contiguous(), data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"])
+            out[i:i + R] = tr.forward(rays, None, {"bg": torch.rand(R, 3, device=imgs.device)}, anneal, training=False)
+        gt = imgs[m].reshape(-1, 3)[:n].float() / 255.0
+        out_ps.append(float(10.0 * torch.log10(1.0 / torch.mean((out - gt) ** 2))))
+    return out_ps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=30000)
+    ap.add_argument("--eval-every", type=int, default=10000)
+    ap.add_argument("--out", default="gpurun_out/psnr_nerfplayer.json")
+    ap.add_argument("--width", type=int, default=480)
+    ap.add_argument("--frames", type=int, default=25)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0"); torch.manual_seed(20231029)
+    R = 4096
+    Wd, Hd = args.width, args.width * 9 // 16
+    cams = synthetic.make_cameras(36, Wd, Hd)
+    times = synthetic.frame_times(100, 100 // args.frames)
+    train = synthetic.render_dataset(cams, times, list(range(30)), dev, chunk_rows=Hd)
+    held = synthetic.render_dataset(cams, times, list(range(30, 36)), dev, chunk_rows=Hd)
+    M, H, W = train["images"].shape[:3]
+    tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, M, aabb_scale=1.5, device=dev, max_steps=args.steps)
+    log = {"config": f"nerfplayer-nerfacto preset, fused trainer, synthetic clip ({M} training images {W}x{H}, 6 cameras held out)", "evals": []}
+    t_train = 0.0
+    for step in range(args.steps):
+        if step % 500 == 0:
+            torch.cuda.synchronize(); t1 = time.time()
+        idx, target = ops.sample_pixels_uniform(torch.rand(R, 3, device=dev), M, H, W, train["images"])
+        rays = ops.generate_rays(idx, train["fx"], train["fy"], train["cx"], train["cy"], train["c2w"], train["times"])
+        tr.train_step(rays, idx[:, 0].contiguous(), target)
+        if step % 500 == 499:
+            torch.cuda.synchronize(); dt = time.time() - t1; t_train += dt
+            ld = {k: float(v) for k, v in tr.loss_dict().items()}
+            print(f"step {step + 1}: {R * 500 / dt:,.0f} rays/s  " + "  ".join(f"{k} {v:.3e}" for k, v in ld.items()), flush=True)
+        if (step + 1) % args.eval_every == 0 or step + 1 == args.steps:
+            ps = eval_psnr(tr, held, 6, anneal_value(step, 1000, 10.0))
+            ps_tr = eval_psnr(tr, train, 4, 1.0)
+            log["evals"].append({"step": step + 1, "psnr_heldout_mean": sum(ps) / len(ps), "psnr_heldout": ps, "psnr_train_views_mean": sum(ps_tr) / len(ps_tr)})
+            print(f"== step {step + 1}: held-out cameras PSNR {sum(ps) / len(ps):.2f} dB; train views {sum(ps_tr) / len(ps_tr):.2f} dB", flush=True)
+    log["train_rays_per_s_mean"] = R * args.steps / max(t_train, 1e-9)
+    os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
+    json.dump(log, open(args.out, "w"), indent=1)
+    print(json.dumps(log["evals"][-1]))
+
+
+if __name__ == "__main__":
+    main()
