@@ -331,6 +331,15 @@ int snerf_tgrid_tv_bwd(const float* embeddings, int64_t rows, int32_t grid_C, in
 int snerf_tgrid_tv_fwd_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
                            int32_t n_slots, float* grad_embeddings, snerf_stream_t stream);
 
+/* TV term folded into the optimiser (fused NeRFPlayer trainer): snerf_tgrid_tv_sign adds the partial sums of |E[r,a] - E[r,b]| into
+ * partial (as snerf_tgrid_tv_fwd) and writes srow[rows] = g_tv * sign(E[r,a] - E[r,b]) / rows from the CURRENT table; then
+ * snerf_adam_step_tv is snerf_adam_step (in place) over the table [rows][grid_C] with +srow[r] added to the gradient of column
+ * col_a and -srow[r] to column col_b -- the dense gradient buffer is never read-modified-written for the TV term. */
+int snerf_tgrid_tv_sign(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
+                        int32_t n_slots, float* srow, snerf_stream_t stream);
+int snerf_adam_step_tv(float* p, float* g, float* m, float* v, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* srow,
+                       float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Ray importance sampling (IST = temporal difference).
  * ------------------------------------------------------------------------------------------------ */

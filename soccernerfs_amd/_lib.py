@@ -108,6 +108,8 @@ def lib():
     l.snerf_tgrid_tv_fwd.argtypes = [P, L, I, I, I, P, I, P]
     l.snerf_tgrid_tv_bwd.argtypes = [P, L, I, I, I, P, P, P]
     l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
+    l.snerf_tgrid_tv_sign.argtypes = [P, L, I, I, I, F, P, I, P, P]
+    l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
     if l.snerf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
@@ -147,6 +149,8 @@ EXPORTS = [
     "snerf_tgrid_tv_fwd",
     "snerf_tgrid_tv_bwd",
     "snerf_tgrid_tv_fwd_bwd",
+    "snerf_tgrid_tv_sign",
+    "snerf_adam_step_tv",
     "snerf_sample_pixels_uniform",
     "snerf_kplanes_scatter_sorted_scales",
     "snerf_raygen",

@@ -198,6 +198,40 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
   }
 }
 
+// Adam over a temporal-grid table [rows][grid_C] with the temporal-TV gradient of two of its columns folded in
+// (TemporalGridEncoder.get_temporal_tv_loss, temporal_grid.py:352-376): srow[r] = weight * sign(E[r,a] - E[r,b]) / rows was
+// written by tgrid_tv_sign_kernel from the OLD table, so the in-place update has no read-after-write hazard and the dense
+// gradient buffer is never read-modified-written for the TV term.
+__global__ __launch_bounds__(256) void adam_tv_kernel(float* p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float step_size,
+                                                     float b1, float b2, float inv_sqrt_bc2, float eps, float grad_scale, int zero_grad, int grid_C, int col_a,
+                                                     int col_b, const float* __restrict__ srow) {
+  const int64_t n4 = n / 4;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;  // n is a multiple of 4 here (rows * grid_C with rows a multiple of 8)
+  float4 pp = ldnt4(p + i * 4), gg = ldnt4(g + i * 4), mm = ldnt4(m + i * 4), vv = ldnt4(v + i * 4);
+  float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+  const int64_t e0 = i * 4;
+  const int64_t row0 = e0 / grid_C;
+  const int c0 = (int)(e0 - row0 * grid_C);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int col = c0 + k;
+    int64_t row = row0;
+    if (col >= grid_C) { col -= grid_C; row += 1; }
+    float gk = G[k] * grad_scale;
+    if (col == col_a) gk += srow[row];
+    else if (col == col_b) gk -= srow[row];
+    if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;
+    M[k] = b1 * M[k] + (1.f - b1) * gk;
+    V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
+    P[k] = P[k] - step_size * (M[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps));
+  }
+  stnt4(p + i * 4, pp);
+  stnt4(m + i * 4, mm);
+  stnt4(v + i * 4, vv);
+  if (zero_grad) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
 }  // namespace snerf
 
 using namespace snerf;
@@ -292,6 +326,24 @@ extern "C" int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const floa
                                       float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
   return snerf_adam_planes_step_range(desc, p_in, p_out, g, m, v, c_space_tv, c_time_smooth, c_sparse, losses, n_slots, lr, beta1, beta2, eps, step,
                                       grad_scale, zero_grad, 0, INT64_MAX & ~(int64_t)3, stream);
+}
+
+extern "C" int snerf_adam_step_tv(float* p, float* g, float* m, float* v, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* srow,
+                                  float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
+  SNERF_REQUIRE(rows >= 1 && grid_C >= 4 && step >= 1, "adam_step_tv: rows=%lld grid_C=%d step=%d", (long long)rows, grid_C, step);
+  SNERF_REQUIRE(col_a >= 0 && col_a < grid_C && col_b >= 0 && col_b < grid_C && col_a != col_b, "adam_step_tv: columns (%d, %d) of %d", col_a, col_b, grid_C);
+  SNERF_REQUIRE(p && g && m && v && srow, "adam_step_tv: null buffer");
+  const int64_t n = rows * grid_C;
+  SNERF_REQUIRE((n & 3) == 0, "adam_step_tv: rows * grid_C = %lld must be a multiple of 4", (long long)n);
+  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step_tv: buffers must be 16-byte aligned");
+  float step_size, inv_sqrt_bc2;
+  adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
+  const int64_t blocks = (n / 4 + 255) / 256;
+  SNERF_REQUIRE(blocks < (1LL << 31), "adam_step_tv: table too large for one launch");
+  hipLaunchKernelGGL(adam_tv_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2, eps,
+                     grad_scale, zero_grad, grid_C, col_a, col_b, srow);
+  SNERF_LAUNCH_CHECK("adam_step_tv");
+  return 0;
 }
 
 extern "C" int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -206,7 +206,31 @@ __global__ __launch_bounds__(256) void tgrid_tv_fwd_bwd_kernel(const float* __re
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(partial + (blockIdx.x % n_slots) * 16, acc);
 }
+// value + per-row signed step for snerf_adam_step_tv: srow[r] = g_over_rows * sign(E[r,a] - E[r,b])
+__global__ __launch_bounds__(256) void tgrid_tv_sign_kernel(const float* __restrict__ E, int64_t rows, int grid_C, int a, int b, float g_over_rows,
+                                                           float* __restrict__ partial, int n_slots, float* __restrict__ srow) {
+  float acc = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+    const float d = E[r * grid_C + a] - E[r * grid_C + b];
+    acc += fabsf(d);
+    srow[r] = ((d > 0.f) - (d < 0.f)) * g_over_rows;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(partial + (blockIdx.x % n_slots) * 16, acc);
+}
 }  // namespace snerf
+
+extern "C" int snerf_tgrid_tv_sign(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
+                                   int32_t n_slots, float* srow, snerf_stream_t stream) {
+  SNERF_REQUIRE(rows >= 1 && grid_C >= 1 && col_a >= 0 && col_a < grid_C && col_b >= 0 && col_b < grid_C && col_a != col_b && n_slots >= 1,
+                "tgrid_tv_sign: rows=%lld grid_C=%d cols=(%d,%d) n_slots=%d", (long long)rows, grid_C, col_a, col_b, n_slots);
+  SNERF_REQUIRE(embeddings && partial && srow, "tgrid_tv_sign: null buffer");
+  const int64_t blocks = (rows + 255) / 256;
+  hipLaunchKernelGGL(snerf::tgrid_tv_sign_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, embeddings, rows, grid_C,
+                     col_a, col_b, g_tv / (float)rows, partial, n_slots, srow);
+  SNERF_LAUNCH_CHECK("tgrid_tv_sign");
+  return 0;
+}
 
 extern "C" int snerf_tgrid_tv_fwd_bwd(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
                                       int32_t n_slots, float* grad_embeddings, snerf_stream_t stream) {

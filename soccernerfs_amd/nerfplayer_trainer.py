@@ -104,6 +104,7 @@ class NerfplayerTrainer:
             "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "sqerr": z(R), "dist_rays": f(R), "inter_rays": [f(R), f(R)],
             "tv": z(3, 64, 16),
         }
+        self._srow = [z(e.embeddings.shape[0]) for e in (self.enc, self.prop_enc[0], self.prop_enc[1])]  # per-row TV step of each table
         self.lib = _lib.lib()
         self.step = 0
         self._steps_since_update = 0
@@ -225,16 +226,26 @@ class NerfplayerTrainer:
                 self._mlp_bwd(net, self.gviews[f"prop{lvl}.mlp"], b["pfeat"][lvl], enc.output_dim, Np, None, 1, 0, b["gdens"][lvl], b["gpfeat"][lvl],
                               enc.output_dim)
                 self._tgrid_bwd(enc, self._coords[lvl], t, Sp, Np, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.table"])
-        # temporal TV of the three tables (temporal_grid.py:352-376; nerfplayer_nerfacto.py:311-316): value + gradient
+        # temporal TV of the three tables (temporal_grid.py:352-376; nerfplayer_nerfacto.py:311-316): one pass over two columns per table
+        # gives the value and the per-row signed step; the gradient itself is added inside the Adam sweep (optimizer_step)
         if cfg.temporal_tv_weight > 0:
             b["tv"].zero_()
-            for k, (enc, name) in enumerate(((self.enc, "field.table"), (self.prop_enc[0], "prop0.table"), (self.prop_enc[1], "prop1.table"))):
+            for k, enc in enumerate((self.enc, self.prop_enc[0], self.prop_enc[1])):
                 row = self.tv_rows[k] if self.tv_rows is not None else int(torch.randint(0, len(enc._index_list_host), [1]).item())
                 ca, cb = enc._index_list_host[row]
                 self._tv_cols[k] = (ca, cb)
                 rows_, gc = enc.embeddings.shape
-                _lib.check(self.lib.snerf_tgrid_tv_fwd_bwd(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, float(cfg.temporal_tv_weight),
-                                                           self._p(b["tv"][k]), 64, self._p(self.gviews[name]), self._st), "tv_fwd_bwd")
+                _lib.check(self.lib.snerf_tgrid_tv_sign(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, float(cfg.temporal_tv_weight),
+                                                        self._p(b["tv"][k]), 64, self._p(self._srow[k]), self._st), "tv_sign")
+
+    def materialize_tv_gradient(self):
+        """Adds the temporal-TV gradient into self.grads explicitly (what the Adam sweep otherwise does on the fly); for parity tests."""
+        if self.cfg.temporal_tv_weight <= 0:
+            return
+        for k, name in enumerate(("field.table", "prop0.table", "prop1.table")):
+            ca, cb = self._tv_cols[k]
+            self.gviews[name][:, ca] += self._srow[k]
+            self.gviews[name][:, cb] -= self._srow[k]
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         b, cfg, R = self.buf, self.cfg, self.R
@@ -247,8 +258,31 @@ class NerfplayerTrainer:
         return d
 
     def optimizer_step(self):
+        """Adam (lr * cosine schedule, eps 1e-12) over the flat buffer, gradient cleared in the sweep; the three tables go through
+        snerf_adam_step_tv, which adds the temporal-TV gradient of their two columns on the fly."""
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
-        ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
+        off = {name: (o, n) for name, _, _, o, n in self.segments}
+        tv = self.cfg.temporal_tv_weight > 0
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        done = 0
+        for k, (name, enc) in enumerate((("prop0.table", self.prop_enc[0]), ("prop1.table", self.prop_enc[1]), ("field.table", self.enc))):
+            o, n = off[name]
+            if o > done:  # the small segments in front of this table
+                sl = slice(done, o)
+                ops.adam_step(self.params[sl], self.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
+            kk = {"field.table": 0, "prop0.table": 1, "prop1.table": 2}[name]
+            if tv:
+                ca, cb = self._tv_cols[kk]
+                rows_, gc = enc.embeddings.shape
+                sl = slice(o, o + n)
+                _lib.check(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
+                                                       C.c_int64(rows_), gc, ca, cb, self._p(self._srow[kk]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
+                                                       st), "adam_step_tv")
+                done = o + n
+            # without TV the table is swept together with what follows
+        if done < self.n_params:
+            sl = slice(done, self.n_params)
+            ops.adam_step(self.params[sl], self.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:

@@ -68,6 +68,7 @@ def test_fused_step_equals_autograd_model():
     tr.tv_rows = rows
     rgb = tr.forward(rays, cams, rng, anneal)
     tr.backward(target, rng, proposal_grads=True)
+    tr.materialize_tv_gradient()  # the Adam sweep adds it on the fly; make it explicit for the comparison
     torch.testing.assert_close(rgb, out["rgb"].detach(), rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(tr.buf["acc"], out["accumulation"].detach()[:, 0], rtol=1e-4, atol=1e-6)
     for i in range(3):
@@ -82,6 +83,38 @@ def test_fused_step_equals_autograd_model():
         scale = float(g_ref.abs().max())
         assert scale > 0, name
         torch.testing.assert_close(g, g_ref, rtol=1e-3, atol=1e-5 * scale, msg=lambda m: f"{name}: {m}")
+
+
+def test_adam_with_tv_folded_in_equals_explicit_gradient():
+    """snerf_tgrid_tv_sign + snerf_adam_step_tv == TV gradient added to the gradient buffer, then plain Adam."""
+    import ctypes as C
+    from soccernerfs_amd import _lib, ops
+
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    rows, gc, a, b, w = 1000, 10, 3, 7, 0.8
+    E = torch.rand(rows, gc, device=DEV, generator=gen) - 0.5
+    E[5, a] = E[5, b]  # sign(0) = 0
+    g = torch.rand(rows, gc, device=DEV, generator=gen) - 0.5
+    m = torch.rand(rows, gc, device=DEV, generator=gen) * 0.1
+    v = torch.rand(rows, gc, device=DEV, generator=gen) * 0.01
+    # reference: explicit gradient, plain Adam
+    d = E[:, a] - E[:, b]
+    g2 = g.clone()
+    g2[:, a] += torch.sign(d) * (w / rows)
+    g2[:, b] -= torch.sign(d) * (w / rows)
+    p_ref, m_ref, v_ref = E.clone().view(-1), m.clone().view(-1), v.clone().view(-1)
+    ops.adam_step(p_ref, g2.view(-1), m_ref, v_ref, 3, 1e-2, eps=1e-12, zero_grad=True)
+    # fused
+    part, srow = torch.zeros(64, 16, device=DEV), torch.empty(rows, device=DEV)
+    L, P = _lib.lib(), ops._ptr
+    _lib.check(L.snerf_tgrid_tv_sign(P(E), C.c_int64(rows), gc, a, b, w, P(part), 64, P(srow), ops._stream()))
+    torch.testing.assert_close(part[:, 0].sum() / rows, d.abs().mean(), rtol=1e-5, atol=0)
+    p2, g3, m2, v2 = E.clone(), g.clone(), m.clone(), v.clone()
+    _lib.check(L.snerf_adam_step_tv(P(p2), P(g3), P(m2), P(v2), C.c_int64(rows), gc, a, b, P(srow), 1e-2, 0.9, 0.999, 1e-12, 3, 1.0, 1, ops._stream()))
+    torch.testing.assert_close(p2.view(-1), p_ref, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(m2.view(-1), m_ref, rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(v2.view(-1), v_ref, rtol=1e-6, atol=1e-9)
+    assert float(g3.abs().max()) == 0.0
 
 
 def test_fused_training_reduces_loss_and_keeps_parameters_finite():
