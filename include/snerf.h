@@ -357,6 +357,14 @@ int snerf_ist_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H
  * cdf[M, H*W] (fp32 inclusive prefix sums of the maps) with the uniform draw u[d].  indices [n,3] int64 = (image, row, col).
  * (torch.multinomial draws without replacement when enough pixels are non-zero; here draws are independent -- identical
  * distribution up to the O(per_image^2 * sum p^2) chance of a repeated pixel.) */
+/* DynamicDataset.compute_isg (NS/data/datasets/dynamic_dataset.py:215-326): out[M,H,W] (fp16) = mean over RGB of r^2 / (r^2 + gamma^2),
+ * r = image - per-camera median image (torch.median over the camera's images: the LOWER median, an input element).  The cameras'
+ * image lists are CSR: cam_off [n_cams+1], cam_img [M] (int32, device); img_cam [M] = camera slot of each image; max_frames = the
+ * longest list (<= 128).  medians: workspace [n_cams,H,W,3] of the images' dtype (also an output). */
+int snerf_isg_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H, int32_t W, int32_t n_cams, const int32_t* cam_off,
+                   const int32_t* cam_img, const int32_t* img_cam, int32_t max_frames, float gamma, void* medians, void* out_f16,
+                   snerf_stream_t stream);
+
 int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, int32_t per_image, const float* u, int32_t n,
                      int64_t* indices, snerf_stream_t stream);
 

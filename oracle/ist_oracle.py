@@ -25,3 +25,15 @@ def compute_ist(images, cam_ids, cam_times, ist_range: float, alpha: float = 0.1
         md = md.mean(dim=2)
         out[i] = torch.where(md > alpha, md, torch.zeros_like(md))
     return out.to(torch.float16)
+
+
+def compute_isg(images, cam_ids, isg_gamma: float = 5e-2):
+    """DynamicDataset.compute_isg (NS/data/datasets/dynamic_dataset.py:284-317): images [M,H,W,3] float32 in [0,1]; cam_ids [M]
+    -> fp16 [M,H,W].  Pinned by tests/golden/g10b_isg.npz (oracle/gen_golden_isg.py calls the reference method itself)."""
+    ids = cam_ids.reshape(-1)
+    out = torch.zeros(images.shape[:3])
+    med = {int(c): torch.median(images[ids == c], dim=0).values for c in torch.unique(ids)}
+    for i in range(images.shape[0]):
+        sq = torch.square(images[i] - med[int(ids[i])])
+        out[i] = (1.0 / 3) * torch.sum(sq / (sq + isg_gamma**2), dim=-1)
+    return out.to(torch.float16)

@@ -110,6 +110,7 @@ def lib():
     l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_tgrid_tv_sign.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P]
+    l.snerf_isg_maps.argtypes = [P, I, I, I, I, I, P, P, P, I, F, P, P, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
     if l.snerf_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libsnerf ABI {l.snerf_abi_version()} != binding {ABI_VERSION}: rebuild the library")
@@ -150,6 +151,7 @@ EXPORTS = [
     "snerf_tgrid_tv_bwd",
     "snerf_tgrid_tv_fwd_bwd",
     "snerf_tgrid_tv_sign",
+    "snerf_isg_maps",
     "snerf_adam_step_tv",
     "snerf_sample_pixels_uniform",
     "snerf_kplanes_scatter_sorted_scales",

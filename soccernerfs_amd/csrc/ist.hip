@@ -42,6 +42,51 @@ __global__ void ist_kernel(const T* __restrict__ images, const int32_t* __restri
   out[(int64_t)i * HW + px] = __float2half(w);    // (:462)
 }
 
+// ---- ISG (global-median) maps: DynamicDataset.compute_isg (dynamic_dataset.py:215-326) ----
+// Step 1, per camera: median over the camera's images of every pixel channel.  torch.median(dim=0) returns the LOWER median, an
+// element of the input (dynamic_dataset.py:292): rank (F - 1) / 2 in sorted order.  One lane per (camera, pixel, channel) selects
+// it by rank counting over the <= MAXF values it holds in a private array.
+constexpr int ISG_MAXF = 128;
+
+template <typename T>
+__global__ void isg_median_kernel(const T* __restrict__ images, const int32_t* __restrict__ cam_off, const int32_t* __restrict__ cam_img, int64_t HW3,
+                                  T* __restrict__ medians) {
+  const int c = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // pixel-channel
+  if (e >= HW3) return;
+  const int b = cam_off[c], F = cam_off[c + 1] - b;
+  T vals[ISG_MAXF];
+  for (int k = 0; k < F; ++k) vals[k] = images[(int64_t)cam_img[b + k] * HW3 + e];
+  const int target = (F - 1) / 2;
+  T med = vals[0];
+  for (int k = 0; k < F; ++k) {
+    const T v = vals[k];
+    int lt = 0, le = 0;
+    for (int j = 0; j < F; ++j) { lt += vals[j] < v; le += vals[j] <= v; }
+    if (lt <= target && target < le) { med = v; break; }
+  }
+  medians[(int64_t)c * HW3 + e] = med;
+}
+
+// Step 2, per image: psi = mean_c r^2 / (r^2 + gamma^2), r = image - median of its camera (:299-301), cast to fp16 (:317)
+template <typename T>
+__global__ void isg_weights_kernel(const T* __restrict__ images, const T* __restrict__ medians, const int32_t* __restrict__ img_cam, int64_t HW,
+                                   float gamma2, __half* __restrict__ out) {
+  const int i = blockIdx.y;
+  const int64_t px = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (px >= HW) return;
+  const T* cur = images + ((int64_t)i * HW + px) * 3;
+  const T* med = medians + ((int64_t)img_cam[i] * HW + px) * 3;
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float r = to_unit<T>(cur[k]) - to_unit<T>(med[k]);
+    const float sq = r * r;
+    acc += sq / (sq + gamma2);
+  }
+  out[(int64_t)i * HW + px] = __float2half((1.0f / 3) * acc);
+}
+
 // draws: for d in [0,n): image = chosen[d / per_image]; pick pixel with probability proportional to its weight by
 // inverting the image's inclusive prefix sum cdf[image][0..HW) at u*total.  indices [n,3] int64 = (image, row, col).
 __global__ void ist_sample_kernel(const float* __restrict__ cdf, int64_t HW, int W, const int64_t* __restrict__ chosen, int per_image,
@@ -78,6 +123,30 @@ extern "C" int snerf_ist_maps(const void* images, int32_t image_dtype, int32_t M
   else
     hipLaunchKernelGGL(ist_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)images, nbr_off, nbr_idx, HW, alpha, (__half*)out_f16);
   SNERF_LAUNCH_CHECK("ist_maps");
+  return 0;
+}
+
+extern "C" int snerf_isg_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H, int32_t W, int32_t n_cams, const int32_t* cam_off,
+                              const int32_t* cam_img, const int32_t* img_cam, int32_t max_frames, float gamma, void* medians, void* out_f16,
+                              snerf_stream_t stream) {
+  SNERF_REQUIRE(M >= 0 && H >= 1 && W >= 1 && n_cams >= 0, "isg_maps: M=%d H=%d W=%d n_cams=%d", M, H, W, n_cams);
+  SNERF_REQUIRE(image_dtype == 0 || image_dtype == 1, "isg_maps: image_dtype=%d (0 = uint8, 1 = float32)", image_dtype);
+  SNERF_REQUIRE(max_frames >= 1 && max_frames <= ISG_MAXF, "isg_maps: %d images of one camera (at most %d)", max_frames, ISG_MAXF);
+  if (M == 0 || n_cams == 0) return 0;
+  SNERF_REQUIRE(images && cam_off && cam_img && img_cam && medians && out_f16, "isg_maps: null buffer");
+  const int64_t HW = (int64_t)H * W;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g1((unsigned)ceil_div(HW * 3, 256), (unsigned)n_cams), g2((unsigned)ceil_div(HW, 256), (unsigned)M);
+  if (image_dtype == 0) {
+    hipLaunchKernelGGL(isg_median_kernel<uint8_t>, g1, dim3(256), 0, st, (const uint8_t*)images, cam_off, cam_img, HW * 3, (uint8_t*)medians);
+    hipLaunchKernelGGL(isg_weights_kernel<uint8_t>, g2, dim3(256), 0, st, (const uint8_t*)images, (const uint8_t*)medians, img_cam, HW, gamma * gamma,
+                       (__half*)out_f16);
+  } else {
+    hipLaunchKernelGGL(isg_median_kernel<float>, g1, dim3(256), 0, st, (const float*)images, cam_off, cam_img, HW * 3, (float*)medians);
+    hipLaunchKernelGGL(isg_weights_kernel<float>, g2, dim3(256), 0, st, (const float*)images, (const float*)medians, img_cam, HW, gamma * gamma,
+                       (__half*)out_f16);
+  }
+  SNERF_LAUNCH_CHECK("isg_maps");
   return 0;
 }
 

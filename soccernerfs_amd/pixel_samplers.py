@@ -36,6 +36,30 @@ def compute_ist(images: torch.Tensor, cam_ids: torch.Tensor, cam_times: torch.Te
     return out
 
 
+def compute_isg(images: torch.Tensor, cam_ids: torch.Tensor, isg_gamma: float = 5e-2) -> torch.Tensor:
+    """DynamicDataset.compute_isg (dynamic_dataset.py:215-326): images [M,H,W,3] (uint8 or float32 in [0,1], HIP device), cam_ids [M]
+    -> fp16 maps [M,H,W] = mean_c r^2 / (r^2 + gamma^2) with r = image - median image of its camera."""
+    if not images.is_cuda or images.dtype not in (torch.uint8, torch.float32):
+        raise RuntimeError("compute_isg: images must be a uint8 or float32 HIP device tensor")
+    images = images.contiguous()
+    M, H, W = images.shape[:3]
+    dev = images.device
+    ids = cam_ids.reshape(-1).to(dev)
+    uniq, inv = torch.unique(ids, return_inverse=True)  # camera slots in ascending id order; small [M] ops
+    order = torch.argsort(inv, stable=True)
+    counts = torch.bincount(inv, minlength=uniq.numel())
+    off = torch.zeros(uniq.numel() + 1, dtype=torch.int32, device=dev)
+    off[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    max_frames = int(counts.max())
+    med = torch.empty(uniq.numel(), H, W, 3, dtype=images.dtype, device=dev)
+    out = torch.empty(M, H, W, dtype=torch.float16, device=dev)
+    cam_img, img_cam = order.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous()  # named: they must outlive the launch
+    _lib.check(_lib.lib().snerf_isg_maps(ops._ptr(images), 0 if images.dtype == torch.uint8 else 1, M, H, W, uniq.numel(), ops._ptr(off),
+                                         ops._ptr(cam_img), ops._ptr(img_cam), max_frames, isg_gamma, ops._ptr(med), ops._ptr(out), ops._stream()),
+               "isg_maps")
+    return out
+
+
 class PixelSampler:
     """Uniform pixel sampler (pixel_samplers.py:24-128)."""
 

@@ -16,3 +16,13 @@ def test_ist_oracle_matches_reference(rng):
     assert torch.all(out[-1] == 1.0)  # the single-image camera: uniform map
     frac = float((out[:-1] > 0).float().mean())
     assert 0.0 < frac < 0.2  # sparse maps: only the moving blob
+
+
+@pytest.mark.parametrize("tag,gamma", [("0_05", 5e-2), ("0_2", 2e-1)])
+def test_isg_oracle_matches_reference_golden(tag, gamma):
+    """G10b (oracle/gen_golden_isg.py): the reference's own compute_isg on the G10 clip."""
+    from oracle import ist_oracle as IO
+
+    g, gb = load_golden("g10_ist"), load_golden("g10b_isg")
+    got = IO.compute_isg(g["images_u8"].float() / 255.0, g["cam_ids"], gamma).float()
+    assert torch.equal(got, gb["isg_" + tag])
