@@ -60,6 +60,68 @@ def compute_isg(images: torch.Tensor, cam_ids: torch.Tensor, isg_gamma: float = 
     return out
 
 
+def weights_cache_name(kind: str, param: float, num_images: int, height: int, eval_split: bool = False) -> str:
+    """File name of the reference's offline weight cache next to the images (a torch.save'd fp16 [M,H,W] tensor):
+    `ist-weights-<range with . -> _>-<split>-<N>-<H>p.pt` (dynamic_dataset.py:362-363) / `isg-weights-<gamma>-<split>-<N>-<H>p.pt` (:237)."""
+    split = "eval" if eval_split else "train"
+    if kind == "ist":
+        return f"ist-weights-{str(param).replace('.', '_')}-{split}-{num_images}-{height}p.pt"
+    if kind == "isg":
+        return f"isg-weights-{param}-{split}-{num_images}-{height}p.pt"
+    raise ValueError("kind must be 'ist' or 'isg'")
+
+
+def load_or_compute_weights(path: str, num_images: int, compute):
+    """The reference's offline cache protocol (dynamic_dataset.py:365-378, 464-468): load the .pt file if it exists and has one map per
+    image, otherwise call compute() and save the result."""
+    import os
+
+    if os.path.exists(path):
+        w = torch.load(path)
+        if w.shape[0] == num_images:
+            return w
+    w = compute()
+    torch.save(w, path)
+    return w
+
+
+def pick_cached_images(cam_times, cam_ids, num_to_sample: int, pick_mode: str = "randsteps", rng=None):
+    """Which images go into the on-device image cache when it is smaller than the dataset: CacheDataloader._get_batch_list
+    (NS/data/utils/dataloaders.py:105-175).  cam_times / cam_ids: one entry per dataset image.  "normal": a random subset;
+    "randsteps": all cameras at the same random time steps (first and last always included); "lowfps": every k-th time step;
+    short-falls are topped up with random images.  rng: a `random.Random` (the reference uses the global `random` module)."""
+    import random as _random
+    from math import ceil
+
+    rng = rng if rng is not None else _random
+    times_all = [float(t) for t in (cam_times.reshape(-1).tolist() if hasattr(cam_times, "reshape") else cam_times)]
+    ids_all = [int(i) for i in (cam_ids.reshape(-1).tolist() if hasattr(cam_ids, "reshape") else cam_ids)]
+    total = len(times_all)
+    if total == num_to_sample:
+        pick_mode = "normal"
+    if pick_mode == "normal":
+        indices = rng.sample(range(total), k=num_to_sample)
+    elif pick_mode in ("randsteps", "lowfps"):
+        times = list(set(times_all))  # the reference does not sort this list (:129)
+        if pick_mode == "randsteps":
+            steps = int(num_to_sample / len(set(ids_all)))
+            picked = [times[0], times[-1]] + rng.sample(times[1:-1], k=steps - 2)
+        else:
+            k = ceil(total / num_to_sample)
+            picked = times[::k]
+            if len(times) % k != 0:
+                picked = picked[:-1]
+        indices = [i for i in range(total) if times_all[i] in picked]
+        left = num_to_sample - len(indices)
+        if left > 0:
+            indices += rng.sample([x for x in range(total) if x not in indices], k=left)
+    else:
+        raise ValueError("Unknown pick_mode: " + pick_mode)
+    if len(indices) != num_to_sample:
+        raise RuntimeError("Not enough images to sample from.")
+    return indices
+
+
 class PixelSampler:
     """Uniform pixel sampler (pixel_samplers.py:24-128)."""
 
