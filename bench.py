@@ -167,6 +167,19 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the optimiser sweep runs on its own stream under the next step's first kernels (async_field_adam): its launch duration in the timed
+    # region includes that sharing.  For context, time it ALONE as well (a few extra steps with the sweep back on the main stream).
+    alone = None
+    if trainer.async_field_adam and not trainer._sharded():
+        trainer.async_field_adam = False
+        trainer.enable_kernel_timing(["adam_planes.field"])
+        for _ in range(20):
+            one_step()
+        torch.cuda.synchronize()
+        alone = trainer.kernel_times_ms().get("adam_planes.field")
+        trainer.disable_kernel_timing()
+        trainer.async_field_adam = True
+
     breakdown = None
     if args.breakdown:
         trainer.enable_kernel_timing(None)
@@ -233,6 +246,10 @@ def main():
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "algorithmic_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
                          "launches_timed": timed[DOMINANT][1],
+                         **({"alone": {"avg_launch_ms": round(alone[0], 4), "frac": round(alg["adam_planes.field"][1] / (alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                       "note": "same kernel with nothing else on the GPU (20 extra steps after the timed region, sweep on the main stream); "
+                                               "in the timed region it shares HBM with the next step's first kernels"}}
+                            if alone is not None and DOMINANT == "adam_planes.field" else {}),
                          "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT},
                          "side_stream_kernels": {k: {"avg_launch_ms": round(v[0], 4), "launches_timed": v[1],
                                                      "frac": round(alg[k][1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
