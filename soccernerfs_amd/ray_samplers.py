@@ -78,8 +78,9 @@ class PDFSampler(Sampler):
     def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False,
                  include_original: bool = True, histogram_padding: float = 0.01) -> None:
         super().__init__(num_samples=num_samples)
-        if include_original:
-            raise NotImplementedError("include_original=True is not on the proposal-sampler path (ray_samplers.py:544 passes False)")
+        # include_original (the class default, :290) merges the existing bins into the new ones (:353-354); the proposal sampler -- the
+        # only user on the hot path -- passes False (:544).  Here it is a torch cat + sort on top of the kernel's bins.
+        self.include_original = include_original
         self.train_stratified, self.single_jitter, self.histogram_padding = train_stratified, single_jitter, histogram_padding
         self.last_inds = None
 
@@ -100,7 +101,18 @@ class PDFSampler(Sampler):
                                kind=c["kind"], histogram_padding=self.histogram_padding, eps=eps, return_inds=return_inds)
         if return_inds:
             self.last_inds = out[2]
-        return _make_samples(ray_bundle, out[0], out[1], c["kind"])
+        sb, eb = out[0], out[1]
+        if self.include_original:
+            sb, _ = torch.sort(torch.cat([c["sbins"], sb], -1), -1)  # ray_samplers.py:353-354
+            nears, fars = ray_bundle.nears, ray_bundle.fars
+            if c["kind"] == "uniform":
+                eb = sb * fars + (1 - sb) * nears
+            else:
+                fn = lambda v: torch.where(v < 1, v / 2, 1 - 1 / (2 * v))
+                inv = lambda v: torch.where(v < 0.5, 2 * v, 1 / (2 - 2 * v))
+                eb = inv(sb * fn(fars) + (1 - sb) * fn(nears))
+            sb, eb = sb.contiguous(), eb.contiguous()
+        return _make_samples(ray_bundle, sb, eb, c["kind"])
 
 
 class ProposalNetworkSampler(Sampler):
