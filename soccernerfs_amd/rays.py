@@ -33,6 +33,21 @@ class Frustums:
     def get_start_positions(self) -> torch.Tensor:
         return self.origins + self.directions * self.starts
 
+    def set_offsets(self, offsets):
+        """rays.py:63-65."""
+        self.offsets = offsets
+
+    def __getitem__(self, idx) -> "Frustums":
+        """Index / mask every field alike, as TensorDataclass does (NS/utils/tensor_dataclass.py:131-140)."""
+        return Frustums(self.origins[idx], self.directions[idx], self.starts[idx], self.ends[idx], self.pixel_area[idx],
+                        None if self.offsets is None else self.offsets[idx])
+
+    @classmethod
+    def get_mock_frustum(cls, device="cpu") -> "Frustums":
+        """rays.py:87-102: a single frustum at the origin looking along +z."""
+        return cls(origins=torch.ones((1, 3), device=device), directions=torch.ones((1, 3), device=device), starts=torch.ones((1, 1), device=device),
+                   ends=torch.ones((1, 1), device=device), pixel_area=torch.ones((1, 1), device=device))
+
 
 class RaySamples:
     """Samples along rays (rays.py:105-170).  Built by RayBundle.get_ray_samples or the samplers."""
