@@ -29,23 +29,6 @@ struct TgridArgs {
   float* gemb;         // bwd
 };
 
-__device__ __forceinline__ uint32_t tg_hash(const uint32_t* pg, int D) {
-  const uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
-  uint32_t r = 0;
-  for (int i = 0; i < D; ++i) r ^= pg[i] * primes[i];
-  return r;
-}
-
-__device__ __forceinline__ uint32_t tg_row(const uint32_t* pg, int D, uint32_t hashmap_size, uint32_t resolution, int gridtype, int align) {
-  uint32_t stride = 1, index = 0;
-  for (int d = 0; d < D && stride <= hashmap_size; ++d) {
-    index += pg[d] * stride;
-    stride *= align ? resolution : (resolution + 1);
-  }
-  if (gridtype == 0 && stride > hashmap_size) index = tg_hash(pg, D);
-  return index % hashmap_size;
-}
-
 // (column, weight) of slot (ch, ab) at a time row; closed form of the reference's sampling_index table + get_temporal_index
 __device__ __forceinline__ void tg_slot_from_time(float t, int C, int n_rows, int ch, int ab, int& col, float& w) {
   const float v = t * (float)(n_rows - 1);
@@ -122,14 +105,35 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
   const bool active = live && !oob && wt != 0.f;
   float acc = 0.f;
   const int ncorner = 1 << D;
+  // Row index of a corner = get_grid_index (.cu:62-88): fast_hash (XOR of coordinate * prime, .cu:46-59) on hashed levels, the
+  // strided sum on dense ones, modulo the level's table size.  Per-axis terms, shared by the 2^D corners: t[d][bit] = (pg[d] + bit) * (prime[d] | dense stride[d]); a corner's row is
+  // their XOR (hashed level) or sum (dense level), then one reduction modulo the table size -- a mask when the size is a power of two
+  // (every hashed level: 2^log2_hashmap_size).  Same values as get_grid_index (.cu:62-88), a third of the integer work.
+  const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+  uint32_t term[3][2];
+  bool hashed;
+  {
+    uint32_t stride = 1;
+    for (int d = 0; d < D && stride <= hashmap_size; ++d) stride *= a.d.align_corners ? resolution : (resolution + 1);
+    hashed = a.d.gridtype == 0 && stride > hashmap_size;
+    uint32_t st = 1;
+    for (int d = 0; d < D; ++d) {
+      const uint32_t m = hashed ? primes[d] : (st <= hashmap_size ? st : 0u);  // dense: axes beyond the overflowing stride do not contribute (.cu:70-74)
+      term[d][0] = pg[d] * m;
+      term[d][1] = (pg[d] + 1u) * m;
+      if (st <= hashmap_size) st *= a.d.align_corners ? resolution : (resolution + 1);
+    }
+  }
+  const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
   for (int idx = 0; idx < ncorner; ++idx) {
     float w = 1.f;
-    uint32_t pl[3];
+    uint32_t index = 0;
     for (int d = 0; d < D; ++d) {
-      if ((idx & (1 << d)) == 0) { w *= 1.f - pos[d]; pl[d] = pg[d]; }
-      else { w *= pos[d]; pl[d] = pg[d] + 1; }
+      const int bit = (idx >> d) & 1;
+      w *= bit ? pos[d] : 1.f - pos[d];
+      index = hashed ? (index ^ term[d][bit]) : (index + term[d][bit]);
     }
-    const uint32_t row = tg_row(pl, D, hashmap_size, resolution, a.d.gridtype, a.d.align_corners);
+    const uint32_t row = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
     const size_t e = ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)col;
     if (active) {
       if (BWD) {
