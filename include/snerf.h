@@ -152,6 +152,8 @@ typedef struct {
 } snerf_mlp_desc;
 
 int64_t snerf_mlp_param_count(const snerf_mlp_desc* desc);
+/* 1 if the fused kernels are instantiated for this shape (else the caller composes the net from library GEMMs), 0 otherwise. */
+int snerf_mlp_supported(const snerf_mlp_desc* desc);
 
 /* Y[N,d_out] (row stride ldy) = MLP(X[N,d_in] (row stride ldx)).  If aux_out != NULL:
  * aux_out[n] = exp(raw output column aux_col) -- trunc_exp's forward (NS/field_components/activations.py:25-41),
@@ -339,6 +341,30 @@ int snerf_tgrid_tv_sign(const float* embeddings, int64_t rows, int32_t grid_C, i
                         int32_t n_slots, float* srow, snerf_stream_t stream);
 int snerf_adam_step_tv(float* p, float* g, float* m, float* v, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* srow,
                        float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Static multiresolution hash grid: tcnn.Encoding(3, {"otype": "HashGrid", "n_levels", "n_features_per_level", "log2_hashmap_size",
+ * "base_resolution", "per_level_scale"}) as the full NeRFPlayer constructs it (NS/fields/nerfplayer_field.py:242-252) and calls it
+ * on the normalised and on the DEFORMED positions (:341-342), so the coordinate gradient is part of the contract.
+ * tiny-cuda-nn (v1.6, Dockerfile:121) is third-party and absent from the reference tree: published algorithm, parity unpinned
+ * (oracle/hashgrid_oracle.py).  No bounds check on coordinates, as tcnn.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t D;              /* input dims (1..3) */
+  int32_t F;              /* n_features_per_level (1,2,4,8) */
+  int32_t L;              /* n_levels (<= 32) */
+  float scale[32];        /* filled by snerf_hashgrid_layout: exp2(l * log2(per_level_scale)) * base_resolution - 1 */
+  int32_t resolution[32]; /* ceil(scale) + 1 */
+  int32_t offsets[33];    /* row offset of each level; offsets[L] = total rows (each level: min(roundup8(res^D), 2^log2_hashmap_size)) */
+} snerf_hashgrid_desc;
+/* HOST ONLY: fills scale/resolution/offsets from (D, L already set) and returns the total row count (< 0 on bad arguments). */
+int64_t snerf_hashgrid_layout(snerf_hashgrid_desc* desc, int32_t base_resolution, float per_level_scale, int32_t log2_hashmap_size);
+/* out[B, L*F] = D-linear interpolation of table[rows, F] per level, level-major. */
+int snerf_hashgrid_encode_fwd(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, float* out,
+                              snerf_stream_t stream);
+/* grad_table [rows, F] (may be NULL) and grad_x [B, D] (may be NULL; needs table) are ACCUMULATED into (atomic fp32): caller zeroes. */
+int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out,
+                              float* grad_table, float* grad_x, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray importance sampling (IST = temporal difference).

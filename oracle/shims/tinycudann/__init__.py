@@ -1,9 +1,11 @@
 """Stub for tiny-cuda-nn: fp32 pure-PyTorch semantics that the build targets.
 
 Network  = bias-free Linear stack, ReLU/None hidden activation, None/Sigmoid output.
-Encoding = real spherical harmonics degree 4 on (2x-1) (tcnn convention), or identity-ish
-           placeholders for encodings that are off the K-Planes / NeRFPlayer-nerfacto path.
+Encoding = real spherical harmonics degree 4 on (2x-1) (tcnn convention); HashGrid = oracle/hashgrid_oracle.py (restatement of the
+           published algorithm, one flat `params` vector as tcnn exposes it); Frequency is construct-only (never called on the path).
 """
+import os
+import sys
 import torch
 from torch import nn
 
@@ -62,7 +64,14 @@ class Encoding(nn.Module):
             self.n_output_dims = n_input_dims * 2 * self.cfg["n_frequencies"]
         elif ot == "HashGrid":
             self.n_output_dims = self.cfg["n_levels"] * self.cfg["n_features_per_level"]
-            self.dummy = nn.Parameter(torch.zeros(1))
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+            from oracle import hashgrid_oracle as HG
+            self._hg = HG
+            c = self.cfg
+            self._geo = (c["n_levels"], c["n_features_per_level"], c["base_resolution"], c["per_level_scale"], c["log2_hashmap_size"])
+            rows = HG.level_geometry(c["n_levels"], c["base_resolution"], c["per_level_scale"], c["log2_hashmap_size"], n_input_dims)[2][-1]
+            gen = torch.Generator().manual_seed(seed)
+            self.params = nn.Parameter((torch.rand(rows * c["n_features_per_level"], generator=gen) * 2 - 1) * 1e-4)
         else:
             raise NotImplementedError(ot)
         self.n_input_dims = n_input_dims
@@ -70,6 +79,8 @@ class Encoding(nn.Module):
         ot = self.cfg["otype"]
         if ot == "SphericalHarmonics":
             return sh4(x.float() * 2.0 - 1.0)
+        if ot == "HashGrid":
+            return self._hg.encode(x.float(), self.params.view(-1, self._geo[1]), *self._geo)
         raise NotImplementedError(ot)
 
 class NetworkWithInputEncoding(nn.Module):

@@ -76,6 +76,11 @@ class TgridDesc(C.Structure):
                 ("align_corners", C.c_int32), ("S", C.c_float), ("offsets", C.c_int32 * 33)]
 
 
+class HashgridDesc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("F", C.c_int32), ("L", C.c_int32), ("scale", C.c_float * 32), ("resolution", C.c_int32 * 32),
+                ("offsets", C.c_int32 * 33)]
+
+
 _lib = None
 
 
@@ -93,6 +98,8 @@ def lib():
     l.snerf_last_error.restype = C.c_char_p
     l.snerf_target_arch.restype = C.c_char_p
     l.snerf_mlp_param_count.restype = C.c_int64
+    l.snerf_hashgrid_layout.restype = C.c_int64
+    l.snerf_hashgrid_layout.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32]
     # float arguments must be declared or ctypes passes them as ints/doubles
     F, I, L, P = C.c_float, C.c_int32, C.c_int64, C.c_void_p
     l.snerf_distortion.argtypes = [P, P, I, I, F, P, P, I, P]
@@ -138,6 +145,7 @@ EXPORTS = [
     "snerf_mlp_param_count",
     "snerf_mlp_fwd",
     "snerf_mlp_bwd",
+    "snerf_mlp_supported",
     "snerf_render_fwd",
     "snerf_render_bwd",
     "snerf_distortion",
@@ -158,6 +166,9 @@ EXPORTS = [
     "snerf_raygen",
     "snerf_aabb_collide",
     "snerf_tgrid_encode_fwd",
+    "snerf_hashgrid_layout",
+    "snerf_hashgrid_encode_fwd",
+    "snerf_hashgrid_encode_bwd",
     "snerf_tgrid_encode_bwd",
     "snerf_ist_maps",
     "snerf_ist_sample",

@@ -633,26 +633,30 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
   return 0;
 }
 
+// (padded input width, hidden width, hidden layers) the fused kernels are instantiated for
+#define SNERF_MLP_SHAPES(X)                                                   \
+  X(16, 64, 1)   /* K-Planes proposal sigma_net 8->64->1 */                   \
+  X(16, 64, 2)   /* K-Planes color_net 15->64->64->3 */                       \
+  X(32, 128, 1)  /* sigma_net, 1 scale */                                     \
+  X(64, 128, 1)  /* 2 scales */                                               \
+  X(96, 128, 1)                                                               \
+  X(128, 128, 1)                                                              \
+  X(160, 128, 1) /* k-planes preset: 5 scales */                              \
+  X(192, 128, 1) /* 6 scales (config 3) */                                    \
+  X(32, 64, 1)   /* default sigma hidden 64; nerfplayer mlp_base 32->64->16 */ \
+  X(64, 64, 1)                                                                \
+  X(128, 64, 1)                                                               \
+  X(160, 64, 1)                                                               \
+  X(16, 16, 1)   /* nerfplayer-nerfacto proposal 10->16->1 */                 \
+  X(32, 64, 2)                                                                \
+  X(48, 64, 2)                                                                \
+  X(64, 64, 2)   /* nerfplayer mlp_head 63->64->64->3 */
+
 static int dispatch(const snerf_mlp_desc* d, const MlpArgs& a, bool bwd, hipStream_t st) {
   const int d0p = (d->d_in + 15) / 16 * 16;
 #define CASE(D0P, H, NH) \
   if (d0p == D0P && d->hidden == H && d->n_hidden == NH) return launch<D0P, H, NH>(a, bwd, st);
-  CASE(16, 64, 1)    // K-Planes proposal sigma_net 8->64->1
-  CASE(16, 64, 2)    // K-Planes color_net 15->64->64->3
-  CASE(32, 128, 1)   // sigma_net, 1 scale
-  CASE(64, 128, 1)   // 2 scales
-  CASE(96, 128, 1)
-  CASE(128, 128, 1)
-  CASE(160, 128, 1)  // k-planes preset: 5 scales
-  CASE(192, 128, 1)  // 6 scales (config 3)
-  CASE(32, 64, 1)    // default sigma hidden 64; nerfplayer mlp_base 32->64->16
-  CASE(64, 64, 1)
-  CASE(128, 64, 1)
-  CASE(160, 64, 1)
-  CASE(16, 16, 1)    // nerfplayer-nerfacto proposal 10->16->1
-  CASE(32, 64, 2)
-  CASE(48, 64, 2)
-  CASE(64, 64, 2)    // nerfplayer mlp_head 63->64->64->3
+  SNERF_MLP_SHAPES(CASE)
 #undef CASE
   set_error("mlp: unsupported shape d_in=%d hidden=%d n_hidden=%d", d->d_in, d->hidden, d->n_hidden);
   return SNERF_ERR_UNSUPPORTED;
@@ -675,6 +679,16 @@ static int fill(const snerf_mlp_desc* d, MlpArgs& a) {
 }  // namespace snerf
 
 using namespace snerf;
+
+extern "C" int snerf_mlp_supported(const snerf_mlp_desc* d) {
+  if (!d || d->d_in < 1 || d->d_in > 192 || d->d_out < 1 || d->d_out > OUTP || d->n_hidden < 1 || d->n_hidden > 2) return 0;
+  const int d0p = (d->d_in + 15) / 16 * 16;
+#define CASE(D0P, H, NH) \
+  if (d0p == D0P && d->hidden == H && d->n_hidden == NH) return 1;
+  SNERF_MLP_SHAPES(CASE)
+#undef CASE
+  return 0;
+}
 
 extern "C" int64_t snerf_mlp_param_count(const snerf_mlp_desc* d) {
   if (!d) return -1;

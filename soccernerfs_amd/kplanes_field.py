@@ -14,10 +14,11 @@ from .tcnn_compat import Network
 
 
 class FieldHeadNames(enum.Enum):
-    """NS/field_components/field_heads.py:28-43 (the two heads this path emits)."""
+    """NS/field_components/field_heads.py:28-43 (the heads this path emits; PROBS only from the full NeRFPlayer field)."""
 
     RGB = "rgb"
     DENSITY = "density"
+    PROBS = "probs"
 
 
 def interpolate_kplanes(pts: torch.Tensor, ms_grids: PlaneSet, concat_features: bool = None, freeze_time_planes: bool = False,

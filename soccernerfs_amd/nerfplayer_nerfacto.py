@@ -107,8 +107,15 @@ class NerfplayerNerfactoModel(nn.Module):
     def forward(self, ray_bundle: RayBundle):
         return self.get_outputs(self.collider(ray_bundle))
 
+    def _background_color(self) -> str:
+        return self.config.background_color
+
     def get_outputs(self, ray_bundle: RayBundle):
         """nerfplayer_nerfacto.py:206-256."""
+        return self._outputs_and_field(ray_bundle)[0]
+
+    def _outputs_and_field(self, ray_bundle: RayBundle):
+        """-> (outputs, field outputs, weights of the final samples)."""
         assert ray_bundle.times is not None, "Time not provided."
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(
             ray_bundle, density_fns=[functools.partial(f, times=ray_bundle.times) for f in self.density_fns])
@@ -116,7 +123,7 @@ class NerfplayerNerfactoModel(nn.Module):
         weights = ray_samples.get_weights(fo[FieldHeadNames.DENSITY])
         weights_list.append(weights)
         ray_samples_list.append(ray_samples)
-        r = render_all(fo[FieldHeadNames.RGB], weights, ray_samples, self.config.background_color, self.training, self.rand_fn)
+        r = render_all(fo[FieldHeadNames.RGB], weights, ray_samples, self._background_color(), self.training, self.rand_fn)
         eb = ray_samples._compact["ebins"]
         steps = (eb[:, :-1] + eb[:, 1:]) / 2
         outputs = {"rgb": r["rgb"], "accumulation": r["accumulation"][:, None],
@@ -132,7 +139,7 @@ class NerfplayerNerfactoModel(nn.Module):
             outputs[f"prop_depth_{i}"] = torch.clip(pr["depth_expected"][:, None], st.min(), st.max())
         if ray_bundle.metadata is not None and "directions_norm" in ray_bundle.metadata:
             outputs["directions_norm"] = ray_bundle.metadata["directions_norm"]
-        return outputs
+        return outputs, fo, weights
 
     def get_metrics_dict(self, outputs, batch):
         """nerfacto.py:309-315."""

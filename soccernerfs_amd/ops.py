@@ -246,6 +246,55 @@ def mlp_forward(x, params, desc: _lib.MlpDesc, aux_col: int = -1):
 
 
 # ----------------------------------------------------------------------------------------------
+# static multiresolution hash grid (tcnn HashGrid)
+# ----------------------------------------------------------------------------------------------
+def hashgrid_desc(n_input_dims: int, n_levels: int, n_features_per_level: int, base_resolution: int, per_level_scale: float,
+                  log2_hashmap_size: int):
+    """-> (descriptor, total rows): the level geometry is computed once, on the host, by the library."""
+    d = _lib.HashgridDesc()
+    d.D, d.F, d.L = n_input_dims, n_features_per_level, n_levels
+    rows = _lib.lib().snerf_hashgrid_layout(C.byref(d), base_resolution, per_level_scale, log2_hashmap_size)
+    if rows < 0:
+        _lib.check(-1, "hashgrid_layout")
+    return d, int(rows)
+
+
+class _HashGrid(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, desc):
+        B = x.shape[0]
+        out = torch.empty(B, desc.L * desc.F, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().snerf_hashgrid_encode_fwd(C.byref(desc), _ptr(table), _ptr(x), C.c_int64(B), _ptr(out), _stream()), "hashgrid_encode_fwd")
+        ctx.desc = desc
+        ctx.save_for_backward(x, table)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, table = ctx.saved_tensors
+        g = g.contiguous()
+        gt = torch.zeros_like(table) if ctx.needs_input_grad[1] else None
+        gx = torch.zeros_like(x) if ctx.needs_input_grad[0] else None
+        if gt is None and gx is None:
+            return None, None, None
+        _lib.check(_lib.lib().snerf_hashgrid_encode_bwd(C.byref(ctx.desc), _ptr(table), _ptr(x), C.c_int64(x.shape[0]), _ptr(g),
+                                                        _ptr(gt) if gt is not None else None, _ptr(gx) if gx is not None else None, _stream()),
+                   "hashgrid_encode_bwd")
+        return gx, gt, None
+
+
+def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, desc: _lib.HashgridDesc) -> torch.Tensor:
+    """x [B, D] -> [B, L*F]; differentiable w.r.t. the flat table and the coordinates."""
+    x = _f32c(x, "hashgrid x")
+    table = _f32c(table, "hashgrid table")
+    if x.dim() != 2 or x.shape[1] != desc.D:
+        raise RuntimeError(f"hashgrid: x must be [B, {desc.D}], got {tuple(x.shape)}")
+    if table.numel() != desc.offsets[desc.L] * desc.F:
+        raise RuntimeError(f"hashgrid: table has {table.numel()} floats, the layout needs {desc.offsets[desc.L] * desc.F}")
+    return _HashGrid.apply(x, table, desc)
+
+
+# ----------------------------------------------------------------------------------------------
 # compositing + ray-level losses
 # ----------------------------------------------------------------------------------------------
 BG_MODES = {"random": 0, "last_sample": 1, "constant": 2}

@@ -1,10 +1,21 @@
-"""`tcnn.Network`-shaped module backed by libsnerf's fp32-MFMA MLP kernels.
+"""`tcnn.Network` / `tcnn.Encoding`-shaped modules backed by libsnerf.
 
 Mirrors tinycudann.Network(n_input_dims, n_output_dims, network_config) as the reference constructs it
 (NS/fields/kplanes_field.py:249-273,397-407): bias-free, ReLU/None hidden activation, None/Sigmoid output,
 one flat `params` vector (tcnn also exposes a single flat parameter).  Layer l is stored row-major
 [d_l][d_{l+1}]; `load_linear_weights` imports torch.nn.Linear-style [out,in] matrices (oracle / checkpoints).
+
+Shapes the fused MFMA kernels are instantiated for (snerf_mlp_supported: one or two hidden layers, <= 16 outputs -- every net of the
+K-Planes and NeRFPlayer-nerfacto presets) run fused.  The full NeRFPlayer field (NS/fields/nerfplayer_field.py:228-316) also has
+three-hidden-layer nets (deformation 3->128x3->3, colour head 15->64x3->3) and a 32-output one (33->64->32): those are composed
+layer by layer from plain library GEMMs on the device (rocBLAS through torch.mm, same flat parameter layout, same fp32 numerics);
+they still refuse CPU tensors.
+
+Encoding mirrors tcnn.Encoding(n_input_dims, encoding_config) for the otypes the reference constructs: "HashGrid" (libsnerf
+hashgrid kernels, one flat `params` vector as tcnn exposes it), "SphericalHarmonics" degree 4, and "Frequency" (constructed at
+nerfplayer_field.py:223-226 but never called on the path: construct-only here).
 """
+import ctypes as C
 import math
 from typing import Dict, Sequence
 
@@ -30,6 +41,8 @@ class Network(nn.Module):
         d.hidden_act = _ACT[network_config["activation"]]
         d.out_act = _OUT[network_config["output_activation"]]
         self.desc = d
+        self.hidden_act, self.out_act = network_config["activation"], network_config["output_activation"]
+        self.fused = bool(_lib.lib().snerf_mlp_supported(C.byref(d)))
         self.dims = [n_input_dims] + [d.hidden] * d.n_hidden + [n_output_dims]
         gen = torch.Generator().manual_seed(seed)
         chunks = []
@@ -57,8 +70,51 @@ class Network(nn.Module):
         return [buf[a:b].detach().view(self.dims[i], self.dims[i + 1]).t().contiguous() for i, a, b in self.layer_slices()]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return ops.mlp_forward(x, self.params, self.desc)
+        if self.fused:
+            return ops.mlp_forward(x, self.params, self.desc)
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("mlp: expected a float32 HIP device tensor (there is no CPU path)")
+        h = x.reshape(-1, x.shape[-1])
+        last = len(self.dims) - 2
+        for i, a, b in self.layer_slices():
+            h = torch.mm(h, self.params[a:b].view(self.dims[i], self.dims[i + 1]))
+            act = self.out_act if i == last else self.hidden_act
+            h = torch.relu(h) if act == "ReLU" else (torch.sigmoid(h) if act == "Sigmoid" else h)
+        return h
 
     def forward_with_exp_head(self, x: torch.Tensor, col: int):
         """Returns (y, exp(raw y[:, col])) -- the fused trunc_exp density head (kplanes_field.py:308-311)."""
+        if not self.fused:
+            raise RuntimeError("forward_with_exp_head needs a shape the fused kernels are instantiated for")
         return ops.mlp_forward(x, self.params, self.desc, aux_col=col)
+
+
+class Encoding(nn.Module):
+    def __init__(self, n_input_dims: int, encoding_config: Dict, seed: int = 1337, device=None):
+        super().__init__()
+        self.n_input_dims, self.cfg = n_input_dims, dict(encoding_config)
+        self.otype = self.cfg["otype"]
+        if self.otype == "HashGrid":
+            c = self.cfg
+            self.desc, rows = ops.hashgrid_desc(n_input_dims, c["n_levels"], c["n_features_per_level"], c["base_resolution"], c["per_level_scale"],
+                                                c["log2_hashmap_size"])
+            self.n_output_dims = c["n_levels"] * c["n_features_per_level"]
+            gen = torch.Generator().manual_seed(seed)
+            init = (torch.rand(rows * c["n_features_per_level"], generator=gen) * 2 - 1) * 1e-4  # tcnn: U(-1e-4, 1e-4)
+            self.params = nn.Parameter(init.to(device) if device is not None else init)
+        elif self.otype == "SphericalHarmonics":
+            if self.cfg["degree"] != 4:
+                raise ValueError("only degree-4 spherical harmonics are built")
+            self.n_output_dims = 16
+        elif self.otype == "Frequency":
+            self.n_output_dims = n_input_dims * 2 * self.cfg["n_frequencies"]
+        else:
+            raise ValueError(f"unsupported encoding otype {self.otype}")
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.otype == "HashGrid":
+            return ops.hashgrid_encode(x.reshape(-1, self.n_input_dims), self.params, self.desc)
+        if self.otype == "SphericalHarmonics":
+            from .sh import sh4_from_unit_dirs
+            return sh4_from_unit_dirs(x * 2.0 - 1.0)
+        raise NotImplementedError("Frequency encoding is constructed by the reference but never evaluated on the path")
