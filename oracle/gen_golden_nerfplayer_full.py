@@ -28,7 +28,7 @@ from nerfstudio.data.scene_box import SceneBox  # noqa: E402
 
 NP.DynMetric = G12._NoMetric
 
-CFG = dict(disable_scene_contraction=True, num_levels=4, features_per_level=2, log2_hashmap_size=13, temporal_dim=8,
+CFG = dict(disable_scene_contraction=True, num_levels=4, features_per_level=2, log2_hashmap_size=12, temporal_dim=8,
            proposal_net_args_list=[{"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 32},
                                    {"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 64}],
            num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8, prob_reg_loss_mult=0.1, depth_weight=0.0)

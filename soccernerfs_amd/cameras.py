@@ -20,13 +20,23 @@ class Cameras:
         self.fx, self.fy, self.cx, self.cy = ex(fx), ex(fy), ex(cx), ex(cy)
         self.width, self.height = int(width), int(height)
         self.times = None if times is None else times.reshape(-1).float().to(dev).contiguous()
+        self.ids = kwargs.get("ids")  # camera uid per image (Broadcast-style parser), carried for the samplers / metrics
+        self.distortion_params = kwargs.get("distortion_params")  # carried only: rays are generated for the pinhole model
+
+    def rescale_output_resolution(self, scaling_factor: float) -> None:
+        """NS/cameras/cameras.py:792-816."""
+        s = float(scaling_factor)
+        self.fx, self.fy, self.cx, self.cy = self.fx * s, self.fy * s, self.cx * s, self.cy * s
+        self.height = int(torch.tensor(float(self.height)).mul(torch.tensor(s)).to(torch.int64))
+        self.width = int(torch.tensor(float(self.width)).mul(torch.tensor(s)).to(torch.int64))
 
     def __len__(self):
         return self.camera_to_worlds.shape[0]
 
     def to(self, device):
         return Cameras(self.camera_to_worlds.to(device), self.fx.to(device), self.fy.to(device), self.cx.to(device), self.cy.to(device),
-                       self.width, self.height, None if self.times is None else self.times.to(device))
+                       self.width, self.height, None if self.times is None else self.times.to(device), ids=self.ids,
+                       distortion_params=self.distortion_params)
 
     def generate_rays(self, camera_indices: torch.Tensor, coords: Optional[torch.Tensor] = None, aabb=None, near_plane=0.0,
                       training=True, **kwargs) -> RayBundle:

@@ -1,0 +1,216 @@
+"""On-disk format of the Broadcast-style release: `transforms.json` + `<k>x/` image directories, parsed as
+NS/data/dataparsers/broadcaststyle_dataparser.py:261-547 does (`Broadcaststyle._generate_dataparser_outputs`), plus the image loader
+that fills the resident uint8 image cache (NS/data/datasets/base_dataset.py:60-95).
+
+Host-side logic only (json + file names + a few 4x4 matrices); no kernels.  What is built: the "all" camera split (the only entry of
+the reference's SETUPS table whose camera names exist in its CAM_IDS table, :44-73,75-192), per-frame or global intrinsics, time steps
+from the file names, fps down-sampling, pose auto-scaling, `orientation_method`/`center_method` "none" (the parser's defaults) and
+"poses" centring, masks / depth file lists.  Distortion parameters are carried but the ray generator here is pinhole-only."""
+import json
+import os
+from dataclasses import dataclass, field
+from pathlib import Path, PurePath
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .cameras import Cameras
+from .scene_colliders import SceneBox
+
+# camera name -> unique id (:44-73)
+CAM_IDS = {**{f"Camera_{i + 1}": i for i in range(20)}, **{f"global_{i + 1}": 20 + i for i in range(8)}}
+# train / eval camera split (:75-192); the other entries of the reference's table name cameras that CAM_IDS does not hold
+SETUPS = {"all": {"train": [f"Camera_{i + 1}" for i in range(19)], "eval": ["Camera_20"]}}
+
+
+@dataclass
+class DataparserOutputs:
+    """NS/data/dataparsers/base_dataparser.py:44-77."""
+
+    image_filenames: List[Path]
+    cameras: Cameras
+    scene_box: SceneBox
+    mask_filenames: Optional[List[Path]] = None
+    dataparser_scale: float = 1.0
+    dataparser_transform: torch.Tensor = field(default_factory=lambda: torch.eye(4)[:3])
+    metadata: Dict = field(default_factory=dict)
+
+
+@dataclass
+class BroadcaststyleDataParserConfig:
+    """:195-236 (defaults of the parser class; the k-planes preset keeps them)."""
+
+    data: Path = Path("data/broadcaststyle/")
+    scale_factor: float = 1.0
+    downscale_factor: Optional[int] = 2
+    scene_scale: float = 1.5
+    orientation_method: str = "none"
+    center_method: str = "none"
+    auto_scale_poses: bool = True
+    depth_unit_scale_factor: float = 0.01
+    depth_maps: str = "none"
+    depth_mask: str = "mask"
+    cam_split_setup: str = "all"
+    cap_box_floor: bool = False
+    static: bool = False
+    static_allimgs: bool = False
+    static_timestep: int = -1
+    fps_downsample: float = 3.0
+
+    def setup(self) -> "Broadcaststyle":
+        return Broadcaststyle(self)
+
+
+def _distortion(src: Dict) -> torch.Tensor:
+    """camera_utils.get_distortion_params: [k1, k2, k3, k4, p1, p2]."""
+    return torch.tensor([float(src.get(k, 0.0)) for k in ("k1", "k2", "k3", "k4", "p1", "p2")])
+
+
+def auto_orient_and_center_poses(poses: torch.Tensor, method: str = "none", center_method: str = "none"):
+    """NS/cameras/camera_utils.py:470-574 for method "none" (the Broadcast-style default)."""
+    origins = poses[..., :3, 3]
+    if center_method == "poses":
+        translation = torch.mean(origins, dim=0)
+    elif center_method == "none":
+        translation = torch.zeros(3)
+    else:
+        raise NotImplementedError(f"center_method {center_method!r} (the Broadcast-style parser uses 'none')")
+    if method != "none":
+        raise NotImplementedError(f"orientation method {method!r} (the Broadcast-style parser uses 'none')")
+    transform = torch.eye(4)
+    transform[:3, 3] = -translation
+    transform = transform[:3, :]
+    return transform @ poses, transform
+
+
+class Broadcaststyle:
+    def __init__(self, config: BroadcaststyleDataParserConfig):
+        self.config = config
+        self.downscale_factor = None
+
+    def _get_fname(self, filepath: PurePath, data_dir: Path, downsample_folder_prefix="images_") -> Path:
+        """:529-547: <dir>/<k>x/<name>."""
+        self.downscale_factor = self.config.downscale_factor
+        old = data_dir / filepath
+        return old.parent / f"{self.config.downscale_factor}x" / old.name
+
+    @staticmethod
+    def _frame_metadata(fname: Path):
+        """:242-259: `<camera name>_<time step>.<ext>`."""
+        head, tail = fname.name.rsplit("_", 1)
+        return int(CAM_IDS[head]), int(tail.split(".")[0])
+
+    def get_dataparser_outputs(self, split: str = "train") -> DataparserOutputs:
+        cfg = self.config
+        data = Path(cfg.data)
+        if cfg.static and cfg.static_timestep == -1:
+            data = data.parent / "broadcaststyle_empty/"
+        if data.suffix == ".json":
+            meta, data_dir = json.load(open(data)), data.parent
+        else:
+            meta, data_dir = json.load(open(data / "transforms.json")), data
+        fixed = {k: k in meta for k in ("fl_x", "fl_y", "cx", "cy", "h", "w")}
+        distort_fixed = any(k in meta for k in ("k1", "k2", "k3", "p1", "p2"))
+        per = {k: [] for k in fixed}
+        image_filenames, mask_filenames, depth_filenames, poses, distort, times, cam_uids = [], [], [], [], [], [], []
+        setup_split = "train" if split == "train" else "eval"
+        other_split = "eval" if setup_split == "train" else "train"
+        split_cams = [CAM_IDS[c] for c in SETUPS[cfg.cam_split_setup][setup_split]]
+        other_cams = [CAM_IDS[c] for c in SETUPS[cfg.cam_split_setup][other_split]]
+        for frame in meta["frames"]:
+            fname = self._get_fname(PurePath(frame["file_path"]), data_dir)
+            if not fname.exists():
+                continue
+            cam_id, time_step = self._frame_metadata(fname)
+            if cam_id not in split_cams and cam_id not in other_cams:
+                continue
+            if cfg.static and not cfg.static_allimgs:
+                if cfg.static_timestep == -1:
+                    if time_step != 0:
+                        continue
+                elif time_step != cfg.static_timestep:
+                    continue
+            cam_uids.append(cam_id)
+            times.append(time_step)
+            for k in fixed:
+                if not fixed[k]:
+                    assert k in frame, f"{k} not specified in frame"
+                    per[k].append(int(frame[k]) if k in ("h", "w") else float(frame[k]))
+            if not distort_fixed:
+                distort.append(_distortion(frame))
+            image_filenames.append(fname)
+            poses.append(np.array(frame["transform_matrix"]))
+            if "mask_path" in frame:
+                mask_filenames.append(self._get_fname(PurePath(frame["mask_path"]), data_dir, downsample_folder_prefix="masks_"))
+            if "depth_file_path" in frame and cfg.depth_maps != "none":
+                dp = frame["depth_file_path"]
+                if cfg.depth_mask != "none":
+                    dp = dp.replace("depth-maps", "depth-maps-" + cfg.depth_mask)
+                if cfg.depth_maps != "depth-maps":
+                    dp = dp.replace("depth-maps", cfg.depth_maps)
+                depth_filenames.append(self._get_fname(PurePath(dp), data_dir, downsample_folder_prefix="depths_"))
+        assert len(image_filenames) != 0, "No image files found. Check the file_paths in transforms.json."
+        assert len(mask_filenames) in (0, len(image_filenames)), "Different number of image and mask filenames."
+        assert len(depth_filenames) in (0, len(image_filenames)), "Different number of image and depth filenames."
+
+        # fps down-sampling (:405-412): keep the time steps linspace(0, T-1, int(T / fps_downsample))
+        times_filter = np.arange(max(times) + 1)
+        if cfg.fps_downsample > 1:
+            base = max(times) + 1
+            times_filter = np.linspace(0, base - 1, int(base / cfg.fps_downsample)).astype(np.int32)
+        indices = [i for i in range(len(image_filenames)) if cam_uids[i] in split_cams and times[i] in times_filter]
+
+        orientation = meta.get("orientation_override", cfg.orientation_method)
+        poses = torch.from_numpy(np.array(poses).astype(np.float32))
+        poses, transform = auto_orient_and_center_poses(poses, method=orientation, center_method=cfg.center_method)
+        scale = 1.0
+        if cfg.auto_scale_poses:
+            scale /= float(torch.max(torch.abs(poses[:, :3, 3])))  # over ALL parsed cameras (both splits), :433-438
+        scale *= cfg.scale_factor
+        poses[:, :3, 3] *= scale
+
+        sel = lambda lst: [lst[i] for i in indices]
+        a = cfg.scene_scale
+        lo = [-a, -a, -0.1] if cfg.cap_box_floor else [-a, -a, -a]
+        scene_box = SceneBox(aabb=torch.tensor([lo, [a, a, a]], dtype=torch.float32))
+        if meta.get("camera_model", "OPENCV") not in ("OPENCV", "PERSPECTIVE", "PINHOLE", "SIMPLE_PINHOLE"):
+            raise NotImplementedError(f"camera model {meta['camera_model']!r}: only perspective cameras are built")
+        idx = torch.tensor(indices, dtype=torch.long)
+        val = lambda k, dt: (dt(meta[k]) if fixed[k] else torch.tensor(per[k], dtype=torch.float32 if dt is float else torch.int32)[idx])
+        fx, fy, cx, cy = val("fl_x", float), val("fl_y", float), val("cx", float), val("cy", float)
+        height, width = val("h", int), val("w", int)
+        tmax = max(times)
+        t = torch.tensor(times, dtype=torch.float32)[idx]
+        t = t / tmax if tmax != 0 else t
+        ids = torch.tensor(cam_uids, dtype=torch.float32)[idx].to(torch.uint8)  # Cameras._init_get_ids (cameras.py:263-272) stores uint8
+        dist = _distortion(meta) if distort_fixed else torch.stack(distort, dim=0)[idx]
+        if isinstance(height, torch.Tensor):
+            if len(set(height.tolist())) != 1 or len(set(width.tolist())) != 1:
+                raise NotImplementedError("cameras of different image sizes")
+            height, width = int(height[0]), int(width[0])
+        cameras = Cameras(camera_to_worlds=poses[idx][:, :3, :4], fx=fx, fy=fy, cx=cx, cy=cy, width=width, height=height, times=t, ids=ids,
+                          distortion_params=dist)
+        assert self.downscale_factor is not None
+        cameras.rescale_output_resolution(1.0 / self.downscale_factor)
+        return DataparserOutputs(image_filenames=sel(image_filenames), cameras=cameras, scene_box=scene_box,
+                                 mask_filenames=sel(mask_filenames) if mask_filenames else None, dataparser_scale=scale,
+                                 dataparser_transform=transform,
+                                 metadata={"depth_filenames": sel(depth_filenames) if depth_filenames else None,
+                                           "depth_unit_scale_factor": cfg.depth_unit_scale_factor, "static": cfg.static})
+
+
+def load_image_cache(image_filenames: List[Path]) -> torch.Tensor:
+    """InputDataset.get_numpy_image (base_dataset.py:60-80) for every file: uint8 [M,H,W,3] (RGBA files are alpha-composited over white
+    only by get_image's float path, :82-95; the resident cache keeps 8-bit RGB and rejects other layouts)."""
+    from PIL import Image
+
+    out = []
+    for f in image_filenames:
+        im = np.array(Image.open(f), dtype="uint8")
+        if im.ndim == 2:
+            im = im[:, :, None].repeat(3, axis=2)
+        if im.shape[2] != 3:
+            raise NotImplementedError(f"{f}: {im.shape[2]} channels; the image cache holds 8-bit RGB")
+        out.append(torch.from_numpy(im))
+    return torch.stack(out)

@@ -750,6 +750,74 @@ class KPlanesTrainer:
         self._steps_since_update += 1  # step_cb (ray_samplers.py:554-557)
         return out
 
+    # ---- nerfstudio checkpoint files (trainer.py:331-380 of the reference; formats in soccernerfs_amd/checkpoint.py) ----
+    def _named_module(self) -> torch.nn.Module:
+        """The trainer's parameters under the reference model's module names (registration order = the reference's parameter order)."""
+        nn = torch.nn
+        root = nn.Module()
+        aabb = lambda: nn.Parameter(torch.tensor(self.aabb, dtype=torch.float32), requires_grad=False)
+        root.field = nn.Module()
+        root.field.aabb = aabb()
+        root.field.grids, root.field.sigma_net, root.field.color_net = self.field_planes, self.sigma_net, self.color_net
+        root.proposal_networks = nn.ModuleList()
+        for pp, pn in zip(self.prop_planes, self.prop_nets):
+            m = nn.Module()
+            m.aabb = aabb()
+            m.grids, m.sigma_net = pp, pn
+            root.proposal_networks.append(m)
+        root.device_indicator_param = nn.Parameter(torch.empty(0))
+        return root
+
+    def _ck_names(self) -> Dict[str, str]:
+        names = {"field.grids.planes": "field.planes", "field.sigma_net.params": "field.sigma", "field.color_net.params": "field.color"}
+        for i in range(len(self.prop_planes)):
+            names[f"proposal_networks.{i}.grids.planes"] = f"prop{i}.planes"
+            names[f"proposal_networks.{i}.sigma_net.params"] = f"prop{i}.mlp"
+        return names
+
+    def _gather_moment_shards(self):
+        """Sharded optimiser: every rank owns 1/world of the field planes' Adam moments; make the full buffers whole on all ranks."""
+        from . import dist as sdist
+
+        off, _, padded = self._field_seg
+        shard = padded // self.world
+        for buf in (self.exp_avg, self.exp_avg_sq):
+            seg = buf[off:off + padded]
+            sdist.all_gather_shards(seg, seg[self.rank * shard:(self.rank + 1) * shard].clone(), self.group)
+
+    def save_checkpoint(self, checkpoint_dir: str, save_only_latest_checkpoint: bool = True) -> Optional[str]:
+        """Writes `step-%09d.ckpt` (rank 0 only; collective when the optimiser is sharded).  The saved step is the index of the last
+        completed iteration, as the reference saves it; load_checkpoint resumes at step + 1."""
+        from . import checkpoint as CK
+
+        self.synchronize()
+        if self._sharded():
+            self._gather_moment_shards()
+        if self.rank != 0:
+            return None
+        moments = {ck: (self.mviews[seg], self.vviews[seg], self.step) for ck, seg in self._ck_names().items()} if self.step > 0 else {}
+        root = self._named_module()
+        hyper = {"lr": self.cfg.lr, "betas": (0.9, 0.999), "eps": self.cfg.adam_eps, "weight_decay": 0, "amsgrad": False}
+        opt = CK.export_optimizer_states(root, moments, {"fields": hyper, "proposal_networks": hyper})
+        return CK.save_checkpoint(checkpoint_dir, max(self.step - 1, 0), root, opt, save_only_latest_checkpoint)
+
+    def load_checkpoint(self, load_dir: str, load_step: Optional[int] = None) -> int:
+        """Parameters (+ Adam moments when the file holds them) from a nerfstudio checkpoint; returns the step training resumes at."""
+        from . import checkpoint as CK
+
+        self.synchronize()
+        root = self._named_module()
+        start, moments = CK.load_checkpoint(load_dir, root, load_step)
+        names = self._ck_names()
+        for ck, (m, v, _) in moments.items():
+            self.mviews[names[ck]].copy_(m.reshape(-1).to(self.dev))
+            self.vviews[names[ck]].copy_(v.reshape(-1).to(self.dev))
+        self._params_alt.copy_(self.params)
+        self.step = start if moments else 0  # Adam bias correction counts optimiser updates; without moments the optimiser restarts
+        self._steps_since_update = 0
+        torch.cuda.synchronize(self.dev)
+        return start
+
     # ---- reference-layout import (parity tests / checkpoint import) ----
     @torch.no_grad()
     def load_oracle_params(self, P: Dict):

@@ -105,7 +105,7 @@ def _full_model(g):
     from soccernerfs_amd.scene_colliders import SceneBox
 
     cfg = NerfplayerModelConfig(
-        num_levels=4, features_per_level=2, log2_hashmap_size=13, temporal_dim=8,
+        num_levels=4, features_per_level=2, log2_hashmap_size=12, temporal_dim=8,
         proposal_net_args_list=[{"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 32},
                                 {"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 64}],
         num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8, prob_reg_loss_mult=0.1)

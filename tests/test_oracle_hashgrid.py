@@ -78,11 +78,11 @@ def test_oracle_field_reproduces_reference_full_model_golden():
     eb = g["ebins_2"]
     pos = o[:, None, :] + d[:, None, :] * ((eb[:, :-1] + eb[:, 1:]) / 2)[..., None]
     scale = TO.resolve_scale(4, 16, 2.0, 2048)  # desired_resolution = 1024 * (aabb.max - aabb.min) (nerfplayer_field.py:277)
-    offsets = TO.level_offsets(4, 16, scale, 13)
+    offsets = TO.level_offsets(4, 16, scale, 12)
     assert offsets[-1] == g["param_field.newness_field.embeddings"].shape[0]
     enc = {"offsets": offsets, "log2_scale": float(np.log2(scale)), "base_res": 16, "gridtype": 0, "level_dim": 2, "table": TO.channel_table(8, 2)}
     params = {str(n): g["param_" + str(n)] for n in g["param_names"]}
-    dens, rgb, probs = HG.nerfplayer_field_forward(pos, times, aabb, (4, 2, 16, 1.4472692012786865, 13), enc, params)
+    dens, rgb, probs = HG.nerfplayer_field_forward(pos, times, aabb, (4, 2, 16, 1.4472692012786865, 12), enc, params)
     w = KO.get_weights(eb[:, 1:] - eb[:, :-1], dens)
     torch.testing.assert_close(w, g["weights_2"], rtol=1e-4, atol=1e-6)
     comp = (w[..., None] * rgb).sum(1) + g["bg"] * (1 - w.sum(1, keepdim=True))

@@ -14,6 +14,7 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--optim", default="snerf", choices=["snerf", "fused", "foreach", "single"])
 ap.add_argument("--no-fuse-tv", action="store_true")
 ap.add_argument("--fused", action="store_true", help="soccernerfs_amd.nerfplayer_trainer.NerfplayerTrainer instead of the autograd model")
+ap.add_argument("--full", action="store_true", help="full NeRFPlayer (`nerfplayer` preset, soccernerfs_amd.nerfplayer.NerfplayerModel) instead of the nerfacto variant")
 ap.add_argument("--profile", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -42,10 +43,16 @@ if args.fused:
     print(json.dumps({"config": "nerfplayer-nerfacto preset (fused trainer)", "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
                       "rays_per_s": R * args.steps / dt}))
     sys.exit(0)
-model = NerfplayerNerfactoModel(NerfplayerNerfactoModelConfig(), SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3])), num_train_data=36 * 100).to(dev).train()
+if args.full:
+    from soccernerfs_amd.nerfplayer import NerfplayerModel, NerfplayerModelConfig
+    model = NerfplayerModel(NerfplayerModelConfig(), SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3])), num_train_data=36 * 100).to(dev).train()
+    main_encoders = [model.field.newness_field, model.field.decomposition_field]
+else:
+    model = NerfplayerNerfactoModel(NerfplayerNerfactoModelConfig(), SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3])), num_train_data=36 * 100).to(dev).train()
+    main_encoders = [model.field.mlp_base]
 model.scene_box.aabb = model.scene_box.aabb.to(dev)
 params = [p for g in model.get_param_groups().values() for p in g if p.requires_grad]
-encoders = [model.field.mlp_base] + [p.encoding for p in model.proposal_networks]
+encoders = main_encoders + [p.encoding for p in model.proposal_networks]
 for e in encoders:
     e.fuse_tv = not args.no_fuse_tv
 if args.optim == "snerf":
@@ -84,5 +91,5 @@ for i in range(args.steps):
     step(args.warmup + i)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-print(json.dumps({"config": "nerfplayer-nerfacto preset (autograd face on HIP ops)", "rays": R, "params": sum(p.numel() for p in params), "optim": args.optim,
+print(json.dumps({"config": ("nerfplayer preset, full NeRFPlayer" if args.full else "nerfplayer-nerfacto preset") + " (autograd face on HIP ops)", "rays": R, "params": sum(p.numel() for p in params), "optim": args.optim,
                   "ms_per_step": dt / args.steps * 1e3, "rays_per_s": R * args.steps / dt}))
