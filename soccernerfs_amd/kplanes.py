@@ -211,3 +211,19 @@ class KPlanesModel(nn.Module):
                 if isinstance(v, torch.Tensor):
                     chunks.setdefault(k, []).append(v)
         return {k: torch.cat(v).view(h, w, *v[0].shape[1:]) for k, v in chunks.items()}
+
+    def get_image_metrics_and_images(self, outputs: Dict[str, torch.Tensor], batch: Dict[str, torch.Tensor]):
+        """kplanes.py:454-498: PSNR / SSIM of a full rendered image against the ground truth, plus the images a viewer would log
+        (side-by-side rgb, raw accumulation / depth maps -- the reference colour-maps them for display, which is viewer code).
+        LPIPS and the RetinaNet-box metrics (DynMetric) need pretrained networks and are not computed."""
+        from .metrics import psnr, structural_similarity_index_measure
+
+        image = batch["image"].to(outputs["rgb"].device)
+        rgb = outputs["rgb"]
+        combined_rgb = torch.cat([image, rgb], dim=1)
+        im, pr = torch.moveaxis(image, -1, 0)[None, ...], torch.moveaxis(rgb, -1, 0)[None, ...]
+        metrics_dict = {"psnr": float(psnr(im, pr)), "ssim": float(structural_similarity_index_measure(im, pr))}
+        images_dict = {"img": combined_rgb, "accumulation": outputs["accumulation"], "depth": outputs["depth"]}
+        for i in range(self.config.num_proposal_iterations):
+            images_dict[f"prop_depth_{i}"] = outputs[f"prop_depth_{i}"]
+        return metrics_dict, images_dict

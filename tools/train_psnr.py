@@ -29,7 +29,9 @@ def eval_psnr(trainer, data, n_images, anneal):
     pick = torch.linspace(0, M - 1, n_images).long().tolist()
     R = trainer.R
     ys, xs = torch.meshgrid(torch.arange(H, device=imgs.device), torch.arange(W, device=imgs.device), indexing="ij")
-    psnrs = []
+    from soccernerfs_amd.metrics import structural_similarity_index_measure as ssim_fn
+
+    psnrs, ssims = [], []
     for m in pick:
         idx = torch.stack([torch.full_like(ys, m), ys, xs], -1).reshape(-1, 3)
         out = torch.empty(H * W, 3, device=imgs.device)
@@ -40,6 +42,9 @@ def eval_psnr(trainer, data, n_images, anneal):
         gt = imgs[m].reshape(-1, 3).float() / 255.0
         mse = torch.mean((out - gt) ** 2)
         psnrs.append(float(10.0 * torch.log10(1.0 / mse)))
+        chw = lambda t: t.view(H, W, 3).permute(2, 0, 1)[None]
+        ssims.append(float(ssim_fn(chw(gt), chw(out))))  # as get_image_metrics_and_images (kplanes.py:469-473)
+    eval_psnr.last_ssim = ssims
     return psnrs
 
 
@@ -102,9 +107,11 @@ def main():
         if (step + 1) % args.eval_every == 0 or step + 1 == args.steps:
             from soccernerfs_amd.trainer import anneal_value
             ps = eval_psnr(trainer, held, args.eval_images, anneal_value(step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope))
+            ss = eval_psnr.last_ssim
             ps_tr = eval_psnr(trainer, train, 4, 1.0)
-            log["evals"].append({"step": step + 1, "psnr_heldout_mean": sum(ps) / len(ps), "psnr_heldout": ps, "psnr_train_views_mean": sum(ps_tr) / len(ps_tr)})
-            print(f"== step {step + 1}: held-out camera PSNR {sum(ps) / len(ps):.2f} dB over {len(ps)} frames; train views {sum(ps_tr) / len(ps_tr):.2f} dB", flush=True)
+            log["evals"].append({"step": step + 1, "psnr_heldout_mean": sum(ps) / len(ps), "psnr_heldout": ps, "ssim_heldout_mean": sum(ss) / len(ss),
+                                 "psnr_train_views_mean": sum(ps_tr) / len(ps_tr)})
+            print(f"== step {step + 1}: held-out camera PSNR {sum(ps) / len(ps):.2f} dB, SSIM {sum(ss) / len(ss):.4f} over {len(ps)} frames; train views {sum(ps_tr) / len(ps_tr):.2f} dB", flush=True)
     log["train_seconds"] = t_train
     log["train_rays_per_s_mean"] = R * args.steps / max(t_train, 1e-9)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
