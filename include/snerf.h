@@ -154,6 +154,13 @@ typedef struct {
 int64_t snerf_mlp_param_count(const snerf_mlp_desc* desc);
 /* 1 if the fused kernels are instantiated for this shape (else the caller composes the net from library GEMMs), 0 otherwise. */
 int snerf_mlp_supported(const snerf_mlp_desc* desc);
+/* Single bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) and its backward (act: 0 none, 1 ReLU, 2 Sigmoid; K, M <= 128): the building
+ * block for tcnn.Network shapes outside the fused table (full NeRFPlayer: NS/fields/nerfplayer_field.py:231-316).  Backward works from the
+ * stored OUTPUT Y: gX[N,K] is written (may be NULL), gW[K,M] is ACCUMULATED (atomic fp32; may be NULL). */
+int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, float* Y, int32_t ldy,
+                    snerf_stream_t stream);
+int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                    const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
 
 /* Y[N,d_out] (row stride ldy) = MLP(X[N,d_in] (row stride ldx)).  If aux_out != NULL:
  * aux_out[n] = exp(raw output column aux_col) -- trunc_exp's forward (NS/field_components/activations.py:25-41),

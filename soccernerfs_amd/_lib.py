@@ -146,6 +146,8 @@ EXPORTS = [
     "snerf_mlp_fwd",
     "snerf_mlp_bwd",
     "snerf_mlp_supported",
+    "snerf_dense_fwd",
+    "snerf_dense_bwd",
     "snerf_render_fwd",
     "snerf_render_bwd",
     "snerf_distortion",

@@ -582,6 +582,183 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// single dense layers: Y = act(X W), and its backward.  Nets outside the fused kernels' shape table (the full NeRFPlayer's
+// three-hidden-layer / 32-output nets, NS/fields/nerfplayer_field.py:231-316) are chained from these: the weight matrix lives in
+// LDS for the whole persistent loop, a TS-row tile of X (and of dZ in the backward) is staged per iteration, activations travel
+// through HBM between layers (N x 128 floats = 100 MB at 196 k samples: ~0.03 ms each way, against ~0.1 ms of MFMA work).
+// ---------------------------------------------------------------------------------------------
+template <int KP, int MP, int TS, bool BWD>
+struct DensePlan {
+  static constexpr int LDX = ld_of(KP), LDM = ld_of(MP), LW = ldw_of(MP);
+  static constexpr int W0 = 0;                       // [KP][LW]
+  static constexpr int XT = W0 + KP * LW;            // [TS][LDX]
+  static constexpr int GZ = XT + TS * LDX;           // bwd: [TS][LDM]
+  static constexpr int TOTAL = GZ + (BWD ? TS * LDM : 0);
+  static constexpr size_t BYTES = (size_t)TOTAL * sizeof(float);
+};
+template <int MP>
+constexpr int dense_waves() { return MP >= 128 ? 8 : 4; }
+
+// MlpArgs reuse: d0 = K, dout = M, W = the [K][M] matrix, hidden_act = 1 -> ReLU, out_act = 1 -> Sigmoid (at most one set)
+template <int KP, int MP, int TS>
+__global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_fwd_kernel(MlpArgs a, int64_t n_tiles) {
+  extern __shared__ __align__(16) float smem[];
+  using P = DensePlan<KP, MP, TS, false>;
+  constexpr int MT = TS / 16, NW = dense_waves<MP>(), NTB = MP / 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  stage_weights(a.W, a.d0, a.dout, smem + P::W0, KP, MP, P::LW);
+  XTile<TS, KP, NW * 64> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();
+    xt.store(smem + P::XT, P::LDX);
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (NTB + NW - 1) / NW; ++j) {
+      const int nt = wave + NW * j;
+      if (nt < NTB) {
+        f32x4 acc[MT] = {};
+        mma_cols<MT, KP>(smem + P::XT, P::LDX, smem + P::W0, P::LW, nt, acc, lane);
+        const int col = nt * 16 + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (row0 + r < a.N && col < a.dout) {
+              float y = acc[m][r];
+              if (a.hidden_act == 1) y = fmaxf(y, 0.f);
+              if (a.out_act == 1) y = 1.f / (1.f + expf(-y));
+              a.Y[(row0 + r) * a.ldy + col] = y;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// a.Y here is the layer's stored OUTPUT (post-activation), read-only: dZ = dY .* act'(Y)
+template <int KP, int MP, int TS>
+__global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpArgs a, int64_t n_tiles) {
+  extern __shared__ __align__(16) float smem[];
+  using P = DensePlan<KP, MP, TS, true>;
+  constexpr int MT = TS / 16, NW = dense_waves<MP>(), KT = KP / 16, NTB = MP / 16, NT = NW * 64;
+  constexpr int NB = (KT * NTB + NW - 1) / NW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* Xs = smem + P::XT;
+  float* Gs = smem + P::GZ;
+  stage_weights(a.W, a.d0, a.dout, smem + P::W0, KP, MP, P::LW);
+  f32x4 dW[NB] = {};
+  XTile<TS, KP, NT> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();
+    xt.store(Xs, P::LDX);
+    for (int idx = threadIdx.x; idx < TS * MP; idx += NT) {
+      const int r = idx / MP, c = idx - r * MP;
+      const int64_t n = n0 + r;
+      float g = 0.f;
+      if (n < a.N && c < a.dout) {
+        g = a.gY[n * a.ldgy + c];
+        const float y = a.Y[n * a.ldy + c];
+        if (a.hidden_act == 1) g = y > 0.f ? g : 0.f;
+        if (a.out_act == 1) g = g * y * (1.f - y);
+      }
+      Gs[r * P::LDM + c] = g;
+    }
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
+    __syncthreads();
+    if (a.gW) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int t = wave + NW * j;
+        if (t < KT * NTB) mma_outer<TS>(Xs, P::LDX, Gs, P::LDM, t / NTB, t % NTB, dW[j], lane);
+      }
+    }
+    if (a.gX) {
+#pragma unroll
+      for (int j = 0; j < (KT + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < KT) {
+          f32x4 acc[MT] = {};
+          mma_cols_T<MT, MP>(Gs, P::LDM, smem + P::W0, P::LW, nt, acc, lane);
+          const int col = nt * 16 + (lane & 15);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[m][r];
+          }
+        }
+      }
+    }
+  }
+  if (a.gW) {
+    const int cl = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int t = wave + NW * j;
+      if (t < KT * NTB) {
+        const int it = t / NTB, nt = t % NTB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = it * 16 + r0 + r, col = nt * 16 + cl;
+          if (row < a.d0 && col < a.dout) atomicAdd(a.gW + (int64_t)row * a.dout + col, dW[j][r]);
+        }
+      }
+    }
+  }
+}
+
+template <int KP, int MP>
+static int launch_dense(const MlpArgs& a, bool bwd, hipStream_t st) {
+  constexpr int TS = 64;
+  const int64_t n_tiles = (a.N + TS - 1) / TS;
+  if (bwd) {
+    using P = DensePlan<KP, MP, TS, true>;
+    static_assert(P::BYTES <= LDS_LIMIT, "dense backward tile does not fit LDS");
+    int per_cu = (int)(LDS_LIMIT / P::BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = dense_bwd_kernel<KP, MP, TS>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(dense_waves<MP>() * 64), P::BYTES, st, a, n_tiles);
+  } else {
+    using P = DensePlan<KP, MP, TS, false>;
+    int per_cu = (int)(LDS_LIMIT / P::BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = dense_fwd_kernel<KP, MP, TS>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(dense_waves<MP>() * 64), P::BYTES, st, a, n_tiles);
+  }
+  SNERF_LAUNCH_CHECK(bwd ? "dense_bwd" : "dense_fwd");
+  return 0;
+}
+
+static int dispatch_dense(int K, int M, const MlpArgs& a, bool bwd, hipStream_t st) {
+  const int kp = K <= 16 ? 16 : (K <= 32 ? 32 : (K <= 48 ? 48 : (K <= 64 ? 64 : 128)));
+  const int mp = M <= 16 ? 16 : (M <= 32 ? 32 : (M <= 64 ? 64 : 128));
+#define CASE(KP, MP) \
+  if (kp == KP && mp == MP) return launch_dense<KP, MP>(a, bwd, st);
+#define ROW(KP) CASE(KP, 16) CASE(KP, 32) CASE(KP, 64) CASE(KP, 128)
+  ROW(16) ROW(32) ROW(48) ROW(64) ROW(128)
+#undef ROW
+#undef CASE
+  set_error("dense: unsupported shape K=%d M=%d", K, M);
+  return SNERF_ERR_UNSUPPORTED;
+}
+
 static bool wreg_enabled() {
   static const bool on = [] { const char* e = getenv("SNERF_MLP_WREG"); return e ? atoi(e) != 0 : true; }();
   return on;
@@ -724,4 +901,31 @@ extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const floa
   SNERF_REQUIRE(!gX || ldgx >= d->d_in, "mlp_bwd: ldgx=%d", ldgx);
   a.X = X; a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
   return dispatch(d, a, true, (hipStream_t)stream);
+}
+
+// One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid); K, M <= 128.
+extern "C" int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, float* Y, int32_t ldy,
+                               snerf_stream_t stream) {
+  SNERF_REQUIRE(K >= 1 && K <= 128 && M >= 1 && M <= 128 && act >= 0 && act <= 2, "dense_fwd: K=%d M=%d act=%d (K, M <= 128)", K, M, act);
+  SNERF_REQUIRE(N >= 0 && ldx >= K && ldy >= M, "dense_fwd: N=%lld ldx=%d ldy=%d", (long long)N, ldx, ldy);
+  if (N == 0) return 0;
+  SNERF_REQUIRE(W && X && Y, "dense_fwd: null buffer");
+  MlpArgs a = {};
+  a.X = X; a.N = N; a.ldx = ldx; a.d0 = K; a.W = W; a.dout = M; a.Y = Y; a.ldy = ldy; a.hidden_act = act == 1; a.out_act = act == 2;
+  return dispatch_dense(K, M, a, false, (hipStream_t)stream);
+}
+
+// Backward of snerf_dense_fwd from the layer's stored output Y: gX[N,K] = dZ W^T (written; may be NULL), gW[K,M] += X^T dZ (atomic; may
+// be NULL), dZ = gY .* act'(Y).
+extern "C" int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                               const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+  SNERF_REQUIRE(K >= 1 && K <= 128 && M >= 1 && M <= 128 && act >= 0 && act <= 2, "dense_bwd: K=%d M=%d act=%d (K, M <= 128)", K, M, act);
+  SNERF_REQUIRE(N >= 0 && ldx >= K && ldy >= M && ldgy >= M && (!gX || ldgx >= K), "dense_bwd: N=%lld ldx=%d ldy=%d ldgy=%d ldgx=%d", (long long)N, ldx,
+                ldy, ldgy, ldgx);
+  if (N == 0) return 0;
+  SNERF_REQUIRE(W && X && Y && gY && (gX || gW), "dense_bwd: null buffer");
+  MlpArgs a = {};
+  a.X = X; a.N = N; a.ldx = ldx; a.d0 = K; a.W = W; a.dout = M; a.Y = const_cast<float*>(Y); a.ldy = ldy; a.hidden_act = act == 1; a.out_act = act == 2;
+  a.gY = gY; a.ldgy = ldgy; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
+  return dispatch_dense(K, M, a, true, (hipStream_t)stream);
 }

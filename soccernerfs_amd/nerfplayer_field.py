@@ -3,8 +3,8 @@ multiresolution hash grid evaluated at the original and at the deformed position
 decomposition) and a 3-way softmax that mixes the stationary / deformed / new features before the decode MLPs.
 
 Kernels: static hash grid -> csrc/hashgrid.hip (with the coordinate gradient the deformation MLP trains on); temporal grids ->
-csrc/tgrid.hip; MLPs -> csrc/mlp.hip where the shape is instantiated (decomposition 32->64->3, decode 32->64->64->16), library
-GEMMs per layer otherwise (tcnn_compat.Network).  Heads built: density + rgb + probs (no transient / semantic / normal heads, as the
+csrc/tgrid.hip; MLPs -> csrc/mlp.hip: fused where the shape is instantiated (decomposition 32->64->3, decode 32->64->64->16), chained
+dense-layer kernels otherwise (tcnn_compat.Network).  Heads built: density + rgb + probs (no transient / semantic / normal heads, as the
 `nerfplayer` preset, NS/configs/method_configs.py:562-614)."""
 import torch
 from torch import nn

@@ -7,9 +7,9 @@ one flat `params` vector (tcnn also exposes a single flat parameter).  Layer l i
 
 Shapes the fused MFMA kernels are instantiated for (snerf_mlp_supported: one or two hidden layers, <= 16 outputs -- every net of the
 K-Planes and NeRFPlayer-nerfacto presets) run fused.  The full NeRFPlayer field (NS/fields/nerfplayer_field.py:228-316) also has
-three-hidden-layer nets (deformation 3->128x3->3, colour head 15->64x3->3) and a 32-output one (33->64->32): those are composed
-layer by layer from plain library GEMMs on the device (rocBLAS through torch.mm, same flat parameter layout, same fp32 numerics);
-they still refuse CPU tensors.
+three-hidden-layer nets (deformation 3->128x3->3, colour head 15->64x3->3) and a 32-output one (33->64->32): those are chained
+layer by layer from libsnerf's single dense-layer kernels (snerf_dense_fwd/bwd: same fp32 MFMA arithmetic, weight matrix resident in
+LDS, activations through HBM between layers; widths <= 128), same flat parameter layout.
 
 Encoding mirrors tcnn.Encoding(n_input_dims, encoding_config) for the otypes the reference constructs: "HashGrid" (libsnerf
 hashgrid kernels, one flat `params` vector as tcnn exposes it), "SphericalHarmonics" degree 4, and "Frequency" (constructed at
@@ -72,15 +72,7 @@ class Network(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.fused:
             return ops.mlp_forward(x, self.params, self.desc)
-        if not x.is_cuda or x.dtype != torch.float32:
-            raise RuntimeError("mlp: expected a float32 HIP device tensor (there is no CPU path)")
-        h = x.reshape(-1, x.shape[-1])
-        last = len(self.dims) - 2
-        for i, a, b in self.layer_slices():
-            h = torch.mm(h, self.params[a:b].view(self.dims[i], self.dims[i + 1]))
-            act = self.out_act if i == last else self.hidden_act
-            h = torch.relu(h) if act == "ReLU" else (torch.sigmoid(h) if act == "Sigmoid" else h)
-        return h
+        return ops.dense_net_forward(x, self.params, self.dims, self.hidden_act, self.out_act)
 
     def forward_with_exp_head(self, x: torch.Tensor, col: int):
         """Returns (y, exp(raw y[:, col])) -- the fused trunc_exp density head (kplanes_field.py:308-311)."""

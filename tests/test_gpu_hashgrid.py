@@ -69,17 +69,17 @@ def test_hashgrid_argument_errors():
         Encoding(3, {"otype": "DenseGrid"})
 
 
-@pytest.mark.parametrize("shape", [(3, 3, 128, 3, "None"), (33, 32, 64, 1, "None"), (15, 3, 64, 3, "Sigmoid")])
+@pytest.mark.parametrize("shape", [(3, 3, 128, 3, "None"), (33, 32, 64, 1, "None"), (15, 3, 64, 3, "Sigmoid"), (40, 7, 32, 4, "None"), (100, 20, 128, 1, "Sigmoid")])
 def test_generic_shape_network_matches_torch(shape):
-    """The full NeRFPlayer's nets outside the fused kernels' table (three hidden layers / 32 outputs): same flat parameter layout,
-    values and gradients as a bias-free torch Linear stack."""
+    """Nets outside the fused kernels' table (three or more hidden layers / more than 16 outputs), chained from the dense-layer kernels:
+    same flat parameter layout, values and gradients as a bias-free torch Linear stack."""
     from soccernerfs_amd.tcnn_compat import Network
 
     d_in, d_out, hidden, nh, out_act = shape
     net = Network(d_in, d_out, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": out_act, "n_neurons": hidden, "n_hidden_layers": nh})
     assert not net.fused
     gen = torch.Generator().manual_seed(5)
-    x = torch.rand(300, d_in, generator=gen) - 0.5
+    x = torch.rand(333, d_in, generator=gen) - 0.5  # ragged: not a multiple of the 64-row tile
     ws = [w.clone().requires_grad_(True) for w in net.linear_weights()]
     h = x.clone().requires_grad_(True)
     y = h
@@ -91,11 +91,15 @@ def test_generic_shape_network_matches_torch(shape):
     net = net.to(DEV)
     xg = x.to(DEV).requires_grad_(True)
     out = net(xg)
-    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out.cpu(), y.detach(), rtol=1e-5, atol=1e-6)
     out.backward(go.to(DEV))
-    torch.testing.assert_close(xg.grad.cpu(), h.grad, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(xg.grad.cpu(), h.grad, rtol=1e-4, atol=1e-6)
     for got, w in zip(net.linear_weights(net.params.grad), ws):
-        torch.testing.assert_close(got.cpu(), w.grad, rtol=1e-3, atol=1e-5)
+        torch.testing.assert_close(got.cpu(), w.grad, rtol=1e-4, atol=1e-5)
+    # inputs that do not need a gradient, strided rows
+    wide = torch.zeros(333, d_in + 5, device=DEV)
+    wide[:, :d_in] = x.to(DEV)
+    torch.testing.assert_close(net(wide[:, :d_in]).cpu(), y.detach(), rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError):
         net(x)  # CPU tensor
 

@@ -104,7 +104,14 @@ def test_mlp_full_size_linearity():
 def test_mlp_unsupported_shape_raises():
     from soccernerfs_amd.tcnn_compat import Network
 
+    # a width the fused table does not hold runs through the dense-layer kernels ...
     net = Network(8, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 48,
                          "n_hidden_layers": 1}).to(DEV)
-    with pytest.raises(RuntimeError, match="unsupported shape"):
-        net(torch.zeros(4, 8, device=DEV))
+    assert not net.fused and net(torch.zeros(4, 8, device=DEV)).shape == (4, 1)
+    with pytest.raises(RuntimeError, match="needs a shape the fused kernels"):
+        net.forward_with_exp_head(torch.zeros(4, 8, device=DEV), 0)
+    # ... widths beyond 128 are refused by the library
+    wide = Network(8, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 256,
+                          "n_hidden_layers": 1}).to(DEV)
+    with pytest.raises(RuntimeError, match="K, M <= 128"):
+        wide(torch.zeros(4, 8, device=DEV))
