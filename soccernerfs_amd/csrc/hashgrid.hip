@@ -7,8 +7,9 @@
 // grid_resolution, pos_fract, grid_index, coherent_prime_hash), restated on the CPU in oracle/hashgrid_oracle.py.
 //
 // Layout: table [rows_total][F] fp32, levels back to back at desc.offsets; out [B][L*F] level-major (tcnn's to-row-major output).
-// One lane per (sample, level), level = blockIdx.y: all lanes of a launch row work on one level's table (<= 4 MB at 2^19 x 2
-// floats), which stays in the XCD L2s while that level is processed.  A corner is one F*4-byte read (8 B at F = 2).
+// level = blockIdx.y: all lanes of a launch row work on one level's table (<= 4 MB at 2^19 x 2 floats), which stays in the XCD L2s
+// while that level is processed.  Forward: one lane per (sample, level), a corner is one F*4-byte read (8 B at F = 2).  Backward: 2F
+// adjacent lanes per (sample, level) (see the kernel).
 // The level geometry (scale, resolution, rows) is computed ONCE on the host by snerf_hashgrid_layout and carried in the descriptor,
 // so host, kernel and oracle agree on it bit for bit.
 #include <math.h>
@@ -28,12 +29,22 @@ struct HgArgs {
   float* gx;            // bwd, may be null: [B, D], accumulated over levels
 };
 
-template <int F, bool BWD>
+template <int F, bool BWD, int HG_CB>
 __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
   const int D = a.d.D;
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // forward: one lane per (sample, level), F features in registers.
+  // backward: 2F adjacent lanes per (sample, level) = (x-corner, feature).  The scatter is bound by atomic REQUESTS (~20 G/s chip-wide;
+  // profiles/r01_kernels.md), not by the duplicated index arithmetic: a corner's F features leave the wave as one request (adjacent
+  // addresses), and so do the two x-corners whenever their rows are neighbours -- always on dense levels (row = x + ...), and on hashed
+  // levels when x is even (prime_x = 1: (x+1) ^ h = (x ^ h) ^ 1).
+  constexpr int LPS = BWD ? (1 << HG_CB) * F : 1;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t b = gid / LPS;
+  const int li = (int)(gid - b * LPS);
+  const int fl = li % F;   // this lane's feature (backward)
+  const int xb = li / F;   // this lane's low corner bits (backward): x first
   const int level = blockIdx.y;
-  if (b >= a.B) return;
+  if (b >= a.B) return;  // B * F is a multiple of F: the F lanes of a sample leave together
   const float scale = a.d.scale[level];
   const uint32_t resolution = (uint32_t)a.d.resolution[level];
   const uint32_t off0 = (uint32_t)a.d.offsets[level];
@@ -65,15 +76,15 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
   }
   const bool pow2 = (rows & (rows - 1u)) == 0u;
 
-  float g[F];
-  if (BWD) {
-#pragma unroll
-    for (int f = 0; f < F; ++f) g[f] = a.gout[b * (a.d.L * F) + level * F + f];
-  }
+  float g = 0.f;
+  if (BWD) g = a.gout[b * (a.d.L * F) + level * F + fl];
   float acc[F] = {};
   float gxd[3] = {0.f, 0.f, 0.f};
-  const int ncorner = 1 << D;
-  for (int idx = 0; idx < ncorner; ++idx) {
+  const int cb = BWD ? (HG_CB < D ? HG_CB : D) : 0;  // corner bits spread over lanes
+  const int ncorner = 1 << (D - cb);
+  if (BWD && xb >= (1 << cb)) g = 0.f;  // D < HG_CB: surplus lanes contribute nothing (they stay for the lane exchanges below)
+  for (int sub = 0; sub < ncorner; ++sub) {
+    const int idx = (sub << cb) | (xb & ((1 << cb) - 1));
     float w = 1.f;
     uint32_t index = 0;
     for (int d = 0; d < D; ++d) {
@@ -88,17 +99,14 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
       for (int f = 0; f < F; ++f) acc[f] += w * a.table[e + f];
     } else {
       if (a.gtable) {
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const float v = w * g[f];
-          if (v != 0.f) atomicAdd(a.gtable + e + f, v);
-        }
+        const float v = w * g;
+        if (v != 0.f) atomicAdd(a.gtable + e + fl, v);
       }
       if (a.gx) {
         // dy/dx_d = scale * sum over corners of (+-1 along d) * prod_{e != d} w_e * value (grid.h dy_dx, linear interpolation)
-        float dot = 0.f;
+        float dot = a.table[e + fl] * g;
 #pragma unroll
-        for (int f = 0; f < F; ++f) dot += a.table[e + f] * g[f];
+        for (int o = 1; o < F; o <<= 1) dot += __shfl_xor(dot, o, 64);  // over the sample's F lanes
         for (int d = 0; d < D; ++d) {
           float wo = 1.f;
           for (int q = 0; q < D; ++q)
@@ -112,9 +120,13 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
 #pragma unroll
     for (int f = 0; f < F; ++f) a.out[b * (a.d.L * F) + level * F + f] = acc[f];
   } else if (a.gx) {
-    for (int d = 0; d < D; ++d) {
-      const float v = gxd[d] * scale;
-      if (v != 0.f) atomicAdd(a.gx + b * D + d, v);
+    for (int o = F; o < LPS; o <<= 1)
+      for (int d = 0; d < D; ++d) gxd[d] += __shfl_xor(gxd[d], o, 64);  // the other corners' lanes
+    if (li == 0) {
+      for (int d = 0; d < D; ++d) {
+        const float v = gxd[d] * scale;
+        if (v != 0.f) atomicAdd(a.gx + b * D + d, v);
+      }
     }
   }
 }
@@ -129,17 +141,24 @@ static int validate(const snerf_hashgrid_desc* d, int64_t B) {
   return 0;
 }
 
-template <bool BWD>
-static int launch(const HgArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(a.B, 256), (unsigned)a.d.L);
+template <bool BWD, int CB>
+static int launch_cb(const HgArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)ceil_div(a.B * (BWD ? (1 << CB) * a.d.F : 1), 256), (unsigned)a.d.L);
   switch (a.d.F) {
-    case 1: hipLaunchKernelGGL((hashgrid_kernel<1, BWD>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((hashgrid_kernel<2, BWD>), grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((hashgrid_kernel<4, BWD>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((hashgrid_kernel<8, BWD>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((hashgrid_kernel<1, BWD, CB>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((hashgrid_kernel<2, BWD, CB>), grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((hashgrid_kernel<4, BWD, CB>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((hashgrid_kernel<8, BWD, CB>), grid, dim3(256), 0, st, a); break;
   }
   SNERF_LAUNCH_CHECK(BWD ? "hashgrid_encode_bwd" : "hashgrid_encode_fwd");
   return 0;
+}
+
+template <bool BWD>
+static int launch(const HgArgs& a, hipStream_t st) {
+  // backward: the two x-corners on adjacent lanes; spreading the y / z corners over lanes as well measured no faster (0.70 / 0.71 ms
+  // against 0.69 for the table scatter, and a slower coordinate gradient) -- the request rate is the bound by then
+  return BWD ? launch_cb<BWD, 1>(a, st) : launch_cb<false, 0>(a, st);
 }
 
 }  // namespace snerf
