@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--adam-under-scatter", action="store_true", help="A-B: sweep the finest scale's planes while the coarser scales are scattered")
     ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
+    ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"], help="MFMA operand type of the one-hidden-layer nets (sigma_net, proposal "
+                    "nets): fp32 = exact; bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
@@ -116,7 +118,7 @@ def main():
 
     # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
     torch.manual_seed(20231029 + rank)
-    cfg = KPlanesTrainConfig()  # the k-planes preset
+    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
@@ -233,7 +235,9 @@ def main():
         line = {
             "metric": "train rays/sec (K-Planes Broadcast-style, whole job)", "value": R * world * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mlp_operands == "fp32" else f"f32 (planes, sampling, compositing, losses, optimiser) + {args.mlp_operands} MFMA operands with f32 accumulation in sigma_net / proposal nets",
+            "data": "synthetic",
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
                        "schedule": "early training: proposal networks updated every 2nd step (every step for the first 10)" if args.start_step < 10 else

@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 1
+#define SNERF_ABI_VERSION 2
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -143,12 +143,16 @@ int snerf_pdf_resample(const snerf_resample_args* args, snerf_stream_t stream);
  * (NS/fields/kplanes_field.py:249-273,397-407; NS/fields/nerfplayer_nerfacto_field.py:94-104,238-248,301-311).
  * d_in -> hidden x n_hidden (ReLU/None) -> d_out (None/Sigmoid); d_out <= 16; hidden in {16,64,128}.
  * Parameters: ONE flat fp32 buffer, layer l stored row-major [d_l][d_{l+1}] (input-major), layers back to back.
- * Computed in exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32).
+ * Computed in exact fp32 on the matrix cores (v_mfma_f32_16x16x4_f32), or with 16-bit operands (v_mfma_f32_16x16x32_bf16 / _f16) when
+ * desc.operands = 1 / 2: parameters, inputs, outputs and gradients stay fp32 either way.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   int32_t d_in, hidden, n_hidden, d_out;
   int32_t hidden_act; /* 0 none, 1 ReLU */
   int32_t out_act;    /* 0 none, 1 Sigmoid */
+  int32_t operands;   /* 0: fp32 MFMA operands (exact fp32, the parity path); 1: bf16, 2: fp16 MFMA operands with fp32 accumulation (2 is
+                         exactly tcnn FullyFusedMLP's arithmetic class); 16-bit forms: one hidden layer of 64 / 128, d_in <= 160
+                         (snerf_mlp_supported tells) */
 } snerf_mlp_desc;
 
 int64_t snerf_mlp_param_count(const snerf_mlp_desc* desc);

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KPlanesDesc(C.Structure):
@@ -52,7 +52,7 @@ class ResampleArgs(C.Structure):
 
 class MlpDesc(C.Structure):
     _fields_ = [("d_in", C.c_int32), ("hidden", C.c_int32), ("n_hidden", C.c_int32), ("d_out", C.c_int32),
-                ("hidden_act", C.c_int32), ("out_act", C.c_int32)]
+                ("hidden_act", C.c_int32), ("out_act", C.c_int32), ("operands", C.c_int32)]
 
 
 class RenderArgs(C.Structure):

@@ -829,7 +829,12 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
   X(48, 64, 2)                                                                \
   X(64, 64, 2)   /* nerfplayer mlp_head 63->64->64->3 */
 
+// bf16-operand kernels (mlp_lp.hip)
+bool mlp_bf16_supported(const snerf_mlp_desc* d);
+int mlp_bf16_dispatch(const snerf_mlp_desc* d, const void* args, bool bwd, hipStream_t st);
+
 static int dispatch(const snerf_mlp_desc* d, const MlpArgs& a, bool bwd, hipStream_t st) {
+  if (d->operands != 0) return mlp_bf16_dispatch(d, &a, bwd, st);
   const int d0p = (d->d_in + 15) / 16 * 16;
 #define CASE(D0P, H, NH) \
   if (d0p == D0P && d->hidden == H && d->n_hidden == NH) return launch<D0P, H, NH>(a, bwd, st);
@@ -846,6 +851,7 @@ static int fill(const snerf_mlp_desc* d, MlpArgs& a) {
   SNERF_REQUIRE(d->n_hidden == 1 || d->n_hidden == 2, "mlp: n_hidden=%d", d->n_hidden);
   SNERF_REQUIRE(d->hidden_act == 0 || d->hidden_act == 1, "mlp: hidden_act=%d", d->hidden_act);
   SNERF_REQUIRE(d->out_act == 0 || d->out_act == 1, "mlp: out_act=%d", d->out_act);
+  SNERF_REQUIRE(d->operands >= 0 && d->operands <= 2, "mlp: operands=%d (0 fp32, 1 bf16, 2 fp16)", d->operands);
   a.d0 = d->d_in; a.dout = d->d_out; a.hidden_act = d->hidden_act; a.out_act = d->out_act;
   int off = 0, prev = d->d_in;
   for (int l = 0; l < d->n_hidden; ++l) { a.woff[l] = off; off += prev * d->hidden; prev = d->hidden; }
@@ -859,6 +865,8 @@ using namespace snerf;
 
 extern "C" int snerf_mlp_supported(const snerf_mlp_desc* d) {
   if (!d || d->d_in < 1 || d->d_in > 192 || d->d_out < 1 || d->d_out > OUTP || d->n_hidden < 1 || d->n_hidden > 2) return 0;
+  if (d->operands == 1 || d->operands == 2) return mlp_bf16_supported(d) ? 1 : 0;
+  if (d->operands != 0) return 0;
   const int d0p = (d->d_in + 15) / 16 * 16;
 #define CASE(D0P, H, NH) \
   if (d0p == D0P && d->hidden == H && d->n_hidden == NH) return 1;

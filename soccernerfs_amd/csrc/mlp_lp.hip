@@ -1,0 +1,450 @@
+// Tiny MLPs with 16-bit MFMA operands and fp32 accumulation (snerf_mlp_desc.operands = 1: bf16, 2: fp16): the precision class of the
+// reference's own MLPs (tcnn FullyFusedMLP computes in fp16 with fp32 accumulation; BASELINE config 2 names bf16) at 16x the matrix rate
+// of the exact fp32 path in mlp.hip.  One hidden layer (sigma_net d_in -> 128 -> 16, proposal nets 8 -> 64 -> 1):
+// NS/fields/kplanes_field.py:249-273,397-407.  Master weights, inputs, outputs, gradients and the weight-gradient accumulators stay
+// fp32; only MFMA operands are rounded (round-to-nearest-even) when they are staged into LDS.  fp16 operands carry the backward's
+// gradient tiles multiplied by 2^13 (a power of two: exact), as tcnn's loss scale does, and saturate instead of overflowing; bf16
+// needs neither.  OPT-IN: the exact fp32 kernels stay the default and the parity path (measured trade-off: profiles/r01_kernels.md).
+//
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row l&15][k = 8(l>>4) .. +8] and B[k = 8(l>>4) .. +8][col l&15] -- 8 CONSECUTIVE k per lane.
+// Every product below is therefore arranged as "both operands row-major along the contraction index" (one ds_read_b128 per operand per
+// MFMA), which means each matrix is kept in LDS in the orientation(s) its products need:
+//   forward   Z1 = X W0        A = X  [TS][K0]      B^T = W0t [H][K0]     (W0 transposed while staging)
+//             Y  = A1 WO       A = A1 [TS][H]       B^T = WOt [16][H]
+//   backward  dZ1 = dY WO^T    A = gzo [TS][32]     B^T = WOr [H][32]     (WO as stored, outputs padded 16 -> 32)
+//             dX  = dZ1 W0^T   A = gz  [TS][H]      B^T = W0r [K0][H]     (W0 as stored)
+//             dW0 = X^T dZ1    A = Xt  [K0][TS]     B^T = gzt [H][TS]     (contraction over the tile's samples: TS = 32 = one MFMA)
+//             dWO = A1^T dY    A = A1t [H][TS]      B^T = gzot [16][TS]
+// The transposed copies cost nothing extra to write from an accumulator: a lane of the C layout holds 4 consecutive ROWS of one column,
+// i.e. 8 contiguous bytes of the transposed image.  Row stride = K + 8 elements (16-B aligned rows, conflict-free b128 reads).
+#include "common.hpp"
+
+namespace snerf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16;
+typedef _Float16 fp16;
+
+template <typename T>
+struct Ops;
+template <>
+struct Ops<bf16> {
+  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+  static constexpr float GS = 1.f;  // gradient tile scale
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ bf16 cvt(float x) { return (bf16)x; }
+  static __device__ __forceinline__ bf16 cvtg(float x) { return (bf16)x; }
+};
+template <>
+struct Ops<fp16> {
+  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+  static constexpr float GS = 8192.f;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ fp16 cvt(float x) { return (fp16)fminf(fmaxf(x, -65504.f), 65504.f); }
+  static __device__ __forceinline__ fp16 cvtg(float x) { return (fp16)fminf(fmaxf(x, -65504.f), 65504.f); }
+};
+
+struct MlpArgs {  // same fields as mlp.hip's (filled there)
+  const float* X; int64_t N; int ldx; int d0;
+  const float* W; int woff[4];
+  int dout;
+  float* Y; int ldy;
+  int hidden_act, out_act;
+  int aux_col; float* aux_out;
+  const float* gY; int ldgy;
+  const float* gaux;
+  float* gX; int ldgx;
+  float* gW;
+};
+
+constexpr int LDS_LIMIT_B = 160 * 1024;
+__host__ __device__ constexpr int ldb(int k) { return k + 8; }
+
+template <typename T>
+__device__ __forceinline__ typename Ops<T>::v8 ld8(const T* p) { return *reinterpret_cast<const typename Ops<T>::v8*>(p); }
+
+// acc[m] (row block m of A, column block nt of the result) += A[., K] * Bt[nt*16 .., K]^T ; both row-major along K
+template <int MT, int K, typename T>
+__device__ __forceinline__ void mma_rr(const T* A, int lda, const T* Bt, int ldbt, int nt, f32x4 (&acc)[MT], int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const T* bp = Bt + (nt * 16 + lr) * ldbt + lk * 8;
+  const T* ap = A + lr * lda + lk * 8;
+#pragma unroll
+  for (int ks = 0; ks < K / 32; ++ks) {
+    const typename Ops<T>::v8 b = ld8(bp + ks * 32);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8(ap + m * 16 * lda + ks * 32), b, acc[m]);
+  }
+}
+
+// accumulator block (rows mt*16.., cols nt*16..) -> row-major image R[row][col] and/or transposed image T[col][row]
+template <typename T>
+__device__ __forceinline__ void store_rt(T* R, int ldr, T* Tr, int ldt, int mt, int nt, const f32x4& v, int lane) {
+  const int col = nt * 16 + (lane & 15);
+  const int row0 = mt * 16 + (lane >> 4) * 4;
+  const typename Ops<T>::v4 t = {Ops<T>::cvtg(v[0]), Ops<T>::cvtg(v[1]), Ops<T>::cvtg(v[2]), Ops<T>::cvtg(v[3])};
+  if (R) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) R[(row0 + r) * ldr + col] = t[r];
+  }
+  if (Tr) *reinterpret_cast<typename Ops<T>::v4*>(Tr + col * ldt + row0) = t;
+}
+
+// W [rows_act][cols_act] fp32 row-major (global) -> LDS as stored (R [rows_pad][ldr], zero padded) and/or transposed (T [cols_pad][ldt])
+template <typename T>
+__device__ __forceinline__ void stage_w(const float* __restrict__ Wg, int rows_act, int cols_act, int rows_pad, int cols_pad, T* R, int ldr, T* Tr, int ldt) {
+  for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += blockDim.x) {
+    const int r = idx / cols_pad, c = idx - r * cols_pad;
+    const T v = Ops<T>::cvt((r < rows_act && c < cols_act) ? Wg[(int64_t)r * cols_act + c] : 0.f);
+    if (R) R[r * ldr + c] = v;
+    if (Tr) Tr[c * ldt + r] = v;
+  }
+}
+
+// X tile: global fp32 -> registers one tile ahead -> LDS (row-major and, for the backward, transposed)
+template <int TS, int K0, int NT>
+struct XTileB {
+  static constexpr int PER = (TS * K0 + NT - 1) / NT;
+  float v[PER];
+  __device__ __forceinline__ void fetch(const MlpArgs& a, int64_t n0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      const int r = idx / K0, c = idx - r * K0;
+      const int64_t n = n0 + r;
+      v[i] = (idx < TS * K0 && n < a.N && c < a.d0) ? a.X[n * a.ldx + c] : 0.f;
+    }
+  }
+  template <typename T>
+  __device__ __forceinline__ void store(T* Xs, int ldx, T* Xt, int ldt) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int idx = threadIdx.x + i * NT;
+      const int r = idx / K0, c = idx - r * K0;
+      if (idx < TS * K0) {
+        const T b = Ops<T>::cvt(v[i]);
+        Xs[r * ldx + c] = b;
+        if (Xt) Xt[c * ldt + r] = b;
+      }
+    }
+  }
+};
+
+template <int H>
+constexpr int waves_b() { return H >= 128 ? 8 : 4; }
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <int K0, int H, int TS>
+struct PlanF {
+  static constexpr int LK0 = ldb(K0), LKH = ldb(H);
+  static constexpr int W0T = 0;                    // [H][LK0]
+  static constexpr int WOT = W0T + H * LK0;        // [16][LKH]
+  static constexpr int XS = WOT + 16 * LKH;        // [TS][LK0]
+  static constexpr int A1 = XS + TS * LK0;         // [TS][LKH]
+  static constexpr int TOTAL = A1 + TS * LKH;
+  static constexpr size_t BYTES = (size_t)TOTAL * 2;
+};
+
+template <typename T, int K0, int H, int TS>
+__global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a, int64_t n_tiles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  using P = PlanF<K0, H, TS>;
+  constexpr int MT = TS / 16, NW = waves_b<H>(), HT = H / 16;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, nullptr, 0, smem + P::W0T, P::LK0);
+  stage_w<T>(a.W + a.woff[1], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
+  const bool relu = a.hidden_act == 1;
+  XTileB<TS, K0, NW * 64> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();
+    xt.store(smem + P::XS, P::LK0, (T*)nullptr, 0);
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+      const int nt = wave + NW * j;
+      if (nt < HT) {
+        f32x4 acc[MT] = {};
+        mma_rr<MT, K0>(smem + P::XS, P::LK0, smem + P::W0T, P::LK0, nt, acc, lane);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 v = acc[m];
+          if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          store_rt<T>(smem + P::A1, P::LKH, nullptr, 0, m, nt, v, lane);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
+      const int mt = wave + NW * j;
+      if (mt < MT) {
+        f32x4 acc[1] = {};
+        mma_rr<1, H>(smem + P::A1 + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
+        const int col = lane & 15;
+        const int64_t row0 = n0 + mt * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = row0 + r;
+          if (n < a.N && col < a.dout) {
+            float y = acc[0][r];
+            if (a.aux_out && col == a.aux_col) a.aux_out[n] = expf(y);  // trunc_exp forward (activations.py:32)
+            if (a.out_act == 1) y = 1.f / (1.f + expf(-y));
+            a.Y[n * a.ldy + col] = y;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (recomputes the forward per tile, as the fp32 kernel)
+// ---------------------------------------------------------------------------------------------
+template <int K0, int H, int TS>
+struct PlanB {
+  static constexpr int LK0 = ldb(K0), LKH = ldb(H), LKO = ldb(32), LKT = ldb(TS);
+  static constexpr int W0T = 0;                    // [H][LK0]   forward
+  static constexpr int W0R = W0T + H * LK0;        // [K0][LKH]  dX
+  static constexpr int WOT = W0R + K0 * LKH;       // [16][LKH]  forward
+  static constexpr int WOR = WOT + 16 * LKH;       // [H][LKO]   dZ1
+  static constexpr int XS = WOR + H * LKO;         // [TS][LK0]
+  static constexpr int XT = XS + TS * LK0;         // [K0][LKT]
+  static constexpr int A1 = XT + K0 * LKT;         // [TS][LKH]
+  static constexpr int A1T = A1 + TS * LKH;        // [H][LKT]; reused for gzt once dWO is done
+  static constexpr int GZ = A1T + H * LKT;         // [TS][LKH]
+  static constexpr int GZO = GZ + TS * LKH;        // [TS][LKO]
+  static constexpr int GZOT = GZO + TS * LKO;      // [16][LKT]
+  static constexpr int TOTAL = GZOT + 16 * LKT;
+  static constexpr size_t BYTES = (size_t)TOTAL * 2;
+};
+
+template <typename T, int K0, int H, int TS>
+__global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  constexpr float GS = Ops<T>::GS;
+  using P = PlanB<K0, H, TS>;
+  static_assert(TS % 32 == 0, "the weight-gradient products contract over the tile's samples in steps of 32");
+  constexpr int MT = TS / 16, NW = waves_b<H>(), HT = H / 16, K0T = K0 / 16;
+  constexpr int NB0 = (K0T * HT + NW - 1) / NW, NBO = (HT + NW - 1) / NW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T *Xs = smem + P::XS, *Xt = smem + P::XT, *A1 = smem + P::A1, *A1t = smem + P::A1T, *gz = smem + P::GZ, *gzt = smem + P::A1T,
+       *gzo = smem + P::GZO, *gzot = smem + P::GZOT;
+  stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, smem + P::W0R, P::LKH, smem + P::W0T, P::LK0);
+  stage_w<T>(a.W + a.woff[1], H, a.dout, H, 32, smem + P::WOR, P::LKO, nullptr, 0);
+  stage_w<T>(a.W + a.woff[1], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
+  // columns 16..31 of gzo (the padded half of the K = 32 contraction) stay zero for the whole kernel
+  for (int idx = threadIdx.x; idx < TS * 16; idx += blockDim.x) gzo[(idx / 16) * P::LKO + 16 + (idx % 16)] = (T)0.f;
+  const bool relu = a.hidden_act == 1;
+  f32x4 dW0[NB0] = {};
+  f32x4 dWo[NBO] = {};
+  XTileB<TS, K0, NW * 64> xt;
+  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();
+    xt.store(Xs, P::LK0, Xt, P::LKT);
+    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
+    __syncthreads();
+    // ---- hidden layer: A1 (row-major) and A1t ----
+#pragma unroll
+    for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+      const int nt = wave + NW * j;
+      if (nt < HT) {
+        f32x4 acc[MT] = {};
+        mma_rr<MT, K0>(Xs, P::LK0, smem + P::W0T, P::LK0, nt, acc, lane);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 v = acc[m];
+          if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          store_rt(A1, P::LKH, A1t, P::LKT, m, nt, v, lane);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- output layer forward + gradient w.r.t. its pre-activation: gzo (row-major, cols 0..15) and gzot ----
+#pragma unroll
+    for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
+      const int mt = wave + NW * j;
+      if (mt < MT) {
+        f32x4 acc[1] = {};
+        mma_rr<1, H>(A1 + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
+        const int col = lane & 15;
+        const int rl0 = mt * 16 + (lane >> 4) * 4;
+        f32x4 gv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = n0 + rl0 + r;
+          float g = 0.f;
+          if (n < a.N && col < a.dout) {
+            const float y = acc[0][r];
+            if (a.gY) g = a.gY[n * a.ldgy + col];
+            if (a.out_act == 1) {
+              const float sg = 1.f / (1.f + expf(-y));
+              g = g * sg * (1.f - sg);
+            }
+            if (a.gaux && col == a.aux_col) g += a.gaux[n] * expf(fminf(fmaxf(y, -15.f), 15.f));  // trunc_exp backward (activations.py:38-39)
+          }
+          gv[r] = g * GS;
+        }
+        store_rt(gzo, P::LKO, gzot, P::LKT, mt, 0, gv, lane);
+      }
+    }
+    __syncthreads();
+    // ---- dWO += A1^T gzo (contraction over the tile's samples) ----
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) {
+      const int it = wave + NW * j;
+      if (it < HT) {
+        f32x4 acc[1] = {dWo[j]};
+        mma_rr<1, TS>(A1t + it * 16 * P::LKT, P::LKT, gzot, P::LKT, 0, acc, lane);
+        dWo[j] = acc[0];
+      }
+    }
+    __syncthreads();  // A1t is overwritten by gzt below
+    // ---- gz = (gzo WO^T) .* relu'(A1): row-major and transposed ----
+#pragma unroll
+    for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+      const int nt = wave + NW * j;
+      if (nt < HT) {
+        f32x4 acc[MT] = {};
+        mma_rr<MT, 32>(gzo, P::LKO, smem + P::WOR, P::LKO, nt, acc, lane);
+        const int col = nt * 16 + (lane & 15);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int row0 = m * 16 + (lane >> 4) * 4;
+          f32x4 v = acc[m];
+          if (relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (!((float)A1[(row0 + r) * P::LKH + col] > 0.f)) v[r] = 0.f;
+          }
+          store_rt(gz, P::LKH, gzt, P::LKT, m, nt, v, lane);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- dW0 += X^T gz ----
+#pragma unroll
+    for (int j = 0; j < NB0; ++j) {
+      const int t = wave + NW * j;
+      if (t < K0T * HT) {
+        f32x4 acc[1] = {dW0[j]};
+        mma_rr<1, TS>(Xt + (t / HT) * 16 * P::LKT, P::LKT, gzt, P::LKT, t % HT, acc, lane);
+        dW0[j] = acc[0];
+      }
+    }
+    // ---- gX = gz W0^T ----
+    if (a.gX) {
+#pragma unroll
+      for (int j = 0; j < (K0T + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < K0T) {
+          f32x4 acc[MT] = {};
+          mma_rr<MT, H>(gz, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
+          const int col = nt * 16 + (lane & 15);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[m][r] * (1.f / GS);
+          }
+        }
+      }
+    }
+  }
+  // ---- flush weight gradients ----
+  if (a.gW) {
+    const int cl = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NB0; ++j) {
+      const int t = wave + NW * j;
+      if (t < K0T * HT) {
+        const int it = t / HT, nt = t % HT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = it * 16 + r0 + r;
+          if (row < a.d0) atomicAdd(a.gW + a.woff[0] + (int64_t)row * H + nt * 16 + cl, dW0[j][r] * (1.f / GS));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) {
+      const int it = wave + NW * j;
+      if (it < HT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (cl < a.dout) atomicAdd(a.gW + a.woff[1] + (int64_t)(it * 16 + r0 + r) * a.dout + cl, dWo[j][r] * (1.f / GS));
+      }
+    }
+  }
+}
+
+template <typename T, int K0, int H>
+static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
+  if (bwd) {
+    constexpr int TS = 32;
+    using P = PlanB<K0, H, TS>;
+    static_assert(P::BYTES <= LDS_LIMIT_B, "bf16 backward tile does not fit LDS");
+    const int64_t n_tiles = (a.N + TS - 1) / TS;
+    int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = mlp_lp_bwd_kernel<T, K0, H, TS>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+  } else {
+    constexpr int TS = 32;
+    using P = PlanF<K0, H, TS>;
+    const int64_t n_tiles = (a.N + TS - 1) / TS;
+    int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int64_t grid = 256 * per_cu;
+    if (grid > n_tiles) grid = n_tiles;
+    auto k = mlp_lp_fwd_kernel<T, K0, H, TS>;
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+  }
+  SNERF_LAUNCH_CHECK(bwd ? "mlp_bwd (16-bit operands)" : "mlp_fwd (16-bit operands)");
+  return 0;
+}
+
+// (input width padded to 32, hidden width) with one hidden layer
+#define SNERF_MLP_BF16_SHAPES(X) X(32, 64) X(32, 128) X(64, 128) X(96, 128) X(128, 128) X(160, 128)
+
+bool mlp_bf16_supported(const snerf_mlp_desc* d) {
+  if (!d || d->n_hidden != 1 || d->d_out > 16 || d->d_in < 1) return false;
+  const int k0 = (d->d_in + 31) / 32 * 32;
+#define CASE(K0, H) \
+  if (k0 == K0 && d->hidden == H) return true;
+  SNERF_MLP_BF16_SHAPES(CASE)
+#undef CASE
+  return false;
+}
+
+int mlp_bf16_dispatch(const snerf_mlp_desc* d, const void* args, bool bwd, hipStream_t st) {
+  const MlpArgs& a = *static_cast<const MlpArgs*>(args);
+  const int k0 = (d->d_in + 31) / 32 * 32;
+#define CASE(K0, H)                                                                       \
+  if (k0 == K0 && d->hidden == H && d->n_hidden == 1)                                     \
+    return d->operands == 2 ? launch_b<fp16, K0, H>(a, bwd, st) : launch_b<bf16, K0, H>(a, bwd, st);
+  SNERF_MLP_BF16_SHAPES(CASE)
+#undef CASE
+  set_error("mlp (16-bit operands): unsupported shape d_in=%d hidden=%d n_hidden=%d (one hidden layer of 64 / 128, d_in <= 160)", d->d_in, d->hidden,
+            d->n_hidden);
+  return SNERF_ERR_UNSUPPORTED;
+}
+
+}  // namespace snerf

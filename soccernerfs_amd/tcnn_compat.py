@@ -29,7 +29,8 @@ _OUT = {"None": 0, "Sigmoid": 1}
 
 
 class Network(nn.Module):
-    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337, device=None):
+    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337, device=None, operands: str = "fp32"):
+        """operands: "fp32" (exact, the parity path), "bf16" or "fp16" (16-bit MFMA operands, fp32 accumulation; fp16 is tcnn's own)."""
         super().__init__()
         otype = network_config.get("otype", "FullyFusedMLP")
         if otype not in ("FullyFusedMLP", "CutlassMLP"):
@@ -40,7 +41,13 @@ class Network(nn.Module):
         d.hidden, d.n_hidden = network_config["n_neurons"], network_config["n_hidden_layers"]
         d.hidden_act = _ACT[network_config["activation"]]
         d.out_act = _OUT[network_config["output_activation"]]
+        if operands not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"operands must be 'fp32', 'bf16' or 'fp16', got {operands!r}")
+        d.operands = {"fp32": 0, "bf16": 1, "fp16": 2}[operands]
+        if d.operands != 0 and not _lib.lib().snerf_mlp_supported(C.byref(d)):
+            raise ValueError(f"16-bit operands are built for one hidden layer of 64 / 128 and d_in <= 160; got {n_input_dims} -> {d.hidden} x {d.n_hidden}")
         self.desc = d
+        self.operands = operands
         self.hidden_act, self.out_act = network_config["activation"], network_config["output_activation"]
         self.fused = bool(_lib.lib().snerf_mlp_supported(C.byref(d)))
         self.dims = [n_input_dims] + [d.hidden] * d.n_hidden + [n_output_dims]

@@ -52,6 +52,10 @@ class KPlanesTrainConfig:
     max_steps: int = 30000
     lr_alpha: float = 0.0
     seed: int = 0
+    # MFMA operand type of the one-hidden-layer nets (sigma_net, proposal sigma nets): "fp32" = exact (parity tests); "fp16" / "bf16" =
+    # 16-bit operands with fp32 accumulation (csrc/mlp_lp.hip; tcnn itself computes these nets in fp16, BASELINE config 2 names bf16).
+    # The two-hidden-layer colour net stays fp32 either way.
+    mlp_operands: str = "fp32"
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -101,8 +105,13 @@ class KPlanesTrainer:
         self.aabb = [[-a, -a, -a], [a, a, a]]
         base = list(cfg.spacetime_resolution)
         reso = [[r * m for r in base[:3]] + base[3:] for m in cfg.multiscale_res]
-        mlp = lambda din, dout, h, nh, act: Network(din, dout, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act,
-                                                               "n_neurons": h, "n_hidden_layers": nh}, seed=int(torch.randint(0, 2**31, (1,), generator=gen)))
+        def mlp(din, dout, h, nh, act):
+            ncfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": h, "n_hidden_layers": nh}
+            seed = int(torch.randint(0, 2**31, (1,), generator=gen))
+            want = cfg.mlp_operands
+            ops_ = want if (nh == 1 and din <= 160 and h in (64, 128)) else "fp32"
+            return Network(din, dout, ncfg, seed=seed, operands=ops_)
+
         self.field_planes = PlaneSet(cfg.feature_dim, reso, concat=True, a=0.1, b=0.5, generator=gen)
         self.sigma_net = mlp(cfg.feature_dim * len(reso), 16, cfg.sigma_net_hidden_dim, 1, "None")
         self.color_net = mlp(15, 3, cfg.rgb_net_hidden_dim, 2, "Sigmoid")

@@ -115,3 +115,72 @@ def test_mlp_unsupported_shape_raises():
                           "n_hidden_layers": 1}).to(DEV)
     with pytest.raises(RuntimeError, match="K, M <= 128"):
         wide(torch.zeros(4, 8, device=DEV))
+
+
+@pytest.mark.parametrize("operands", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(160, 16, 128, "None"), (8, 1, 64, "None"), (96, 16, 128, "Sigmoid"), (50, 5, 128, "None")])
+def test_16bit_operand_mlp(shape, operands):
+    """desc.operands = 1 / 2: bf16 / fp16 MFMA operands, fp32 accumulation.  (a) equals an emulation that rounds exactly the tensors the kernel rounds
+    (inputs, weights, hidden activations, upstream gradients) and accumulates in fp32; (b) stays within SURVEY §8d's tolerance for
+    the bf16 MLP path against the exact fp32 kernels (density rtol 2e-2, rgb atol 4e-3)."""
+    from soccernerfs_amd.tcnn_compat import Network
+
+    d_in, d_out, hidden, out_act = shape
+    cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": out_act, "n_neurons": hidden, "n_hidden_layers": 1}
+    dt, GS = (torch.bfloat16, 1.0) if operands == "bf16" else (torch.float16, 8192.0)
+    _bf = lambda t: t.to(dt).to(torch.float32)                # operand rounding
+    _bg = lambda t: (t * GS).to(dt).to(torch.float32) / GS    # gradient tiles: rounded after the power-of-two scale (fp16)
+    net = Network(d_in, d_out, cfg, operands=operands).to(DEV)
+    ref = Network(d_in, d_out, cfg).to(DEV)
+    with torch.no_grad():
+        ref.params.copy_(net.params)
+    gen = torch.Generator().manual_seed(11)
+    N = 1000  # ragged against the 32-sample tile
+    x = (torch.rand(N, d_in, generator=gen) - 0.3).to(DEV)
+    go = (torch.rand(N, d_out, generator=gen) - 0.5).to(DEV)
+    gaux = (torch.rand(N, generator=gen) - 0.5).to(DEV)
+    W0, WO = [w.t().contiguous() for w in net.linear_weights()]  # [in, out]
+    xg = x.clone().requires_grad_(True)
+    y, aux = net.forward_with_exp_head(xg, 0)
+    (y * go).sum().backward(retain_graph=True)
+    gx_y, gw_y = xg.grad.clone(), net.params.grad.clone()
+    # ---- (a) emulation ----
+    a1 = torch.relu(_bf(x) @ _bf(W0))
+    z = _bf(a1) @ _bf(WO)
+    y_em = torch.sigmoid(z) if out_act == "Sigmoid" else z
+    # elementwise: a hidden activation that sits on a bf16 rounding boundary may round the other way (fp32 accumulation order), which moves
+    # an output by one bf16 ulp of that activation times a weight; the mean error shows that nothing systematic is off
+    torch.testing.assert_close(y, y_em, rtol=5e-3, atol=2e-3)
+    assert float((y - y_em).detach().abs().mean()) < 2e-5 * max(1.0, float(y_em.abs().mean()))
+    torch.testing.assert_close(aux, torch.exp(z[:, 0]), rtol=5e-3, atol=2e-3)
+    gpre = go * (y_em * (1 - y_em) if out_act == "Sigmoid" else 1.0)
+    gwo_em = _bf(a1).t() @ _bg(gpre)
+    gz = (_bg(gpre) @ _bf(WO).t()) * (a1 > 0)
+    gw0_em = _bf(x).t() @ _bg(gz)
+    gx_em = _bg(gz) @ _bf(W0).t()
+    got0, goto = [w.t() for w in net.linear_weights(gw_y)]
+    for got, want in ((gx_y, gx_em), (got0, gw0_em), (goto, gwo_em)):
+        torch.testing.assert_close(got, want, rtol=5e-3, atol=5e-3 * float(want.abs().max()))
+        assert float((got - want).abs().mean()) < 2e-4 * float(want.abs().mean() + 1e-12)
+    # ---- (b) against the exact fp32 path ----
+    xr = x.clone().requires_grad_(True)
+    yr, auxr = ref.forward_with_exp_head(xr, 0)
+    torch.testing.assert_close(aux, auxr, rtol=2e-2, atol=1e-3)
+    torch.testing.assert_close(y, yr, rtol=2e-2, atol=4e-3)
+    (yr * go).sum().backward()
+    rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-20))
+    # gradients: relative L2 distance to the exact path (operand rounding + ReLU masks of near-zero pre-activations; measured 3-4 % for bf16)
+    lim = 8e-2 if operands == "bf16" else 2e-2  # fp16 measured 1.1 %
+    assert rel(gx_y, xr.grad) < lim and rel(gw_y, ref.params.grad) < lim
+    # trunc_exp head gradient and a forward-only call without the head
+    net.params.grad = None
+    xg2 = x.clone().requires_grad_(True)
+    y2, aux2 = net.forward_with_exp_head(xg2, 0)
+    (aux2 * gaux).sum().backward()
+    gpre2 = torch.zeros_like(go)
+    gpre2[:, 0] = gaux * torch.exp(z[:, 0].clamp(-15, 15))
+    gx2_em = _bg((_bg(gpre2) @ _bf(WO).t()) * (a1 > 0)) @ _bf(W0).t()
+    torch.testing.assert_close(xg2.grad, gx2_em, rtol=5e-3, atol=5e-3 * float(gx2_em.abs().max()))
+    torch.testing.assert_close(net(x), y.detach(), rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        Network(15, 3, {**cfg, "n_hidden_layers": 2, "n_neurons": 64}, operands=operands)

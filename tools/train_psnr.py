@@ -55,11 +55,12 @@ def main():
     ap.add_argument("--eval-every", type=int, default=10000)
     ap.add_argument("--out", default="gpurun_out/psnr.json")
     ap.add_argument("--seed", type=int, default=20231029)
+    ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"])
     ap.add_argument("--check-finite", type=int, default=0, help="every N steps: stop at the first non-finite parameter / Adam state and say where")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(args.seed)
-    cfg = KPlanesTrainConfig(max_steps=30000)
+    cfg = KPlanesTrainConfig(max_steps=30000, mlp_operands=args.mlp_operands)
     R = 4096
     trainer = KPlanesTrainer(cfg, R, dev)
     cams = synthetic.make_cameras(20, 960, 540)
