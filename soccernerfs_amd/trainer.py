@@ -10,6 +10,7 @@ one fused Adam sweep that also clears the gradients.  `soccernerfs_amd.kplanes.K
 nerfstudio-shaped (autograd) face of the same kernels; tests check the two against each other and the oracle.
 """
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -469,6 +470,9 @@ class KPlanesTrainer:
                 self._reg_sweep()
 
         def proposal_chain(after=None):
+            if getattr(self, "prop_on_main", False):  # A/B: same kernel order, the proposal chain not concurrent with the field chain
+                self._proposal_backward(proposal_grads)
+                return
             st = self._stream("prop")
             st.wait_stream(main) if after is None else st.wait_event(after)
             if reg_done is not None:
@@ -747,7 +751,8 @@ class KPlanesTrainer:
         if self._pipeline_adam:
             self.buf["reg"].zero_()
             self._reg_zeroed = True
-        self.backward(target, rng, proposal_grads=updated, include_reg=not fuse, defer_prop_join=fuse and self.world == 1)
+        self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
+                      defer_prop_join=fuse and self.world == 1 and getattr(self, "defer_prop", True))
         self._pipeline_adam = False
         if self._sharded():
             self._sharded_optimizer_step()

@@ -56,6 +56,10 @@ def main():
     ap.add_argument("--out", default="gpurun_out/psnr.json")
     ap.add_argument("--seed", type=int, default=20231029)
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"])
+    ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
+    ap.add_argument("--sync-adam", action="store_true", help="field-plane optimiser sweep on the main stream (A/B)")
+    ap.add_argument("--prop-on-main", action="store_true", help="proposal backward on the main stream, before the field chain (A/B)")
+    ap.add_argument("--no-defer", action="store_true", help="join the proposal chain at the end of backward (A/B)")
     ap.add_argument("--check-finite", type=int, default=0, help="every N steps: stop at the first non-finite parameter / Adam state and say where")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -63,6 +67,11 @@ def main():
     cfg = KPlanesTrainConfig(max_steps=30000, mlp_operands=args.mlp_operands)
     R = 4096
     trainer = KPlanesTrainer(cfg, R, dev)
+    if args.no_overlap:
+        trainer.overlap, trainer.async_field_adam = False, False
+    if args.sync_adam:
+        trainer.async_field_adam = False
+    trainer.prop_on_main, trainer.defer_prop = args.prop_on_main, not args.no_defer
     cams = synthetic.make_cameras(20, 960, 540)
     times = synthetic.frame_times(100, 3)
     train = synthetic.render_dataset(cams, times, list(range(19)), dev, chunk_rows=540)
