@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"], help="MFMA operand type of the one-hidden-layer nets (sigma_net, proposal "
                     "nets): fp32 = exact; bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16)")
+    ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
@@ -126,6 +127,7 @@ def main():
         trainer.shard_optimizer = False
     trainer.step = args.start_step
     trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
+    trainer.prop_on_main = args.prop_on_main
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)
