@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from .plane_set import PlaneSet
-from .tcnn_compat import Encoding, Network
+from .tcnn_compat import Network
 from .temporal_grid import TemporalGridEncoder
 
 

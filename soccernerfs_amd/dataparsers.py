@@ -7,7 +7,6 @@ the reference's SETUPS table whose camera names exist in its CAM_IDS table, :44-
 from the file names, fps down-sampling, pose auto-scaling, `orientation_method`/`center_method` "none" (the parser's defaults) and
 "poses" centring, masks / depth file lists.  Distortion parameters are carried but the ray generator here is pinhole-only."""
 import json
-import os
 from dataclasses import dataclass, field
 from pathlib import Path, PurePath
 from typing import Dict, List, Optional

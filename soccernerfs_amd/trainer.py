@@ -10,7 +10,6 @@ one fused Adam sweep that also clears the gradients.  `soccernerfs_amd.kplanes.K
 nerfstudio-shaped (autograd) face of the same kernels; tests check the two against each other and the oracle.
 """
 import ctypes as C
-import os
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple

@@ -3,7 +3,7 @@ table-gradient backward, coordinate-gradient backward, both -- for coordinates i
 Dev tool."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from soccernerfs_amd import _lib, ops
+from soccernerfs_amd import _lib
 from soccernerfs_amd.tcnn_compat import Encoding
 
 dev = "cuda:0"

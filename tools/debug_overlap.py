@@ -3,7 +3,7 @@ backward, per parameter segment.  Dev tool for a suspected stream race (16-bit M
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soccernerfs_amd import ops, synthetic
-from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer, anneal_value
+from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
 dev = torch.device("cuda:0")
 op = sys.argv[1] if len(sys.argv) > 1 else "bf16"
