@@ -192,7 +192,7 @@ template <int C, int NP>
 static int launch_bwd(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, float* gp,
                       hipStream_t st) {
   // consecutive samples walked (and run-length-combined) by one lane group; SNERF_BWD_RUN is a tuning knob
-  static const int run = [] { const char* e = getenv("SNERF_BWD_RUN"); int v = e ? atoi(e) : 16; return v > 0 ? v : 16; }();
+  static const int run = [] { const char* e = getenv("SNERF_BWD_RUN"); int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();  // 64: A/B in profiles/r01_kernels.md
   int64_t groups = (N + run - 1) / run;
   int64_t threads = groups * (2 * C);
   hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, run);
