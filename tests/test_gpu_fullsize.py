@@ -210,3 +210,92 @@ def test_config4_model_trains_at_preset_size():
         opt.step()
         losses.append(float(ld["rgb_loss"].detach()))
     assert losses[-1] < losses[0], losses
+
+
+def test_full_nerfplayer_hashgrid_full_size():
+    """The full NeRFPlayer's static grid at the `nerfplayer` preset's size (16 levels x 2 features, 2^18-row levels, 48 x 4096 samples),
+    through size-independent properties: a constant table is reproduced exactly (interpolation weights sum to one at every level, inside
+    and outside [0,1]); its coordinate gradient vanishes; gradient mass is conserved by the table scatter; the encoding is linear in the
+    table; the coordinate gradient matches a central finite difference of the encoding itself."""
+    from soccernerfs_amd.tcnn_compat import Encoding
+
+    enc = Encoding(3, {"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2, "log2_hashmap_size": 18, "base_resolution": 16,
+                       "per_level_scale": 1.4472692012786865}).to(DEV)
+    B = 48 * 4096
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    x = (torch.rand(B, 3, device=DEV, generator=gen) * 1.4 - 0.2).requires_grad_(True)  # a fifth of the points leave [0,1] (deformed positions do)
+    k = -0.625
+    with torch.no_grad():
+        enc.params.fill_(k)
+    out = enc(x)
+    assert out.shape == (B, 32)
+    torch.testing.assert_close(out, torch.full_like(out, k), rtol=1e-6, atol=0)
+    go = torch.rand(B, 32, device=DEV, generator=gen) - 0.3
+    out.backward(go)
+    torch.testing.assert_close(enc.params.grad.double().sum(), go.double().sum(), rtol=1e-5, atol=1e-3)
+    assert float(x.grad.abs().max()) <= 1e-3 * 4096 * abs(k) * 1e-3  # d(constant)/dx = 0 up to the cancellation of O(scale * k) terms
+    # linearity in the table
+    with torch.no_grad():
+        t1 = torch.rand(enc.params.shape, device=DEV, generator=gen) - 0.5
+        t2 = torch.rand(enc.params.shape, device=DEV, generator=gen) - 0.5
+        xs = x.detach()[:65536]
+        enc.params.copy_(t1); a = enc(xs)
+        enc.params.copy_(t2); b = enc(xs)
+        enc.params.copy_(2.0 * t1 - 3.0 * t2); c = enc(xs)
+    torch.testing.assert_close(c, 2.0 * a - 3.0 * b, rtol=1e-4, atol=1e-5)
+    # coordinate gradient against a finite difference on the coarse levels (cells wide enough for the step)
+    with torch.no_grad():
+        enc.params.copy_(t1)
+    xq = (torch.rand(4096, 3, device=DEV, generator=gen) * 0.9 + 0.05).requires_grad_(True)
+    w = torch.zeros(32, device=DEV)
+    w[:6] = torch.tensor([1.0, -2.0, 0.5, 1.5, -1.0, 2.0], device=DEV)  # levels 0..2: resolution 16, 24, 34
+    (enc(xq) * w).sum().backward()
+    eps = 1e-4
+    for d in range(3):
+        dx = torch.zeros(1, 3, device=DEV)
+        dx[0, d] = eps
+        with torch.no_grad():
+            fd = ((enc(xq.detach() + dx) - enc(xq.detach() - dx)) * w).sum(-1) / (2 * eps)
+        # points whose +-eps neighbourhood crosses a cell border see a kink: compare the robust bulk
+        err = (fd - xq.grad[:, d]).abs()
+        assert float(err.median()) < 2e-2 * float(fd.abs().median() + 1e-6) and float((err < 0.05 * (fd.abs() + 1.0)).float().mean()) > 0.97
+
+
+def test_16bit_operand_mlp_full_size():
+    """Opt-in bf16 / fp16 MFMA operands at the K-Planes preset's sizes (sigma_net 160 -> 128 -> 16 over 64 x 4096 samples, proposal net
+    8 -> 64 -> 1 over 256 x 4096): deterministic (two launches agree bit for bit on every atomics-free output), row-permutation
+    equivariant, and within the stated tolerance of the exact fp32 kernels."""
+    from soccernerfs_amd.tcnn_compat import Network
+
+    for d_in, d_out, hidden, N in ((160, 16, 128, 64 * 4096), (8, 1, 64, 256 * 4096)):
+        cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": hidden, "n_hidden_layers": 1}
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        x = torch.rand(N, d_in, device=DEV, generator=gen) - 0.3
+        go = torch.rand(N, d_out, device=DEV, generator=gen) - 0.5
+        ref = Network(d_in, d_out, cfg).to(DEV)
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        yr.backward(go)
+        perm = torch.randperm(N, device=DEV, generator=gen)
+        for operands in ("bf16", "fp16"):
+            net = Network(d_in, d_out, cfg, operands=operands).to(DEV)
+            with torch.no_grad():
+                net.params.copy_(ref.params)
+            xg = x.clone().requires_grad_(True)
+            y = net(xg)
+            y.backward(go)
+            gw = net.params.grad.clone()
+            net.params.grad = None
+            xg2 = x.clone().requires_grad_(True)
+            y2 = net(xg2)
+            y2.backward(go)
+            assert torch.equal(y, y2) and torch.equal(xg.grad, xg2.grad)
+            torch.testing.assert_close(net.params.grad, gw, rtol=1e-4, atol=1e-5 * float(gw.abs().max()))  # flushed with atomics
+            with torch.no_grad():
+                torch.testing.assert_close(net(x[perm]), y.detach()[perm], rtol=0, atol=0)
+            # raw (pre-activation) outputs of O(1): operand rounding of 2^-9 (bf16) / 2^-12 (fp16) relative, summed over 128 hidden units
+            torch.testing.assert_close(y, yr, rtol=2e-2, atol=(1e-2 if operands == "bf16" else 2e-3) * max(1.0, float(yr.detach().abs().max())))
+            rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-20))
+            assert rel(y, yr) < (5e-3 if operands == "bf16" else 1e-3)
+            lim = 8e-2 if operands == "bf16" else 2e-2
+            assert rel(xg.grad, xr.grad) < lim and rel(gw, ref.params.grad) < lim, (operands, rel(xg.grad, xr.grad), rel(gw, ref.params.grad))
