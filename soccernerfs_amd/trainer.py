@@ -796,7 +796,7 @@ class KPlanesTrainer:
         shard = padded // self.world
         for buf in (self.exp_avg, self.exp_avg_sq):
             seg = buf[off:off + padded]
-            sdist.all_gather_shards(seg, seg[self.rank * shard:(self.rank + 1) * shard].clone(), self.group)
+            sdist.all_gather_shards(seg, seg[self.rank * shard:(self.rank + 1) * shard].clone(), self.pg)
 
     def save_checkpoint(self, checkpoint_dir: str, save_only_latest_checkpoint: bool = True) -> Optional[str]:
         """Writes `step-%09d.ckpt` (rank 0 only; collective when the optimiser is sharded).  The saved step is the index of the last

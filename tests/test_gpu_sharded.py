@@ -112,10 +112,21 @@ def _worker_main():
         tr.train_step(rays, target, rng)
     tr.synchronize()
     reg = tr.loss_dict()
-    torch.save({"segments": {name: tr.views[name].cpu() for name in tr.views}, "m": {name: tr.mviews[name].cpu() for name in tr.mviews},
-                "gmax": float(tr.grads.abs().max()), "space_tv": float(reg["space_tv_loss"]), "step": tr.step},
-               os.path.join(outdir, f"rank{rank}_{int(shard)}.pt"))
+    snap = {"segments": {name: tr.views[name].cpu() for name in tr.views}, "m": {name: tr.mviews[name].cpu() for name in tr.mviews},
+            "gmax": float(tr.grads.abs().max()), "space_tv": float(reg["space_tv_loss"]), "step": tr.step}
+    ck = tr.save_checkpoint(os.path.join(outdir, f"ckpt{int(shard)}"))  # collective when the optimiser is sharded (gathers the moment shards)
+    assert (ck is not None) == (rank == 0)
+    torch.save(snap, os.path.join(outdir, f"rank{rank}_{int(shard)}.pt"))
     dist.destroy_process_group()
+
+
+def KPlanesTrainerForResume(tmp_path, shard):
+    from soccernerfs_amd.trainer import KPlanesTrainer
+
+    tr = KPlanesTrainer(_small_cfg(), 48, DEV)
+    tr.load_checkpoint(os.path.join(tmp_path, f"ckpt{int(shard)}"))
+    tr.synchronize()
+    return tr
 
 
 def _free_port():
@@ -165,6 +176,22 @@ def test_two_ranks_on_one_gpu_match_mean_gradient_reference(tmp_path, shard):
     want_tv = float(ref.loss_dict()["space_tv_loss"])
     for r in range(2):
         assert abs(res[r]["space_tv"] - want_tv) <= 2e-3 * abs(want_tv) + 1e-9
+    # the checkpoint rank 0 wrote holds the WHOLE Adam state (the shards are gathered first) under the reference's names
+    from soccernerfs_amd import checkpoint as CK
+
+    files = os.listdir(os.path.join(tmp_path, f"ckpt{int(shard)}"))
+    assert files == [f"step-{n_steps - 1:09d}.ckpt"]
+    ck = torch.load(os.path.join(tmp_path, f"ckpt{int(shard)}", files[0]), map_location="cpu", weights_only=False)
+    moments = CK.import_optimizer_states(ref._named_module(), ck["optimizers"])
+    m_ck = moments["field.grids.planes"][0].reshape(-1)
+    m_ref = ref.mviews["field.planes"].cpu()
+    half = m_ref.numel() // 2
+    assert float(m_ck[:half].abs().max()) > 0 and float(m_ck[half:].abs().max()) > 0
+    torch.testing.assert_close(m_ck, m_ref, rtol=0, atol=2e-3 * float(m_ref.abs().max()))
+    resumed = KPlanesTrainerForResume(tmp_path, shard)
+    assert resumed.step == n_steps
+    for name in ref.views:
+        assert torch.equal(resumed.views[name].cpu(), res[0]["segments"][name]), name
 
 
 def test_sharded_step_through_rccl_world_size_one():
