@@ -42,6 +42,8 @@ def parse():
                     "schedule (proposal networks updated every 5th step, kplanes.py:254-259) instead of the every-step schedule of early training")
     ap.add_argument("--adam-under-scatter", action="store_true", help="A-B: sweep the finest scale's planes while the coarser scales are scattered")
     ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
+    ap.add_argument("--grad-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
+                    "gradient on the links (fp32 = the reference's DDP semantics; bf16 halves the reduce-scatter bytes, opt-in)")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"], help="MFMA operand type of the one-hidden-layer nets (sigma_net, proposal "
                     "nets): fp32 = exact; bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16)")
@@ -128,6 +130,7 @@ def main():
     trainer.step = args.start_step
     trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
     trainer.prop_on_main = args.prop_on_main
+    trainer.grad_transport = args.grad_transport
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)

@@ -579,7 +579,16 @@ class KPlanesTrainer:
 
         o, _, npad = self._field_seg
         with self._span("reduce_scatter.field"):
-            self._rs_work = sdist.reduce_scatter_sum(self._g_shard, self.grads[o:o + npad], self.pg, async_op=True)
+            if getattr(self, "grad_transport", "fp32") == "bf16":
+                # opt-in: half the bytes on the links (each rank rounds its own gradient to bf16, the SUM is formed in bf16 by the collective);
+                # NOT the reference's fp32 DDP all-reduce -- the optimiser then sees gradients with ~2^-9 relative rounding
+                if getattr(self, "_g16", None) is None:
+                    self._g16 = torch.empty(npad, dtype=torch.bfloat16, device=self.dev)
+                    self._g16_shard = torch.empty(npad // self.world, dtype=torch.bfloat16, device=self.dev)
+                self._g16.copy_(self.grads[o:o + npad])
+                self._rs_work = sdist.reduce_scatter_sum(self._g16_shard, self._g16, self.pg, async_op=True)
+            else:
+                self._rs_work = sdist.reduce_scatter_sum(self._g_shard, self.grads[o:o + npad], self.pg, async_op=True)
 
     def _sharded_optimizer_step(self):
         """After backward() (all side streams joined): all-reduce of the small segments, Adam + regularisers on this rank's shard
@@ -603,7 +612,7 @@ class KPlanesTrainer:
             self._reg_work.wait()  # last step's regulariser-value reduction still reads buf["reg"]
         self.buf["reg"].zero_()
         self._rs_work.wait()
-        self.grads[o + lo:o + lo + shard].copy_(self._g_shard)
+        self.grads[o + lo:o + lo + shard].copy_(self._g16_shard if getattr(self, "grad_transport", "fp32") == "bf16" else self._g_shard)
         with self._span("adam_planes.field"):
             if hi > lo:
                 ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
