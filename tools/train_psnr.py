@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--out", default="gpurun_out/psnr.json")
     ap.add_argument("--seed", type=int, default=20231029)
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"])
+    ap.add_argument("--also-eval-fp32", action="store_true", help="16-bit operands: evaluate the final model a second time with the exact fp32 MLP kernels (paired comparison)")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
     ap.add_argument("--sync-adam", action="store_true", help="field-plane optimiser sweep on the main stream (A/B)")
     ap.add_argument("--prop-on-main", action="store_true", help="proposal backward on the main stream, before the field chain (A/B)")
@@ -122,6 +123,19 @@ def main():
             log["evals"].append({"step": step + 1, "psnr_heldout_mean": sum(ps) / len(ps), "psnr_heldout": ps, "ssim_heldout_mean": sum(ss) / len(ss),
                                  "psnr_train_views_mean": sum(ps_tr) / len(ps_tr)})
             print(f"== step {step + 1}: held-out camera PSNR {sum(ps) / len(ps):.2f} dB, SSIM {sum(ss) / len(ss):.4f} over {len(ps)} frames; train views {sum(ps_tr) / len(ps_tr):.2f} dB", flush=True)
+    if args.also_eval_fp32 and args.mlp_operands != "fp32":
+        nets = [trainer.sigma_net] + list(trainer.prop_nets)
+        saved = [n.desc.operands for n in nets]
+        for n in nets:
+            n.desc.operands = 0
+        ps32 = eval_psnr(trainer, held, args.eval_images, 1.0)
+        ss32 = eval_psnr.last_ssim
+        tr32 = eval_psnr(trainer, train, 4, 1.0)
+        for n, o in zip(nets, saved):
+            n.desc.operands = o
+        log["evals"][-1].update({"fp32_eval_psnr_heldout_mean": sum(ps32) / len(ps32), "fp32_eval_ssim_heldout_mean": sum(ss32) / len(ss32),
+                                 "fp32_eval_psnr_train_views_mean": sum(tr32) / len(tr32)})
+        print(f"== same weights evaluated with fp32 MLP kernels: held-out {sum(ps32) / len(ps32):.2f} dB, SSIM {sum(ss32) / len(ss32):.4f}; train views {sum(tr32) / len(tr32):.2f} dB", flush=True)
     log["train_seconds"] = t_train
     log["train_rays_per_s_mean"] = R * args.steps / max(t_train, 1e-9)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
