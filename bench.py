@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
     ap.add_argument("--grad-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
                     "gradient on the links (fp32 = the reference's DDP semantics; bf16 halves the reduce-scatter bytes, opt-in)")
+    ap.add_argument("--param-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: fp32 = all-gather the new field planes "
+                    "(reference semantics); bf16 = all-gather the parameter UPDATES in bf16 and apply them identically on every rank (opt-in)")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"], help="MFMA operand type of the one-hidden-layer nets (sigma_net, proposal "
                     "nets): fp32 = exact; bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16)")
@@ -131,6 +133,7 @@ def main():
     trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
     trainer.prop_on_main = args.prop_on_main
     trainer.grad_transport = args.grad_transport
+    trainer.param_transport = args.param_transport
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)

@@ -561,6 +561,12 @@ class KPlanesTrainer:
         if self._ag_work is not None:
             self._ag_work.wait()
             self._ag_work = None
+            if getattr(self, "_delta_pending", False):
+                # bf16 parameter transport: what was gathered are the ranks' parameter UPDATES; every rank (the owner of a shard
+                # included) forms new = old + bf16(update), so the replicas stay bit-identical.  params / _params_alt were swapped since.
+                o, _, npad = self._field_seg
+                torch.add(self._params_alt[o:o + npad], self._d16_full, out=self.params[o:o + npad])
+                self._delta_pending = False
         ev = getattr(self, "_field_adam_done", None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -618,9 +624,22 @@ class KPlanesTrainer:
                 ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
                                      self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
                                      self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=False, shard_range=(lo, hi))
-        self._p_shard.copy_(new[o + lo:o + lo + shard])
-        with self._span("all_gather.field"):
-            self._ag_work = sdist.all_gather_shards(new[o:o + npad], self._p_shard, self.pg, async_op=True)
+        if getattr(self, "param_transport", "fp32") == "bf16":
+            # opt-in: gather the shard's UPDATE in bf16 (half the bytes; 2^-9 relative rounding of the update, not of the parameter);
+            # applied in _wait_params.  NOT the reference's semantics (replicas hold old + bf16(update) instead of the fp32 Adam result).
+            if getattr(self, "_d16_full", None) is None:
+                self._d16_full = torch.zeros(npad, dtype=torch.bfloat16, device=self.dev)
+                self._d16_shard = torch.zeros(shard, dtype=torch.bfloat16, device=self.dev)
+            self._d16_shard.zero_()
+            if hi > lo:
+                self._d16_shard[:hi - lo].copy_(new[o + lo:o + hi] - self.params[o + lo:o + hi])
+            with self._span("all_gather.field"):
+                self._ag_work = sdist.all_gather_shards(self._d16_full, self._d16_shard, self.pg, async_op=True)
+            self._delta_pending = True
+        else:
+            self._p_shard.copy_(new[o + lo:o + lo + shard])
+            with self._span("all_gather.field"):
+                self._ag_work = sdist.all_gather_shards(new[o:o + npad], self._p_shard, self.pg, async_op=True)
         for w in self._ar_work:
             w.wait()
         for i in range(2):

@@ -110,6 +110,7 @@ def _worker_main():
     tr = KPlanesTrainer(_small_cfg(), R, DEV, process_group=dist.group.WORLD)
     tr.shard_optimizer = shard
     tr.grad_transport = transport
+    tr.param_transport = transport
     for k in range(n_steps):
         rays, target, rng = _batch(R, rank, k)
         tr.train_step(rays, target, rng)
@@ -256,7 +257,8 @@ def test_bench_script_two_ranks_on_one_gpu(tmp_path):
 
 
 def test_bf16_gradient_transport_two_ranks(tmp_path):
-    """Opt-in bf16 transport of the field-plane gradient (bench.py --grad-transport bf16): replicas stay bit-identical to each other and the
+    """Opt-in bf16 transport of the field-plane gradient and of the parameter updates (bench.py --grad-transport bf16 --param-transport
+    bf16): replicas stay bit-identical to each other and the
     parameters stay close to the fp32-transport reference (Adam's normalised step is insensitive to 2^-9 relative gradient rounding except
     where a gradient is rounding noise around zero)."""
     n_steps, R = 3, 48
