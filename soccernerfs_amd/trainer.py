@@ -91,6 +91,13 @@ class KPlanesTrainer:
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         # world > 1: reduce-scatter + sharded Adam + all-gather for the field planes instead of one all-reduce (see dist.py)
         self.shard_optimizer = self.world > 1
+        # opt-in half-width transports of the sharded step: "bf16" rounds the field-plane gradient before the reduce-scatter /
+        # gathers the parameter UPDATES in bf16; "fp32" (default) keeps the reference's DDP semantics
+        self.grad_transport, self.param_transport = "fp32", "fp32"
+        self._delta_pending, self._g16, self._d16_full = False, None, None
+        # A/B switches of the stream layout (tools/train_psnr.py, bench.py): proposal backward on the main stream; join of the proposal
+        # chain deferred into the optimiser step
+        self.prop_on_main, self.defer_prop = False, True
         # async_field_adam: the field planes' optimiser sweep runs on its own stream under the NEXT step's pixel draw / ray generation /
         # proposal levels (which read only the small segments); forward() joins it before the field gather, loss_dict() and
         # synchronize() join it for outside readers -- call synchronize() before reading parameters / Adam state / gradients from
@@ -469,7 +476,7 @@ class KPlanesTrainer:
                 self._reg_sweep()
 
         def proposal_chain(after=None):
-            if getattr(self, "prop_on_main", False):  # A/B: same kernel order, the proposal chain not concurrent with the field chain
+            if self.prop_on_main:  # A/B: same kernel order, the proposal chain not concurrent with the field chain
                 self._proposal_backward(proposal_grads)
                 return
             st = self._stream("prop")
@@ -561,7 +568,7 @@ class KPlanesTrainer:
         if self._ag_work is not None:
             self._ag_work.wait()
             self._ag_work = None
-            if getattr(self, "_delta_pending", False):
+            if self._delta_pending:
                 # bf16 parameter transport: what was gathered are the ranks' parameter UPDATES; every rank (the owner of a shard
                 # included) forms new = old + bf16(update), so the replicas stay bit-identical.  params / _params_alt were swapped since.
                 o, _, npad = self._field_seg
@@ -585,10 +592,10 @@ class KPlanesTrainer:
 
         o, _, npad = self._field_seg
         with self._span("reduce_scatter.field"):
-            if getattr(self, "grad_transport", "fp32") == "bf16":
+            if self.grad_transport == "bf16":
                 # opt-in: half the bytes on the links (each rank rounds its own gradient to bf16, the SUM is formed in bf16 by the collective);
                 # NOT the reference's fp32 DDP all-reduce -- the optimiser then sees gradients with ~2^-9 relative rounding
-                if getattr(self, "_g16", None) is None:
+                if self._g16 is None:
                     self._g16 = torch.empty(npad, dtype=torch.bfloat16, device=self.dev)
                     self._g16_shard = torch.empty(npad // self.world, dtype=torch.bfloat16, device=self.dev)
                 self._g16.copy_(self.grads[o:o + npad])
@@ -618,16 +625,16 @@ class KPlanesTrainer:
             self._reg_work.wait()  # last step's regulariser-value reduction still reads buf["reg"]
         self.buf["reg"].zero_()
         self._rs_work.wait()
-        self.grads[o + lo:o + lo + shard].copy_(self._g16_shard if getattr(self, "grad_transport", "fp32") == "bf16" else self._g_shard)
+        self.grads[o + lo:o + lo + shard].copy_(self._g16_shard if self.grad_transport == "bf16" else self._g_shard)
         with self._span("adam_planes.field"):
             if hi > lo:
                 ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
                                      self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
                                      self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=False, shard_range=(lo, hi))
-        if getattr(self, "param_transport", "fp32") == "bf16":
+        if self.param_transport == "bf16":
             # opt-in: gather the shard's UPDATE in bf16 (half the bytes; 2^-9 relative rounding of the update, not of the parameter);
             # applied in _wait_params.  NOT the reference's semantics (replicas hold old + bf16(update) instead of the fp32 Adam result).
-            if getattr(self, "_d16_full", None) is None:
+            if self._d16_full is None:
                 self._d16_full = torch.zeros(npad, dtype=torch.bfloat16, device=self.dev)
                 self._d16_shard = torch.zeros(shard, dtype=torch.bfloat16, device=self.dev)
             self._d16_shard.zero_()
@@ -779,7 +786,7 @@ class KPlanesTrainer:
             self.buf["reg"].zero_()
             self._reg_zeroed = True
         self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
-                      defer_prop_join=fuse and self.world == 1 and getattr(self, "defer_prop", True))
+                      defer_prop_join=fuse and self.world == 1 and self.defer_prop)
         self._pipeline_adam = False
         if self._sharded():
             self._sharded_optimizer_step()
