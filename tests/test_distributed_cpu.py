@@ -115,7 +115,19 @@ def _shard_worker(rank, world, port, outdir):
     sdist.all_gather_shards(full, new_shard.contiguous(), pg, async_op=True).wait()
     ref_g = g.clone()
     sdist.all_reduce_sum_(ref_g, pg, async_op=True).wait()
-    torch.save((full, p - 0.1 * ref_g / world), os.path.join(outdir, f"s{rank}.pt"))
+    # half-width transports (opt-in): gradients rounded to bf16 before the reduce-scatter, parameter UPDATES gathered in bf16
+    # and applied by every rank -- the owner of a shard included -- to its OLD parameters
+    g16 = (torch.sin(torch.arange(n, dtype=torch.float32) * 0.37 + rank) * 3.0).to(torch.bfloat16)
+    shard16 = torch.empty(n // world, dtype=torch.bfloat16)
+    sdist.reduce_scatter_sum(shard16, g16, pg, async_op=True).wait()
+    upd = (-0.1 * shard16.float() / world).to(torch.bfloat16)
+    upd_full = torch.empty(n, dtype=torch.bfloat16)
+    sdist.all_gather_shards(upd_full, upd, pg, async_op=True).wait()
+    new16 = torch.add(p, upd_full)  # fp32 + bf16 -> fp32, the same expression on every rank
+    g16_all = [torch.empty_like(g16) for _ in range(world)]
+    dist.all_gather(g16_all, g16, group=pg)
+    want_sum = sum(t.float() for t in g16_all)  # exact sum of the rounded gradients
+    torch.save((full, p - 0.1 * ref_g / world, new16, shard16.float(), want_sum[lo:lo + n // world]), os.path.join(outdir, f"s{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -130,9 +142,12 @@ def test_reduce_scatter_shard_all_gather_equals_all_reduce(tmp_path):
     for p in procs:
         p.join(240)
         assert p.exitcode == 0
-    (f0, r0), (f1, r1) = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    (f0, r0, n0, s0, w0), (f1, r1, n1, s1, w1) = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
     assert torch.equal(f0, f1) and torch.equal(r0, r1)
     torch.testing.assert_close(f0, r0, rtol=0, atol=0)
+    assert n0.dtype == torch.float32 and torch.equal(n0, n1)  # replicas stay bit-identical with the bf16 update transport
+    for s_, w_ in ((s0, w0), (s1, w1)):  # bf16 reduce-scatter: the sum of two bf16 values, rounded once
+        torch.testing.assert_close(s_, w_, rtol=2 ** -8, atol=1e-6)
 
 
 def test_single_process_is_identity():
