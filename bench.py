@@ -279,7 +279,10 @@ def main():
             try:
                 ev = json.load(open(psnr_file))["evals"][-1]
                 line["psnr_30k"] = {"held_out_camera_db": round(ev["psnr_heldout_mean"], 2), "train_views_db": round(ev["psnr_train_views_mean"], 2),
-                                    "step": ev["step"], "source": "profiles/r01_psnr_30k.json (tools/train_psnr.py, same preset and synthetic scene)"}
+                                    "step": ev["step"], "source": "profiles/r01_psnr_30k.json (tools/train_psnr.py, same preset and synthetic scene)",
+                                    "all_runs_held_out_camera_db": [35.5, 37.3, 38.85, 38.9, 39.18, 39.3],
+                                    "all_runs_note": "six fp32 30 k-step runs (atomic accumulation order makes runs diverge; profiles/r01_kernels.md); "
+                                                     "the last one, on the round's final code: 38.85 dB, SSIM 0.9956 (profiles/r01_psnr_30k_run6.json)"}
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:
