@@ -58,6 +58,7 @@ def make_tree(root: Path, per_frame: bool, gen):
                 fr.update({k: (v + (1.0 if k.startswith("fl") else 0) * cams.index(c)) for k, v in intr.items()})
                 fr["k1"] = 0.001 * t
                 fr["mask_path"] = f"masks/{c}_{t:04d}.png"
+                fr["depth_file_path"] = f"depth-maps/{c}_{t:04d}.png"
             meta["frames"].append(fr)
             if not (c == "Camera_2" and t == 3):  # one missing file
                 existing.append(f"images/2x/{c}_{t:04d}.png")
@@ -74,13 +75,16 @@ def g14():
 
     gen = torch.Generator().manual_seed(3)
     cases = []
-    for per_frame, fps in ((False, 3.0), (True, 1.0), (True, 2.0)):
+    for per_frame, fps, extra in ((False, 3.0, {}), (True, 1.0, {}), (True, 2.0, {}),
+                                  (True, 1.0, {"depth_maps": "depth-maps", "depth_mask": "mask"}),
+                                  (True, 1.0, {"depth_maps": "depth-maps_field", "depth_mask": "none", "static": True, "static_timestep": 2,
+                                               "cap_box_floor": True, "scene_scale": 2.0, "scale_factor": 0.5, "auto_scale_poses": False})):
         tmp = Path(tempfile.mkdtemp())
         try:
             text, existing = make_tree(tmp, per_frame, gen)
-            case = {"transforms": text, "existing": existing, "fps_downsample": fps, "splits": {}}
+            case = {"transforms": text, "existing": existing, "fps_downsample": fps, "options": extra, "splits": {}}
             for split in ("train", "val"):
-                cfg = BroadcaststyleDataParserConfig(data=tmp, fps_downsample=fps)
+                cfg = BroadcaststyleDataParserConfig(data=tmp, fps_downsample=fps, **extra)
                 out = cfg.setup().get_dataparser_outputs(split)
                 cam = out.cameras
                 case["splits"][split] = {
@@ -89,6 +93,8 @@ def g14():
                     "c2w": cam.camera_to_worlds.tolist(), "fx": cam.fx.flatten().tolist(), "fy": cam.fy.flatten().tolist(),
                     "cx": cam.cx.flatten().tolist(), "cy": cam.cy.flatten().tolist(), "height": cam.height.flatten().tolist(),
                     "width": cam.width.flatten().tolist(), "times": cam.times.flatten().tolist(), "ids": cam.ids.flatten().tolist(),
+                    "depth_filenames": None if out.metadata["depth_filenames"] is None else [str(Path(f).relative_to(tmp)) for f in out.metadata["depth_filenames"]],
+                    "static": bool(out.metadata["static"]),
                     "distortion": cam.distortion_params.tolist(), "aabb": out.scene_box.aabb.tolist(), "scale": out.dataparser_scale,
                     "transform": out.dataparser_transform.tolist()}
             cases.append(case)

@@ -11,7 +11,7 @@ import torch
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("case_idx", [0, 1, 2])
+@pytest.mark.parametrize("case_idx", [0, 1, 2, 3, 4])
 def test_broadcaststyle_parser_matches_reference(tmp_path, case_idx):
     from soccernerfs_amd.dataparsers import BroadcaststyleDataParserConfig
 
@@ -22,10 +22,13 @@ def test_broadcaststyle_parser_matches_reference(tmp_path, case_idx):
         p.parent.mkdir(parents=True, exist_ok=True)
         p.touch()
     for split, want in case["splits"].items():
-        out = BroadcaststyleDataParserConfig(data=tmp_path, fps_downsample=case["fps_downsample"]).setup().get_dataparser_outputs(split)
+        out = BroadcaststyleDataParserConfig(data=tmp_path, fps_downsample=case["fps_downsample"], **case.get("options", {})).setup().get_dataparser_outputs(split)
         assert [str(Path(f).relative_to(tmp_path)) for f in out.image_filenames] == want["image_filenames"]
         got_masks = None if out.mask_filenames is None else [str(Path(f).relative_to(tmp_path)) for f in out.mask_filenames]
         assert got_masks == want["mask_filenames"]
+        got_depth = out.metadata["depth_filenames"]
+        assert (None if got_depth is None else [str(Path(f).relative_to(tmp_path)) for f in got_depth]) == want["depth_filenames"]
+        assert out.metadata["static"] == want["static"]
         cam = out.cameras
         M = len(want["image_filenames"])
         assert len(cam) == M
