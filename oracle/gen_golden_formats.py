@@ -4,6 +4,7 @@ G14  Broadcaststyle._generate_dataparser_outputs (NS/data/dataparsers/broadcasts
      `transforms.json` trees (global intrinsics / per-frame intrinsics, missing files, a camera outside the split, masks, fps
      down-sampling 1 and 3): file selection, poses after auto-scaling, intrinsics after the down-scale, times, ids, scene box.
      -> tests/golden/g14_dataparser.json (inputs: the json text and the list of files that exist; outputs as lists).
+G14b the same for Stadiumwide (NS/data/dataparsers/stadiumwide_dataparser.py) -> tests/golden/g14b_stadiumwide.json.
 G15  a checkpoint holding what the reference's Trainer.save_checkpoint (NS/engine/trainer.py:353-380) saves -- the dict
      {"step", "pipeline": pipeline.state_dict(), "optimizers": {group: Adam.state_dict()}, "scalers": GradScaler.state_dict()} --
      for the reference's own small KPlanesModel and torch.optim.Adam objects after three steps, plus that model's eval-mode outputs
@@ -105,6 +106,46 @@ def g14():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB;", [(len(c["splits"]["train"]["image_filenames"]), len(c["splits"]["val"]["image_filenames"])) for c in cases])
 
 
+def g14b():
+    """Stadiumwide._generate_dataparser_outputs (NS/data/dataparsers/stadiumwide_dataparser.py) on a synthetic tree: ring cameras of three
+    groups + two close-up cameras, 4 time steps, per-frame intrinsics."""
+    from nerfstudio.data.dataparsers.stadiumwide_dataparser import StadiumwideDataParserConfig
+
+    gen = torch.Generator().manual_seed(9)
+    names = [f"Ext Left-Left-{i}" for i in (0, 3, 9)] + [f"Middle-Right-{i}" for i in (1, 5)] + ["Ext Op Left-High Behind Left-9", "Center", "Shooter"]
+    cases = []
+    for extra in ({"nb_train_cameras": 110}, {"nb_train_cameras": 12, "closeup_training": True, "fps_downsample": 2.0}):
+        tmp = Path(tempfile.mkdtemp())
+        try:
+            meta = {"frames": []}
+            existing = []
+            for ci, c in enumerate(names):
+                pose = _pose(gen)
+                for t in range(4):
+                    meta["frames"].append({"file_path": f"images/{c}_{t:04d}.png", "transform_matrix": pose, "fl_x": 900.0 + ci, "fl_y": 905.0, "cx": 480.0,
+                                           "cy": 270.0, "w": 960, "h": 540})
+                    existing.append(f"images/2x/{c}_{t:04d}.png")
+            (tmp / "images" / "2x").mkdir(parents=True)
+            for f in existing:
+                (tmp / f).touch()
+            text = json.dumps(meta)
+            (tmp / "transforms.json").write_text(text)
+            case = {"transforms": text, "existing": existing, "options": extra, "splits": {}}
+            for split in ("train", "val"):
+                out = StadiumwideDataParserConfig(data=tmp, **extra).setup().get_dataparser_outputs(split)
+                cam = out.cameras
+                case["splits"][split] = {"image_filenames": [str(Path(f).relative_to(tmp)) for f in out.image_filenames],
+                                         "c2w": cam.camera_to_worlds.tolist(), "fx": cam.fx.flatten().tolist(), "times": cam.times.flatten().tolist(),
+                                         "ids": cam.ids.flatten().tolist(), "aabb": out.scene_box.aabb.tolist(), "scale": out.dataparser_scale,
+                                         "height": cam.height.flatten().tolist(), "width": cam.width.flatten().tolist()}
+            cases.append(case)
+        finally:
+            shutil.rmtree(tmp)
+    path = os.path.join(ROOT, "tests", "golden", "g14b_stadiumwide.json")
+    json.dump(cases, open(path, "w"))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB;", [(len(c["splits"]["train"]["image_filenames"]), len(c["splits"]["val"]["image_filenames"])) for c in cases])
+
+
 def g15():
     import nerfstudio.models.kplanes as km
     from nerfstudio.cameras.rays import RayBundle
@@ -162,4 +203,5 @@ def g15():
 
 if __name__ == "__main__":
     g14()
+    g14b()
     g15()

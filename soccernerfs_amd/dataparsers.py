@@ -84,9 +84,22 @@ def auto_orient_and_center_poses(poses: torch.Tensor, method: str = "none", cent
 
 
 class Broadcaststyle:
+    empty_scene_dir = "broadcaststyle_empty/"  # :263-264
+    has_depth = True
+
     def __init__(self, config: BroadcaststyleDataParserConfig):
         self.config = config
         self.downscale_factor = None
+
+    def _cam_id(self, name: str) -> int:
+        return int(CAM_IDS[name])
+
+    def _split_cameras(self, split: str):
+        """-> (cameras of this split, cameras of the other split or None = keep every parsed camera for the pose scaling)."""
+        setup_split = "train" if split == "train" else "eval"
+        other_split = "eval" if setup_split == "train" else "train"
+        return ([CAM_IDS[c] for c in SETUPS[self.config.cam_split_setup][setup_split]],
+                [CAM_IDS[c] for c in SETUPS[self.config.cam_split_setup][other_split]])
 
     def _get_fname(self, filepath: PurePath, data_dir: Path, downsample_folder_prefix="images_") -> Path:
         """:529-547: <dir>/<k>x/<name>."""
@@ -94,17 +107,16 @@ class Broadcaststyle:
         old = data_dir / filepath
         return old.parent / f"{self.config.downscale_factor}x" / old.name
 
-    @staticmethod
-    def _frame_metadata(fname: Path):
+    def _frame_metadata(self, fname: Path):
         """:242-259: `<camera name>_<time step>.<ext>`."""
         head, tail = fname.name.rsplit("_", 1)
-        return int(CAM_IDS[head]), int(tail.split(".")[0])
+        return self._cam_id(head), int(tail.split(".")[0])
 
     def get_dataparser_outputs(self, split: str = "train") -> DataparserOutputs:
         cfg = self.config
         data = Path(cfg.data)
         if cfg.static and cfg.static_timestep == -1:
-            data = data.parent / "broadcaststyle_empty/"
+            data = data.parent / self.empty_scene_dir
         if data.suffix == ".json":
             meta, data_dir = json.load(open(data)), data.parent
         else:
@@ -113,16 +125,13 @@ class Broadcaststyle:
         distort_fixed = any(k in meta for k in ("k1", "k2", "k3", "p1", "p2"))
         per = {k: [] for k in fixed}
         image_filenames, mask_filenames, depth_filenames, poses, distort, times, cam_uids = [], [], [], [], [], [], []
-        setup_split = "train" if split == "train" else "eval"
-        other_split = "eval" if setup_split == "train" else "train"
-        split_cams = [CAM_IDS[c] for c in SETUPS[cfg.cam_split_setup][setup_split]]
-        other_cams = [CAM_IDS[c] for c in SETUPS[cfg.cam_split_setup][other_split]]
+        split_cams, other_cams = self._split_cameras(split)
         for frame in meta["frames"]:
             fname = self._get_fname(PurePath(frame["file_path"]), data_dir)
             if not fname.exists():
                 continue
             cam_id, time_step = self._frame_metadata(fname)
-            if cam_id not in split_cams and cam_id not in other_cams:
+            if other_cams is not None and cam_id not in split_cams and cam_id not in other_cams:
                 continue
             if cfg.static and not cfg.static_allimgs:
                 if cfg.static_timestep == -1:
@@ -142,7 +151,7 @@ class Broadcaststyle:
             poses.append(np.array(frame["transform_matrix"]))
             if "mask_path" in frame:
                 mask_filenames.append(self._get_fname(PurePath(frame["mask_path"]), data_dir, downsample_folder_prefix="masks_"))
-            if "depth_file_path" in frame and cfg.depth_maps != "none":
+            if self.has_depth and "depth_file_path" in frame and cfg.depth_maps != "none":
                 dp = frame["depth_file_path"]
                 if cfg.depth_mask != "none":
                     dp = dp.replace("depth-maps", "depth-maps-" + cfg.depth_mask)
@@ -195,8 +204,58 @@ class Broadcaststyle:
         return DataparserOutputs(image_filenames=sel(image_filenames), cameras=cameras, scene_box=scene_box,
                                  mask_filenames=sel(mask_filenames) if mask_filenames else None, dataparser_scale=scale,
                                  dataparser_transform=transform,
-                                 metadata={"depth_filenames": sel(depth_filenames) if depth_filenames else None,
-                                           "depth_unit_scale_factor": cfg.depth_unit_scale_factor, "static": cfg.static})
+                                 metadata=({"depth_filenames": sel(depth_filenames) if depth_filenames else None,
+                                            "depth_unit_scale_factor": cfg.depth_unit_scale_factor, "static": cfg.static} if self.has_depth
+                                           else {"static": cfg.static}))
+
+
+# ---- stadium-wide scene (NS/data/dataparsers/stadiumwide_dataparser.py): 110 ring cameras in 11 named groups of 10 + 6 close-up cameras ----
+CAMERA_LOCATIONS = ["Ext Left-Left", "Left-Middle", "Middle-Right", "Right-Ext Right", "Ext Right-High Behind Right",
+                    "High Behind Right-Ext Op Right", "Ext Op Right-Op Right", "Op Right-Op Middle", "Op Middle-Op Left", "Op Left-Ext Op Left",
+                    "Ext Op Left-High Behind Left"]  # :49-61, ids 10 * group + local id
+CLOSE_CAMERAS = {"Center": 110, "GoalLeft": 111, "GoalRight": 112, "PlayerLeft": 113, "PlayerRight": 114, "Shooter": 115}  # :63-70
+
+
+def get_cam_id(cam_name: str) -> int:
+    """stadiumwide_dataparser.py:73-79."""
+    if "-" in cam_name:
+        group, local = cam_name.rsplit("-", 1)
+        return CAMERA_LOCATIONS.index(group) * 10 + int(local)
+    return CLOSE_CAMERAS[cam_name]
+
+
+@dataclass
+class StadiumwideDataParserConfig(BroadcaststyleDataParserConfig):
+    """:83-118: as the Broadcast-style config with these defaults and two extra fields (no depth maps)."""
+
+    data: Path = Path("data/stadiumwide/")
+    scene_scale: float = 1.0
+    cam_split_setup: str = "low"
+    fps_downsample: float = 1.0
+    nb_train_cameras: int = 110
+    closeup_training: bool = False
+
+    def setup(self) -> "Stadiumwide":
+        return Stadiumwide(self)
+
+
+class Stadiumwide(Broadcaststyle):
+    """Same file layout; camera ids from the group names; eval = the six close-up cameras, train = nb_train_cameras ring cameras spread
+    evenly over the 110 (:271-281); every parsed camera takes part in the pose scaling."""
+
+    empty_scene_dir = "stadium_players_empty/"
+    has_depth = False
+
+    def _cam_id(self, name: str) -> int:
+        return get_cam_id(name)
+
+    def _split_cameras(self, split: str):
+        cams = list(range(110, 116))
+        if split == "train":
+            cams = np.linspace(0, 109, self.config.nb_train_cameras).astype(np.int32).tolist()
+            if self.config.closeup_training:
+                cams = cams + list(range(110, 116))
+        return cams, None
 
 
 def load_image_cache(image_filenames: List[Path]) -> torch.Tensor:

@@ -169,3 +169,31 @@ def test_checkpoint_names_for_the_nerfplayer_models():
     again = CK.reference_state_dict(model, prefix="")
     for name, v in ref_state.items():
         assert torch.equal(again[name], v), name
+
+
+@pytest.mark.parametrize("case_idx", [0, 1])
+def test_stadiumwide_parser_matches_reference(tmp_path, case_idx):
+    """G14b: the stadium-wide scene's parser (config 4's data): camera ids from the group names, eval = the close-up cameras, train = ring
+    cameras spread evenly over the 110, every parsed camera in the pose scaling."""
+    from soccernerfs_amd.dataparsers import StadiumwideDataParserConfig, get_cam_id
+
+    assert get_cam_id("Ext Left-Left-0") == 0 and get_cam_id("Middle-Right-5") == 25 and get_cam_id("Ext Op Left-High Behind Left-9") == 109
+    assert get_cam_id("Shooter") == 115
+    case = json.load(open(os.path.join(GOLD, "g14b_stadiumwide.json")))[case_idx]
+    (tmp_path / "transforms.json").write_text(case["transforms"])
+    for f in case["existing"]:
+        p = tmp_path / f
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.touch()
+    for split, want in case["splits"].items():
+        out = StadiumwideDataParserConfig(data=tmp_path, **case["options"]).setup().get_dataparser_outputs(split)
+        assert [str(Path(f).relative_to(tmp_path)) for f in out.image_filenames] == want["image_filenames"]
+        cam = out.cameras
+        M = len(want["image_filenames"])
+        torch.testing.assert_close(cam.camera_to_worlds, torch.tensor(want["c2w"]), rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(cam.fx, torch.tensor(want["fx"]), rtol=1e-6, atol=0)
+        torch.testing.assert_close(cam.times, torch.tensor(want["times"]), rtol=0, atol=0)
+        assert cam.ids.tolist() == want["ids"] and [cam.height] * M == want["height"] and [cam.width] * M == want["width"]
+        torch.testing.assert_close(out.scene_box.aabb, torch.tensor(want["aabb"]), rtol=0, atol=0)
+        assert abs(out.dataparser_scale - want["scale"]) <= 1e-7 * abs(want["scale"])
+        assert "depth_filenames" not in out.metadata
