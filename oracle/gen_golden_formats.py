@@ -79,7 +79,8 @@ def g14():
     for per_frame, fps, extra in ((False, 3.0, {}), (True, 1.0, {}), (True, 2.0, {}),
                                   (True, 1.0, {"depth_maps": "depth-maps", "depth_mask": "mask"}),
                                   (True, 1.0, {"depth_maps": "depth-maps_field", "depth_mask": "none", "static": True, "static_timestep": 2,
-                                               "cap_box_floor": True, "scene_scale": 2.0, "scale_factor": 0.5, "auto_scale_poses": False})):
+                                               "cap_box_floor": True, "scene_scale": 2.0, "scale_factor": 0.5, "auto_scale_poses": False}),
+                                  (False, 1.0, {"orientation_method": "up", "center_method": "poses"})):
         tmp = Path(tempfile.mkdtemp())
         try:
             text, existing = make_tree(tmp, per_frame, gen)

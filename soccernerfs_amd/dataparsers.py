@@ -66,17 +66,38 @@ def _distortion(src: Dict) -> torch.Tensor:
     return torch.tensor([float(src.get(k, 0.0)) for k in ("k1", "k2", "k3", "k4", "p1", "p2")])
 
 
+def rotation_matrix(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Rotation taking direction a to direction b (Rodrigues; NS/cameras/camera_utils.py:404-429).  Exactly opposite vectors are not
+    handled (the reference perturbs one of them randomly)."""
+    a = a / torch.linalg.norm(a)
+    b = b / torch.linalg.norm(b)
+    v = torch.linalg.cross(a, b)
+    c = torch.dot(a, b)
+    if c < -1 + 1e-8:
+        raise ValueError("rotation_matrix: opposite vectors")
+    s = torch.linalg.norm(v)
+    k = torch.tensor([[0.0, -float(v[2]), float(v[1])], [float(v[2]), 0.0, -float(v[0])], [-float(v[1]), float(v[0]), 0.0]])
+    return torch.eye(3) + k + k @ k * ((1 - c) / (s ** 2 + 1e-8))
+
+
 def auto_orient_and_center_poses(poses: torch.Tensor, method: str = "none", center_method: str = "none"):
-    """NS/cameras/camera_utils.py:470-574 for method "none" (the Broadcast-style default)."""
+    """NS/cameras/camera_utils.py:470-574 for the methods "none" (the Broadcast-style default) and "up" (mean camera up-axis to +z);
+    centring "none" / "poses"."""
     origins = poses[..., :3, 3]
     if center_method == "poses":
         translation = torch.mean(origins, dim=0)
     elif center_method == "none":
         translation = torch.zeros(3)
     else:
-        raise NotImplementedError(f"center_method {center_method!r} (the Broadcast-style parser uses 'none')")
+        raise NotImplementedError(f"center_method {center_method!r} (built: 'none', 'poses')")
+    if method == "up":
+        up = torch.mean(poses[:, :3, 1], dim=0)
+        up = up / torch.linalg.norm(up)
+        rotation = rotation_matrix(up, torch.tensor([0.0, 0.0, 1.0]))
+        transform = torch.cat([rotation, rotation @ -translation[..., None]], dim=-1)
+        return transform @ poses, transform
     if method != "none":
-        raise NotImplementedError(f"orientation method {method!r} (the Broadcast-style parser uses 'none')")
+        raise NotImplementedError(f"orientation method {method!r} (built: 'none', 'up')")
     transform = torch.eye(4)
     transform[:3, 3] = -translation
     transform = transform[:3, :]
