@@ -5,6 +5,7 @@ G14  Broadcaststyle._generate_dataparser_outputs (NS/data/dataparsers/broadcasts
      down-sampling 1 and 3): file selection, poses after auto-scaling, intrinsics after the down-scale, times, ids, scene box.
      -> tests/golden/g14_dataparser.json (inputs: the json text and the list of files that exist; outputs as lists).
 G14b the same for Stadiumwide (NS/data/dataparsers/stadiumwide_dataparser.py) -> tests/golden/g14b_stadiumwide.json.
+G14c the same for Stadium (NS/data/dataparsers/stadium_dataparser.py) -> tests/golden/g14c_stadium.json.
 G15  a checkpoint holding what the reference's Trainer.save_checkpoint (NS/engine/trainer.py:353-380) saves -- the dict
      {"step", "pipeline": pipeline.state_dict(), "optimizers": {group: Adam.state_dict()}, "scalers": GradScaler.state_dict()} --
      for the reference's own small KPlanesModel and torch.optim.Adam objects after three steps, plus that model's eval-mode outputs
@@ -147,6 +148,47 @@ def g14b():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB;", [(len(c["splits"]["train"]["image_filenames"]), len(c["splits"]["val"]["image_filenames"])) for c in cases])
 
 
+def g14c():
+    """Stadium._generate_dataparser_outputs (NS/data/dataparsers/stadium_dataparser.py: the parser the nerfplayer presets name) on synthetic
+    trees: `images_2/<group>-<camera>_<time>.png`, pose orientation "up" + centring "poses" (its defaults), 95 % camera split."""
+    from nerfstudio.data.dataparsers.stadium_dataparser import StadiumDataParserConfig
+
+    gen = torch.Generator().manual_seed(13)
+    cases = []
+    for names, extra, splits in (([f"Ext Left-Left-{i}" for i in range(10)] + [f"Left-Middle-{i}" for i in range(10)], {}, ("train", "val")),
+                                 (["Ext Left-Left-0", "Ext Left-Left-3", "Middle-Right-5", "Ext Op Left-High Behind Left-9"],
+                                  {"train_split_percentage": 0.5, "orientation_method": "none", "center_method": "none"}, ("train",))):
+        tmp = Path(tempfile.mkdtemp())
+        try:
+            meta = {"frames": [], "fl_x": 800.0, "fl_y": 805.0, "cx": 480.0, "cy": 270.0, "w": 960, "h": 540}
+            existing = []
+            for c in names:
+                pose = _pose(gen)
+                for t in range(3):
+                    meta["frames"].append({"file_path": f"images/{c}_{t:04d}.png", "transform_matrix": pose, "depth_file_path": f"depths/{c}_{t:04d}.png"})
+                    existing.append(f"images_2/{c}_{t:04d}.png")
+            (tmp / "images_2").mkdir(parents=True)
+            for f in existing:
+                (tmp / f).touch()
+            text = json.dumps(meta)
+            (tmp / "transforms.json").write_text(text)
+            case = {"transforms": text, "existing": existing, "options": extra, "splits": {}}
+            for split in splits:
+                out = StadiumDataParserConfig(data=tmp, **extra).setup().get_dataparser_outputs(split)
+                cam = out.cameras
+                case["splits"][split] = {"image_filenames": [str(Path(f).relative_to(tmp)) for f in out.image_filenames],
+                                         "depth_filenames": [str(Path(f).relative_to(tmp)) for f in out.metadata["depth_filenames"]],
+                                         "c2w": cam.camera_to_worlds.tolist(), "fx": cam.fx.flatten().tolist(), "times": cam.times.flatten().tolist(),
+                                         "ids": cam.ids.flatten().tolist(), "aabb": out.scene_box.aabb.tolist(), "scale": out.dataparser_scale,
+                                         "transform": out.dataparser_transform.tolist()}
+            cases.append(case)
+        finally:
+            shutil.rmtree(tmp)
+    path = os.path.join(ROOT, "tests", "golden", "g14c_stadium.json")
+    json.dump(cases, open(path, "w"))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB;", [{k: len(v["image_filenames"]) for k, v in c["splits"].items()} for c in cases])
+
+
 def g15():
     import nerfstudio.models.kplanes as km
     from nerfstudio.cameras.rays import RayBundle
@@ -205,4 +247,5 @@ def g15():
 if __name__ == "__main__":
     g14()
     g14b()
+    g14c()
     g15()

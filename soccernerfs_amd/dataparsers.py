@@ -128,6 +128,41 @@ class Broadcaststyle:
         old = data_dir / filepath
         return old.parent / f"{self.config.downscale_factor}x" / old.name
 
+    guard_zero_time = True
+
+    def _keep_time_step(self, time_step: int) -> bool:
+        """Static-scene options (:329-335)."""
+        cfg = self.config
+        if cfg.static and not cfg.static_allimgs:
+            return time_step == (0 if cfg.static_timestep == -1 else cfg.static_timestep)
+        return True
+
+    def _depth_path(self, frame: Dict) -> Optional[str]:
+        """:379-389."""
+        cfg = self.config
+        if not (self.has_depth and "depth_file_path" in frame and cfg.depth_maps != "none"):
+            return None
+        dp = frame["depth_file_path"]
+        if cfg.depth_mask != "none":
+            dp = dp.replace("depth-maps", "depth-maps-" + cfg.depth_mask)
+        if cfg.depth_maps != "depth-maps":
+            dp = dp.replace("depth-maps", cfg.depth_maps)
+        return dp
+
+    def _select(self, cam_uids: List[int], times: List[int], split: str, split_cams) -> List[int]:
+        """fps down-sampling (:405-412: keep the time steps linspace(0, T-1, int(T / fps_downsample))) and the split's cameras."""
+        times_filter = np.arange(max(times) + 1)
+        if self.config.fps_downsample > 1:
+            base = max(times) + 1
+            times_filter = np.linspace(0, base - 1, int(base / self.config.fps_downsample)).astype(np.int32)
+        return [i for i in range(len(cam_uids)) if cam_uids[i] in split_cams and times[i] in times_filter]
+
+    def _metadata(self, depth_filenames) -> Dict:
+        cfg = self.config
+        if not self.has_depth:
+            return {"static": cfg.static}
+        return {"depth_filenames": depth_filenames, "depth_unit_scale_factor": cfg.depth_unit_scale_factor, "static": cfg.static}
+
     def _frame_metadata(self, fname: Path):
         """:242-259: `<camera name>_<time step>.<ext>`."""
         head, tail = fname.name.rsplit("_", 1)
@@ -154,12 +189,8 @@ class Broadcaststyle:
             cam_id, time_step = self._frame_metadata(fname)
             if other_cams is not None and cam_id not in split_cams and cam_id not in other_cams:
                 continue
-            if cfg.static and not cfg.static_allimgs:
-                if cfg.static_timestep == -1:
-                    if time_step != 0:
-                        continue
-                elif time_step != cfg.static_timestep:
-                    continue
+            if not self._keep_time_step(time_step):
+                continue
             cam_uids.append(cam_id)
             times.append(time_step)
             for k in fixed:
@@ -172,23 +203,14 @@ class Broadcaststyle:
             poses.append(np.array(frame["transform_matrix"]))
             if "mask_path" in frame:
                 mask_filenames.append(self._get_fname(PurePath(frame["mask_path"]), data_dir, downsample_folder_prefix="masks_"))
-            if self.has_depth and "depth_file_path" in frame and cfg.depth_maps != "none":
-                dp = frame["depth_file_path"]
-                if cfg.depth_mask != "none":
-                    dp = dp.replace("depth-maps", "depth-maps-" + cfg.depth_mask)
-                if cfg.depth_maps != "depth-maps":
-                    dp = dp.replace("depth-maps", cfg.depth_maps)
+            dp = self._depth_path(frame)
+            if dp is not None:
                 depth_filenames.append(self._get_fname(PurePath(dp), data_dir, downsample_folder_prefix="depths_"))
         assert len(image_filenames) != 0, "No image files found. Check the file_paths in transforms.json."
         assert len(mask_filenames) in (0, len(image_filenames)), "Different number of image and mask filenames."
         assert len(depth_filenames) in (0, len(image_filenames)), "Different number of image and depth filenames."
 
-        # fps down-sampling (:405-412): keep the time steps linspace(0, T-1, int(T / fps_downsample))
-        times_filter = np.arange(max(times) + 1)
-        if cfg.fps_downsample > 1:
-            base = max(times) + 1
-            times_filter = np.linspace(0, base - 1, int(base / cfg.fps_downsample)).astype(np.int32)
-        indices = [i for i in range(len(image_filenames)) if cam_uids[i] in split_cams and times[i] in times_filter]
+        indices = self._select(cam_uids, times, split, split_cams)
 
         orientation = meta.get("orientation_override", cfg.orientation_method)
         poses = torch.from_numpy(np.array(poses).astype(np.float32))
@@ -211,7 +233,7 @@ class Broadcaststyle:
         height, width = val("h", int), val("w", int)
         tmax = max(times)
         t = torch.tensor(times, dtype=torch.float32)[idx]
-        t = t / tmax if tmax != 0 else t
+        t = t / tmax if (tmax != 0 or not self.guard_zero_time) else t
         ids = torch.tensor(cam_uids, dtype=torch.float32)[idx].to(torch.uint8)  # Cameras._init_get_ids (cameras.py:263-272) stores uint8
         dist = _distortion(meta) if distort_fixed else torch.stack(distort, dim=0)[idx]
         if isinstance(height, torch.Tensor):
@@ -225,9 +247,7 @@ class Broadcaststyle:
         return DataparserOutputs(image_filenames=sel(image_filenames), cameras=cameras, scene_box=scene_box,
                                  mask_filenames=sel(mask_filenames) if mask_filenames else None, dataparser_scale=scale,
                                  dataparser_transform=transform,
-                                 metadata=({"depth_filenames": sel(depth_filenames) if depth_filenames else None,
-                                            "depth_unit_scale_factor": cfg.depth_unit_scale_factor, "static": cfg.static} if self.has_depth
-                                           else {"static": cfg.static}))
+                                 metadata=self._metadata(sel(depth_filenames) if depth_filenames else None))
 
 
 # ---- stadium-wide scene (NS/data/dataparsers/stadiumwide_dataparser.py): 110 ring cameras in 11 named groups of 10 + 6 close-up cameras ----
@@ -277,6 +297,82 @@ class Stadiumwide(Broadcaststyle):
             if self.config.closeup_training:
                 cams = cams + list(range(110, 116))
         return cams, None
+
+
+@dataclass
+class StadiumDataParserConfig:
+    """NS/data/dataparsers/stadium_dataparser.py:72-110 (the parser the nerfplayer presets name, method_configs.py:573,627)."""
+
+    data: Path = Path("data/stadium/")
+    scale_factor: float = 1.0
+    downscale_factor: Optional[int] = 2
+    scene_scale: float = 1.5
+    orientation_method: str = "up"
+    center_method: str = "poses"
+    auto_scale_poses: bool = True
+    train_split_percentage: float = 0.95
+    depth_unit_scale_factor: float = 1e-3
+    camera_location: str = "Op Right-Op Middle"  # unused by the reference's code path as it stands (its filter is commented out)
+    # fields the shared parsing code reads; the stadium parser has no such options
+    cap_box_floor: bool = False
+    static: bool = False
+    static_allimgs: bool = False
+    static_timestep: int = -1
+    fps_downsample: float = 1.0
+
+    def setup(self) -> "Stadium":
+        return Stadium(self)
+
+
+class Stadium(Broadcaststyle):
+    """Files `<group name>-<camera in group>_<time step>.<ext>` under `images_<k>/`; unique camera id = 10 * group + camera; the
+    training split = ceil(95 %) of the cameras, evenly spaced, the rest evaluates (:289-306); depth maps listed whenever present."""
+
+    has_depth = True
+    guard_zero_time = False  # :367 divides by max(times) unconditionally
+
+    def _get_fname(self, filepath: PurePath, data_dir: Path, downsample_folder_prefix="images_") -> Path:
+        """:404-433 with an explicit downscale factor (the automatic choice opens image files and is not built)."""
+        if self.config.downscale_factor is None:
+            raise NotImplementedError("automatic downscale factor")
+        self.downscale_factor = self.config.downscale_factor
+        if self.downscale_factor > 1:
+            return data_dir / f"{downsample_folder_prefix}{self.downscale_factor}" / filepath.name
+        return data_dir / filepath
+
+    def _frame_metadata(self, fname: Path):
+        """:120-144."""
+        loc, rest = fname.name.rsplit("-", 1)
+        cam, tail = rest.split("_")[:2]
+        return CAMERA_LOCATIONS.index(loc) * 10 + int(cam), int(tail.split(".")[0])
+
+    def _split_cameras(self, split: str):
+        return None, None  # chosen after parsing, from the cameras actually present
+
+    def _keep_time_step(self, time_step: int) -> bool:
+        return True
+
+    def _depth_path(self, frame: Dict) -> Optional[str]:
+        return frame.get("depth_file_path")
+
+    def _select(self, cam_uids, times, split, split_cams):
+        import math
+
+        num_cams = len(np.unique(cam_uids))
+        num_train = math.ceil(num_cams * self.config.train_split_percentage)
+        i_train = np.linspace(0, num_cams - 1, num_train, dtype=int)
+        i_eval = np.setdiff1d(np.arange(num_cams), i_train)
+        if split == "train":
+            chosen = i_train
+        elif split in ("val", "test"):
+            chosen = i_eval
+        else:
+            raise ValueError(f"Unknown dataparser split {split}")
+        # as the reference: camera INDICES are compared with camera IDS (the same thing when every camera of the ring is present)
+        return [i for i in range(len(cam_uids)) if cam_uids[i] in chosen]
+
+    def _metadata(self, depth_filenames) -> Dict:
+        return {"depth_filenames": depth_filenames, "depth_unit_scale_factor": self.config.depth_unit_scale_factor}
 
 
 def load_image_cache(image_filenames: List[Path]) -> torch.Tensor:

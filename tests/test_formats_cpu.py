@@ -197,3 +197,32 @@ def test_stadiumwide_parser_matches_reference(tmp_path, case_idx):
         torch.testing.assert_close(out.scene_box.aabb, torch.tensor(want["aabb"]), rtol=0, atol=0)
         assert abs(out.dataparser_scale - want["scale"]) <= 1e-7 * abs(want["scale"])
         assert "depth_filenames" not in out.metadata
+
+
+@pytest.mark.parametrize("case_idx", [0, 1])
+def test_stadium_parser_matches_reference(tmp_path, case_idx):
+    """G14c: the parser the nerfplayer presets name (stadium_dataparser.py): `images_<k>/` layout, ids from `<group>-<camera>`, pose
+    orientation "up" + centring "poses", percentage camera split (incl. its index-vs-id comparison on a sparse ring), depth lists."""
+    from soccernerfs_amd.dataparsers import StadiumDataParserConfig
+
+    case = json.load(open(os.path.join(GOLD, "g14c_stadium.json")))[case_idx]
+    (tmp_path / "transforms.json").write_text(case["transforms"])
+    for f in case["existing"]:
+        p = tmp_path / f
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.touch()
+    for split, want in case["splits"].items():
+        out = StadiumDataParserConfig(data=tmp_path, **case["options"]).setup().get_dataparser_outputs(split)
+        assert [str(Path(f).relative_to(tmp_path)) for f in out.image_filenames] == want["image_filenames"]
+        assert [str(Path(f).relative_to(tmp_path)) for f in out.metadata["depth_filenames"]] == want["depth_filenames"]
+        cam = out.cameras
+        torch.testing.assert_close(cam.camera_to_worlds, torch.tensor(want["c2w"]), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(cam.fx, torch.tensor(want["fx"]), rtol=1e-6, atol=0)
+        torch.testing.assert_close(cam.times, torch.tensor(want["times"]), rtol=0, atol=0)
+        assert cam.ids.tolist() == want["ids"]
+        torch.testing.assert_close(out.scene_box.aabb, torch.tensor(want["aabb"]), rtol=0, atol=0)
+        assert abs(out.dataparser_scale - want["scale"]) <= 1e-6 * abs(want["scale"])
+        torch.testing.assert_close(out.dataparser_transform, torch.tensor(want["transform"]), rtol=1e-5, atol=1e-6)
+        assert set(out.metadata) == {"depth_filenames", "depth_unit_scale_factor"}
+    with pytest.raises(ValueError):
+        StadiumDataParserConfig(data=tmp_path, **case["options"]).setup().get_dataparser_outputs("bogus")
