@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 2
+#define SNERF_ABI_VERSION 3
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -88,6 +88,14 @@ int snerf_kplanes_gather_fwd(const snerf_kplanes_desc* desc, const float* planes
 int snerf_kplanes_gather_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords,
                              int64_t N, const float* grad_out, float* grad_planes, snerf_stream_t stream);
 
+/* Deterministic accumulation.  Float atomics make a sum depend on the order in which wavefronts arrive (torch's own
+ * grid_sampler_2d_backward has the same property on GPUs).  The _fx entry points accumulate into 64-bit fixed-point cells instead
+ * (value * 2^50; integer adds are associative, so two runs give the same bits) and snerf_fx_to_float converts a cell buffer into float
+ * gradients (out = or += cells * 2^-50) and clears it.  Same layout as the float gradient buffer. */
+int snerf_kplanes_gather_bwd_fx(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords,
+                                int64_t N, const float* grad_out, int64_t* grad_planes_fx, snerf_stream_t stream);
+int snerf_fx_to_float(int64_t* fx, float* out, int64_t n, int32_t accumulate, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Per-ray sampling ops.  One wavefront per ray; S <= 320 samples per ray.
  * "sbins" = bin edges in the normalised spacing domain [0,1]; "ebins" = the same edges in euclidean
@@ -105,9 +113,12 @@ int snerf_spaced_bins(const float* nears, const float* fars, const float* t_rand
  * deltas = ebins[:,1:] - ebins[:,:-1]. */
 int snerf_weights_fwd(const float* density, const float* ebins, int32_t R, int32_t S, float* weights, snerf_stream_t stream);
 
-/* Backward of get_weights w.r.t. density.  accumulate != 0: grad_density += ...; else overwritten. */
+/* Backward of get_weights w.r.t. density.  accumulate != 0: grad_density += ...; else overwritten.
+ * Where autograd would produce a non-finite gradient (0 * inf: an overflowed density on a zero-width bin) the kernel emits 0 and, if
+ * nonfinite_flag != NULL, stores 1 there -- the `nonfinite` field of the parameter group's snerf_adam_dyn, so that the optimiser step
+ * can be skipped as the reference's GradScaler does (NS/engine/trainer.py:394-408). */
 int snerf_weights_bwd(const float* density, const float* ebins, const float* grad_weights, int32_t R, int32_t S,
-                      float* grad_density, int32_t accumulate, snerf_stream_t stream);
+                      float* grad_density, int32_t accumulate, int32_t* nonfinite_flag, snerf_stream_t stream);
 
 /* PDFSampler.generate_ray_samples with include_original=False (ray_samplers.py:274-369) preceded by the
  * weight annealing of ProposalNetworkSampler (:584), optionally fused behind get_weights.
@@ -178,6 +189,9 @@ int snerf_mlp_fwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * NULL = not needed).  The forward is recomputed tile by tile; nothing is saved between fwd and bwd. */
 int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                   int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* Same with the weight gradients accumulated into fixed-point cells (see snerf_kplanes_gather_bwd_fx). */
+int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                     int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Compositing and ray-level losses (one wavefront per ray, S <= 320).
@@ -238,11 +252,34 @@ int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_t S, const 
 int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* grad, float c_space_tv, float c_time_smooth,
                     float c_sparse, float* losses, int32_t n_slots, int32_t overwrite, snerf_stream_t stream);
 
+/* Device-resident optimiser state of ONE parameter group (= one torch optimiser of the reference: "fields", "proposal_networks",
+ * NS/models/kplanes.py:311-316).  It lets a step be skipped without a host round trip, which is how the reference treats non-finite
+ * gradients: GradScaler.step(optimizer) skips optimizer.step() when found_inf is set for that optimiser (NS/engine/trainer.py:394-408,
+ * NS/engine/optimizers.py:130-139), Adam's own step counter then does not advance while the LR scheduler does.
+ *   producers (snerf_weights_bwd) store 1 into `nonfinite`;
+ *   snerf_adam_prepare (one tiny launch per group and step, before the group's Adam kernels): skip = policy == 1 && (nonfinite ||
+ *     force_nonfinite); clears nonfinite; if skipped ++skipped, else ++t and step_size = lr / (1 - beta1^t), inv_sqrt_bc2 =
+ *     1 / sqrt(1 - beta2^t);
+ *   the Adam entry points, given `dyn` != NULL, ignore their `step` argument, read {step_size, inv_sqrt_bc2, skip} from it and on a
+ *     skipped step leave p, m, v untouched (p_out = p) and only clear the gradient; non-finite gradient ELEMENTS that still reach them
+ *     are dropped and counted in `dropped`. */
+typedef struct {
+  int32_t nonfinite;
+  int32_t t;           /* optimiser steps taken (Adam's state["step"]) */
+  int32_t skipped;     /* steps skipped */
+  int32_t dropped;     /* gradient elements dropped */
+  float step_size;
+  float inv_sqrt_bc2;
+  int32_t skip;
+  int32_t _pad;
+} snerf_adam_dyn;
+int snerf_adam_prepare(snerf_adam_dyn* dyn, float lr, float beta1, float beta2, int32_t policy, int32_t force_nonfinite, snerf_stream_t stream);
+
 /* torch.optim.Adam single-tensor step (no weight decay, no amsgrad) on a flat buffer; `step` is 1-based.
  * g is first multiplied by grad_scale (e.g. 1/world_size after an all-reduce SUM) and, if zero_grad != 0, cleared.
- * The new parameters go to p_out (may equal p: in place). */
+ * The new parameters go to p_out (may equal p: in place).  dyn: NULL, or the group's device-side state (above). */
 int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                    int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+                    int32_t step, float grad_scale, int32_t zero_grad, snerf_adam_dyn* dyn, snerf_stream_t stream);
 
 /* Adam over one K-Planes plane set with the plane regularisers (snerf_plane_reg) fused in: the regulariser gradient is
  * formed from the +-1/+-2 neighbours of the OLD parameters inside the optimiser sweep and never touches HBM; g holds the
@@ -250,7 +287,8 @@ int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, 
  * the plane set's segment (same layout as `planes`).  losses / n_slots as in snerf_plane_reg (may be NULL). */
 int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
                            float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
-                           float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+                           float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_adam_dyn* dyn,
+                           snerf_stream_t stream);
 
 /* Same, restricted to the floats [range_lo, range_hi) of the segment (both multiples of 4): the optimiser shard of one rank when
  * the gradient is reduce-scattered instead of all-reduced (DDP + ZeroRedundancyOptimizer semantics; the reference's DDP wrapper
@@ -259,7 +297,7 @@ int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, fl
 int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
                                  float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
                                  float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, int64_t range_lo, int64_t range_hi,
-                                 snerf_stream_t stream);
+                                 snerf_adam_dyn* dyn, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray generation + collider.
@@ -351,7 +389,8 @@ int snerf_tgrid_tv_fwd_bwd(const float* embeddings, int64_t rows, int32_t grid_C
 int snerf_tgrid_tv_sign(const float* embeddings, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, float g_tv, float* partial,
                         int32_t n_slots, float* srow, snerf_stream_t stream);
 int snerf_adam_step_tv(float* p, float* g, float* m, float* v, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* srow,
-                       float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream);
+                       float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_adam_dyn* dyn,
+                       snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Static multiresolution hash grid: tcnn.Encoding(3, {"otype": "HashGrid", "n_levels", "n_features_per_level", "log2_hashmap_size",
@@ -412,7 +451,9 @@ int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chos
  *      Depends only on the sample coordinates -> can run on a side stream as soon as they are known.
  *      Workspace sizes (elements) from snerf_kplanes_sort_workspace: hist[hist_cells], rank[index_elems] (int32) and
  *      sorted_rec[index_elems][4] (float: sample id bits, the two normalised plane coordinates, 0)  (index_elems = n_planes * N).
- *   2. snerf_kplanes_gradvec      : gvec[scale*n_planes+plane][N][C] = dL/d(interpolated value of that plane) per sample.
+ *   2. snerf_kplanes_gradvec      : gvec[scale*n_planes+plane][N][C] = dL/d(interpolated value of that plane) per sample; elements are
+ *      fp32 (gvec_bf16 = 0: exact, the parity path) or bf16 (gvec_bf16 = 1: half the bytes of the largest intermediate of the step; the
+ *      scatter still accumulates in fp32).
  *   3. snerf_kplanes_scatter_sorted: walks each segment in sorted order, applies the bilinear weights, run-length-combines
  *      equal texel rows and ACCUMULATES into grad_planes with one 2*C-float atomic instruction per run.
  * ------------------------------------------------------------------------------------------------ */
@@ -420,12 +461,12 @@ int snerf_kplanes_sort_workspace(const snerf_kplanes_desc* desc, int64_t N, int6
 int snerf_kplanes_sort_samples(const snerf_kplanes_desc* desc, const snerf_coords* coords, int64_t N, int32_t* hist, int32_t* rank,
                                float* sorted_rec, snerf_stream_t stream);
 int snerf_kplanes_gradvec(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_out,
-                          float* gvec, snerf_stream_t stream);
-int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+                          void* gvec, int32_t gvec_bf16, snerf_stream_t stream);
+int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,
                                  float* grad_planes, snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
-int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,
                                         float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 
 #ifdef __cplusplus

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KPlanesDesc(C.Structure):
@@ -53,6 +53,12 @@ class ResampleArgs(C.Structure):
 class MlpDesc(C.Structure):
     _fields_ = [("d_in", C.c_int32), ("hidden", C.c_int32), ("n_hidden", C.c_int32), ("d_out", C.c_int32),
                 ("hidden_act", C.c_int32), ("out_act", C.c_int32), ("operands", C.c_int32)]
+
+
+class AdamDyn(C.Structure):
+    """snerf_adam_dyn: device-resident optimiser state of one parameter group (8 x 4 bytes; lives in a torch int32[8] tensor)."""
+    _fields_ = [("nonfinite", C.c_int32), ("t", C.c_int32), ("skipped", C.c_int32), ("dropped", C.c_int32),
+                ("step_size", C.c_float), ("inv_sqrt_bc2", C.c_float), ("skip", C.c_int32), ("_pad", C.c_int32)]
 
 
 class RenderArgs(C.Structure):
@@ -105,9 +111,12 @@ def lib():
     l.snerf_distortion.argtypes = [P, P, I, I, F, P, P, I, P]
     l.snerf_interlevel.argtypes = [P, P, I, P, P, I, I, F, P, P, P]
     l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, I, I, P]
-    l.snerf_adam_step.argtypes = [P, P, P, P, P, L, F, F, F, F, I, F, I, P]
-    l.snerf_adam_planes_step.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, P]
-    l.snerf_adam_planes_step_range.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, L, L, P]
+    l.snerf_adam_step.argtypes = [P, P, P, P, P, L, F, F, F, F, I, F, I, P, P]
+    l.snerf_adam_planes_step.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, P, P]
+    l.snerf_adam_planes_step_range.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, L, L, P, P]
+    l.snerf_adam_prepare.argtypes = [P, F, F, F, I, I, P]
+    l.snerf_weights_bwd.argtypes = [P, P, P, I, I, P, I, P, P]
+    l.snerf_fx_to_float.argtypes = [P, P, L, I, P]
     l.snerf_aabb_collide.argtypes = [P, P, I, P, F, I, P, P, P]
     l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]
     l.snerf_render_mse_bwd.argtypes = [P, P, P, I, P, P, F, I, I, P, P, P, P]
@@ -116,7 +125,7 @@ def lib():
     l.snerf_tgrid_tv_bwd.argtypes = [P, L, I, I, I, P, P, P]
     l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_tgrid_tv_sign.argtypes = [P, L, I, I, I, F, P, I, P, P]
-    l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P]
+    l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P, P]
     l.snerf_isg_maps.argtypes = [P, I, I, I, I, I, P, P, P, I, F, P, P, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
     if l.snerf_abi_version() != ABI_VERSION:
@@ -178,4 +187,8 @@ EXPORTS = [
     "snerf_kplanes_sort_samples",
     "snerf_kplanes_gradvec",
     "snerf_kplanes_scatter_sorted",
+    "snerf_kplanes_gather_bwd_fx",
+    "snerf_fx_to_float",
+    "snerf_mlp_bwd_fx",
+    "snerf_adam_prepare",
 ]

@@ -50,6 +50,23 @@ __device__ __forceinline__ float wave_inclusive_scan(float v, int lane) {
   return v;
 }
 
+// ---- deterministic gradient accumulation (KPlanesTrainConfig.deterministic) ----
+// Float atomics make a sum depend on the order in which wavefronts arrive.  In deterministic mode gradients are accumulated as 2^50-scaled
+// 64-bit integers instead (integer addition is associative: any order gives the same bits) and converted back once per step
+// (snerf_fx_to_float).  Range +-8192, resolution 8.9e-16; a non-finite contribution adds nothing.
+constexpr double FX_SCALE = 1125899906842624.0;  // 2^50
+__device__ __forceinline__ void fx_atomic_add(long long* p, float v) {
+  if (!(fabsf(v) <= 3.402823466e+38f)) return;
+  double x = (double)v * FX_SCALE;
+  x = fmin(fmax(x, -4.0e18), 4.0e18);
+  atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double2ll_rn(x));
+}
+// one accumulator that is either a float (atomic fp32 add) or a fixed-point cell
+template <bool FX>
+__device__ __forceinline__ void grad_add(float* g, long long* gfx, int64_t idx, float v) {
+  if (FX) fx_atomic_add(gfx + idx, v); else atomicAdd(g + idx, v);
+}
+
 // nan_to_num with torch defaults (nan->0, +inf->FLT_MAX, -inf->-FLT_MAX)
 __device__ __forceinline__ float nan_to_num(float v) {
   if (v != v) return 0.f;

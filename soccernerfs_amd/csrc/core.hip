@@ -19,7 +19,33 @@ int check_hip(hipError_t e, const char* what) {
   set_error("%s: %s", what, hipGetErrorString(e));
   return (int)e;
 }
+
+// fixed-point gradient cells -> float gradients (deterministic mode, common.hpp): out (+)= fx * 2^-50; the cells are cleared
+__global__ __launch_bounds__(256) void fx_to_float_kernel(long long* __restrict__ fx, float* __restrict__ out, int64_t n, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long q = fx[i];
+  if (q != 0) {
+    const float v = (float)((double)q * (1.0 / FX_SCALE));
+    out[i] = accumulate ? out[i] + v : v;
+    fx[i] = 0;
+  } else if (!accumulate) {
+    out[i] = 0.f;
+  }
+}
 }  // namespace snerf
+
+extern "C" int snerf_fx_to_float(int64_t* fx, float* out, int64_t n, int32_t accumulate, snerf_stream_t stream) {
+  SNERF_REQUIRE(n >= 0, "fx_to_float: n=%lld", (long long)n);
+  if (n == 0) return 0;
+  SNERF_REQUIRE(fx && out, "fx_to_float: null buffer");
+  const int64_t blocks = (n + 255) / 256;
+  SNERF_REQUIRE(blocks < (1LL << 31), "fx_to_float: n too large for one launch");
+  hipLaunchKernelGGL(snerf::fx_to_float_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<long long*>(fx), out, n,
+                     accumulate);
+  int rc = snerf::check_hip(hipGetLastError(), "fx_to_float");
+  return rc;
+}
 
 extern "C" int snerf_abi_version(void) { return SNERF_ABI_VERSION; }
 extern "C" const char* snerf_last_error(void) { return snerf::g_err; }

@@ -73,10 +73,10 @@ __device__ __forceinline__ float xor_lanes(float x) {
   }
 }
 
-template <int C, int NP>
+template <int C, int NP, bool FX>
 __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_desc d, const float* __restrict__ planes,
                                                                 snerf_coords c, int64_t N, const float* __restrict__ gout,
-                                                                float* __restrict__ gplanes, int run) {
+                                                                float* __restrict__ gplanes, long long* __restrict__ gplanes_fx, int run) {
   constexpr int LPS = 2 * C;  // lanes per sample
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t group = gid / LPS;
@@ -137,13 +137,13 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
         const AxisTap& tx = tap[A[q]];
         const AxisTap& ty = tap[B[q]];
         const int W = res[A[q]];
-        float* gbase = gplanes + d.off[s][q] + li;
+        const int64_t gbase = d.off[s][q] + li;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           const int key = (r ? ty.i1 : ty.i0) * W + tx.i0;
           const float val = gq * (r ? ty.w1 : ty.w0);
           if (key != pend_key[q][r]) {
-            if (pend_val[q][r] != 0.f) atomicAdd(gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
+            if (pend_val[q][r] != 0.f) grad_add<FX>(gplanes, gplanes_fx, gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
             pend_key[q][r] = key;
             pend_val[q][r] = val;
           } else {
@@ -154,10 +154,10 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
     }
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      float* gbase = gplanes + d.off[s][q] + li;
+      const int64_t gbase = d.off[s][q] + li;
 #pragma unroll
       for (int r = 0; r < 2; ++r)
-        if (pend_val[q][r] != 0.f) atomicAdd(gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
+        if (pend_val[q][r] != 0.f) grad_add<FX>(gplanes, gplanes_fx, gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
     }
   }
 }
@@ -190,12 +190,13 @@ static int launch_fwd(const snerf_kplanes_desc* d, const float* planes, const sn
 }
 template <int C, int NP>
 static int launch_bwd(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, float* gp,
-                      hipStream_t st) {
-  // consecutive samples walked (and run-length-combined) by one lane group; SNERF_BWD_RUN is a tuning knob
-  static const int run = [] { const char* e = getenv("SNERF_BWD_RUN"); int v = e ? atoi(e) : 64; return v > 0 ? v : 64; }();  // 64: A/B in profiles/r01_kernels.md
+                      long long* gp_fx, hipStream_t st) {
+  // consecutive samples walked (and run-length-combined) by one lane group (16 / 32 / 64 / 128 measured: profiles/r01_kernels.md)
+  constexpr int run = 64;
   int64_t groups = (N + run - 1) / run;
   int64_t threads = groups * (2 * C);
-  hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, run);
+  if (gp_fx) hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP, true>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, gp_fx, run);
+  else hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP, false>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, gp_fx, run);
   SNERF_LAUNCH_CHECK("kplanes_gather_bwd");
   return 0;
 }
@@ -232,5 +233,14 @@ extern "C" int snerf_kplanes_gather_bwd(const snerf_kplanes_desc* desc, const fl
   if (rc) return rc;
   if (N == 0) return 0;
   SNERF_REQUIRE(planes && grad_out && grad_planes, "kplanes_gather_bwd: null buffer");
-  DISPATCH_C_NP(launch_bwd, desc, planes, coords, N, grad_out, grad_planes, (hipStream_t)stream);
+  DISPATCH_C_NP(launch_bwd, desc, planes, coords, N, grad_out, grad_planes, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int snerf_kplanes_gather_bwd_fx(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                                           const float* grad_out, int64_t* grad_planes_fx, snerf_stream_t stream) {
+  int rc = validate(desc, coords, N);
+  if (rc) return rc;
+  if (N == 0) return 0;
+  SNERF_REQUIRE(planes && grad_out && grad_planes_fx, "kplanes_gather_bwd_fx: null buffer");
+  DISPATCH_C_NP(launch_bwd, desc, planes, coords, N, grad_out, nullptr, reinterpret_cast<long long*>(grad_planes_fx), (hipStream_t)stream);
 }

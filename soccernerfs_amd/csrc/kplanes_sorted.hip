@@ -174,10 +174,21 @@ __global__ __launch_bounds__(256) void scan_add_kernel(int32_t* __restrict__ dat
     if (base + k < n) data[base + k] += add;
 }
 
+// gvec rows are fp32 (exact: the parity path) or bf16 (half the 2 GB round trip between pass A and pass B; the scatter still accumulates
+// in fp32, each contribution carries a 2^-9 relative rounding)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_gq(float* gv, int64_t idx, float4 g) { *reinterpret_cast<float4*>(gv + idx) = g; }
+__device__ __forceinline__ void store_gq(__bf16* gv, int64_t idx, float4 g) {
+  const bf16x4 b = {(__bf16)g.x, (__bf16)g.y, (__bf16)g.z, (__bf16)g.w};
+  *reinterpret_cast<bf16x4*>(gv + idx) = b;
+}
+__device__ __forceinline__ float load_g(const float* gv, int64_t idx) { return gv[idx]; }
+__device__ __forceinline__ float load_g(const __bf16* gv, int64_t idx) { return (float)gv[idx]; }
+
 // ---- pass A: gradient w.r.t. each plane's interpolated value, sample-major ----
-template <int C, int NP>
+template <int C, int NP, typename GV>
 __global__ __launch_bounds__(256) void gradvec_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c, int64_t N,
-                                                     const float* __restrict__ gout, float* __restrict__ gvec) {
+                                                     const float* __restrict__ gout, GV* __restrict__ gvec) {
   constexpr int LPS = C / 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = gid / LPS;
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(256) void gradvec_kernel(snerf_kplanes_desc d, cons
     for (int q = 0; q < NP; ++q) {
       const float4 gq = f4_mul(pre, suf[q + 1]);
       pre = f4_mul(pre, v[q]);
-      *reinterpret_cast<float4*>(gvec + ((int64_t)(s * NP + q) * N + n) * C + cg * 4) = gq;
+      store_gq(gvec, ((int64_t)(s * NP + q) * N + n) * C + cg * 4, gq);
     }
   }
 }
@@ -214,8 +225,8 @@ __global__ __launch_bounds__(256) void gradvec_kernel(snerf_kplanes_desc d, cons
 // ---- pass B: sorted run-length scatter ----
 // One lane group (2*C lanes = (x-corner, channel)) walks RUN consecutive SORTED records {n, fx, fy}.  Records are read
 // UNROLL at a time (wave-uniform addresses), the UNROLL gvec rows are fetched together, then combined in order.
-template <int C, int NP>
-__global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
+template <int C, int NP, typename GV>
+__global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc d, int64_t N, const GV* __restrict__ gvec,
                                                             const float4* __restrict__ sorted_rec, float* __restrict__ gplanes, int run,
                                                             int64_t groups_per_seg, int seg_begin, int per_scale) {
   constexpr int LPS = 2 * C;
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
   seg_axes<NP>(q, a, b);
   const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
   const float4* rec = sorted_rec + (int64_t)(per_scale ? seg : q) * N + i0;  // the plane's order is shared by all scales unless per_scale
-  const float* gv = gvec + (int64_t)seg * N * C + ch;
+  const GV* gv = gvec + (int64_t)seg * N * C + ch;
   float* gbase = gplanes + d.off[s][q] + li;
   int pend_key[2] = {-1, -1};
   float pend_val[2] = {0.f, 0.f};
@@ -259,7 +270,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
           const int uu = (u0 + u) < m ? (u0 + u) : (m - 1);
-          g[u] = gv[(int64_t)__builtin_amdgcn_readlane(nn, uu) * C];
+          g[u] = load_g(gv, (int64_t)__builtin_amdgcn_readlane(nn, uu) * C);
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(256) void scatter_sorted_kernel(snerf_kplanes_desc 
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) r[u] = rec[i + u < cnt ? i + u : cnt - 1];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) g[u] = gv[(int64_t)__float_as_int(r[u].x) * C];
+    for (int u = 0; u < UNROLL; ++u) g[u] = load_g(gv, (int64_t)__float_as_int(r[u].x) * C);
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if (i + u < cnt) {
@@ -384,8 +395,8 @@ struct BitonicK<1> {
   static __device__ __forceinline__ void run(uint32_t (&)[4], int) {}
 };
 
-template <int NP>
-__global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
+template <int NP, typename GV>
+__global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc d, int64_t N, const GV* __restrict__ gvec,
                                                              const float4* __restrict__ sorted_rec, float* __restrict__ gplanes,
                                                              int64_t groups_per_seg, int seg_begin, int per_scale) {
   constexpr int C = 32, CH = 256, UNROLL = 16;
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
   seg_axes<NP>(q, a, b);
   const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
   const float4* rec = sorted_rec + (int64_t)(per_scale ? seg : q) * N + i0;
-  const float* gseg = gvec + (int64_t)seg * N * C;  // wave-uniform base; rows are addressed with 32-bit element offsets
+  const GV* gseg = gvec + (int64_t)seg * N * C;  // wave-uniform base; rows are addressed with 32-bit element offsets
   float* gch = gplanes + d.off[s][q] + ch;
   uint32_t* R = s_rec[wave];
   const bool sortable = (int64_t)W * H <= (1 << 23);  // key << 8 | index must fit 31 bits (the launcher guarantees N * C < 2^31)
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
     // the small per-entry fields are re-read from LDS when the entry is processed, so only g[] stays in registers
     float g[UNROLL];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) g[u] = gseg[R[(e0 + u) * 8] + ch];  // wave-uniform LDS address: broadcast
+    for (int u = 0; u < UNROLL; ++u) g[u] = load_g(gseg, (int64_t)(R[(e0 + u) * 8] + ch));  // wave-uniform LDS address: broadcast
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 1]);
@@ -510,8 +521,9 @@ static int build_segs(const snerf_kplanes_desc* d, SegTable& st) {
     SNERF_REQUIRE(st.fine[k] <= 32768, "kplanes_sort: resolution %d too large for the Morton key", st.fine[k]);
     st.fine_rm[k] = fine;
   }
-  static const int per_scale = [] { const char* e = getenv("SNERF_SORT_PER_SCALE"); return e ? atoi(e) : 0; }();
-  st.per_scale = per_scale && d->n_scales > 1;
+  // one shared order per plane (a separate global sort per scale costs +0.5 ms of sorting for -0.3 ms of pass B: profiles/r01_kernels.md;
+  // the per-scale branches of the kernels are kept for the descriptor field `per_scale`, which stays 0)
+  st.per_scale = 0;
   st.n_scales = d->n_scales;
   for (int s = 0; s < d->n_scales; ++s)
     for (int k = 0; k < 4; ++k) st.res[s][k] = d->res[s][k];
@@ -612,15 +624,18 @@ extern "C" int snerf_kplanes_sort_samples(const snerf_kplanes_desc* desc, const 
 }
 
 template <int C, int NP>
-static int launch_gradvec(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, float* gvec, hipStream_t st) {
-  hipLaunchKernelGGL((gradvec_kernel<C, NP>), dim3((unsigned)ceil_div(N * (C / 4), 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gvec);
+static int launch_gradvec(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, void* gvec, int gvec_bf16,
+                          hipStream_t st) {
+  const dim3 grid((unsigned)ceil_div(N * (C / 4), 256));
+  if (gvec_bf16) hipLaunchKernelGGL((gradvec_kernel<C, NP, __bf16>), grid, dim3(256), 0, st, *d, planes, *c, N, gout, (__bf16*)gvec);
+  else hipLaunchKernelGGL((gradvec_kernel<C, NP, float>), grid, dim3(256), 0, st, *d, planes, *c, N, gout, (float*)gvec);
   SNERF_LAUNCH_CHECK("kplanes_gradvec");
   return 0;
 }
 template <int C, int NP>
-static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const float* gvec, const float4* sorted_n, float* gp, int scale_begin,
+static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const void* gvec, int gvec_bf16, const float4* sorted_n, float* gp, int scale_begin,
                                  int scale_end, hipStream_t st) {
-  static const int run = [] { const char* e = getenv("SNERF_SORTED_RUN"); int v = e ? atoi(e) : 256; return v > 0 ? v : 256; }();
+  constexpr int run = 256;
   const int64_t groups_per_seg = (N + run - 1) / run;
   // the kernel stops at segment n_scales * NP: hand it a descriptor that ends at scale_end
   snerf_kplanes_desc dd = *d;
@@ -628,17 +643,21 @@ static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const f
   SegTable stb;
   int rc = build_segs(d, stb);
   if (rc) return rc;
-  static const int grouped = [] { const char* e = getenv("SNERF_SCATTER_GROUPED"); return e ? atoi(e) : 1; }();
-  if (C == 32 && grouped && N * C < (1LL << 31)) {  // 32-bit gvec row offsets inside the kernel
+  if (C == 32 && N * C < (1LL << 31)) {  // 32-bit gvec row offsets inside the kernel
     const int64_t gps = (N + 255) / 256;
-    hipLaunchKernelGGL((scatter_grouped_kernel<NP>), dim3((unsigned)ceil_div(gps * (scale_end - scale_begin) * NP, 4)), dim3(256), 0, st, dd, N, gvec,
-                       sorted_n, gp, gps, scale_begin * NP, stb.per_scale);
+    const dim3 grid((unsigned)ceil_div(gps * (scale_end - scale_begin) * NP, 4));
+    if (gvec_bf16) hipLaunchKernelGGL((scatter_grouped_kernel<NP, __bf16>), grid, dim3(256), 0, st, dd, N, (const __bf16*)gvec, sorted_n, gp, gps,
+                                      scale_begin * NP, stb.per_scale);
+    else hipLaunchKernelGGL((scatter_grouped_kernel<NP, float>), grid, dim3(256), 0, st, dd, N, (const float*)gvec, sorted_n, gp, gps, scale_begin * NP,
+                            stb.per_scale);
     SNERF_LAUNCH_CHECK("kplanes_scatter_grouped");
     return 0;
   }
   const int64_t threads = groups_per_seg * (scale_end - scale_begin) * NP * (2 * C);
-  hipLaunchKernelGGL((scatter_sorted_kernel<C, NP>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, dd, N, gvec, sorted_n, gp, run,
-                     groups_per_seg, scale_begin * NP, stb.per_scale);
+  if (gvec_bf16) hipLaunchKernelGGL((scatter_sorted_kernel<C, NP, __bf16>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, dd, N,
+                                    (const __bf16*)gvec, sorted_n, gp, run, groups_per_seg, scale_begin * NP, stb.per_scale);
+  else hipLaunchKernelGGL((scatter_sorted_kernel<C, NP, float>), dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, st, dd, N, (const float*)gvec,
+                          sorted_n, gp, run, groups_per_seg, scale_begin * NP, stb.per_scale);
   SNERF_LAUNCH_CHECK("kplanes_scatter_sorted");
   return 0;
 }
@@ -657,15 +676,15 @@ static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const f
   } while (0)
 
 extern "C" int snerf_kplanes_gradvec(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_out,
-                                     float* gvec, snerf_stream_t stream) {
+                                     void* gvec, int32_t gvec_bf16, snerf_stream_t stream) {
   int rc = check_desc(desc, coords, N);
   if (rc) return rc;
   if (N == 0) return 0;
   SNERF_REQUIRE(planes && grad_out && gvec, "kplanes_gradvec: null buffer");
-  DISPATCH2(launch_gradvec, desc, planes, coords, N, grad_out, gvec, (hipStream_t)stream);
+  DISPATCH2(launch_gradvec, desc, planes, coords, N, grad_out, gvec, gvec_bf16, (hipStream_t)stream);
 }
 
-extern "C" int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+extern "C" int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,
                                                    float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
   snerf_coords dummy = {};
   int rc = check_desc(desc, &dummy, N);
@@ -674,11 +693,12 @@ extern "C" int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* des
                 scale_begin, scale_end, desc->n_scales);
   if (N == 0 || scale_begin == scale_end) return 0;
   SNERF_REQUIRE(gvec && sorted_rec && grad_planes, "kplanes_scatter_sorted: null buffer");
-  DISPATCH2(launch_scatter_sorted, desc, N, gvec, reinterpret_cast<const float4*>(sorted_rec), grad_planes, scale_begin, scale_end, (hipStream_t)stream);
+  DISPATCH2(launch_scatter_sorted, desc, N, gvec, gvec_bf16, reinterpret_cast<const float4*>(sorted_rec), grad_planes, scale_begin, scale_end,
+            (hipStream_t)stream);
 }
 
-extern "C" int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const float* gvec, const float* sorted_rec,
+extern "C" int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,
                                             float* grad_planes, snerf_stream_t stream) {
   SNERF_REQUIRE(desc, "kplanes_scatter_sorted: null descriptor");
-  return snerf_kplanes_scatter_sorted_scales(desc, N, gvec, sorted_rec, grad_planes, 0, desc->n_scales, stream);
+  return snerf_kplanes_scatter_sorted_scales(desc, N, gvec, gvec_bf16, sorted_rec, grad_planes, 0, desc->n_scales, stream);
 }

@@ -36,7 +36,12 @@ struct MlpArgs {
   const float* gaux;
   float* gX; int ldgx;
   float* gW;
+  long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
 };
+
+__device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
+  if (a.gWfx) fx_atomic_add(a.gWfx + idx, v); else atomicAdd(a.gW + idx, v);
+}
 
 __host__ __device__ constexpr int ld_of(int width) { return ((width + 31) / 32) * 32 + 2; }  // = 2 mod 32
 __host__ __device__ constexpr int ldw_of(int n) { return n == OUTP ? 18 : ld_of(n); }
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
   }
 
   // ---- flush weight gradients (each 16-lane group adds 64 contiguous bytes) ----
-  if (a.gW) {
+  if (a.gW || a.gWfx) {
     const int cl = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = it * 16 + r0 + r, col = nt * 16 + cl;
-          if (row < a.d0) atomicAdd(a.gW + a.woff[0] + (int64_t)row * H + col, dW0[j][r]);
+          if (row < a.d0) gw_add(a, a.woff[0] + (int64_t)row * H + col, dW0[j][r]);
         }
       }
     }
@@ -566,7 +571,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
         if (t < HT * HT) {
           const int it = t / HT, nt = t % HT;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(a.gW + a.woff[1] + (int64_t)(it * 16 + r0 + r) * H + nt * 16 + cl, dWh[j][r]);
+          for (int r = 0; r < 4; ++r) gw_add(a, a.woff[1] + (int64_t)(it * 16 + r0 + r) * H + nt * 16 + cl, dWh[j][r]);
         }
       }
     }
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(waves_of<H>() * 64) void mlp_bwd_kernel(MlpArgs a, 
       if (it < HT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (cl < a.dout) atomicAdd(a.gW + a.woff[NH] + (int64_t)(it * 16 + r0 + r) * a.dout + cl, dWo[j][r]);
+          if (cl < a.dout) gw_add(a, a.woff[NH] + (int64_t)(it * 16 + r0 + r) * a.dout + cl, dWo[j][r]);
       }
     }
   }
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpAr
       }
     }
   }
-  if (a.gW) {
+  if (a.gW || a.gWfx) {
     const int cl = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = it * 16 + r0 + r, col = nt * 16 + cl;
-          if (row < a.d0 && col < a.dout) atomicAdd(a.gW + (int64_t)row * a.dout + col, dW[j][r]);
+          if (row < a.d0 && col < a.dout) gw_add(a, (int64_t)row * a.dout + col, dW[j][r]);
         }
       }
     }
@@ -759,11 +764,6 @@ static int dispatch_dense(int K, int M, const MlpArgs& a, bool bwd, hipStream_t 
   return SNERF_ERR_UNSUPPORTED;
 }
 
-static bool wreg_enabled() {
-  static const bool on = [] { const char* e = getenv("SNERF_MLP_WREG"); return e ? atoi(e) != 0 : true; }();
-  return on;
-}
-
 template <int D0P, int H, int NH>
 static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
   if (bwd) {
@@ -779,7 +779,7 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_of<H>() * 64), P::BYTES, st, a, n_tiles);
-  } else if (NH == 1 && H / 16 == waves_of<H>() && wreg_enabled()) {
+  } else if (NH == 1 && H / 16 == waves_of<H>()) {
     constexpr int TS = H >= 128 ? 16 : 64;
     using P = PlanWreg<D0P, H, TS>;
     const int64_t n_tiles = (a.N + TS - 1) / TS;
@@ -895,8 +895,8 @@ extern "C" int snerf_mlp_fwd(const snerf_mlp_desc* d, const float* W, const floa
   return dispatch(d, a, false, (hipStream_t)stream);
 }
 
-extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
-                             int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                        int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream) {
   MlpArgs a = {};
   int rc = fill(d, a);
   if (rc) return rc;
@@ -908,7 +908,18 @@ extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const floa
   SNERF_REQUIRE(!gaux || (aux_col >= 0 && aux_col < d->d_out), "mlp_bwd: aux_col=%d", aux_col);
   SNERF_REQUIRE(!gX || ldgx >= d->d_in, "mlp_bwd: ldgx=%d", ldgx);
   a.X = X; a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
+  a.gWfx = gWfx;
   return dispatch(d, a, true, (hipStream_t)stream);
+}
+
+extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                             int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+  return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream);
+}
+
+extern "C" int snerf_mlp_bwd_fx(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream) {
+  return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, nullptr, reinterpret_cast<long long*>(gW_fx), stream);
 }
 
 // One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid); K, M <= 128.

@@ -1,7 +1,7 @@
 // Tiny MLPs with 16-bit MFMA operands and fp32 accumulation (snerf_mlp_desc.operands = 1: bf16, 2: fp16): the precision class of the
 // reference's own MLPs (tcnn FullyFusedMLP computes in fp16 with fp32 accumulation; BASELINE config 2 names bf16) at 16x the matrix rate
-// of the exact fp32 path in mlp.hip.  One hidden layer (sigma_net d_in -> 128 -> 16, proposal nets 8 -> 64 -> 1):
-// NS/fields/kplanes_field.py:249-273,397-407.  Master weights, inputs, outputs, gradients and the weight-gradient accumulators stay
+// of the exact fp32 path in mlp.hip.  One hidden layer (sigma_net d_in -> 128 -> 16, proposal nets 8 -> 64 -> 1) or two (color_net
+// 15 -> 64 -> 64 -> 3): NS/fields/kplanes_field.py:249-273,397-407.  Master weights, inputs, outputs, gradients and the weight-gradient accumulators stay
 // fp32; only MFMA operands are rounded (round-to-nearest-even) when they are staged into LDS.  fp16 operands carry the backward's
 // gradient tiles multiplied by 2^13 (a power of two: exact), as tcnn's loss scale does, and saturate instead of overflowing; bf16
 // needs neither.  OPT-IN: the exact fp32 kernels stay the default and the parity path (measured trade-off: profiles/r01_kernels.md).
@@ -57,7 +57,12 @@ struct MlpArgs {  // same fields as mlp.hip's (filled there)
   const float* gaux;
   float* gX; int ldgx;
   float* gW;
+  long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
 };
+
+__device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
+  if (a.gWfx) fx_atomic_add(a.gWfx + idx, v); else atomicAdd(a.gW + idx, v);
+}
 
 constexpr int LDS_LIMIT_B = 160 * 1024;
 __host__ __device__ constexpr int ldb(int k) { return k + 8; }
@@ -138,26 +143,30 @@ constexpr int waves_b() { return H >= 128 ? 8 : 4; }
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int K0, int H, int TS>
+template <int K0, int H, int NH, int TS>
 struct PlanF {
   static constexpr int LK0 = ldb(K0), LKH = ldb(H);
   static constexpr int W0T = 0;                    // [H][LK0]
-  static constexpr int WOT = W0T + H * LK0;        // [16][LKH]
+  static constexpr int W1T = W0T + H * LK0;        // [H][LKH]   (NH == 2)
+  static constexpr int WOT = W1T + (NH == 2 ? H * LKH : 0);  // [16][LKH]
   static constexpr int XS = WOT + 16 * LKH;        // [TS][LK0]
   static constexpr int A1 = XS + TS * LK0;         // [TS][LKH]
-  static constexpr int TOTAL = A1 + TS * LKH;
+  static constexpr int A2 = A1 + TS * LKH;         // [TS][LKH]  (NH == 2)
+  static constexpr int TOTAL = A2 + (NH == 2 ? TS * LKH : 0);
   static constexpr size_t BYTES = (size_t)TOTAL * 2;
 };
 
-template <typename T, int K0, int H, int TS>
+template <typename T, int K0, int H, int NH, int TS>
 __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
-  using P = PlanF<K0, H, TS>;
+  using P = PlanF<K0, H, NH, TS>;
   constexpr int MT = TS / 16, NW = waves_b<H>(), HT = H / 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, nullptr, 0, smem + P::W0T, P::LK0);
-  stage_w<T>(a.W + a.woff[1], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
+  if (NH == 2) stage_w<T>(a.W + a.woff[1], H, H, H, H, nullptr, 0, smem + P::W1T, P::LKH);
+  stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
+  const T* Alast = smem + (NH == 2 ? P::A2 : P::A1);
   const bool relu = a.hidden_act == 1;
   XTileB<TS, K0, NW * 64> xt;
   xt.fetch(a, (int64_t)blockIdx.x * TS);
@@ -182,12 +191,29 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a
       }
     }
     __syncthreads();
+    if (NH == 2) {
+#pragma unroll
+      for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < HT) {
+          f32x4 acc[MT] = {};
+          mma_rr<MT, H>(smem + P::A1, P::LKH, smem + P::W1T, P::LKH, nt, acc, lane);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 v = acc[m];
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            store_rt<T>(smem + P::A2, P::LKH, nullptr, 0, m, nt, v, lane);
+          }
+        }
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
       const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc[1] = {};
-        mma_rr<1, H>(smem + P::A1 + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
+        mma_rr<1, H>(Alast + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
         const int col = lane & 15;
         const int64_t row0 = n0 + mt * 16 + (lane >> 4) * 4;
 #pragma unroll
@@ -208,43 +234,53 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a
 // ---------------------------------------------------------------------------------------------
 // backward (recomputes the forward per tile, as the fp32 kernel)
 // ---------------------------------------------------------------------------------------------
-template <int K0, int H, int TS>
+template <int K0, int H, int NH, int TS>
 struct PlanB {
   static constexpr int LK0 = ldb(K0), LKH = ldb(H), LKO = ldb(32), LKT = ldb(TS);
   static constexpr int W0T = 0;                    // [H][LK0]   forward
   static constexpr int W0R = W0T + H * LK0;        // [K0][LKH]  dX
-  static constexpr int WOT = W0R + K0 * LKH;       // [16][LKH]  forward
-  static constexpr int WOR = WOT + 16 * LKH;       // [H][LKO]   dZ1
+  static constexpr int W1T = W0R + K0 * LKH;       // [H][LKH]   forward, layer 1 (NH == 2)
+  static constexpr int W1R = W1T + (NH == 2 ? H * LKH : 0);  // [H][LKH]  dA1 (NH == 2)
+  static constexpr int WOT = W1R + (NH == 2 ? H * LKH : 0);  // [16][LKH]  forward
+  static constexpr int WOR = WOT + 16 * LKH;       // [H][LKO]   dZ_last
   static constexpr int XS = WOR + H * LKO;         // [TS][LK0]
   static constexpr int XT = XS + TS * LK0;         // [K0][LKT]
   static constexpr int A1 = XT + K0 * LKT;         // [TS][LKH]
-  static constexpr int A1T = A1 + TS * LKH;        // [H][LKT]; reused for gzt once dWO is done
-  static constexpr int GZ = A1T + H * LKT;         // [TS][LKH]
-  static constexpr int GZO = GZ + TS * LKH;        // [TS][LKO]
+  static constexpr int A1T = A1 + TS * LKH;        // [H][LKT]; reused for the transposed gradient of Z1 once its weight-gradient product is done
+  static constexpr int A2 = A1T + H * LKT;         // [TS][LKH]  (NH == 2)
+  static constexpr int A2T = A2 + (NH == 2 ? TS * LKH : 0);  // [H][LKT]; reused for the transposed gradient of Z2
+  static constexpr int GZ = A2T + (NH == 2 ? H * LKT : 0);   // [TS][LKH]  gradient of Z_last
+  static constexpr int GZ1 = GZ + TS * LKH;        // [TS][LKH]  gradient of Z1 (NH == 2)
+  static constexpr int GZO = GZ1 + (NH == 2 ? TS * LKH : 0);  // [TS][LKO]
   static constexpr int GZOT = GZO + TS * LKO;      // [16][LKT]
   static constexpr int TOTAL = GZOT + 16 * LKT;
   static constexpr size_t BYTES = (size_t)TOTAL * 2;
 };
 
-template <typename T, int K0, int H, int TS>
+template <typename T, int K0, int H, int NH, int TS>
 __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
   constexpr float GS = Ops<T>::GS;
-  using P = PlanB<K0, H, TS>;
+  using P = PlanB<K0, H, NH, TS>;
   static_assert(TS % 32 == 0, "the weight-gradient products contract over the tile's samples in steps of 32");
   constexpr int MT = TS / 16, NW = waves_b<H>(), HT = H / 16, K0T = K0 / 16;
-  constexpr int NB0 = (K0T * HT + NW - 1) / NW, NBO = (HT + NW - 1) / NW;
+  constexpr int NB0 = (K0T * HT + NW - 1) / NW, NBO = (HT + NW - 1) / NW, NBH = (HT * HT + NW - 1) / NW;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  T *Xs = smem + P::XS, *Xt = smem + P::XT, *A1 = smem + P::A1, *A1t = smem + P::A1T, *gz = smem + P::GZ, *gzt = smem + P::A1T,
-       *gzo = smem + P::GZO, *gzot = smem + P::GZOT;
+  // "last" = the hidden layer in front of the output layer (layer 1 when NH == 1)
+  T *Xs = smem + P::XS, *Xt = smem + P::XT, *A1 = smem + P::A1, *A1t = smem + P::A1T, *gzo = smem + P::GZO, *gzot = smem + P::GZOT;
+  T *Al = NH == 2 ? smem + P::A2 : A1, *Alt = NH == 2 ? smem + P::A2T : A1t;  // last hidden activations (row-major / transposed)
+  T *gz = smem + P::GZ, *gzt = Alt;                                          // gradient of Z_last; its transposed image reuses Alt
+  T *gz1 = NH == 2 ? smem + P::GZ1 : gz, *gz1t = NH == 2 ? A1t : gzt;        // gradient of Z1
   stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, smem + P::W0R, P::LKH, smem + P::W0T, P::LK0);
-  stage_w<T>(a.W + a.woff[1], H, a.dout, H, 32, smem + P::WOR, P::LKO, nullptr, 0);
-  stage_w<T>(a.W + a.woff[1], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
+  if (NH == 2) stage_w<T>(a.W + a.woff[1], H, H, H, H, smem + P::W1R, P::LKH, smem + P::W1T, P::LKH);
+  stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 32, smem + P::WOR, P::LKO, nullptr, 0);
+  stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
   // columns 16..31 of gzo (the padded half of the K = 32 contraction) stay zero for the whole kernel
   for (int idx = threadIdx.x; idx < TS * 16; idx += blockDim.x) gzo[(idx / 16) * P::LKO + 16 + (idx % 16)] = (T)0.f;
   const bool relu = a.hidden_act == 1;
   f32x4 dW0[NB0] = {};
+  f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
   XTileB<TS, K0, NW * 64> xt;
   xt.fetch(a, (int64_t)blockIdx.x * TS);
@@ -270,13 +306,30 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
       }
     }
     __syncthreads();
+    if (NH == 2) {  // ---- second hidden layer: A2 and A2t ----
+#pragma unroll
+      for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < HT) {
+          f32x4 acc[MT] = {};
+          mma_rr<MT, H>(A1, P::LKH, smem + P::W1T, P::LKH, nt, acc, lane);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 v = acc[m];
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            store_rt(Al, P::LKH, Alt, P::LKT, m, nt, v, lane);
+          }
+        }
+      }
+      __syncthreads();
+    }
     // ---- output layer forward + gradient w.r.t. its pre-activation: gzo (row-major, cols 0..15) and gzot ----
 #pragma unroll
     for (int j = 0; j < (MT + NW - 1) / NW; ++j) {
       const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc[1] = {};
-        mma_rr<1, H>(A1 + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
+        mma_rr<1, H>(Al + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
         const int col = lane & 15;
         const int rl0 = mt * 16 + (lane >> 4) * 4;
         f32x4 gv;
@@ -299,18 +352,18 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
       }
     }
     __syncthreads();
-    // ---- dWO += A1^T gzo (contraction over the tile's samples) ----
+    // ---- dWO += A_last^T gzo (contraction over the tile's samples) ----
 #pragma unroll
     for (int j = 0; j < NBO; ++j) {
       const int it = wave + NW * j;
       if (it < HT) {
         f32x4 acc[1] = {dWo[j]};
-        mma_rr<1, TS>(A1t + it * 16 * P::LKT, P::LKT, gzot, P::LKT, 0, acc, lane);
+        mma_rr<1, TS>(Alt + it * 16 * P::LKT, P::LKT, gzot, P::LKT, 0, acc, lane);
         dWo[j] = acc[0];
       }
     }
-    __syncthreads();  // A1t is overwritten by gzt below
-    // ---- gz = (gzo WO^T) .* relu'(A1): row-major and transposed ----
+    __syncthreads();  // Alt is overwritten by gzt below
+    // ---- gz = (gzo WO^T) .* relu'(A_last): row-major and transposed ----
 #pragma unroll
     for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
       const int nt = wave + NW * j;
@@ -325,20 +378,55 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
           if (relu) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (!((float)A1[(row0 + r) * P::LKH + col] > 0.f)) v[r] = 0.f;
+              if (!((float)Al[(row0 + r) * P::LKH + col] > 0.f)) v[r] = 0.f;
           }
           store_rt(gz, P::LKH, gzt, P::LKT, m, nt, v, lane);
         }
       }
     }
     __syncthreads();
-    // ---- dW0 += X^T gz ----
+    if (NH == 2) {
+      // ---- dW1 += A1^T gz (contraction over the tile's samples) ----
+#pragma unroll
+      for (int j = 0; j < NBH; ++j) {
+        const int t = wave + NW * j;
+        if (t < HT * HT) {
+          f32x4 acc[1] = {dWh[j]};
+          mma_rr<1, TS>(A1t + (t / HT) * 16 * P::LKT, P::LKT, gzt, P::LKT, t % HT, acc, lane);
+          dWh[j] = acc[0];
+        }
+      }
+      __syncthreads();  // A1t is overwritten by gz1t below
+      // ---- gz1 = (gz W1^T) .* relu'(A1): row-major and transposed ----
+#pragma unroll
+      for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < HT) {
+          f32x4 acc[MT] = {};
+          mma_rr<MT, H>(gz, P::LKH, smem + P::W1R, P::LKH, nt, acc, lane);
+          const int col = nt * 16 + (lane & 15);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int row0 = m * 16 + (lane >> 4) * 4;
+            f32x4 v = acc[m];
+            if (relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (!((float)A1[(row0 + r) * P::LKH + col] > 0.f)) v[r] = 0.f;
+            }
+            store_rt(gz1, P::LKH, gz1t, P::LKT, m, nt, v, lane);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- dW0 += X^T gz1 ----
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
       const int t = wave + NW * j;
       if (t < K0T * HT) {
         f32x4 acc[1] = {dW0[j]};
-        mma_rr<1, TS>(Xt + (t / HT) * 16 * P::LKT, P::LKT, gzt, P::LKT, t % HT, acc, lane);
+        mma_rr<1, TS>(Xt + (t / HT) * 16 * P::LKT, P::LKT, gz1t, P::LKT, t % HT, acc, lane);
         dW0[j] = acc[0];
       }
     }
@@ -349,7 +437,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
         const int nt = wave + NW * j;
         if (nt < K0T) {
           f32x4 acc[MT] = {};
-          mma_rr<MT, H>(gz, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
+          mma_rr<MT, H>(gz1, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
           const int col = nt * 16 + (lane & 15);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
@@ -363,7 +451,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
     }
   }
   // ---- flush weight gradients ----
-  if (a.gW) {
+  if (a.gW || a.gWfx) {
     const int cl = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
@@ -373,7 +461,17 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = it * 16 + r0 + r;
-          if (row < a.d0) atomicAdd(a.gW + a.woff[0] + (int64_t)row * H + nt * 16 + cl, dW0[j][r] * (1.f / GS));
+          if (row < a.d0) gw_add(a, a.woff[0] + (int64_t)row * H + nt * 16 + cl, dW0[j][r] * (1.f / GS));
+        }
+      }
+    }
+    if (NH == 2) {
+#pragma unroll
+      for (int j = 0; j < NBH; ++j) {
+        const int t = wave + NW * j;
+        if (t < HT * HT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gw_add(a, a.woff[1] + (int64_t)((t / HT) * 16 + r0 + r) * H + (t % HT) * 16 + cl, dWh[j][r] * (1.f / GS));
         }
       }
     }
@@ -383,36 +481,36 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
       if (it < HT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (cl < a.dout) atomicAdd(a.gW + a.woff[1] + (int64_t)(it * 16 + r0 + r) * a.dout + cl, dWo[j][r] * (1.f / GS));
+          if (cl < a.dout) gw_add(a, a.woff[NH] + (int64_t)(it * 16 + r0 + r) * a.dout + cl, dWo[j][r] * (1.f / GS));
       }
     }
   }
 }
 
-template <typename T, int K0, int H>
+template <typename T, int K0, int H, int NH>
 static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
   if (bwd) {
     constexpr int TS = 32;
-    using P = PlanB<K0, H, TS>;
+    using P = PlanB<K0, H, NH, TS>;
     static_assert(P::BYTES <= LDS_LIMIT_B, "bf16 backward tile does not fit LDS");
     const int64_t n_tiles = (a.N + TS - 1) / TS;
     int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    auto k = mlp_lp_bwd_kernel<T, K0, H, TS>;
+    auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
   } else {
     constexpr int TS = 32;
-    using P = PlanF<K0, H, TS>;
+    using P = PlanF<K0, H, NH, TS>;
     const int64_t n_tiles = (a.N + TS - 1) / TS;
     int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    auto k = mlp_lp_fwd_kernel<T, K0, H, TS>;
+    auto k = mlp_lp_fwd_kernel<T, K0, H, NH, TS>;
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
@@ -421,14 +519,15 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
   return 0;
 }
 
-// (input width padded to 32, hidden width) with one hidden layer
-#define SNERF_MLP_BF16_SHAPES(X) X(32, 64) X(32, 128) X(64, 128) X(96, 128) X(128, 128) X(160, 128)
+// (input width padded to 32, hidden width, hidden layers)
+#define SNERF_MLP_BF16_SHAPES(X) X(32, 64, 1) X(32, 128, 1) X(64, 128, 1) X(96, 128, 1) X(128, 128, 1) X(160, 128, 1) \
+  X(32, 64, 2) /* K-Planes color_net 15->64->64->3 */ X(64, 64, 2) /* nerfplayer mlp_head 63->64->64->3 */
 
 bool mlp_bf16_supported(const snerf_mlp_desc* d) {
-  if (!d || d->n_hidden != 1 || d->d_out > 16 || d->d_in < 1) return false;
+  if (!d || d->d_out > 16 || d->d_in < 1) return false;
   const int k0 = (d->d_in + 31) / 32 * 32;
-#define CASE(K0, H) \
-  if (k0 == K0 && d->hidden == H) return true;
+#define CASE(K0, H, NH) \
+  if (k0 == K0 && d->hidden == H && d->n_hidden == NH) return true;
   SNERF_MLP_BF16_SHAPES(CASE)
 #undef CASE
   return false;
@@ -437,13 +536,12 @@ bool mlp_bf16_supported(const snerf_mlp_desc* d) {
 int mlp_bf16_dispatch(const snerf_mlp_desc* d, const void* args, bool bwd, hipStream_t st) {
   const MlpArgs& a = *static_cast<const MlpArgs*>(args);
   const int k0 = (d->d_in + 31) / 32 * 32;
-#define CASE(K0, H)                                                                       \
-  if (k0 == K0 && d->hidden == H && d->n_hidden == 1)                                     \
-    return d->operands == 2 ? launch_b<fp16, K0, H>(a, bwd, st) : launch_b<bf16, K0, H>(a, bwd, st);
+#define CASE(K0, H, NH)                                                                   \
+  if (k0 == K0 && d->hidden == H && d->n_hidden == NH)                                    \
+    return d->operands == 2 ? launch_b<fp16, K0, H, NH>(a, bwd, st) : launch_b<bf16, K0, H, NH>(a, bwd, st);
   SNERF_MLP_BF16_SHAPES(CASE)
 #undef CASE
-  set_error("mlp (16-bit operands): unsupported shape d_in=%d hidden=%d n_hidden=%d (one hidden layer of 64 / 128, d_in <= 160)", d->d_in, d->hidden,
-            d->n_hidden);
+  set_error("mlp (16-bit operands): unsupported shape d_in=%d hidden=%d n_hidden=%d", d->d_in, d->hidden, d->n_hidden);
   return SNERF_ERR_UNSUPPORTED;
 }
 

@@ -28,7 +28,31 @@ struct RegArgs {
   // optimiser sharding (one rank updates floats [range_lo, range_hi) of the segment): the grid starts at workgroup blk_base
   int blk_base;
   int64_t range_lo, range_hi;
+  snerf_adam_dyn* dyn;               // device-side step state (snerf_adam_prepare); null: step_size / inv_sqrt_bc2 above are used
 };
+
+// Device-side optimiser state of one parameter group (snerf.h: snerf_adam_dyn).  The kernels read {step_size, inv_sqrt_bc2, skip} from
+// it when given, so that a step can be skipped (the reference's GradScaler semantics) without the host ever reading the flag.
+struct DynConsts { float step_size, inv_sqrt_bc2; int skip; };
+__device__ __forceinline__ DynConsts load_dyn(const snerf_adam_dyn* dyn, float step_size, float inv_sqrt_bc2) {
+  DynConsts c = {step_size, inv_sqrt_bc2, 0};
+  if (dyn) { c.step_size = dyn->step_size; c.inv_sqrt_bc2 = dyn->inv_sqrt_bc2; c.skip = dyn->skip; }
+  return c;
+}
+
+__global__ void adam_prepare_kernel(snerf_adam_dyn* dyn, float lr, float b1, float b2, int policy, int force_nonfinite) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int nf = dyn->nonfinite | force_nonfinite;
+  const int skip = (policy == 1 && nf) ? 1 : 0;
+  dyn->nonfinite = 0;
+  dyn->skip = skip;
+  if (skip) { dyn->skipped += 1; return; }
+  const int t = dyn->t + 1;
+  dyn->t = t;
+  const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+  dyn->step_size = (float)((double)lr / bc1);
+  dyn->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
@@ -118,20 +142,28 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
       const int64_t o = a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
       // g, m, v are touched exactly once per step: stream them past the caches (nontemporal) so that L2 keeps the parameter lines
       // the neighbouring lanes re-read for the regulariser stencil
+      const DynConsts dc = load_dyn(a.dyn, a.step_size, a.inv_sqrt_bc2);
+      if (dc.skip) {  // skipped step (non-finite gradient somewhere in this parameter group): p, m, v unchanged, gradient cleared
+        stnt4(a.p_out + o, t);
+        if (a.zero_grad) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
+      } else {
       float4 gg = ldnt4(a.grad + o), mm = ldnt4(a.m + o), vv = ldnt4(a.v + o), pp = t;
       float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* RG = &g.x;
+      int ndrop = 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float gk = G[k] * a.grad_scale + RG[k];
-        if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;  // a non-finite gradient element is dropped, never written into m / v / p
+        if (!(fabsf(gk) <= 3.402823466e+38f)) { gk = 0.f; ++ndrop; }  // a non-finite gradient element is dropped (and counted), never written into m / v / p
         M[k] = a.b1 * M[k] + (1.f - a.b1) * gk;
         V[k] = a.b2 * V[k] + (1.f - a.b2) * gk * gk;
-        P[k] = P[k] - a.step_size * (M[k] / (sqrtf(V[k]) * a.inv_sqrt_bc2 + a.eps));
+        P[k] = P[k] - dc.step_size * (M[k] / (sqrtf(V[k]) * dc.inv_sqrt_bc2 + a.eps));
       }
+      if (ndrop && a.dyn) atomicAdd(&a.dyn->dropped, ndrop);
       stnt4(a.p_out + o, pp);
       stnt4(a.m + o, mm);
       stnt4(a.v + o, vv);
       if (a.zero_grad) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
     } else if (a.grad) {
       float* gp = a.grad + a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
       if (a.overwrite) {
@@ -162,24 +194,40 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
 // Optionally zeroes g afterwards (saves a separate memset sweep) and scales g first (gradient mean over ranks).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                  int64_t n, float step_size, float b1, float b2, float inv_sqrt_bc2, float eps,
-                                                  float grad_scale, int zero_grad) {
+                                                  int64_t n, float step_size_h, float b1, float b2, float inv_sqrt_bc2_h, float eps,
+                                                  float grad_scale, int zero_grad, snerf_adam_dyn* dyn) {
   // one float4 per lane, every buffer streamed past the caches once (nontemporal): as plane_reg_kernel's Adam path, which reaches
   // 6.1 TB/s against 4.6 TB/s for a 4096-workgroup grid-stride loop with cached accesses
   const int64_t n4 = n / 4;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const DynConsts dc = load_dyn(dyn, step_size_h, inv_sqrt_bc2_h);
+  const float step_size = dc.step_size, inv_sqrt_bc2 = dc.inv_sqrt_bc2;
+  if (dc.skip) {  // skipped step: p, m, v unchanged, gradient cleared
+    if (i < n4) {
+      if (p_out != p) stnt4(p_out + i * 4, ldnt4(p + i * 4));
+      if (zero_grad) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+      const int64_t j = n4 * 4 + threadIdx.x;
+      p_out[j] = p[j];
+      if (zero_grad) g[j] = 0.f;
+    }
+    return;
+  }
   if (i < n4) {
     float4 pp = ldnt4(p + i * 4), gg = ldnt4(g + i * 4), mm = ldnt4(m + i * 4), vv = ldnt4(v + i * 4);
     float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+    int ndrop = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float gk = G[k] * grad_scale;
-      if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;  // a non-finite gradient element is dropped, never written into m / v / p
+      if (!(fabsf(gk) <= 3.402823466e+38f)) { gk = 0.f; ++ndrop; }  // a non-finite gradient element is dropped (and counted), never written into m / v / p
       M[k] = b1 * M[k] + (1.f - b1) * gk;
       V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
       float denom = sqrtf(V[k]) * inv_sqrt_bc2 + eps;
       P[k] = P[k] - step_size * (M[k] / denom);
     }
+    if (ndrop && dyn) atomicAdd(&dyn->dropped, ndrop);
     stnt4(p_out + i * 4, pp);
     stnt4(m + i * 4, mm);
     stnt4(v + i * 4, vv);
@@ -189,7 +237,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
     int64_t i = n4 * 4 + threadIdx.x;
     float gk = g[i] * grad_scale;
-    if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;
+    if (!(fabsf(gk) <= 3.402823466e+38f)) { gk = 0.f; if (dyn) atomicAdd(&dyn->dropped, 1); }
     float mk = b1 * m[i] + (1.f - b1) * gk;
     float vk = b2 * v[i] + (1.f - b2) * gk * gk;
     m[i] = mk; v[i] = vk;
@@ -202,12 +250,18 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
 // (TemporalGridEncoder.get_temporal_tv_loss, temporal_grid.py:352-376): srow[r] = weight * sign(E[r,a] - E[r,b]) / rows was
 // written by tgrid_tv_sign_kernel from the OLD table, so the in-place update has no read-after-write hazard and the dense
 // gradient buffer is never read-modified-written for the TV term.
-__global__ __launch_bounds__(256) void adam_tv_kernel(float* p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float step_size,
-                                                     float b1, float b2, float inv_sqrt_bc2, float eps, float grad_scale, int zero_grad, int grid_C, int col_a,
-                                                     int col_b, const float* __restrict__ srow) {
+__global__ __launch_bounds__(256) void adam_tv_kernel(float* p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float step_size_h,
+                                                     float b1, float b2, float inv_sqrt_bc2_h, float eps, float grad_scale, int zero_grad, int grid_C, int col_a,
+                                                     int col_b, const float* __restrict__ srow, snerf_adam_dyn* dyn) {
   const int64_t n4 = n / 4;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;  // n is a multiple of 4 here (rows * grid_C with rows a multiple of 8)
+  const DynConsts dc = load_dyn(dyn, step_size_h, inv_sqrt_bc2_h);
+  const float step_size = dc.step_size, inv_sqrt_bc2 = dc.inv_sqrt_bc2;
+  if (dc.skip) {
+    if (zero_grad) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
   float4 pp = ldnt4(p + i * 4), gg = ldnt4(g + i * 4), mm = ldnt4(m + i * 4), vv = ldnt4(v + i * 4);
   float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
   const int64_t e0 = i * 4;
@@ -221,7 +275,7 @@ __global__ __launch_bounds__(256) void adam_tv_kernel(float* p, float* __restric
     float gk = G[k] * grad_scale;
     if (col == col_a) gk += srow[row];
     else if (col == col_b) gk -= srow[row];
-    if (!(fabsf(gk) <= 3.402823466e+38f)) gk = 0.f;
+    if (!(fabsf(gk) <= 3.402823466e+38f)) { gk = 0.f; if (dyn) atomicAdd(&dyn->dropped, 1); }
     M[k] = b1 * M[k] + (1.f - b1) * gk;
     V[k] = b2 * V[k] + (1.f - b2) * gk * gk;
     P[k] = P[k] - step_size * (M[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps));
@@ -277,13 +331,13 @@ static void adam_consts(float lr, float beta1, float beta2, int step, float& ste
 extern "C" int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
                                             float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
                                             float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, int64_t range_lo,
-                                            int64_t range_hi, snerf_stream_t stream) {
+                                            int64_t range_hi, snerf_adam_dyn* dyn, snerf_stream_t stream) {
   SNERF_REQUIRE(desc && p_in && p_out && g && m && v, "adam_planes_step: null argument");
   SNERF_REQUIRE(p_in != p_out, "adam_planes_step: parameters must ping-pong (p_in != p_out): the regulariser reads neighbours of the old values");
   SNERF_REQUIRE(desc->n_scales >= 1 && desc->n_scales <= SNERF_MAX_SCALES, "adam_planes_step: n_scales=%d", desc->n_scales);
   SNERF_REQUIRE(desc->C == 8 || desc->C == 16 || desc->C == 32, "adam_planes_step: C=%d unsupported", desc->C);
   SNERF_REQUIRE(desc->n_coords == 3 || desc->n_coords == 4, "adam_planes_step: n_coords=%d", desc->n_coords);
-  SNERF_REQUIRE(step >= 1 && (!losses || n_slots >= 1), "adam_planes_step: step=%d n_slots=%d", step, n_slots);
+  SNERF_REQUIRE((step >= 1 || dyn) && (!losses || n_slots >= 1), "adam_planes_step: step=%d n_slots=%d", step, n_slots);
   SNERF_REQUIRE(range_lo >= 0 && (range_lo & 3) == 0 && (range_hi & 3) == 0, "adam_planes_step: range [%lld, %lld) must be float4-aligned",
                 (long long)range_lo, (long long)range_hi);
   RegArgs a = {};
@@ -291,8 +345,8 @@ extern "C" int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, cons
   a.n_planes = desc->n_coords == 4 ? 6 : 3;
   a.planes = p_in; a.grad = g; a.c_tv = c_space_tv; a.c_smooth = c_time_smooth; a.c_l1 = c_sparse; a.losses = losses; a.n_slots = n_slots;
   a.p_out = p_out; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
-  a.range_lo = range_lo; a.range_hi = range_hi;
-  adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
+  a.range_lo = range_lo; a.range_hi = range_hi; a.dyn = dyn;
+  if (!dyn) adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
   static const int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3}, PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
   int64_t blocks = 0, b_lo = INT64_MAX, b_hi = -1;  // workgroups [b_lo, b_hi] hold every float4 of the range (memory order == grid order)
   for (int s = 0; s < desc->n_scales; ++s)
@@ -323,42 +377,53 @@ extern "C" int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, cons
 
 extern "C" int snerf_adam_planes_step(const snerf_kplanes_desc* desc, const float* p_in, float* p_out, float* g, float* m, float* v,
                                       float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
-                                      float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
+                                      float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_adam_dyn* dyn,
+                                      snerf_stream_t stream) {
   return snerf_adam_planes_step_range(desc, p_in, p_out, g, m, v, c_space_tv, c_time_smooth, c_sparse, losses, n_slots, lr, beta1, beta2, eps, step,
-                                      grad_scale, zero_grad, 0, INT64_MAX & ~(int64_t)3, stream);
+                                      grad_scale, zero_grad, 0, INT64_MAX & ~(int64_t)3, dyn, stream);
 }
 
 extern "C" int snerf_adam_step_tv(float* p, float* g, float* m, float* v, int64_t rows, int32_t grid_C, int32_t col_a, int32_t col_b, const float* srow,
-                                  float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
-  SNERF_REQUIRE(rows >= 1 && grid_C >= 4 && step >= 1, "adam_step_tv: rows=%lld grid_C=%d step=%d", (long long)rows, grid_C, step);
+                                  float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grad, snerf_adam_dyn* dyn,
+                                  snerf_stream_t stream) {
+  SNERF_REQUIRE(rows >= 1 && grid_C >= 4 && (step >= 1 || dyn), "adam_step_tv: rows=%lld grid_C=%d step=%d", (long long)rows, grid_C, step);
   SNERF_REQUIRE(col_a >= 0 && col_a < grid_C && col_b >= 0 && col_b < grid_C && col_a != col_b, "adam_step_tv: columns (%d, %d) of %d", col_a, col_b, grid_C);
   SNERF_REQUIRE(p && g && m && v && srow, "adam_step_tv: null buffer");
   const int64_t n = rows * grid_C;
   SNERF_REQUIRE((n & 3) == 0, "adam_step_tv: rows * grid_C = %lld must be a multiple of 4", (long long)n);
   SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step_tv: buffers must be 16-byte aligned");
-  float step_size, inv_sqrt_bc2;
-  adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
+  float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+  if (!dyn) adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
   const int64_t blocks = (n / 4 + 255) / 256;
   SNERF_REQUIRE(blocks < (1LL << 31), "adam_step_tv: table too large for one launch");
   hipLaunchKernelGGL(adam_tv_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2, eps,
-                     grad_scale, zero_grad, grid_C, col_a, col_b, srow);
+                     grad_scale, zero_grad, grid_C, col_a, col_b, srow, dyn);
   SNERF_LAUNCH_CHECK("adam_step_tv");
   return 0;
 }
 
 extern "C" int snerf_adam_step(const float* p, float* p_out, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                               int32_t step, float grad_scale, int32_t zero_grad, snerf_stream_t stream) {
-  SNERF_REQUIRE(n >= 0 && step >= 1, "adam_step: n=%lld step=%d (1-based)", (long long)n, step);
+                               int32_t step, float grad_scale, int32_t zero_grad, snerf_adam_dyn* dyn, snerf_stream_t stream) {
+  SNERF_REQUIRE(n >= 0 && (step >= 1 || dyn), "adam_step: n=%lld step=%d (1-based)", (long long)n, step);
   if (n == 0) return 0;
   SNERF_REQUIRE(p && p_out && g && m && v, "adam_step: null buffer");
   SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)p_out | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: buffers must be 16-byte aligned");
-  float step_size, inv_sqrt_bc2;
-  adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
+  float step_size = 0.f, inv_sqrt_bc2 = 0.f;
+  if (!dyn) adam_consts(lr, beta1, beta2, step, step_size, inv_sqrt_bc2);
   int64_t n4 = (n + 3) / 4;
   int64_t blocks = (n4 + 255) / 256;
   SNERF_REQUIRE(blocks < (1LL << 31), "adam_step: n=%lld too large for one launch", (long long)n);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, p_out, g, m, v, n, step_size, beta1, beta2, inv_sqrt_bc2,
-                     eps, grad_scale, zero_grad);
+                     eps, grad_scale, zero_grad, dyn);
   SNERF_LAUNCH_CHECK("adam_step");
+  return 0;
+}
+
+extern "C" int snerf_adam_prepare(snerf_adam_dyn* dyn, float lr, float beta1, float beta2, int32_t policy, int32_t force_nonfinite,
+                                  snerf_stream_t stream) {
+  SNERF_REQUIRE(dyn, "adam_prepare: null state");
+  SNERF_REQUIRE(policy == 0 || policy == 1, "adam_prepare: policy=%d (0 drop elements, 1 skip the step)", policy);
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dyn, lr, beta1, beta2, policy, force_nonfinite);
+  SNERF_LAUNCH_CHECK("adam_prepare");
   return 0;
 }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restrict__ density, const float* __restrict__ ebins,
                                                          const float* __restrict__ gw, int R, int S, float* __restrict__ gdens,
-                                                         int accumulate) {
+                                                         int accumulate, int32_t* __restrict__ nonfinite_flag) {
   __shared__ float s_a[RAYS_PER_BLOCK][MAX_S + 1];
   __shared__ float s_b[RAYS_PER_BLOCK][MAX_S + 1];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
   __syncthreads();
   // gw_i * w_i (0 where the forward weight was non-finite: nan_to_num passes no gradient there)
   float gwterm[5], Tk[5], ek[5];
+  bool bad = false;  // a value that autograd would have turned into a non-finite gradient (the reference's GradScaler then skips the step)
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     int i = lane + 64 * k;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
       // a non-finite weight (density = exp(x) overflowed to inf on a zero-width bin: 0 * inf) passes no gradient, as nan_to_num
       // does -- and must not leave a NaN factor behind: 0 * NaN is NaN (seen once in ~20 k training steps: one NaN here reaches
       // every parameter through the sigma net and the TV stencil within a few steps)
-      if (!fin) { Tk[k] = 0.f; ek[k] = 0.f; }
+      if (!fin) { Tk[k] = 0.f; ek[k] = 0.f; bad = bad || live; }
     }
   }
   __syncthreads();
@@ -271,10 +272,11 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
       float e0 = ebins[(int64_t)r * (S + 1) + i], e1 = ebins[(int64_t)r * (S + 1) + i + 1];
       float gdd = g * Tk[k] * ek[k] - aux[i];
       float out = gdd * (e1 - e0);
-      if (!(fabsf(out) <= 3.402823466e+38f)) out = 0.f;  // inf * 0 / NaN: no gradient (the reference's GradScaler would skip such a step)
+      if (!(fabsf(out) <= 3.402823466e+38f)) { out = 0.f; bad = true; }  // inf * 0 / NaN: no gradient (the reference's GradScaler skips such a step)
       if (accumulate) gdens[(int64_t)r * S + i] += out; else gdens[(int64_t)r * S + i] = out;
     }
   }
+  if (bad && nonfinite_flag) *nonfinite_flag = 1;  // plain store of a constant: racing writers agree
 }
 
 }  // namespace snerf
@@ -311,12 +313,12 @@ extern "C" int snerf_weights_fwd(const float* density, const float* ebins, int32
 }
 
 extern "C" int snerf_weights_bwd(const float* density, const float* ebins, const float* grad_weights, int32_t R, int32_t S,
-                                 float* grad_density, int32_t accumulate, snerf_stream_t stream) {
+                                 float* grad_density, int32_t accumulate, int32_t* nonfinite_flag, snerf_stream_t stream) {
   SNERF_REQUIRE(R >= 0 && S >= 1 && S <= MAX_S, "weights_bwd: R=%d S=%d (S <= %d)", R, S, MAX_S);
   if (R == 0) return 0;
   SNERF_REQUIRE(density && ebins && grad_weights && grad_density, "weights_bwd: null buffer");
   hipLaunchKernelGGL(weights_bwd_kernel, dim3(ceil_div(R, RAYS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, density, ebins, grad_weights,
-                     R, S, grad_density, accumulate);
+                     R, S, grad_density, accumulate, nonfinite_flag);
   SNERF_LAUNCH_CHECK("weights_bwd");
   return 0;
 }

@@ -73,6 +73,18 @@ def all_reduce_sum_(t: torch.Tensor, group, async_op: bool = False):
     return _Done()
 
 
+def all_reduce_max_(t: torch.Tensor, group):
+    """MAX all-reduce in place (tiny tensors: the optimiser's non-finite flags)."""
+    if _is_nccl(group):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    elif t.is_cuda:
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+
+
 def reduce_scatter_sum(out_shard: torch.Tensor, full: torch.Tensor, group, async_op: bool = False):
     """out_shard (numel n) = this rank's slice [rank*n, (rank+1)*n) of the SUM over ranks of `full` (numel world*n)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)

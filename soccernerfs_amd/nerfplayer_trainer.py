@@ -203,7 +203,7 @@ class NerfplayerTrainer:
                                                  2.0 / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]), self._st), "render_mse_bwd")
         _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, cfg.distortion_loss_mult / R, self._p(b["dist_rays"]),
                                              self._p(b["gw"][2]), 1, self._st), "distortion")
-        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
+        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0, None,
                                               self._st), "weights_bwd")
         # colour head: gX = [dSH (unused) | d geo | d appearance | pad]
         self._mlp_bwd(self.head, self.gviews["field.head"], b["hx"], 64, N2, b["grgb"], 3, -1, None, b["ghx"], 64)
@@ -222,7 +222,7 @@ class NerfplayerTrainer:
             if proposal_grads:
                 enc, net = self.prop_enc[lvl], self.prop_mlp[lvl]
                 _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp, self._p(b["gdens"][lvl]),
-                                                      0, self._st), "weights_bwd")
+                                                      0, None, self._st), "weights_bwd")
                 self._mlp_bwd(net, self.gviews[f"prop{lvl}.mlp"], b["pfeat"][lvl], enc.output_dim, Np, None, 1, 0, b["gdens"][lvl], b["gpfeat"][lvl],
                               enc.output_dim)
                 self._tgrid_bwd(enc, self._coords[lvl], t, Sp, Np, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.table"])
@@ -264,25 +264,27 @@ class NerfplayerTrainer:
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         tv = self.cfg.temporal_tv_weight > 0
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # one plain sweep per run of segments between (and after) the tables; with the TV term each table gets its own sweep that adds
+        # the TV gradient of its two columns.  Every parameter is stepped exactly once (`done` = first float not yet swept).
         done = 0
-        for k, (name, enc) in enumerate((("prop0.table", self.prop_enc[0]), ("prop1.table", self.prop_enc[1]), ("field.table", self.enc))):
-            o, n = off[name]
-            if o > done:  # the small segments in front of this table
-                sl = slice(done, o)
-                ops.adam_step(self.params[sl], self.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
-            kk = {"field.table": 0, "prop0.table": 1, "prop1.table": 2}[name]
-            if tv:
+        plain = lambda lo, hi: ops.adam_step(self.params[lo:hi], self.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.step + 1, lr,
+                                             eps=self.adam_eps, zero_grad=True)
+        if tv:
+            for name in ("prop0.table", "prop1.table", "field.table"):
+                o, n = off[name]
+                if o > done:  # the small segments in front of this table
+                    plain(done, o)
+                kk = {"field.table": 0, "prop0.table": 1, "prop1.table": 2}[name]
+                enc = self.enc if kk == 0 else self.prop_enc[kk - 1]
                 ca, cb = self._tv_cols[kk]
                 rows_, gc = enc.embeddings.shape
                 sl = slice(o, o + n)
                 _lib.check(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
                                                        C.c_int64(rows_), gc, ca, cb, self._p(self._srow[kk]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
-                                                       st), "adam_step_tv")
+                                                       None, st), "adam_step_tv")
                 done = o + n
-            # without TV the table is swept together with what follows
         if done < self.n_params:
-            sl = slice(done, self.n_params)
-            ops.adam_step(self.params[sl], self.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
+            plain(done, self.n_params)
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:

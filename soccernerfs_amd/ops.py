@@ -71,14 +71,19 @@ class _KPlanesGather(torch.autograd.Function):
 class SortedScatter:
     """Workspace + driver of the sorted plane-gradient scatter (csrc/kplanes_sorted.hip) for a fixed sample count N."""
 
-    def __init__(self, ps: PlaneSet, N: int, device):
+    def __init__(self, ps: PlaneSet, N: int, device, gvec_dtype: torch.dtype = torch.float32):
+        """gvec_dtype: element type of the per-plane gradient vectors between pass A and pass B -- float32 (exact) or bfloat16 (half the
+        bytes of the step's largest intermediate; the scatter accumulates in fp32 either way)."""
+        if gvec_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("gvec_dtype must be torch.float32 or torch.bfloat16")
         self.ps, self.N, self.desc = ps, N, ps.desc()
+        self.gvec_bf16 = int(gvec_dtype == torch.bfloat16)
         hc, ie = C.c_int64(0), C.c_int64(0)
         _lib.check(_lib.lib().snerf_kplanes_sort_workspace(C.byref(self.desc), C.c_int64(N), C.byref(hc), C.byref(ie)), "sort_workspace")
         self.hist = torch.empty(hc.value, dtype=torch.int32, device=device)
         self.rank = torch.empty(ie.value, dtype=torch.int32, device=device)
         self.sorted_rec = torch.empty(ie.value, 4, dtype=torch.float32, device=device)  # {sample id bits, pixel x, pixel y, 0}
-        self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=torch.float32, device=device)  # [scale*planes+plane][N][C]
+        self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=gvec_dtype, device=device)  # [scale*planes+plane][N][C]
 
     def sort(self, coords: _lib.Coords, stream=None):
         _lib.check(_lib.lib().snerf_kplanes_sort_samples(C.byref(self.desc), C.byref(coords), C.c_int64(self.N), _ptr(self.hist), _ptr(self.rank),
@@ -86,9 +91,9 @@ class SortedScatter:
 
     def scatter(self, planes, coords: _lib.Coords, gout, gplanes, stream=None):
         st = stream if stream is not None else _stream()
-        _lib.check(_lib.lib().snerf_kplanes_gradvec(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gout), _ptr(self.gvec), st),
+        _lib.check(_lib.lib().snerf_kplanes_gradvec(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gout), _ptr(self.gvec), self.gvec_bf16, st),
                    "gradvec")
-        _lib.check(_lib.lib().snerf_kplanes_scatter_sorted(C.byref(self.desc), C.c_int64(self.N), _ptr(self.gvec), _ptr(self.sorted_rec), _ptr(gplanes), st),
+        _lib.check(_lib.lib().snerf_kplanes_scatter_sorted(C.byref(self.desc), C.c_int64(self.N), _ptr(self.gvec), self.gvec_bf16, _ptr(self.sorted_rec), _ptr(gplanes), st),
                    "scatter_sorted")
 
 
@@ -145,7 +150,7 @@ class _Weights(torch.autograd.Function):
         R, S = density.shape
         gw = gw.contiguous()
         gd = torch.empty_like(density)
-        _lib.check(_lib.lib().snerf_weights_bwd(_ptr(density), _ptr(ebins), _ptr(gw), R, S, _ptr(gd), 0, _stream()), "weights_bwd")
+        _lib.check(_lib.lib().snerf_weights_bwd(_ptr(density), _ptr(ebins), _ptr(gw), R, S, _ptr(gd), 0, None, _stream()), "weights_bwd")
         return gd, None
 
 
@@ -497,25 +502,47 @@ def plane_regularizers(ps: PlaneSet) -> torch.Tensor:
     return _PlaneReg.apply(ps.planes, ps)
 
 
+def new_adam_dyn(device) -> torch.Tensor:
+    """Device-resident optimiser state of one parameter group (snerf_adam_dyn, include/snerf.h): int32[8], zero-initialised.
+    [0] nonfinite flag, [1] Adam steps taken, [2] steps skipped, [3] gradient elements dropped."""
+    return torch.zeros(8, dtype=torch.int32, device=device)
+
+
+def adam_prepare(dyn: torch.Tensor, lr: float, betas=(0.9, 0.999), policy: str = "skip_step", force_nonfinite: bool = False):
+    """Once per parameter group and step, before its Adam kernels: decides whether the step is skipped (GradScaler semantics,
+    NS/engine/trainer.py:394-408), advances the device-side step counter and the bias corrections."""
+    _lib.check(_lib.lib().snerf_adam_prepare(_ptr(dyn), lr, betas[0], betas[1], {"drop_elements": 0, "skip_step": 1}[policy], int(force_nonfinite),
+                                             _stream()), "adam_prepare")
+
+
 def adam_step(p, g, m, v, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12, grad_scale: float = 1.0, zero_grad: bool = False,
-              p_out=None):
-    """Fused Adam on flat fp32 buffers (1-based step); in place unless p_out is given."""
+              p_out=None, dyn: Optional[torch.Tensor] = None):
+    """Fused Adam on flat fp32 buffers (1-based step); in place unless p_out is given.  dyn: the group's device-side state
+    (adam_prepare) -- `step` is then ignored."""
     for t in (p, g, m, v):
         _f32c(t, "adam buffer")
     _lib.check(_lib.lib().snerf_adam_step(_ptr(p), _ptr(p if p_out is None else p_out), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, betas[0], betas[1], eps,
-                                          step, grad_scale, int(zero_grad), _stream()), "adam_step")
+                                          step, grad_scale, int(zero_grad), _ptr(dyn) if dyn is not None else None, _stream()), "adam_step")
 
 
 def adam_planes_step(ps: PlaneSet, p_in, p_out, g, m, v, coefs, losses, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12,
-                     grad_scale: float = 1.0, zero_grad: bool = True, shard_range=None):
+                     grad_scale: float = 1.0, zero_grad: bool = True, shard_range=None, dyn: Optional[torch.Tensor] = None):
     """Adam over one plane set with the plane regularisers fused in (ping-pong p_in -> p_out). coefs = (space_tv, time_smooth, sparse).
     shard_range = (lo, hi): update only floats [lo, hi) of the segment (this rank's optimiser shard); all tensors are whole segments."""
     desc = ps.desc()
     lo, hi = (0, ps.numel + 3 & ~3) if shard_range is None else shard_range
     _lib.check(_lib.lib().snerf_adam_planes_step_range(C.byref(desc), _ptr(p_in), _ptr(p_out), _ptr(g), _ptr(m), _ptr(v), coefs[0], coefs[1], coefs[2],
                                                        _ptr(losses) if losses is not None else None, REG_SLOTS if losses is not None else 0, lr,
-                                                       betas[0], betas[1], eps, step, grad_scale, int(zero_grad), int(lo), int(hi), _stream()),
+                                                       betas[0], betas[1], eps, step, grad_scale, int(zero_grad), int(lo), int(hi),
+                                                       _ptr(dyn) if dyn is not None else None, _stream()),
                "adam_planes_step")
+
+
+def fx_to_float(fx: torch.Tensor, out: torch.Tensor, accumulate: bool = False):
+    """Deterministic mode: fixed-point gradient cells (int64, value * 2^50) -> float gradients; clears the cells."""
+    if fx.dtype != torch.int64 or out.dtype != torch.float32 or fx.numel() != out.numel():
+        raise RuntimeError("fx_to_float: need an int64 cell buffer and a float32 buffer of the same length")
+    _lib.check(_lib.lib().snerf_fx_to_float(_ptr(fx), _ptr(out), fx.numel(), int(accumulate), _stream()), "fx_to_float")
 
 
 def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_plane: float = 0.0, training: bool = True):

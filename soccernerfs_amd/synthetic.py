@@ -5,9 +5,10 @@ Geometry constants follow the reference's Broadcast-style parser defaults (SURVE
 100 frames at 25 fps subsampled by fps_downsample (3 -> 33 frames per camera, 627 train images),
 camera translations scaled so max|t| = 1, scene_scale 1.5 => aabb [-1.5,1.5]^3, times = frame/max_frame in [0,1]
 (NS/data/dataparsers/broadcaststyle_dataparser.py:166-232,408-480).  Content is an analytic scene ray-cast on
-the GPU with torch ops: a static textured ground plane plus a "player" (two stacked spheres) and a ball on a
-parabolic arc that together cover <~1 % of the pixels, so temporal-difference (IST) maps are sparse.
-Data plumbing only -- not part of the measured hot path.
+the GPU with torch ops: a static textured ground plane plus three "players" (two stacked spheres each, a few pixels wide,
+moving a few body widths during the clip) and a ball on a parabolic arc.  Together they cover ~0.5 % of a frame and their
+motion sweeps ~2 % of the pixels over the clip, so temporal-difference (IST) maps are sparse as in the real footage
+(REF/data/README.md:17; the round-1 scene swept 25 %).  Data plumbing only -- not part of the measured hot path.
 """
 import math
 from typing import Dict
@@ -31,6 +32,31 @@ def make_cameras(n_cams: int = 20, width: int = 960, height: int = 540, device="
     return {"c2w": c2w.to(device), "fx": torch.full((n_cams,), focal, device=device), "fy": torch.full((n_cams,), focal, device=device),
             "cx": torch.full((n_cams,), width / 2.0, device=device), "cy": torch.full((n_cams,), height / 2.0, device=device),
             "width": width, "height": height}
+
+
+def make_novel_cameras(n: int = 3, width: int = 960, height: int = 540, n_train_cams: int = 20, device="cpu") -> Dict[str, torch.Tensor]:
+    """Evaluation-only cameras BETWEEN the training cameras of make_cameras (half-way angles, mid height): interpolated novel views,
+    rendered from the analytic scene.  They share make_cameras' translation scale so that both sets live in one world frame."""
+    ref = make_cameras(n_train_cams, width, height)
+    raw_max = max(max(abs(math.sin(math.radians(-60 + 120 * i / (n_train_cams - 1)))), abs(math.cos(math.radians(-60 + 120 * i / (n_train_cams - 1)))),
+                      0.35 + 0.15 * (i % 3)) for i in range(n_train_cams))
+    c2w = []
+    for j in range(n):
+        i = (j + 0.5) * (n_train_cams - 1) / n  # between two training cameras
+        i = math.floor(i) + 0.5
+        ang = math.radians(-60 + 120 * i / (n_train_cams - 1))
+        pos = torch.tensor([math.sin(ang) * 1.0, -math.cos(ang) * 1.0, 0.42]) / raw_max
+        target = torch.tensor([0.1 * math.sin(2 * j + 1), 0.08 * math.cos(3 * j), 0.0])
+        fwd = torch.nn.functional.normalize(target - pos, dim=0)
+        right = torch.nn.functional.normalize(torch.linalg.cross(fwd, torch.tensor([0.0, 0.0, 1.0])), dim=0)
+        up = torch.linalg.cross(right, fwd)
+        c2w.append(torch.cat([torch.stack([right, up, -fwd], dim=1), pos[:, None]], dim=1))
+    c2w = torch.stack(c2w).float()
+    out = {k: (v[:1].expand(n).clone() if torch.is_tensor(v) and v.dim() == 1 else v) for k, v in ref.items()}
+    out["c2w"] = c2w.to(device)
+    for k in ("fx", "fy", "cx", "cy"):
+        out[k] = out[k].to(device)
+    return out
 
 
 def frame_times(n_frames: int = 100, fps_downsample: int = 3) -> torch.Tensor:
@@ -62,12 +88,21 @@ def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
     inside = (pg[:, 0].abs() < 1.45) & (pg[:, 1].abs() < 1.45)
     col = torch.where((torch.isfinite(tg) & inside)[:, None], green, sky)
     depth = torch.where(torch.isfinite(tg) & inside, tg, torch.full_like(tg, float("inf")))
-    # dynamic content
+    # dynamic content: three players (torso + head) that move a few body widths during the clip, and a ball on a parabolic arc
     tt = time
-    ball_c = torch.stack([-0.6 + 1.2 * tt, 0.2 * torch.sin(6.28 * tt), -0.07 + 1.2 * tt * (1 - tt)], -1)
-    body_c = torch.stack([0.4 * torch.cos(3.14 * tt), -0.3 + 0.5 * tt, torch.full_like(tt, -0.04)], -1)
-    head_c = body_c + torch.tensor([0.0, 0.0, 0.085], device=o.device)
-    for c, r, rgb in ((ball_c, 0.03, (0.95, 0.95, 0.9)), (body_c, 0.06, (0.85, 0.1, 0.1)), (head_c, 0.03, (0.9, 0.75, 0.6))):
+    z0 = torch.full_like(tt, -0.08)
+    head_up = torch.tensor([0.0, 0.0, 0.028], device=o.device)
+    players = (
+        (torch.stack([0.25 + 0.07 * tt, -0.20 + 0.04 * torch.sin(3.14 * tt), z0], -1), (0.85, 0.1, 0.1)),
+        (torch.stack([-0.35 + 0.05 * torch.cos(3.14 * tt), 0.15 + 0.06 * tt, z0], -1), (0.1, 0.15, 0.8)),
+        (torch.stack([-0.05 - 0.06 * tt, 0.35 - 0.05 * tt * tt, z0], -1), (0.95, 0.85, 0.1)),
+    )
+    ball_c = torch.stack([-0.25 + 0.4 * tt, 0.08 * torch.sin(6.28 * tt), -0.09 + 0.5 * tt * (1 - tt)], -1)
+    spheres = [(ball_c, 0.008, (0.95, 0.95, 0.9))]
+    for body_c, shirt in players:
+        spheres.append((body_c, 0.02, shirt))
+        spheres.append((body_c + head_up, 0.01, (0.9, 0.75, 0.6)))
+    for c, r, rgb in spheres:
         t = _sphere_hit(o, d, c, r)
         hit = t < depth
         n = torch.nn.functional.normalize(o + d * t.clamp(max=1e4)[:, None] - c, dim=-1)

@@ -45,7 +45,8 @@ class Network(nn.Module):
             raise ValueError(f"operands must be 'fp32', 'bf16' or 'fp16', got {operands!r}")
         d.operands = {"fp32": 0, "bf16": 1, "fp16": 2}[operands]
         if d.operands != 0 and not _lib.lib().snerf_mlp_supported(C.byref(d)):
-            raise ValueError(f"16-bit operands are built for one hidden layer of 64 / 128 and d_in <= 160; got {n_input_dims} -> {d.hidden} x {d.n_hidden}")
+            raise ValueError(f"16-bit operands are built for d_in <= 160 -> 128 | d_in <= 32 -> 64 (one hidden layer) and d_in <= 64 -> 64 -> 64; "
+                             f"got {n_input_dims} -> {d.hidden} x {d.n_hidden}")
         self.desc = d
         self.operands = operands
         self.hidden_act, self.out_act = network_config["activation"], network_config["output_activation"]

@@ -52,10 +52,30 @@ class KPlanesTrainConfig:
     max_steps: int = 30000
     lr_alpha: float = 0.0
     seed: int = 0
-    # MFMA operand type of the one-hidden-layer nets (sigma_net, proposal sigma nets): "fp32" = exact (parity tests); "fp16" / "bf16" =
+    # MFMA operand type of every net (sigma_net, color_net, proposal sigma nets): "fp32" = exact (parity tests); "fp16" / "bf16" =
     # 16-bit operands with fp32 accumulation (csrc/mlp_lp.hip; tcnn itself computes these nets in fp16, BASELINE config 2 names bf16).
-    # The two-hidden-layer colour net stays fp32 either way.
     mlp_operands: str = "fp32"
+    # ---- execution switches (defaults = the measured best; bench.py / tools expose them for A-B runs) ----
+    overlap: bool = True              # independent kernel chains on role streams (False: everything on the caller's stream)
+    async_field_adam: bool = True     # field planes' optimiser sweep on its own stream under the NEXT step's proposal levels
+    adam_under_scatter: bool = False  # sweep the finest scale while the coarser scales are scattered (measured +1 %: off)
+    bwd_chunks: int = 1               # ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)
+    prop_on_main: bool = False        # proposal backward on the main stream ahead of the field chain
+    defer_prop: bool = True           # join the proposal chain only in front of the proposal planes' own optimiser kernels
+    sorted_scatter: bool = True       # sorted / grouped plane-gradient scatter for the field (csrc/kplanes_sorted.hip)
+    sorted_scatter_proposals: bool = False
+    fuse_reg_into_adam: bool = True   # plane regularisers inside the optimiser sweep (ping-pong parameter buffers)
+    shard_optimizer: bool = True      # world > 1: reduce-scatter -> Adam on a 1/world shard -> all-gather (False: one all-reduce)
+    grad_transport: str = "fp32"      # world > 1, sharded: "bf16" halves the reduce-scatter bytes (not the reference's fp32 DDP)
+    param_transport: str = "fp32"     # world > 1, sharded: "bf16" gathers the parameter UPDATES in bf16
+    # fixed-point (int64) gradient accumulation instead of float atomics: sums no longer depend on the order in which wavefronts
+    # arrive, so two runs from one seed are bit-identical (debugging / reproducibility; ~2x slower steps)
+    deterministic: bool = False
+    # what a non-finite gradient does.  "skip_step": the whole optimiser step of that parameter group is skipped, as the
+    # reference's GradScaler does (NS/engine/trainer.py:394-408, one found_inf per optimiser); "drop_elements": only the
+    # non-finite elements are dropped (round-1 behaviour)
+    nonfinite_policy: str = "skip_step"
+    fused_field: bool = False
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -90,23 +110,26 @@ class KPlanesTrainer:
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         # world > 1: reduce-scatter + sharded Adam + all-gather for the field planes instead of one all-reduce (see dist.py)
-        self.shard_optimizer = self.world > 1
+        self.shard_optimizer = self.world > 1 and cfg.shard_optimizer
         # opt-in half-width transports of the sharded step: "bf16" rounds the field-plane gradient before the reduce-scatter /
         # gathers the parameter UPDATES in bf16; "fp32" (default) keeps the reference's DDP semantics
-        self.grad_transport, self.param_transport = "fp32", "fp32"
+        self.grad_transport, self.param_transport = cfg.grad_transport, cfg.param_transport
         self._delta_pending, self._g16, self._d16_full = False, None, None
-        # A/B switches of the stream layout (tools/train_psnr.py, bench.py): proposal backward on the main stream; join of the proposal
-        # chain deferred into the optimiser step
-        self.prop_on_main, self.defer_prop = False, True
+        # execution switches (KPlanesTrainConfig); plain attributes so that A-B tools can flip them between steps.
         # async_field_adam: the field planes' optimiser sweep runs on its own stream under the NEXT step's pixel draw / ray generation /
         # proposal levels (which read only the small segments); forward() joins it before the field gather, loss_dict() and
         # synchronize() join it for outside readers -- call synchronize() before reading parameters / Adam state / gradients from
-        # outside a train step.  +3-5 % (bench.py --sync-adam for A-B).  adam_under_scatter (sweep the finest scale while the coarser
-        # scales are still being scattered) measured +1 % and stays off.
-        self.async_field_adam = True
-        self.adam_under_scatter = False
+        # outside a train step.  +3-5 % (bench.py --sync-adam for A-B).
+        self.overlap, self.bwd_chunks = cfg.overlap, cfg.bwd_chunks
+        self.prop_on_main, self.defer_prop = cfg.prop_on_main, cfg.defer_prop
+        self.async_field_adam, self.adam_under_scatter = cfg.async_field_adam, cfg.adam_under_scatter
         self._field_adam_done = None
+        self._prop_pending = None
+        self._grad_scale = 1.0
+        self._pipeline_adam, self._early_adam_hi, self._reg_zeroed = False, None, False
+        self._dyn_step = 0
         self._rs_work = self._ar_work = self._ag_work = self._reg_work = None
+        self._side = {}  # role -> HIP stream, created on first use
         gen = torch.Generator().manual_seed(cfg.seed)
         a = cfg.aabb_scale
         self.aabb = [[-a, -a, -a], [a, a, a]]
@@ -115,9 +138,7 @@ class KPlanesTrainer:
         def mlp(din, dout, h, nh, act):
             ncfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": h, "n_hidden_layers": nh}
             seed = int(torch.randint(0, 2**31, (1,), generator=gen))
-            want = cfg.mlp_operands
-            ops_ = want if (nh == 1 and din <= 160 and h in (64, 128)) else "fp32"
-            return Network(din, dout, ncfg, seed=seed, operands=ops_)
+            return Network(din, dout, ncfg, seed=seed, operands=cfg.mlp_operands)
 
         self.field_planes = PlaneSet(cfg.feature_dim, reso, concat=True, a=0.1, b=0.5, generator=gen)
         self.sigma_net = mlp(cfg.feature_dim * len(reso), 16, cfg.sigma_net_hidden_dim, 1, "None")
@@ -155,8 +176,14 @@ class KPlanesTrainer:
             self.params[o:o + n].copy_(getattr(mod, attr).detach())
             self.gviews[name], self.mviews[name], self.vviews[name] = self.grads[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n]
         self._repoint(self.params)
+        # device-resident optimiser state per parameter group (= per torch optimiser of the reference, kplanes.py:311-316): skip-step flag,
+        # Adam step counter, counters of skipped steps / dropped elements (include/snerf.h: snerf_adam_dyn)
+        self._dyn = {"fields": ops.new_adam_dyn(self.dev), "proposal_networks": ops.new_adam_dyn(self.dev)}
+        self._prepared = set()
+        # deterministic mode: gradients accumulate as 64-bit fixed point (same layout as self.grads) and are converted once per step
+        self.grads_fx = torch.zeros(off, dtype=torch.int64, device=self.dev) if cfg.deterministic else None
         # the regulariser-fused optimiser sweep reads neighbours of the OLD parameters: parameters ping-pong between two buffers
-        self.fuse_reg_into_adam = True
+        self.fuse_reg_into_adam = cfg.fuse_reg_into_adam
         self._params_alt = torch.zeros_like(self.params)
         if self.world > 1:
             shard = self._field_seg[2] // self.world
@@ -184,13 +211,14 @@ class KPlanesTrainer:
         }
         self._timing, self._timing_all = None, False
         # sorted plane-gradient scatter for the main field (csrc/kplanes_sorted.hip): ~6x fewer atomic requests
-        self.sorted_scatter = True
-        self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev)
+        self.sorted_scatter = cfg.sorted_scatter
+        self._gvec_dtype = torch.float32 if cfg.mlp_operands == "fp32" else torch.bfloat16  # 16-bit gradient vectors ride with 16-bit MLP operands
+        self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype)
         self._ss.desc = self.field_planes.desc()
         self._sort_done = None
         # sorted scatter for the proposal planes too (opt-in; measured SLOWER at the preset: the planes are small enough that their
         # atomics are served by L2 -- 0.5 M of 19 M requests reach memory -- while sorting 1.5 M samples x 6 planes costs ~0.6 ms)
-        self.sorted_scatter_proposals = False
+        self.sorted_scatter_proposals = cfg.sorted_scatter_proposals
         self._ss_prop = None
         self._sort_done_prop = [None, None]
         self.step = 0                 # completed optimiser steps
@@ -253,10 +281,19 @@ class KPlanesTrainer:
       with self._span("kplanes_gather_fwd.field" if desc is self._desc_field else "kplanes_gather_fwd.prop"):
         _lib.check(self.lib.snerf_kplanes_gather_fwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(out), self._st), "gather_fwd")
 
+    def _fx(self, gview: torch.Tensor) -> torch.Tensor:
+        """The fixed-point cells behind a view of self.grads (deterministic mode)."""
+        o = gview.storage_offset() - self.grads.storage_offset()
+        return self.grads_fx[o:o + gview.numel()]
+
     def _scatter(self, desc, planes, coords, N, gout, gplanes):
       with self._span("kplanes_gather_bwd.field" if desc is self._desc_field else "kplanes_gather_bwd.prop"):
-        _lib.check(self.lib.snerf_kplanes_gather_bwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(gout), self._p(gplanes),
-                                                     self._st), "gather_bwd")
+        if self.grads_fx is not None:
+            _lib.check(self.lib.snerf_kplanes_gather_bwd_fx(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(gout),
+                                                            self._p(self._fx(gplanes)), self._st), "gather_bwd_fx")
+        else:
+            _lib.check(self.lib.snerf_kplanes_gather_bwd(C.byref(desc), self._p(planes), C.byref(coords), C.c_int64(N), self._p(gout), self._p(gplanes),
+                                                         self._st), "gather_bwd")
 
     def _mlp_fwd(self, net, X, ldx, N, Y, ldy, aux_col=-1, aux=None):
       with self._span(f"mlp_fwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
@@ -265,9 +302,11 @@ class KPlanesTrainer:
 
     def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
       with self._span(f"mlp_bwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
-        _lib.check(self.lib.snerf_mlp_bwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
-                                          self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
-                                          self._p(gX) if gX is not None else None, ldgx, self._p(self.gviews[gname]), self._st), "mlp_bwd")
+        fn = self.lib.snerf_mlp_bwd_fx if self.grads_fx is not None else self.lib.snerf_mlp_bwd
+        gw = self._fx(self.gviews[gname]) if self.grads_fx is not None else self.gviews[gname]
+        _lib.check(fn(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
+                      self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
+                      self._p(gX) if gX is not None else None, ldgx, self._p(gw), self._st), "mlp_bwd")
 
     def _resample(self, lvl, rand, anneal):
         """density[lvl] -> weights[lvl] (stored) -> PDF sample level lvl+1 bins."""
@@ -311,9 +350,9 @@ class KPlanesTrainer:
             if lvl < 2:
                 self._gather(self._desc_prop[lvl], self.prop_planes[lvl].planes, co, N, b["pfeat"][lvl])
                 self._sort_done_prop[lvl] = None
-                if training and self.sorted_scatter_proposals and R == self.R:
+                if training and self.sorted_scatter_proposals and self.grads_fx is None and R == self.R:
                     if self._ss_prop is None:
-                        self._ss_prop = [ops.SortedScatter(self.prop_planes[l], R * self.S[l], self.dev) for l in range(2)]
+                        self._ss_prop = [ops.SortedScatter(self.prop_planes[l], R * self.S[l], self.dev, self._gvec_dtype) for l in range(2)]
                     main = torch.cuda.current_stream()
                     st = self._stream("sort")
                     st.wait_stream(main)
@@ -325,7 +364,7 @@ class KPlanesTrainer:
             else:
                 self._wait_params()
                 self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
-                if training and self.sorted_scatter and R == self.R:
+                if training and self.sorted_scatter and self.grads_fx is None and R == self.R:
                     # sort the nerf-level samples per (scale, plane) on a side stream.  Started AFTER the (memory-bound) gather so
                     # that it runs under the MFMA-bound MLP forward / backward that follow on the main stream.
                     main = torch.cuda.current_stream()
@@ -368,8 +407,6 @@ class KPlanesTrainer:
     def _stream(self, role: str):
         """Side stream by role, created on first use (so the common path holds main + "sort" + "prop" only: HIP multiplexes
         streams onto GPU_MAX_HW_QUEUES = 4 hardware queues and chains sharing a queue do not overlap)."""
-        if not hasattr(self, "_side"):
-            self._side = {}
         if role not in self._side:
             self._side[role] = torch.cuda.Stream(device=self.dev)
         return self._side[role]
@@ -399,22 +436,22 @@ class KPlanesTrainer:
         self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1], sl(b["gfeat"]), F)
         rays = self.rays
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
-        if self.sorted_scatter and self._sort_done is not None and r0 == 0 and r1 == self.R:
+        if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:
             torch.cuda.current_stream().wait_event(self._sort_done)
             ss = self._ss
             with self._span("kplanes_gradvec.field"):
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
-                                                          self._p(b["gfeat"]), self._p(ss.gvec), self._st), "gradvec")
+                                                          self._p(b["gfeat"]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
             ns = len(self.cfg.multiscale_res)
-            early = getattr(self, "_pipeline_adam", False) and ns > 1
+            early = self._pipeline_adam and ns > 1
             with self._span("kplanes_scatter_sorted.field"):
                 # finest scale first: it holds ~3/4 of the plane parameters, so its optimiser sweep (HBM-bound) can start on a side
                 # stream while the other scales are still being scattered (atomic-bound)
                 if early:
-                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
                                                                             self._p(self.gviews["field.planes"]), ns - 1, ns, self._st), "scatter_sorted")
                     self._adam_field_range(self._finest_offset(), None, side=True)
-                _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
                                                                         self._p(self.gviews["field.planes"]), 0, ns - 1 if early else ns, self._st),
                            "scatter_sorted")
         else:
@@ -431,7 +468,7 @@ class KPlanesTrainer:
             if proposal_grads:
                 N = R * Sp
                 _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp,
-                                                      self._p(b["gdens"][lvl]), 0, self._st), "weights_bwd")
+                                                      self._p(b["gdens"][lvl]), 0, self._p(self._dyn["proposal_networks"]), self._st), "weights_bwd")
                 self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
                               b["gpfeat"][lvl], cfg.proposal_feature_dim)
                 if self.sorted_scatter_proposals and self._sort_done_prop[lvl] is not None:
@@ -439,9 +476,9 @@ class KPlanesTrainer:
                     ss = self._ss_prop[lvl]
                     with self._span("kplanes_gradvec.prop"):
                         _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.prop_planes[lvl].planes), C.byref(self._coords[lvl]),
-                                                                  C.c_int64(N), self._p(b["gpfeat"][lvl]), self._p(ss.gvec), self._st), "gradvec")
+                                                                  C.c_int64(N), self._p(b["gpfeat"][lvl]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
                     with self._span("kplanes_scatter_sorted.prop"):
-                        _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(N), self._p(ss.gvec), self._p(ss.sorted_rec),
+                        _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
                                                                          self._p(self.gviews[f"prop{lvl}.planes"]), self._st), "scatter_sorted")
                 else:
                     self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl],
@@ -458,10 +495,10 @@ class KPlanesTrainer:
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
         S2 = self.S[2]
         main = torch.cuda.current_stream()
-        overlap = getattr(self, "overlap", True)
+        overlap = self.overlap
         sharded = self._sharded()  # the field-plane gradient leaves for the reduce-scatter as soon as it is complete, and the
         #                            proposal backward runs AFTER it, under the collective
-        n_chunks = max(1, min(getattr(self, "bwd_chunks", 1), R)) if overlap and not sharded else 1
+        n_chunks = max(1, min(self.bwd_chunks, R)) if overlap and not sharded else 1
         joins = []
         reg_done = None
         if include_reg:
@@ -498,7 +535,7 @@ class KPlanesTrainer:
         _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, co["distortion_loss"] / R, self._p(b["dist_rays"]),
                                              self._p(b["gw"][2]), 1, self._st), "distortion")
         _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
-                                              self._st), "weights_bwd")
+                                              self._p(self._dyn["fields"]), self._st), "weights_bwd")
         if reg_done is not None:
             main.wait_event(reg_done)
         if n_chunks == 1:
@@ -533,7 +570,7 @@ class KPlanesTrainer:
                 main.wait_stream(st)
 
     def _join_prop(self):
-        if getattr(self, "_prop_pending", None) is not None:
+        if self._prop_pending is not None:
             torch.cuda.current_stream().wait_stream(self._prop_pending)
             self._prop_pending = None
 
@@ -544,7 +581,7 @@ class KPlanesTrainer:
         self._join_prop()
         if self._reg_work is not None:
             self._reg_work.wait()  # sharded optimiser: the field planes' regulariser values are summed across ranks asynchronously
-        if getattr(self, "_field_adam_done", None) is not None:
+        if self._field_adam_done is not None:
             torch.cuda.current_stream().wait_event(self._field_adam_done)  # the regulariser values come out of the (async) optimiser sweep
         d = dict(self.last)
         d["rgb_loss"] = b["sqerr"].sum() / (3 * R) * co["rgb_loss"]
@@ -574,7 +611,7 @@ class KPlanesTrainer:
                 o, _, npad = self._field_seg
                 torch.add(self._params_alt[o:o + npad], self._d16_full, out=self.params[o:o + npad])
                 self._delta_pending = False
-        ev = getattr(self, "_field_adam_done", None)
+        ev = self._field_adam_done
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             self._field_adam_done = None
@@ -591,6 +628,7 @@ class KPlanesTrainer:
         from . import dist as sdist
 
         o, _, npad = self._field_seg
+        self._convert_fx(o, o + npad)
         with self._span("reduce_scatter.field"):
             if self.grad_transport == "bf16":
                 # opt-in: half the bytes on the links (each rank rounds its own gradient to bf16, the SUM is formed in bf16 by the collective);
@@ -602,6 +640,42 @@ class KPlanesTrainer:
                 self._rs_work = sdist.reduce_scatter_sum(self._g16_shard, self._g16, self.pg, async_op=True)
             else:
                 self._rs_work = sdist.reduce_scatter_sum(self._g_shard, self.grads[o:o + npad], self.pg, async_op=True)
+
+    def _prepare_group(self, name: str, lr: float):
+        """Once per step and parameter group, on the current stream, after the group's gradient producers and before its Adam kernels:
+        skip decision + device-side step counter / bias corrections (ops.adam_prepare)."""
+        if name in self._prepared:
+            return
+        if self._dyn_step != self.step:  # self.step was set from outside (checkpoint load, bench --start-step): Adam's counter follows
+            for d in self._dyn.values():
+                d[1] = self.step
+            self._dyn_step = self.step
+        if self.world > 1:  # DDP all-reduces the gradients, so a non-finite value on one rank is one on every rank: share the flag
+            from . import dist as sdist
+
+            sdist.all_reduce_max_(self._dyn[name][:1], self.pg)
+        ops.adam_prepare(self._dyn[name], lr, policy=self.cfg.nonfinite_policy)
+        self._prepared.add(name)
+
+    def _finish_step(self):
+        self._prepared.clear()
+        self.step += 1
+        self._dyn_step = self.step
+
+    def _convert_fx(self, lo: int = 0, hi: Optional[int] = None):
+        """Deterministic mode: fixed-point cells [lo, hi) -> self.grads (added; the cells are cleared)."""
+        if self.grads_fx is not None:
+            hi = self.n_params if hi is None else hi
+            ops.fx_to_float(self.grads_fx[lo:hi], self.grads[lo:hi], accumulate=True)
+
+    def skipped_steps(self) -> Dict[str, int]:
+        """Optimiser steps skipped so far per parameter group (non-finite gradients under nonfinite_policy = "skip_step") and
+        gradient elements dropped by the Adam kernels.  Synchronises."""
+        out = {}
+        for name, d in self._dyn.items():
+            h = d.cpu().tolist()
+            out[name] = {"adam_steps": h[1], "skipped": h[2], "dropped_elements": h[3]}
+        return out
 
     def _sharded_optimizer_step(self):
         """After backward() (all side streams joined): all-reduce of the small segments, Adam + regularisers on this rank's shard
@@ -617,6 +691,11 @@ class KPlanesTrainer:
         lo = self.rank * shard
         hi = min(lo + shard, _align4(n))
         new = self._params_alt
+        self._convert_fx(0, o)
+        self._convert_fx(o + npad, None)
+        self._prepare_group("fields", lr)
+        self._prepare_group("proposal_networks", lr)
+        dyn_f, dyn_p = self._dyn["fields"], self._dyn["proposal_networks"]
         # small segments: [prop0 planes | prop0 mlp | prop1 planes | prop1 mlp] before the field planes, [sigma | color] after them
         with self._span("allreduce_grads"):
             small = [self.grads[:o], self.grads[o + npad:]]
@@ -630,7 +709,8 @@ class KPlanesTrainer:
             if hi > lo:
                 ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
                                      self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
-                                     self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=False, shard_range=(lo, hi))
+                                     self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=False, shard_range=(lo, hi),
+                                     dyn=dyn_f)
         if self.param_transport == "bf16":
             # opt-in: gather the shard's UPDATE in bf16 (half the bytes; 2^-9 relative rounding of the update, not of the parameter);
             # applied in _wait_params.  NOT the reference's semantics (replicas hold old + bf16(update) instead of the fp32 Adam result).
@@ -655,24 +735,25 @@ class KPlanesTrainer:
                 ops.adam_planes_step(ps, self.views[name], new[off[name][0]:off[name][0] + off[name][1]], self.gviews[name], self.mviews[name],
                                      self.vviews[name], tuple(co[k] for k in ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
                                                                               "sparse_transients_proposal_loss")),
-                                     self.buf["reg"][1 + i], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs)
+                                     self.buf["reg"][1 + i], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, dyn=dyn_p)
         self._adam_mlps(new, off, lr, gs)
         self.grads[o:o + npad].zero_()  # the shard kernel leaves the gradient alone: clear the whole segment for the next step
         # regulariser VALUES of the field planes are per-shard partial sums: add them up across ranks (logging only)
         self._reg_work = sdist.all_reduce_sum_(self.buf["reg"][0], self.pg, async_op=True)
         self._params_alt = self.params
         self._repoint(new)
-        self.step += 1
+        self._finish_step()
 
     def _adam_mlps(self, new, off, lr, gs):
         with self._span("adam_step.mlps"):
             # MLP segments: prop0.mlp, prop1.mlp and the adjacent field.sigma + field.color
             o0, n0 = off["field.sigma"]
             o1, n1 = off["field.color"]
-            for o, n in (off["prop0.mlp"], off["prop1.mlp"], (o0, o1 + n1 - o0)):
+            dyn_f, dyn_p = self._dyn["fields"], self._dyn["proposal_networks"]
+            for (o, n), dyn in ((off["prop0.mlp"], dyn_p), (off["prop1.mlp"], dyn_p), ((o0, o1 + n1 - o0), dyn_f)):
                 n4 = (n + 3) // 4 * 4
                 ops.adam_step(self.params[o:o + n4], self.grads[o:o + n4], self.exp_avg[o:o + n4], self.exp_avg_sq[o:o + n4], self.step + 1, lr,
-                              eps=self.cfg.adam_eps, grad_scale=gs, zero_grad=True, p_out=new[o:o + n4])
+                              eps=self.cfg.adam_eps, grad_scale=gs, zero_grad=True, p_out=new[o:o + n4], dyn=dyn)
 
     def _finest_offset(self) -> int:
         """First float of the finest scale's planes inside the field-plane segment (planes are laid out scale-major)."""
@@ -689,7 +770,8 @@ class KPlanesTrainer:
         args = (self.field_planes, self.params[o:o + n], self._params_alt[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
                 self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
                 self.buf["reg"][0], self.step + 1, lr)
-        kw = dict(eps=cfg.adam_eps, grad_scale=getattr(self, "_grad_scale", 1.0), zero_grad=True, shard_range=rng_)
+        self._prepare_group("fields", lr)
+        kw = dict(eps=cfg.adam_eps, grad_scale=self._grad_scale, zero_grad=True, shard_range=rng_, dyn=self._dyn["fields"])
         if not side:
             with self._span("adam_planes.field"):
                 ops.adam_planes_step(*args, **kw)
@@ -708,6 +790,7 @@ class KPlanesTrainer:
 
         if self.world > 1:
             self._join_prop()
+            self._convert_fx()
         with self._span("allreduce_grads"):
             self._grad_scale = sdist.allreduce_flat_(self.grads, self.pg)
 
@@ -715,23 +798,30 @@ class KPlanesTrainer:
         """Adam(lr*cosine, eps 1e-12) over the whole flat buffer + gradient clear (Optimizers.optimizer_step_all/scheduler_step_all)."""
         cfg, co = self.cfg, self.cfg.loss_coefficients
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
-        gs = getattr(self, "_grad_scale", 1.0)
+        gs = self._grad_scale
+        if self.grads_fx is not None:
+            self._join_prop()
+            self._convert_fx()
         if not fused_reg:
             self._join_prop()
-            with self._span("adam_step"):
-                ops.adam_step(self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=True)
-            self.step += 1
+            self._prepare_group("fields", lr)
+            self._prepare_group("proposal_networks", lr)
+            with self._span("adam_step"):  # one sweep per parameter group (= per torch optimiser of the reference)
+                for lo, hi, g in ((0, self.n_proposal_params, "proposal_networks"), (self.n_proposal_params, self.n_params, "fields")):
+                    ops.adam_step(self.params[lo:hi], self.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.step + 1, lr, eps=cfg.adam_eps,
+                                  grad_scale=gs, zero_grad=True, dyn=self._dyn[g])
+            self._finish_step()
             return
         # regularisers fused into the sweep: plane sets go through snerf_adam_planes_step (values land in buf["reg"]), the MLP
         # segments through the plain kernel; everything writes the OTHER parameter buffer, which then becomes live
         new = self._params_alt
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         sl = lambda t, name: t[off[name][0]:off[name][0] + off[name][1]]
-        early_hi = getattr(self, "_early_adam_hi", None)
+        early_hi = self._early_adam_hi
         self._early_adam_hi = None
-        async_field = getattr(self, "async_field_adam", False) and getattr(self, "overlap", True)
+        async_field = self.async_field_adam and self.overlap
         if early_hi is None:
-            if not getattr(self, "_reg_zeroed", False):
+            if not self._reg_zeroed:
                 self.buf["reg"].zero_()
             # async: the big sweep goes to the "adam" stream and is NOT joined here -- the next step's pixel draw, ray generation and
             # proposal levels (which read only the small segments updated below) run under it; forward() joins before the field gather
@@ -744,16 +834,19 @@ class KPlanesTrainer:
             torch.cuda.current_stream().wait_stream(self._stream("adam"))
         self._reg_zeroed = False
         self._join_prop()  # the proposal gradients are needed from here on
+        self._prepare_group("fields", lr)
+        self._prepare_group("proposal_networks", lr)
         sets = [(f"prop{i}.planes", self.prop_planes[i], ("space_tv_proposal_loss", "time_smoothness_proposal_loss",
                                                           "sparse_transients_proposal_loss"), 1 + i) for i in range(2)]
         for name, ps, keys, row in sets:
             with self._span("adam_planes." + name.split(".")[0]):
                 ops.adam_planes_step(ps, sl(self.params, name), sl(new, name), self.gviews[name], self.mviews[name], self.vviews[name],
-                                     tuple(co[k] for k in keys), self.buf["reg"][row], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs)
+                                     tuple(co[k] for k in keys), self.buf["reg"][row], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs,
+                                     dyn=self._dyn["proposal_networks"])
         self._adam_mlps(new, off, lr, gs)
         self._params_alt = self.params
         self._repoint(new)
-        self.step += 1
+        self._finish_step()
 
     def random_draws(self) -> Dict[str, torch.Tensor]:
         """The step's uniform draws (torch.rand on the current device stream), shaped as the reference's samplers draw them."""
@@ -780,8 +873,8 @@ class KPlanesTrainer:
         fuse = self.fuse_reg_into_adam
         # single GPU: no gradient exchange between scatter and optimiser, so the optimiser sweep of the finest scale overlaps the scatter
         # of the coarser ones
-        self._pipeline_adam = (fuse and self.world == 1 and not self._sharded() and self.sorted_scatter and getattr(self, "overlap", True)
-                               and getattr(self, "adam_under_scatter", False))
+        self._pipeline_adam = (fuse and self.world == 1 and not self._sharded() and self.sorted_scatter and self.overlap
+                               and self.adam_under_scatter)
         if self._pipeline_adam:
             self.buf["reg"].zero_()
             self._reg_zeroed = True

@@ -175,6 +175,14 @@ def test_sorted_scatter_equals_direct_scatter_and_oracle(C, ms, concat, N):
     got = torch.zeros_like(ps.planes)
     ss.scatter(ps.planes, co, goutd, got)
     torch.testing.assert_close(got, direct, rtol=1e-4, atol=1e-5)
+    # bf16 gradient vectors between pass A and pass B (the production path with 16-bit MLP operands): every contribution is rounded to 8
+    # significant bits before the fp32 accumulation -> relative L2 error ~2^-9 / sqrt(#contributions), no bias
+    ss16 = ops.SortedScatter(ps, N, dev, gvec_dtype=torch.bfloat16)
+    ss16.sort(co)
+    got16 = torch.zeros_like(ps.planes)
+    ss16.scatter(ps.planes, co, goutd, got16)
+    assert float((got16 - direct).norm() / direct.norm()) < 3e-3
+    assert abs(float((got16 - direct).sum() / direct.abs().sum())) < 1e-4
     if N < 20000:
         ref = KO.interpolate_kplanes(pts, ref_grids, concat)
         ref.backward(gout)

@@ -183,4 +183,54 @@ def test_16bit_operand_mlp(shape, operands):
     torch.testing.assert_close(xg2.grad, gx2_em, rtol=5e-3, atol=5e-3 * float(gx2_em.abs().max()))
     torch.testing.assert_close(net(x), y.detach(), rtol=0, atol=0)
     with pytest.raises(ValueError):
-        Network(15, 3, {**cfg, "n_hidden_layers": 2, "n_neurons": 64}, operands=operands)
+        Network(15, 3, {**cfg, "n_hidden_layers": 2, "n_neurons": 128}, operands=operands)  # not in the 16-bit shape table
+
+
+@pytest.mark.parametrize("operands", ["bf16", "fp16"])
+@pytest.mark.parametrize("shape", [(15, 3, "Sigmoid"), (63, 3, "Sigmoid"), (15, 3, "None")])
+def test_16bit_operand_two_hidden_layers(shape, operands):
+    """The colour net (15 -> 64 -> 64 -> 3, NS/fields/kplanes_field.py:263-273) with 16-bit MFMA operands: equals an emulation that rounds what the
+    kernel rounds, and stays within SURVEY 8d's bf16 tolerance (rgb atol 4e-3) of the exact fp32 kernels."""
+    from soccernerfs_amd.tcnn_compat import Network
+
+    d_in, d_out, out_act = shape
+    cfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": out_act, "n_neurons": 64, "n_hidden_layers": 2}
+    dt, GS = (torch.bfloat16, 1.0) if operands == "bf16" else (torch.float16, 8192.0)
+    _bf = lambda t: t.to(dt).to(torch.float32)
+    _bg = lambda t: (t * GS).to(dt).to(torch.float32) / GS
+    net = Network(d_in, d_out, cfg, operands=operands).to(DEV)
+    ref = Network(d_in, d_out, cfg).to(DEV)
+    with torch.no_grad():
+        ref.params.copy_(net.params)
+    gen = torch.Generator().manual_seed(5)
+    N = 1111
+    x = (torch.rand(N, d_in, generator=gen) - 0.3).to(DEV)
+    go = (torch.rand(N, d_out, generator=gen) - 0.5).to(DEV)
+    W0, W1, WO = [w.t().contiguous() for w in net.linear_weights()]
+    xg = x.clone().requires_grad_(True)
+    y = net(xg)
+    (y * go).sum().backward()
+    a1 = torch.relu(_bf(x) @ _bf(W0))
+    a2 = torch.relu(_bf(a1) @ _bf(W1))
+    z = _bf(a2) @ _bf(WO)
+    y_em = torch.sigmoid(z) if out_act == "Sigmoid" else z
+    torch.testing.assert_close(y, y_em, rtol=5e-3, atol=2e-3)
+    assert float((y - y_em).detach().abs().mean()) < 5e-5 * max(1.0, float(y_em.abs().mean()))
+    gpre = go * (y_em * (1 - y_em) if out_act == "Sigmoid" else 1.0)
+    gwo_em = _bf(a2).t() @ _bg(gpre)
+    gz2 = (_bg(gpre) @ _bf(WO).t()) * (a2 > 0)
+    gw1_em = _bf(a1).t() @ _bg(gz2)
+    gz1 = (_bg(gz2) @ _bf(W1).t()) * (a1 > 0)
+    gw0_em = _bf(x).t() @ _bg(gz1)
+    gx_em = _bg(gz1) @ _bf(W0).t()
+    g0, g1, g_o = [w.t() for w in net.linear_weights(net.params.grad)]
+    for got, want in ((xg.grad, gx_em), (g0, gw0_em), (g1, gw1_em), (g_o, gwo_em)):
+        torch.testing.assert_close(got, want, rtol=1e-2, atol=1e-2 * float(want.abs().max()))
+        assert float((got - want).abs().mean()) < 1e-3 * float(want.abs().mean() + 1e-12)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    torch.testing.assert_close(y, yr, rtol=2e-2, atol=4e-3)
+    (yr * go).sum().backward()
+    rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-20))
+    lim = 1e-1 if operands == "bf16" else 3e-2
+    assert rel(xg.grad, xr.grad) < lim and rel(net.params.grad, ref.params.grad) < lim

@@ -110,7 +110,7 @@ def test_adam_with_tv_folded_in_equals_explicit_gradient():
     _lib.check(L.snerf_tgrid_tv_sign(P(E), C.c_int64(rows), gc, a, b, w, P(part), 64, P(srow), ops._stream()))
     torch.testing.assert_close(part[:, 0].sum() / rows, d.abs().mean(), rtol=1e-5, atol=0)
     p2, g3, m2, v2 = E.clone(), g.clone(), m.clone(), v.clone()
-    _lib.check(L.snerf_adam_step_tv(P(p2), P(g3), P(m2), P(v2), C.c_int64(rows), gc, a, b, P(srow), 1e-2, 0.9, 0.999, 1e-12, 3, 1.0, 1, ops._stream()))
+    _lib.check(L.snerf_adam_step_tv(P(p2), P(g3), P(m2), P(v2), C.c_int64(rows), gc, a, b, P(srow), 1e-2, 0.9, 0.999, 1e-12, 3, 1.0, 1, None, ops._stream()))
     torch.testing.assert_close(p2.view(-1), p_ref, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(m2.view(-1), m_ref, rtol=1e-6, atol=1e-8)
     torch.testing.assert_close(v2.view(-1), v_ref, rtol=1e-6, atol=1e-9)

@@ -173,7 +173,7 @@ def test_weights_bwd_with_overflowed_density_stays_finite():
     gw = torch.rand(R, S, generator=gen) - 0.5
     d, e, g = dens.to("cuda:0"), eb.to("cuda:0").contiguous(), gw.to("cuda:0")
     out = torch.empty_like(d)
-    _lib.check(_lib.lib().snerf_weights_bwd(ops._ptr(d), ops._ptr(e), ops._ptr(g), R, S, ops._ptr(out), 0, ops._stream()))
+    _lib.check(_lib.lib().snerf_weights_bwd(ops._ptr(d), ops._ptr(e), ops._ptr(g), R, S, ops._ptr(out), 0, None, ops._stream()))
     assert bool(torch.isfinite(out).all())
     # rays without overflow are unaffected: compare with autograd of the oracle formula
     from oracle import kplanes_oracle as KO
