@@ -428,11 +428,6 @@ int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const float* tabl
 int snerf_ist_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H, int32_t W, const int32_t* nbr_off,
                    const int32_t* nbr_idx, float alpha, void* out_f16, snerf_stream_t stream);
 
-/* Weighted pixel draw of DynamicBasedPixelSampler.sample_method (NS/data/pixel_samplers.py:369-411): draw d takes its image from
- * chosen_images[d / per_image] and a pixel with probability proportional to the image's weight map, by inverse-CDF on
- * cdf[M, H*W] (fp32 inclusive prefix sums of the maps) with the uniform draw u[d].  indices [n,3] int64 = (image, row, col).
- * (torch.multinomial draws without replacement when enough pixels are non-zero; here draws are independent -- identical
- * distribution up to the O(per_image^2 * sum p^2) chance of a repeated pixel.) */
 /* DynamicDataset.compute_isg (NS/data/datasets/dynamic_dataset.py:215-326): out[M,H,W] (fp16) = mean over RGB of r^2 / (r^2 + gamma^2),
  * r = image - per-camera median image (torch.median over the camera's images: the LOWER median, an input element).  The cameras'
  * image lists are CSR: cam_off [n_cams+1], cam_img [M] (int32, device); img_cam [M] = camera slot of each image; max_frames = the
@@ -441,8 +436,15 @@ int snerf_isg_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H
                    const int32_t* cam_img, const int32_t* img_cam, int32_t max_frames, float gamma, void* medians, void* out_f16,
                    snerf_stream_t stream);
 
-int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, int32_t per_image, const float* u, int32_t n,
-                     int64_t* indices, snerf_stream_t stream);
+/* Weighted pixel draws of DynamicBasedPixelSampler.sample_method (NS/data/pixel_samplers.py:369-411): slot j = draws [j * per_image,
+ * min((j + 1) * per_image, n)) takes its image from chosen_images[j] and pixels with probability proportional to the image's weight map,
+ * by inverse-CDF on cdf[M, H*W] (fp32 inclusive prefix sums of the maps) with the uniform draws u[n].  As torch.multinomial with the
+ * reference's replacement flag (:400-402): WITHOUT replacement inside a slot when nonzero_counts[image] >= the slot's draws (a drawn
+ * pixel's weight leaves the distribution of the slot's later draws), with replacement otherwise (or always, if nonzero_counts is NULL).
+ * per_image <= 1024.  indices [n,3] int64 = (image, row, col).  oracle/ist_oracle.py::sample restates the loop: identical indices for
+ * identical (cdf, chosen, u). */
+int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, const int32_t* nonzero_counts, int32_t per_image,
+                     const float* u, int32_t n, int64_t* indices, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Sorted plane-gradient scatter (same result as snerf_kplanes_gather_bwd, ~6x fewer atomic requests on training batches).

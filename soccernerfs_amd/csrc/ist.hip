@@ -87,23 +87,62 @@ __global__ void isg_weights_kernel(const T* __restrict__ images, const T* __rest
   out[(int64_t)i * HW + px] = __float2half((1.0f / 3) * acc);
 }
 
-// draws: for d in [0,n): image = chosen[d / per_image]; pick pixel with probability proportional to its weight by
-// inverting the image's inclusive prefix sum cdf[image][0..HW) at u*total.  indices [n,3] int64 = (image, row, col).
-__global__ void ist_sample_kernel(const float* __restrict__ cdf, int64_t HW, int W, const int64_t* __restrict__ chosen, int per_image,
-                                  const float* __restrict__ u, int n, int64_t* __restrict__ indices) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= n) return;
-  const int64_t img = chosen[d / per_image];
+// Weighted pixel draws of DynamicBasedPixelSampler.sample_method (NS/data/pixel_samplers.py:369-411).  Slot j of the chosen images
+// receives draws [j * per_image, min((j + 1) * per_image, n)); a draw picks a pixel with probability proportional to its weight by
+// inverting the image's inclusive prefix sums cdf[image][0..HW) at u * (remaining mass).
+// torch.multinomial's replacement flag, as the reference sets it (:400-402): WITHOUT replacement when the map has at least as many
+// non-zero pixels as the slot draws -- a drawn pixel's weight is then removed from the distribution for the slot's later draws
+// (sequential removal: the distribution torch.multinomial(replacement=False) samples from; which uniform lands where is RNG-specific,
+// so the draws u are explicit inputs and the oracle restates this loop) -- otherwise with replacement.
+// One wavefront per slot (~62 slots x 10 draws per step); the removed pixels of a slot sit in LDS and every probe of the binary search
+// subtracts their mass lane-parallel.  The order-sensitive arithmetic is in double, where it is EXACT (weights are fp32 differences of the
+// prefix sums: sums of <= 1024 of them fit 53 bits), so kernel and oracle agree bit for bit whatever the summation order.
+constexpr int IST_MAX_PER_IMAGE = 1024;
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(64) void ist_sample_kernel(const float* __restrict__ cdf, int64_t HW, int W, const int64_t* __restrict__ chosen,
+                                                        const int32_t* __restrict__ nnz, int per_image, const float* __restrict__ u, int n,
+                                                        int64_t* __restrict__ indices) {
+  __shared__ int32_t rem_idx[IST_MAX_PER_IMAGE];
+  __shared__ double rem_w[IST_MAX_PER_IMAGE];
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  const int d0 = slot * per_image;
+  if (d0 >= n) return;
+  const int cnt = (n - d0) < per_image ? (n - d0) : per_image;
+  const int64_t img = chosen[slot];
   const float* c = cdf + img * HW;
-  const float target = u[d] * c[HW - 1];
-  int64_t lo = 0, hi = HW - 1;  // first index with c[idx] > target
-  while (lo < hi) {
-    int64_t mid = (lo + hi) >> 1;
-    if (c[mid] > target) hi = mid; else lo = mid + 1;
+  const bool without = nnz != nullptr && nnz[img] >= cnt;
+  double removed = 0.0;
+  const double total = (double)c[HW - 1];
+  for (int k = 0; k < cnt; ++k) {
+    const double target = (double)u[d0 + k] * (total - removed);
+    // first index whose (adjusted) prefix sum exceeds target
+    int64_t lo = 0, hi = HW - 1;
+    while (lo < hi) {  // wave-uniform
+      const int64_t mid = (lo + hi) >> 1;
+      double adj = 0.0;
+      if (without) {
+        for (int r = lane; r < k; r += 64)
+          if (rem_idx[r] <= mid) adj += rem_w[r];
+        adj = wave_sum_f64(adj);
+      }
+      if ((double)c[mid] - adj > target) hi = mid; else lo = mid + 1;
+    }
+    if (without) {
+      const double w = (double)c[lo] - (lo > 0 ? (double)c[lo - 1] : 0.0);
+      if (lane == 0) { rem_idx[k] = (int32_t)lo; rem_w[k] = w; }
+      removed += w;
+      __syncthreads();  // one wave per workgroup: orders the LDS write before the next draw's reads
+    }
+    if (lane == 0) {
+      indices[(int64_t)(d0 + k) * 3 + 0] = img;
+      indices[(int64_t)(d0 + k) * 3 + 1] = lo / W;
+      indices[(int64_t)(d0 + k) * 3 + 2] = lo % W;
+    }
   }
-  indices[(int64_t)d * 3 + 0] = img;
-  indices[(int64_t)d * 3 + 1] = lo / W;
-  indices[(int64_t)d * 3 + 2] = lo % W;
 }
 
 }  // namespace snerf
@@ -150,13 +189,16 @@ extern "C" int snerf_isg_maps(const void* images, int32_t image_dtype, int32_t M
   return 0;
 }
 
-extern "C" int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, int32_t per_image, const float* u, int32_t n,
-                                int64_t* indices, snerf_stream_t stream) {
-  SNERF_REQUIRE(n >= 0 && per_image >= 1 && H >= 1 && W >= 1, "ist_sample: n=%d per_image=%d", n, per_image);
+extern "C" int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, const int32_t* nonzero_counts, int32_t per_image,
+                                const float* u, int32_t n, int64_t* indices, snerf_stream_t stream) {
+  SNERF_REQUIRE(n >= 0 && per_image >= 1 && per_image <= IST_MAX_PER_IMAGE && H >= 1 && W >= 1, "ist_sample: n=%d per_image=%d (<= %d)", n, per_image,
+                IST_MAX_PER_IMAGE);
   if (n == 0) return 0;
   SNERF_REQUIRE(cdf && chosen_images && u && indices, "ist_sample: null buffer");
-  hipLaunchKernelGGL(ist_sample_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, cdf, (int64_t)H * W, W, chosen_images, per_image, u, n,
-                     indices);
+  SNERF_REQUIRE((int64_t)H * W < (1LL << 31), "ist_sample: image too large");
+  const int slots = ceil_div(n, per_image);
+  hipLaunchKernelGGL(ist_sample_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, cdf, (int64_t)H * W, W, chosen_images, nonzero_counts,
+                     per_image, u, n, indices);
   SNERF_LAUNCH_CHECK("ist_sample");
   return 0;
 }

@@ -145,7 +145,7 @@ class PixelSampler:
         c, y, x = indices[:, 0], indices[:, 1], indices[:, 2]
         out = {}
         for key, value in batch.items():
-            if key in ("image_idx", "iter_steps", "ist_cdf", "ist_nonempty") or value is None or not isinstance(value, torch.Tensor):
+            if key in ("image_idx", "iter_steps", "ist_cdf", "ist_nonempty", "ist_nnz") or value is None or not isinstance(value, torch.Tensor):
                 continue
             v = value[c, y, x]
             out[key] = v.float() / 255.0 if v.dtype == torch.uint8 else v
@@ -162,7 +162,8 @@ class PixelSampler:
 
 class DynamicBasedPixelSampler(PixelSampler):
     """IST/ISG importance sampling (pixel_samplers.py:329-426): floor(is_pixel_ratio * R) rays are drawn from the weight maps,
-    10 * ceil(num_ist / M) per image from randomly chosen non-empty images, the rest uniformly; active after iters_to_start_ist."""
+    10 * ceil(num_ist / M) per image from randomly chosen non-empty images -- without replacement inside an image whenever it has enough
+    non-zero pixels, as torch.multinomial is called at :400-402 --, the rest uniformly; active after iters_to_start_ist."""
 
     def __init__(self, num_rays_per_batch: int, keep_full_image: bool = False, is_pixel_ratio: float = 0.15, iters_to_start_ist: int = 2000,
                  **kwargs) -> None:
@@ -176,6 +177,7 @@ class DynamicBasedPixelSampler(PixelSampler):
         M = w.shape[0]
         batch["ist_cdf"] = torch.cumsum(w.reshape(M, -1).float(), dim=1).contiguous()
         batch["ist_nonempty"] = (batch["ist_cdf"][:, -1] > 0).nonzero()[:, 0].contiguous()
+        batch["ist_nnz"] = (w.reshape(M, -1) > 0).sum(1).to(torch.int32).contiguous()  # len(torch.nonzero(weight_map)) of :400-402
         return batch
 
     def sample_method(self, batch_size: int, num_images: int, image_height: int, image_width: int, mask=None, batch: Optional[Dict] = None,
@@ -195,8 +197,8 @@ class DynamicBasedPixelSampler(PixelSampler):
             chosen = nonempty[torch.randperm(nonempty.numel(), device=device)[:k]].contiguous()  # random.shuffle + skip empty maps (:376-399)
             u = torch.rand(n, device=device)
             idx = torch.empty(n, 3, dtype=torch.int64, device=device)
-            _lib.check(_lib.lib().snerf_ist_sample(ops._ptr(batch["ist_cdf"]), image_height, image_width, ops._ptr(chosen), per_image, ops._ptr(u), n,
-                                                   ops._ptr(idx), ops._stream()), "ist_sample")
+            _lib.check(_lib.lib().snerf_ist_sample(ops._ptr(batch["ist_cdf"]), image_height, image_width, ops._ptr(chosen), ops._ptr(batch["ist_nnz"]),
+                                                   per_image, ops._ptr(u), n, ops._ptr(idx), ops._stream()), "ist_sample")
             parts.append(idx)
         parts.append(super().sample_method(batch_size - n, num_images, image_height, image_width, device=device))
         return torch.cat(parts, dim=0)

@@ -55,6 +55,12 @@ class KPlanesTrainConfig:
     # MFMA operand type of every net (sigma_net, color_net, proposal sigma nets): "fp32" = exact (parity tests); "fp16" / "bf16" =
     # 16-bit operands with fp32 accumulation (csrc/mlp_lp.hip; tcnn itself computes these nets in fp16, BASELINE config 2 names bf16).
     mlp_operands: str = "fp32"
+    sigma_operands: Optional[str] = None   # per-net overrides of mlp_operands (A-B runs): field sigma_net / color_net / proposal nets
+    color_operands: Optional[str] = None
+    proposal_operands: Optional[str] = None
+    # element type of the per-plane gradient vectors between the two passes of the sorted scatter: "fp32", "bf16", or "auto" = fp32 with
+    # fp32 MLP operands (the exact parity path), bf16 otherwise
+    gvec_dtype: str = "auto"
     # ---- execution switches (defaults = the measured best; bench.py / tools expose them for A-B runs) ----
     overlap: bool = True              # independent kernel chains on role streams (False: everything on the caller's stream)
     async_field_adam: bool = True     # field planes' optimiser sweep on its own stream under the NEXT step's proposal levels
@@ -135,17 +141,17 @@ class KPlanesTrainer:
         self.aabb = [[-a, -a, -a], [a, a, a]]
         base = list(cfg.spacetime_resolution)
         reso = [[r * m for r in base[:3]] + base[3:] for m in cfg.multiscale_res]
-        def mlp(din, dout, h, nh, act):
+        def mlp(din, dout, h, nh, act, operands):
             ncfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": h, "n_hidden_layers": nh}
             seed = int(torch.randint(0, 2**31, (1,), generator=gen))
-            return Network(din, dout, ncfg, seed=seed, operands=cfg.mlp_operands)
+            return Network(din, dout, ncfg, seed=seed, operands=operands or cfg.mlp_operands)
 
         self.field_planes = PlaneSet(cfg.feature_dim, reso, concat=True, a=0.1, b=0.5, generator=gen)
-        self.sigma_net = mlp(cfg.feature_dim * len(reso), 16, cfg.sigma_net_hidden_dim, 1, "None")
-        self.color_net = mlp(15, 3, cfg.rgb_net_hidden_dim, 2, "Sigmoid")
+        self.sigma_net = mlp(cfg.feature_dim * len(reso), 16, cfg.sigma_net_hidden_dim, 1, "None", cfg.sigma_operands)
+        self.color_net = mlp(15, 3, cfg.rgb_net_hidden_dim, 2, "Sigmoid", cfg.color_operands)
         self.prop_planes = [PlaneSet(cfg.proposal_feature_dim, [list(r)], concat=False, a=0.1, b=0.15, generator=gen)
                             for r in cfg.proposal_resolutions]
-        self.prop_nets = [mlp(cfg.proposal_feature_dim, 1, 64, 1, "None") for _ in cfg.proposal_resolutions]
+        self.prop_nets = [mlp(cfg.proposal_feature_dim, 1, 64, 1, "None", cfg.proposal_operands) for _ in cfg.proposal_resolutions]
         # ---- flatten: [proposal_networks | fields], each segment 16-B aligned ----
         self.segments = []  # (name, module, attr, offset, numel)
         off = 0
@@ -212,7 +218,8 @@ class KPlanesTrainer:
         self._timing, self._timing_all = None, False
         # sorted plane-gradient scatter for the main field (csrc/kplanes_sorted.hip): ~6x fewer atomic requests
         self.sorted_scatter = cfg.sorted_scatter
-        self._gvec_dtype = torch.float32 if cfg.mlp_operands == "fp32" else torch.bfloat16  # 16-bit gradient vectors ride with 16-bit MLP operands
+        gv = cfg.gvec_dtype if cfg.gvec_dtype != "auto" else ("fp32" if cfg.mlp_operands == "fp32" else "bf16")
+        self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[gv]
         self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype)
         self._ss.desc = self.field_planes.desc()
         self._sort_done = None

@@ -68,6 +68,7 @@ def test_dynamic_sampler_counts_and_distribution():
         hits.index_put_((ist[:, 0], ist[:, 1], ist[:, 2]), torch.ones(num_ist), accumulate=True)
         rest = idx[num_ist:]
         assert int(rest[:, 0].max()) < M and int(rest[:, 1].max()) < H and int(rest[:, 2].max()) < W
+        # torch.multinomial(..., replacement=False) (pixel_samplers.py:400-402): 24 non-zero pixels < 160 draws here -> WITH replacement
     # within one image the empirical pixel distribution follows the weights
     m = int(hits.sum((1, 2)).argmax())
     p_emp = hits[m, 5:9, 10:16].flatten() / hits[m].sum()
@@ -80,6 +81,60 @@ def test_dynamic_sampler_counts_and_distribution():
     assert out["image"].shape == (R, 3) and out["image"].dtype == torch.float32 and float(out["image"].max()) <= 1.0
     assert out["indices"].shape == (R, 3) and int(out["indices"][:, 0].min()) >= 100  # remapped through image_idx
     assert out["ist_weights"].shape == (R,)
+
+
+def test_ist_draws_match_oracle_and_do_not_repeat_pixels():
+    """snerf_ist_sample == oracle/ist_oracle.py::sample on the same (cdf, chosen images, uniforms): identical indices; no pixel twice inside
+    a slot whenever the map has enough non-zero pixels (torch.multinomial(replacement=False), pixel_samplers.py:400-402), replacement
+    otherwise; the per-slot counts of :393-397; and the sequential-removal distribution (first draw ~ w, second ~ w without the first)."""
+    import ctypes as C
+
+    from oracle import ist_oracle as IO
+    from soccernerfs_amd import _lib, ops
+
+    gen = torch.Generator().manual_seed(3)
+    M, H, W = 12, 16, 24
+    w = torch.zeros(M, H, W)
+    w[:, 3:9, 4:14] = (torch.rand(M, 6, 10, generator=gen) * 0.85 + 0.15)
+    w[2] = 0.0
+    w[2, 5, 5:8] = torch.tensor([0.9, 0.3, 0.6])  # 3 non-zero pixels < 10 draws: replacement
+    w[4] = 0.0
+    w[4, 1, 1:13] = 0.5                            # exactly 12 >= 10: without replacement, heavy depletion
+    w = w.half().float()
+    cdf = torch.cumsum(w.reshape(M, -1), dim=1).contiguous()
+    nnz = (w.reshape(M, -1) > 0).sum(1).to(torch.int32)
+    chosen = torch.tensor([4, 2, 0, 7, 11, 5], dtype=torch.int64)
+    per_image, n = 10, 57  # the last slot is clipped to 7 draws
+    u = torch.rand(n, generator=gen)
+    u[3], u[17] = 0.0, 0.99999994  # the ends of the interval
+    idx = torch.empty(n, 3, dtype=torch.int64, device=DEV)
+    keep = [cdf.to(DEV), chosen.to(DEV), nnz.to(DEV), u.to(DEV)]
+    _lib.check(_lib.lib().snerf_ist_sample(ops._ptr(keep[0]), H, W, ops._ptr(keep[1]), ops._ptr(keep[2]), per_image, ops._ptr(keep[3]), n, ops._ptr(idx),
+                                           ops._stream()))
+    idx = idx.cpu()
+    pix, img = IO.sample(cdf.numpy(), chosen.tolist(), nnz.numpy(), per_image, u.numpy())
+    assert torch.equal(idx[:, 0], torch.from_numpy(img)) and torch.equal(idx[:, 1] * W + idx[:, 2], torch.from_numpy(pix))
+    assert torch.all(w[idx[:, 0], idx[:, 1], idx[:, 2]] > 0)
+    for slot in range(6):
+        p = (idx[slot * 10:(slot + 1) * 10, 1] * W + idx[slot * 10:(slot + 1) * 10, 2]).tolist()
+        if slot == 1:
+            assert len(set(p)) <= 3 and len(p) == 10  # image 2: with replacement
+        else:
+            assert len(set(p)) == len(p) == (7 if slot == 5 else 10)
+    # distribution of the second draw of a slot: P(j second) = sum_i p_i p_j / (1 - p_i)
+    wv = torch.tensor([0.5, 0.2, 0.2, 0.1])
+    cdf2 = torch.cumsum(wv, 0)[None].contiguous().to(DEV)
+    T = 20000
+    uu = torch.rand(2 * T, generator=gen).to(DEV)
+    ch, nz = torch.zeros(T, dtype=torch.int64, device=DEV), torch.tensor([4], dtype=torch.int32, device=DEV)
+    out = torch.empty(2 * T, 3, dtype=torch.int64, device=DEV)
+    _lib.check(_lib.lib().snerf_ist_sample(ops._ptr(cdf2), 1, 4, ops._ptr(ch), ops._ptr(nz), 2, ops._ptr(uu), 2 * T, ops._ptr(out), ops._stream()))
+    first, second = out[0::2, 2].cpu(), out[1::2, 2].cpu()
+    assert bool((first != second).all())
+    p = wv / wv.sum()
+    p2 = torch.stack([sum(p[i] * p[j] / (1 - p[i]) for i in range(4) if i != j) for j in range(4)])
+    for emp, ref in ((torch.bincount(first, minlength=4) / T, p), (torch.bincount(second, minlength=4) / T, p2)):
+        assert float(((emp - ref) ** 2 / ref).sum() * T) < 25.0  # chi-square, 3 dof: P(> 25) ~ 1.5e-5
 
 
 @pytest.mark.parametrize("tag,gamma", [("0_05", 5e-2), ("0_2", 2e-1)])

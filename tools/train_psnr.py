@@ -65,7 +65,8 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     torch.manual_seed(seed)
     random.seed(seed)
     cfg = KPlanesTrainConfig(max_steps=args.schedule_steps, mlp_operands=args.mlp_operands, seed=seed, deterministic=args.deterministic,
-                             nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field)
+                             nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, gvec_dtype=args.gvec_dtype,
+                             sigma_operands=args.sigma_operands, color_operands=args.color_operands, proposal_operands=args.proposal_operands)
     R = 4096
     trainer = KPlanesTrainer(cfg, R, dev)
     if args.no_overlap:
@@ -122,6 +123,10 @@ def main():
     ap.add_argument("--eval-every", type=int, default=10000)
     ap.add_argument("--out", default="gpurun_out/psnr.json")
     ap.add_argument("--mlp-operands", default="bf16", choices=["fp32", "bf16", "fp16"])
+    ap.add_argument("--gvec-dtype", default="auto", choices=["auto", "fp32", "bf16"])
+    ap.add_argument("--sigma-operands", default=None)
+    ap.add_argument("--color-operands", default=None)
+    ap.add_argument("--proposal-operands", default=None)
     ap.add_argument("--deterministic", action="store_true", help="fixed-point gradient accumulation: bit-identical reruns")
     ap.add_argument("--nonfinite-policy", default="skip_step", choices=["skip_step", "drop_elements"])
     ap.add_argument("--no-fused-field", action="store_true")
@@ -142,7 +147,8 @@ def main():
     sets = {"camera_20": (held, pick(held)), "novel": (novel, pick(novel)),
             "train": (train, torch.linspace(0, train["images"].shape[0] - 1, 4).long().tolist())}
     log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps,
-           "mlp_operands": args.mlp_operands, "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
+           "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
+           "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
            "fused_field": not args.no_fused_field,
            "eval_sets": {"camera_20": "20th arc camera (reference 'all' split eval camera; extrapolated view), %d frames" % len(sets["camera_20"][1]),
                          "novel": "3 evaluation-only cameras between training cameras (interpolated views), %d images" % len(sets["novel"][1]),
