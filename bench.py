@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
+DEFAULT_OPERANDS = "bf16"  # BASELINE.json configs[1]: "1xMI355X bf16"
+PROFILE_TAG = "r02"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
 
 
 def parse():
@@ -47,14 +49,16 @@ def parse():
     ap.add_argument("--param-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: fp32 = all-gather the new field planes "
                     "(reference semantics); bf16 = all-gather the parameter UPDATES in bf16 and apply them identically on every rank (opt-in)")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
-    ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16", "fp16"], help="MFMA operand type of the one-hidden-layer nets (sigma_net, proposal "
-                    "nets): fp32 = exact; bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16)")
+    ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
+                    "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
+    ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
 
-def cpu_baseline(rays_per_step=256, steps=2):
+def cpu_baseline(rays_per_step=256, steps=4):
     """The oracle's K-Planes train step (fwd + autograd bwd + Adam) at the preset's plane sizes, on the host cores."""
     from oracle import kplanes_oracle as KO  # the checker; only timed here, never on the product path
 
@@ -153,10 +157,43 @@ def main():
                                  near_plane=cfg.near_plane, training=True)
         return trainer.train_step(rays, target)
 
+    # steady-state region: the schedule past step 5000 (proposal networks updated every 5th step) with DynamicBasedPixelSampler active
+    # (15 % of the rays drawn from the IST maps, NS/data/pixel_samplers.py:340-426).  The maps and their prefix sums are computed once,
+    # outside the timed region, as the reference's CacheDataloader does at start-up (NS/data/utils/dataloaders.py:78-91).
+    steady = not args.no_steady_state
+    if steady:
+        from soccernerfs_amd.pixel_samplers import DynamicBasedPixelSampler, compute_ist
+
+        ist = compute_ist(images, data["cam_id"], data["times"], ist_range=1.0)  # method_configs.py:503
+        batch = {"image": images, "image_idx": torch.arange(M, device=dev), "ist_weights": ist, "iter_steps": 6000}
+        sampler = DynamicBasedPixelSampler(R, is_pixel_ratio=0.15, iters_to_start_ist=2000)
+        DynamicBasedPixelSampler.prepare(batch)
+        ist_fraction = float((ist > 0).float().mean())
+
+    def one_step_steady():
+        idx = sampler.sample_method(R, M, H, W, batch=batch, device=dev)
+        target = images[idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
+        rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=trainer.aabb,
+                                 near_plane=cfg.near_plane, training=True)
+        return trainer.train_step(rays, target)
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    def timed(step_fn, n):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step_fn()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
 
     for _ in range(args.warmup):
         one_step()
@@ -164,18 +201,23 @@ def main():
     CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
             "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop"]
     trainer.enable_kernel_timing(CAND)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
     trainer.disable_kernel_timing()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    steady_line = None
+    if steady:
+        trainer.synchronize()
+        trainer.step, trainer._steps_since_update = max(args.start_step, 6000), 0
+        for _ in range(max(args.warmup, 5)):
+            one_step_steady()
+        el2 = timed(one_step_steady, args.steps)
+        steady_line = {"value": R * world * args.steps / el2, "unit": "rays/s", "ms_per_step": el2 / args.steps * 1e3, "steps": args.steps,
+                       "schedule": f"optimiser steps {trainer.step - args.steps}..{trainer.step}: proposal networks updated every {cfg.proposal_update_every}th step",
+                       "pixel_sampler": "DynamicBasedPixelSampler: 15 % of the rays from the IST maps (10 per image, without replacement), the rest uniform; "
+                                        "maps + prefix sums precomputed outside the timed region",
+                       "ist_nonzero_fraction": round(ist_fraction, 4)}
+        trainer.synchronize()
+        trainer.step, trainer._steps_since_update = args.start_step + args.warmup + args.steps, 0
 
     # the optimiser sweep runs on its own stream under the next step's first kernels (async_field_adam): its launch duration in the timed
     # region includes that sharing.  For context, time it ALONE as well (a few extra steps with the sweep back on the main stream).
@@ -222,29 +264,32 @@ def main():
         # them (the proposal scatter: 0.35 ms per updated step alone, ~1.2 ms while gradvec / pass B run next to it), so elapsed time says
         # little about their cost; they are reported, not ranked
         SIDE = ("kplanes_gather_bwd.prop",)
-        timed = {k: v for k, v in kt.items() if k in alg and k not in SIDE}
+        timed_k = {k: v for k, v in kt.items() if k in alg and k not in SIDE}
         side = {k: v for k, v in kt.items() if k in SIDE}
-        per_step = lambda k: timed[k][0] * timed[k][1]
-        DOMINANT = max(timed, key=per_step)
-        # the optimiser sweep and the sorted scatter are within a few % of each other: on a near-tie report the sweep, whose
-        # algorithmic bytes are exact (PMC traffic = 1.01x) -- the scatter's SURVEY-convention bytes ignore run-length combining
-        if "adam_planes.field" in timed and per_step("adam_planes.field") >= 0.9 * per_step(DOMINANT):
-            DOMINANT = "adam_planes.field"
+        per_step = lambda k: timed_k[k][0] * timed_k[k][1]
+        DOMINANT = max(timed_k, key=per_step)  # the measured maximum; kernels within 10 % of it are listed under near_ties
+        near_ties = [k for k in timed_k if k != DOMINANT and per_step(k) >= 0.9 * per_step(DOMINANT)]
         bound, alg_bytes, kdesc = alg[DOMINANT]
-        dom_ms = timed[DOMINANT][0]
+        dom_ms = timed_k[DOMINANT][0]
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         peak = HBM_PEAK_GBS if bound == "hbm" else 157300.0  # fp32 MFMA peak, GFLOP/s
         # HBM traffic of that kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately; profiles/r01_pmc_*):
         # counters cannot be read inside this process, so the committed per-launch figure for exactly this workload is quoted.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        traffic, traffic_source = None, None
+        pmc = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
         if os.path.exists(pmc) and R == 4096 and world == 1:
             traffic = json.load(open(pmc)).get(DOMINANT, {}).get("traffic_bytes_per_launch")
+            if traffic is not None:
+                traffic_source = (f"NOT measured in this run: quoted from profiles/{PROFILE_TAG}_pmc_traffic.json = 2 x FETCH_SIZE + WRITE_SIZE per launch of this "
+                                  f"kernel, separate rocprofv3 --pmc passes of `bench.py --steps 6 --warmup 2 --images 38` (tools/collect_profiles.sh)")
         line = {
             "metric": "train rays/sec (K-Planes Broadcast-style, whole job)", "value": R * world * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.mlp_operands == "fp32" else f"f32 (planes, sampling, compositing, losses, optimiser) + {args.mlp_operands} MFMA operands with f32 accumulation in sigma_net / proposal nets",
+            "dtype": "f32" if args.mlp_operands == "fp32" else args.mlp_operands,
+            "dtype_note": "exact fp32 everywhere (the parity path)" if args.mlp_operands == "fp32" else
+                          f"{args.mlp_operands} MFMA operands with f32 accumulation in every MLP (sigma_net, color_net, proposal nets) and bf16 per-plane gradient "
+                          "vectors between the two scatter passes; planes, sampling, compositing, losses, gradient accumulation and the optimiser are f32",
             "data": "synthetic",
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
@@ -256,13 +301,14 @@ def main():
                            "planes (= one all-reduce's bytes), small segments: all-reduce" if trainer._sharded() else
                            f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step")},
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "algorithmic_per_launch": alg_bytes, "avg_launch_ms": dom_ms,
-                         "launches_timed": timed[DOMINANT][1],
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": alg_bytes,
+                         "avg_launch_ms": dom_ms, "near_ties": near_ties,
+                         "launches_timed": timed_k[DOMINANT][1],
                          **({"alone": {"avg_launch_ms": round(alone[0], 4), "frac": round(alg["adam_planes.field"][1] / (alone[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                                        "note": "same kernel with nothing else on the GPU (20 extra steps after the timed region, sweep on the main stream); "
                                                "in the timed region it shares HBM with the next step's first kernels"}}
                             if alone is not None and DOMINANT == "adam_planes.field" else {}),
-                         "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT},
+                         "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed_k.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT},
                          "side_stream_kernels": {k: {"avg_launch_ms": round(v[0], 4), "launches_timed": v[1],
                                                      "frac": round(alg[k][1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                                                      "note": "runs beside the main chain on its own stream; duration stretched by co-running kernels "
@@ -270,23 +316,26 @@ def main():
                          "other_kernels_note": "fractions below use SURVEY 8d algorithmic bytes (4 texels per bilinear tap, no cache credit): a value "
                                                "above 1 means caches / run-length combining removed traffic, not that a peak was exceeded",
                          "other_kernels_frac": {k: round(alg[k][1] / (v[0] * 1e-3) / 1e9 / (HBM_PEAK_GBS if alg[k][0] == "hbm" else 157300.0), 3)
-                                                for k, v in timed.items() if k != DOMINANT}},
+                                                for k, v in timed_k.items() if k != DOMINANT}},
         }
-        # second half of BASELINE.json's metric (PSNR@30k): not re-measured here (a 30 k-step run takes minutes) -- the committed result of
-        # tools/train_psnr.py on this workload is quoted with its source
-        psnr_file = os.path.join(ROOT, "profiles", "r01_psnr_30k.json")
-        if os.path.exists(psnr_file):
-            try:
-                ev = json.load(open(psnr_file))["evals"][-1]
-                line["psnr_30k"] = {"held_out_camera_db": round(ev["psnr_heldout_mean"], 2), "train_views_db": round(ev["psnr_train_views_mean"], 2),
-                                    "step": ev["step"], "source": "profiles/r01_psnr_30k.json (tools/train_psnr.py, same preset and synthetic scene)",
-                                    "all_runs_held_out_camera_db": [35.5, 37.3, 38.85, 38.9, 39.18, 39.3],
-                                    "all_runs_note": "six fp32 30 k-step runs (atomic accumulation order makes runs diverge; profiles/r01_kernels.md); "
-                                                     "the last one, on the round's final code: 38.85 dB, SSIM 0.9956 (profiles/r01_psnr_30k_run6.json)"}
-            except Exception:
-                pass
+        if steady_line is not None:
+            line["steady_state"] = steady_line
+        # second half of BASELINE.json's metric (PSNR@30k): not re-measured here (a 30 k-step run takes minutes) -- the committed results of
+        # tools/train_psnr.py on this workload are read from their files and quoted with their source
+        psnr = {}
+        for op in ("bf16", "fp32"):
+            f = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_psnr_30k_{op}.json")
+            if os.path.exists(f):
+                try:
+                    d = json.load(open(f))
+                    psnr[op] = {"source": f"profiles/{PROFILE_TAG}_psnr_30k_{op}.json (tools/train_psnr.py: same preset, same synthetic scene, {len(d['runs'])} seeds)",
+                                **{k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in d["summary"].items()}}
+                except Exception as e:  # a malformed file must not take the bench line down
+                    psnr[op] = {"source": os.path.basename(f), "error": str(e)}
+        if psnr:
+            line["psnr_30k"] = psnr
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps)
         if breakdown:
             tot = sum(v[0] * v[1] for v in breakdown.values()) / 20
             print(f"per-step kernel time by group (sum {tot:.3f} ms):", file=sys.stderr)

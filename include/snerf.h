@@ -240,6 +240,14 @@ int snerf_distortion(const float* weights, const float* sbins, int32_t R, int32_
 int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_t S, const float* p_bins, const float* w_prop, int32_t Sp,
                      int32_t R, float grad_scale, float* loss_rays, float* g_wprop, snerf_stream_t stream);
 
+/* ds_nerf_depth_loss behind depth_loss, one sampling level (NS/model_components/losses.py:213-235,261-311; called per level with
+ * weight 1/3 at NS/models/kplanes.py:395-409): loss_rays[R] (may be NULL) = [D > 0] * sum_s -log(w_s + 1e-7) *
+ * exp(-(t_s - D)^2 / (2 sigma)) * (e_{s+1} - e_s) with t_s the bin centre and D = termination_depth (x directions_norm if that is not
+ * NULL: depth maps holding z-distances, is_euclidean_depth = False); g_weights (may be NULL) (+)= grad_scale * d loss_r / d w.  The caller
+ * supplies grad_scale = coefficient / (levels * R) (torch.mean over rays). */
+int snerf_depth_loss(const float* weights, const float* ebins, const float* termination_depth, const float* directions_norm, float sigma,
+                     int32_t R, int32_t S, float grad_scale, float* loss_rays, float* g_weights, int32_t accumulate, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense per-step sweeps.
  * ------------------------------------------------------------------------------------------------ */

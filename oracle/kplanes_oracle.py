@@ -400,6 +400,22 @@ def distortion_loss(weights, sdist):
     return torch.mean(lossfun_distortion(sdist, weights))
 
 
+def ds_nerf_depth_loss(weights, termination_depth, steps, lengths, sigma):
+    """NS/model_components/losses.py:213-235.  weights, steps, lengths [R,S]; termination_depth [R]; sigma scalar."""
+    mask = (termination_depth > 0).to(weights.dtype)
+    loss = -torch.log(weights + EPS) * torch.exp(-((steps - termination_depth[:, None]) ** 2) / (2 * sigma)) * lengths
+    return torch.mean(loss.sum(-1) * mask)
+
+
+def depth_loss(weights, ebins, termination_depth, sigma, directions_norm=None, is_euclidean: bool = True):
+    """depth_loss, DS_NERF branch (losses.py:261-311): z-distance maps are scaled by the ray direction norms (:302-303); steps are the bin
+    centres (:304), lengths the bin widths (:307).  ebins [R,S+1]."""
+    if not is_euclidean:
+        termination_depth = termination_depth * directions_norm
+    starts, ends = ebins[:, :-1], ebins[:, 1:]
+    return ds_nerf_depth_loss(weights, termination_depth, (starts + ends) / 2, ends - starts, sigma)
+
+
 def plane_tv(t, only_w: bool = False):
     """compute_plane_tv, losses.py:356-366."""
     h_tv = torch.square(t[..., 1:, :] - t[..., :-1, :]).mean()

@@ -109,6 +109,7 @@ def lib():
     # float arguments must be declared or ctypes passes them as ints/doubles
     F, I, L, P = C.c_float, C.c_int32, C.c_int64, C.c_void_p
     l.snerf_distortion.argtypes = [P, P, I, I, F, P, P, I, P]
+    l.snerf_depth_loss.argtypes = [P, P, P, P, F, I, I, F, P, P, I, P]
     l.snerf_interlevel.argtypes = [P, P, I, P, P, I, I, F, P, P, P]
     l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, I, I, P]
     l.snerf_adam_step.argtypes = [P, P, P, P, P, L, F, F, F, F, I, F, I, P, P]
@@ -191,4 +192,5 @@ EXPORTS = [
     "snerf_fx_to_float",
     "snerf_mlp_bwd_fx",
     "snerf_adam_prepare",
+    "snerf_depth_loss",
 ]

@@ -236,9 +236,51 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ds_nerf_depth_loss (losses.py:213-235) behind depth_loss (:261-311, DS_NERF branch) for one sampling level:
+//   loss_r = [D_r > 0] * sum_s -log(w_s + 1e-7) * exp(-(t_s - D_r)^2 / (2 sigma)) * (e_{s+1} - e_s),  t_s = (e_s + e_{s+1}) / 2,
+//   D_r = termination depth (x directions_norm when the depth maps hold z-distances), mean over rays by the caller's grad_scale.
+// One wavefront per ray; g_weights (+)= grad_scale * d loss_r / d w.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void depth_loss_kernel(const float* __restrict__ weights, const float* __restrict__ ebins, const float* __restrict__ term,
+                                                        const float* __restrict__ dir_norm, float sigma, int R, int S, float grad_scale,
+                                                        float* __restrict__ loss_rays, float* __restrict__ g_weights, int accumulate) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wv;
+  if (ray >= R) return;
+  float D = term[ray];
+  if (dir_norm) D = D * dir_norm[ray];
+  const bool on = D > 0.f;
+  float total = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float e0 = ebins[(int64_t)ray * (S + 1) + i], e1 = ebins[(int64_t)ray * (S + 1) + i + 1];
+    const float w = weights[(int64_t)ray * S + i];
+    const float t = (e0 + e1) / 2.f;
+    const float k = expf(-((t - D) * (t - D)) / (2.f * sigma)) * (e1 - e0);
+    total += -logf(w + 1.0e-7f) * k;
+    if (g_weights) {
+      const float g = on ? grad_scale * (-k / (w + 1.0e-7f)) : 0.f;
+      if (accumulate) g_weights[(int64_t)ray * S + i] += g; else g_weights[(int64_t)ray * S + i] = g;
+    }
+  }
+  total = wave_sum(total);
+  if (lane == 0 && loss_rays) loss_rays[ray] = on ? total : 0.f;
+}
+
 }  // namespace snerf
 
 using namespace snerf;
+
+extern "C" int snerf_depth_loss(const float* weights, const float* ebins, const float* termination_depth, const float* directions_norm, float sigma,
+                                int32_t R, int32_t S, float grad_scale, float* loss_rays, float* g_weights, int32_t accumulate, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && S >= 1 && S <= MAXS && sigma > 0.f, "depth_loss: R=%d S=%d sigma=%g", R, S, (double)sigma);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(weights && ebins && termination_depth, "depth_loss: null buffer");
+  hipLaunchKernelGGL(depth_loss_kernel, dim3(ceil_div(R, RPB)), dim3(256), 0, (hipStream_t)stream, weights, ebins, termination_depth, directions_norm, sigma,
+                     R, S, grad_scale, loss_rays, g_weights, accumulate);
+  SNERF_LAUNCH_CHECK("depth_loss");
+  return 0;
+}
 
 extern "C" int snerf_render_fwd(const snerf_render_args* p, snerf_stream_t stream) {
   SNERF_REQUIRE(p, "render_fwd: null args");

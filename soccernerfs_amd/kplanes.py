@@ -9,7 +9,8 @@ import torch
 from torch import nn
 
 from .kplanes_field import FieldHeadNames, KPlanesDensityField, KPlanesField
-from .losses import MSELoss, distortion_loss, interlevel_loss, space_tv_loss, sparse_transients_loss, time_smoothness_loss
+from .losses import (MSELoss, depth_loss, distortion_loss, interlevel_loss, plane_regularizer_terms, space_tv_loss, sparse_transients_loss,
+                     time_smoothness_loss)
 from .ray_samplers import ProposalNetworkSampler, UniformSampler
 from .rays import RayBundle
 from .renderers import render_all
@@ -53,6 +54,13 @@ class KPlanesModelConfig:
         "sparse_transients_loss": 0.0001, "space_tv_proposal_loss": 0.0002, "time_smoothness_proposal_loss": 0.00001,
         "sparse_transients_proposal_loss": 0.0001, "depth_loss": 0.05})
     eval_num_rays_per_chunk: int = 32768
+    # depth supervision (kplanes.py:162-172): used only when the batch carries "depth_image" (the Broadcast-style default is depth_maps="none")
+    is_euclidean_depth: bool = True
+    depth_sigma: float = 0.01
+    should_decay_sigma: bool = False
+    starting_depth_sigma: float = 0.2
+    sigma_decay_rate: float = 0.99985
+    depth_loss_type: int = 1  # losses.DepthLossType.DS_NERF
 
     @staticmethod
     def k_planes_preset() -> "KPlanesModelConfig":
@@ -167,11 +175,28 @@ class KPlanesModel(nn.Module):
             outputs["directions_norm"] = ray_bundle.metadata["directions_norm"]
         return outputs
 
+    def _get_sigma(self) -> float:
+        """kplanes.py:508-515: the depth uncertainty, optionally decayed towards config.depth_sigma once per call."""
+        if not hasattr(self, "depth_sigma"):
+            self.depth_sigma = self.config.starting_depth_sigma if self.config.should_decay_sigma else self.config.depth_sigma
+        if self.config.should_decay_sigma:
+            self.depth_sigma = max(self.config.sigma_decay_rate * self.depth_sigma, self.config.depth_sigma)
+        return self.depth_sigma
+
     def get_metrics_dict(self, outputs, batch):
-        """kplanes.py:390-412 (PSNR; depth supervision is not part of the soccer datasets)."""
+        """kplanes.py:390-412: PSNR and, when the batch carries depth maps, the depth loss averaged over the sampling levels."""
         image = batch["image"].to(self.device)
         mse = torch.mean((outputs["rgb"] - image) ** 2)
-        return {"psnr": 10.0 * torch.log10(1.0 / mse)}
+        metrics_dict = {"psnr": 10.0 * torch.log10(1.0 / mse)}
+        if "depth_image" in batch and self.training and self.config.loss_coefficients.get("depth_loss", 0) > 0:
+            sigma = self._get_sigma()
+            termination_depth = batch["depth_image"].to(self.device)
+            n = len(outputs["weights_list"])
+            metrics_dict["depth_loss"] = sum(
+                depth_loss(weights=outputs["weights_list"][i], ray_samples=outputs["ray_samples_list"][i], termination_depth=termination_depth,
+                           predicted_depth=outputs["depth"], sigma=sigma, directions_norm=outputs.get("directions_norm"),
+                           is_euclidean=self.config.is_euclidean_depth, depth_loss_type=self.config.depth_loss_type) / n for i in range(n))
+        return metrics_dict
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
         """kplanes.py:414-452, scaled by misc.scale_dict (only keys present in loss_coefficients)."""
@@ -184,19 +209,23 @@ class KPlanesModel(nn.Module):
             if "interlevel_loss" in coef:
                 loss_dict["interlevel_loss"] = interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
             nerf, prop = self.field.grids, [p.grids for p in self.proposal_networks]
+            # one sweep per plane set yields all three regulariser terms (the reference walks every plane once per loss name)
+            t_nerf, t_prop = plane_regularizer_terms(nerf), plane_regularizer_terms(prop)
             if "space_tv_loss" in coef:
-                loss_dict["space_tv_loss"] = space_tv_loss(nerf)
+                loss_dict["space_tv_loss"] = space_tv_loss(nerf, t_nerf)
             if "space_tv_proposal_loss" in coef:
-                loss_dict["space_tv_proposal_loss"] = space_tv_loss(prop)
+                loss_dict["space_tv_proposal_loss"] = space_tv_loss(prop, t_prop)
             if len(self.config.spacetime_resolution) > 3:
                 if "sparse_transients_loss" in coef:
-                    loss_dict["sparse_transients_loss"] = sparse_transients_loss(nerf)
+                    loss_dict["sparse_transients_loss"] = sparse_transients_loss(nerf, t_nerf)
                 if "sparse_transients_proposal_loss" in coef:
-                    loss_dict["sparse_transients_proposal_loss"] = sparse_transients_loss(prop)
+                    loss_dict["sparse_transients_proposal_loss"] = sparse_transients_loss(prop, t_prop)
                 if "time_smoothness_loss" in coef:
-                    loss_dict["time_smoothness_loss"] = time_smoothness_loss(nerf)
+                    loss_dict["time_smoothness_loss"] = time_smoothness_loss(nerf, t_nerf)
                 if "time_smoothness_proposal_loss" in coef:
-                    loss_dict["time_smoothness_proposal_loss"] = time_smoothness_loss(prop)
+                    loss_dict["time_smoothness_proposal_loss"] = time_smoothness_loss(prop, t_prop)
+            if "depth_image" in batch and coef.get("depth_loss", 0) > 0:
+                loss_dict["depth_loss"] = metrics_dict["depth_loss"]  # kplanes.py:448-449
         return {k: v * coef[k] if k in coef else v for k, v in loss_dict.items()}
 
     @torch.no_grad()

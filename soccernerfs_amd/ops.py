@@ -474,6 +474,31 @@ def interlevel_loss(weights_list, sbins_list):
     return total
 
 
+class _DepthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, ebins, term, dnorm, sigma: float):
+        R, S = weights.shape
+        loss_rays = torch.empty(R, dtype=torch.float32, device=weights.device)
+        gw = torch.empty_like(weights)
+        _lib.check(_lib.lib().snerf_depth_loss(_ptr(weights), _ptr(ebins), _ptr(term), _ptr(dnorm) if dnorm is not None else None, sigma, R, S, 1.0 / R,
+                                               _ptr(loss_rays), _ptr(gw), 0, _stream()), "depth_loss")
+        ctx.save_for_backward(gw)
+        return loss_rays.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (gw,) = ctx.saved_tensors
+        return gw * g, None, None, None, None
+
+
+def ds_nerf_depth_loss(weights, ebins, termination_depth, sigma: float, directions_norm=None):
+    """depth_loss with DepthLossType.DS_NERF for one sampling level (losses.py:213-235,261-311): weights [R,S], euclidean bin edges
+    [R,S+1], termination_depth [R]; directions_norm [R] when the depth maps hold z-distances (is_euclidean = False), else None."""
+    dn = _f32c(directions_norm, "directions_norm").reshape(-1) if directions_norm is not None else None
+    return _DepthLoss.apply(_f32c(weights, "weights"), _f32c(ebins.detach(), "ebins"), _f32c(termination_depth, "termination_depth").reshape(-1), dn,
+                            float(sigma))
+
+
 REG_SLOTS = 1024  # partial-sum slots of the regulariser values (one 64-B line each)
 
 

@@ -44,7 +44,10 @@ class KPlanesTrainConfig:
     loss_coefficients: Dict[str, float] = field(default_factory=lambda: {
         "rgb_loss": 1.0, "interlevel_loss": 1.0, "distortion_loss": 0.001, "space_tv_loss": 0.0002,
         "time_smoothness_loss": 0.001, "sparse_transients_loss": 0.0001, "space_tv_proposal_loss": 0.0002,
-        "time_smoothness_proposal_loss": 0.00001, "sparse_transients_proposal_loss": 0.0001})
+        "time_smoothness_proposal_loss": 0.00001, "sparse_transients_proposal_loss": 0.0001, "depth_loss": 0.05})
+    # depth supervision (NS/models/kplanes.py:162-172,395-409): active only when train_step / backward receive termination depths
+    depth_sigma: float = 0.01
+    is_euclidean_depth: bool = True
     # optimiser + schedule (method_configs.py:546-557)
     lr: float = 1e-2
     adam_eps: float = 1e-12
@@ -131,6 +134,7 @@ class KPlanesTrainer:
         self.async_field_adam, self.adam_under_scatter = cfg.async_field_adam, cfg.adam_under_scatter
         self._field_adam_done = None
         self._prop_pending = None
+        self._depth = None
         self._grad_scale = 1.0
         self._pipeline_adam, self._early_adam_hi, self._reg_zeroed = False, None, False
         self._dyn_step = 0
@@ -213,6 +217,7 @@ class KPlanesTrainer:
             "rgb": f(R * S2, 3), "grgb": f(R * S2, 3),
             "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "g_rgb_out": f(R, 3),
             "dist_rays": f(R), "inter_rays": [f(R), f(R)], "sqerr": torch.zeros(R, dtype=torch.float32, device=self.dev),
+            "depth_rays": [f(R), f(R), f(R)],
             "reg": torch.zeros(3, ops.REG_SLOTS, 16, dtype=torch.float32, device=self.dev),  # [field|prop0|prop1][slot][16]
         }
         self._timing, self._timing_all = None, False
@@ -464,6 +469,16 @@ class KPlanesTrainer:
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
 
+    def _depth_loss(self, lvl: int, with_grad: bool):
+        """ds_nerf depth loss of one sampling level (kplanes.py:395-409: every level, weight 1/3); its gradient is ADDED to gw[lvl]."""
+        if self._depth is None:
+            return
+        cfg, b, R = self.cfg, self.buf, self.R
+        dn = None if cfg.is_euclidean_depth else self.rays["directions_norm"]
+        _lib.check(self.lib.snerf_depth_loss(self._p(b["w"][lvl]), self._p(b["eb"][lvl]), self._p(self._depth), self._p(dn) if dn is not None else None,
+                                             cfg.depth_sigma, R, self.S[lvl], cfg.loss_coefficients["depth_loss"] / (3 * R), self._p(b["depth_rays"][lvl]),
+                                             self._p(b["gw"][lvl]) if with_grad else None, 1, self._st), "depth_loss")
+
     def _proposal_backward(self, proposal_grads: bool):
         """Proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592)."""
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
@@ -472,6 +487,7 @@ class KPlanesTrainer:
             _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
                                                  co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
                                                  self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
+            self._depth_loss(lvl, with_grad=proposal_grads)  # adds to the interlevel gradient just written
             if proposal_grads:
                 N = R * Sp
                 _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp,
@@ -492,7 +508,7 @@ class KPlanesTrainer:
                                   self.gviews[f"prop{lvl}.planes"])
 
     def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True,
-                 defer_prop_join: bool = False):
+                 defer_prop_join: bool = False, depth: Optional[torch.Tensor] = None):
         """Accumulates d(total loss)/d(params) into self.grads (which must be zero on entry: Adam clears it); fills
         self.last with the (scaled) loss terms.
 
@@ -502,6 +518,8 @@ class KPlanesTrainer:
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
         S2 = self.S[2]
         main = torch.cuda.current_stream()
+        # depth supervision: termination depths [R] (batch["depth_image"]); None or a zero coefficient switches the term off
+        self._depth = ops._f32c(depth, "depth").reshape(-1) if depth is not None and co.get("depth_loss", 0) > 0 else None
         overlap = self.overlap
         sharded = self._sharded()  # the field-plane gradient leaves for the reduce-scatter as soon as it is complete, and the
         #                            proposal backward runs AFTER it, under the collective
@@ -541,6 +559,7 @@ class KPlanesTrainer:
                                                  self._st), "render_mse_bwd")
         _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, co["distortion_loss"] / R, self._p(b["dist_rays"]),
                                              self._p(b["gw"][2]), 1, self._st), "distortion")
+        self._depth_loss(2, with_grad=True)
         _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0,
                                               self._p(self._dyn["fields"]), self._st), "weights_bwd")
         if reg_done is not None:
@@ -597,6 +616,8 @@ class KPlanesTrainer:
         reg = b["reg"][:, :, :3].sum(1)  # [3 plane sets, 3 terms]
         d["space_tv_loss"], d["time_smoothness_loss"], d["sparse_transients_loss"] = (
             reg[0, 0] * co["space_tv_loss"], reg[0, 1] * co["time_smoothness_loss"], reg[0, 2] * co["sparse_transients_loss"])
+        if self._depth is not None:
+            d["depth_loss"] = sum(r.mean() for r in b["depth_rays"]) / 3 * co["depth_loss"]
         pr = reg[1] + reg[2]
         d["space_tv_proposal_loss"], d["time_smoothness_proposal_loss"], d["sparse_transients_proposal_loss"] = (
             pr[0] * co["space_tv_proposal_loss"], pr[1] * co["time_smoothness_proposal_loss"], pr[2] * co["sparse_transients_proposal_loss"])
@@ -868,8 +889,10 @@ class KPlanesTrainer:
             o += R * c
         return {"t_rand": out[0], "u": [out[1], out[2]], "bg": out[3]}
 
-    def train_step(self, rays: Dict[str, torch.Tensor], target: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None):
-        """One full training iteration (callbacks included): returns the rendered rgb [R,3] (a work buffer)."""
+    def train_step(self, rays: Dict[str, torch.Tensor], target: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None,
+                   depth: Optional[torch.Tensor] = None):
+        """One full training iteration (callbacks included): returns the rendered rgb [R,3] (a work buffer).  depth: termination depths [R]
+        of the batch (batch["depth_image"]) when the dataset has depth maps."""
         cfg = self.cfg
         anneal = anneal_value(self.step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope)
         # the sampler's own step counter lags by one: it is set by the AFTER_TRAIN_ITERATION callback (kplanes.py:340-346)
@@ -886,7 +909,7 @@ class KPlanesTrainer:
             self.buf["reg"].zero_()
             self._reg_zeroed = True
         self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
-                      defer_prop_join=fuse and self.world == 1 and self.defer_prop)
+                      defer_prop_join=fuse and self.world == 1 and self.defer_prop, depth=depth)
         self._pipeline_adam = False
         if self._sharded():
             self._sharded_optimizer_step()

@@ -176,3 +176,69 @@ def test_render_mse_bwd_equals_render_bwd_of_mse_gradient():
     torch.testing.assert_close(grgb, grgb_ref, rtol=1e-6, atol=1e-9)
     torch.testing.assert_close(sq, ((out - target) ** 2).sum(-1), rtol=1e-6, atol=0)
     torch.testing.assert_close(sq.sum() / (3 * R) * coef, torch.nn.functional.mse_loss(out, target) * coef, rtol=1e-5, atol=0)
+
+
+def test_depth_loss_golden():
+    """snerf_depth_loss (DS-NeRF depth supervision, losses.py:213-235,261-311) vs the reference's own values and gradients (G8b)."""
+    from soccernerfs_amd import ops
+
+    g = load_golden("g8b_depth")
+    d = lambda k: g[k].to(DEV).contiguous()
+    for tag, eucl in (("eucl_s001", True), ("eucl_s02", True), ("z_s02", False)):
+        w = d("weights").requires_grad_(True)
+        val = ops.ds_nerf_depth_loss(w, d("bins"), d("termination_depth"), float(g["sigma_" + tag]), None if eucl else d("directions_norm"))
+        (val * 2.0).backward()
+        torch.testing.assert_close(val.detach().cpu(), torch.as_tensor(g["loss_" + tag]), rtol=2e-5, atol=1e-8)
+        # 1 / (w + 1e-7) at w = 0 or 1e-9 amplifies the last ulp of expf: relative tolerance only
+        torch.testing.assert_close(w.grad.cpu() / 2.0, g["grad_" + tag], rtol=2e-5, atol=1e-9)
+
+
+def test_trainer_depth_supervision_matches_oracle():
+    """Fused trainer with termination depths: loss value and every gradient segment equal the oracle with the depth term on all three levels."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
+
+    E = dict(base_res=(16, 16, 16, 4), multiscale=(1, 2), feat_dim=32, prop_res=((24, 24, 24, 4), (32, 32, 32, 4)), prop_feat=8,
+             sigma_hidden=128, color_hidden=64, aabb_scale=1.5, seed=9)
+    P = KO.make_kplanes_params(**E)
+    leaves = KO.all_param_tensors(P)
+    for x in leaves:
+        x.requires_grad_(True)
+    R = 48
+    cfg = KPlanesTrainConfig(aabb_scale=1.5, spacetime_resolution=E["base_res"], multiscale_res=E["multiscale"], feature_dim=32,
+                             proposal_resolutions=E["prop_res"], proposal_feature_dim=8, num_proposal_samples_per_ray=(64, 32),
+                             num_nerf_samples_per_ray=16, depth_sigma=0.05)
+    tr = KPlanesTrainer(cfg, R, DEV)
+    tr.load_oracle_params(P)
+    gen = torch.Generator().manual_seed(12)
+    o = (torch.rand(R, 3, generator=gen) * 2 - 1) * 1.2
+    dd = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)
+    times, target = torch.rand(R, 1, generator=gen), torch.rand(R, 3, generator=gen)
+    depth = torch.rand(R, generator=gen) * 2 + 0.3
+    depth[::7] = 0.0  # rays without a depth value
+    rng = {"t_rand": torch.rand(R, 65, generator=gen), "u": [torch.rand(R, 33, generator=gen), torch.rand(R, 17, generator=gen)],
+           "bg": torch.rand(R, 3, generator=gen)}
+    out = KO.kplanes_forward(P, {"origins": o, "directions": dd, "times": times}, rng, (64, 32), 16, anneal=0.3)
+    ld = KO.kplanes_loss_dict(P, out, target)
+    ld["depth_loss"] = 0.05 * sum(KO.depth_loss(w, e, depth, 0.05) for w, e in zip(out["weights_list"], out["eucl_list"])) / 3
+    sum(ld.values()).backward()
+    dv = lambda z: z.to(DEV).contiguous()
+    rngd = {"t_rand": dv(rng["t_rand"]), "u": [dv(rng["u"][0]), dv(rng["u"][1])], "bg": dv(rng["bg"])}
+    tr.forward({"origins": dv(o), "directions": dv(dd), "times": dv(times)}, rngd, 0.3, training=True)
+    tr.backward(dv(target), rngd, proposal_grads=True, depth=dv(depth))
+    got = tr.loss_dict()
+    torch.testing.assert_close(got["depth_loss"].cpu(), ld["depth_loss"].detach(), rtol=1e-3, atol=1e-8)
+    torch.testing.assert_close(sum(got.values()).cpu(), sum(ld.values()).detach(), rtol=2e-3, atol=1e-7)
+    torch.cuda.synchronize()
+    gref = tr.field_planes.to_reference(tr.gviews["field.planes"])
+    for s in range(2):
+        for p in range(6):
+            want = P["field_grids"][s][p].grad
+            torch.testing.assert_close(gref[s][p].cpu(), want, rtol=5e-3, atol=2e-3 * float(want.abs().max()) + 1e-9)
+    for lvl in range(2):
+        gp = tr.prop_planes[lvl].to_reference(tr.gviews[f"prop{lvl}.planes"])[0]
+        for p in range(6):
+            want = P["prop_grids"][lvl][p].grad
+            torch.testing.assert_close(gp[p].cpu(), want, rtol=5e-3, atol=2e-3 * float(want.abs().max()) + 1e-9)
+    # without depths the term is absent and the gradient differs
+    assert "depth_loss" in got

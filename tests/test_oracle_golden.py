@@ -238,3 +238,14 @@ def test_adam_matches_torch():
         opt.step()
         KO.adam_step(p, grad, m, v, step, 1e-2)
         close(p, ref.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_g8b_depth_loss():
+    """oracle depth_loss (DS-NeRF) vs the reference's own depth_loss on explicit inputs: values and gradients (G8b)."""
+    g = load_golden("g8b_depth")
+    for tag, eucl in (("eucl_s001", True), ("eucl_s02", True), ("z_s02", False)):
+        w = g["weights"].clone().requires_grad_(True)
+        val = KO.depth_loss(w, g["bins"], g["termination_depth"], float(g["sigma_" + tag]), g["directions_norm"], eucl)
+        val.backward()
+        torch.testing.assert_close(val.detach(), torch.as_tensor(g["loss_" + tag]), rtol=1e-6, atol=1e-8)
+        torch.testing.assert_close(w.grad, g["grad_" + tag], rtol=1e-5, atol=1e-9)
