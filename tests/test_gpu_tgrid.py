@@ -295,3 +295,25 @@ def test_nerfplayer_model_matches_reference_golden():
         assert abs(float(got.double().abs().sum()) - gabs) <= 3e-3 * gabs + 1e-9, name
         probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
         torch.testing.assert_close(probe, g["gprobe_" + name], rtol=5e-3, atol=1e-7 + 2e-3 * float(g["gprobe_" + name].abs().max()))
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_interpolation_matches_reference_hash_encoding(name):
+    """G9c: csrc/tgrid.hip on hashed levels == the reference's own HashEncoding.pytorch_fwd + get_temporal_index (corner order, trilinear
+    weights, hash and channel blending executed by reference code; oracle/gen_golden_tgrid_interp.py), with the time rows derived in-kernel
+    and passed explicitly."""
+    from tests.conftest import load_golden
+    from soccernerfs_amd.temporal_grid import TemporalGridEncoder
+
+    g = load_golden("g9c_tgrid_interp")
+    tdim, C, L, log2T, H = [int(v) for v in g[f"{name}_cfg"]]
+    enc = TemporalGridEncoder(temporal_dim=tdim, level_dim=C, num_levels=L, log2_hashmap_size=log2T, base_resolution=H,
+                              per_level_scale=float(g[f"{name}_per_level_scale"]))
+    assert enc.offsets.tolist() == g[f"{name}_offsets"].tolist()
+    with torch.no_grad():
+        enc.embeddings.copy_(g[f"{name}_emb"])
+    enc = enc.to(DEV)
+    x, t = g[f"{name}_x"].to(DEV), g[f"{name}_times"][:, None].to(DEV)
+    for explicit in (False, True):
+        out = enc(x, t, explicit_rows=explicit)
+        torch.testing.assert_close(out.cpu(), g[f"{name}_out"], rtol=1e-5, atol=2e-6)

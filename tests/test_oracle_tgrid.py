@@ -132,3 +132,19 @@ def test_oracle_fields_reproduce_reference_model_golden():
     comp = (w[..., None] * rgb).sum(1) + g["bg"] * (1 - w.sum(1, keepdim=True))
     torch.testing.assert_close(comp, g["rgb"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(w.sum(1, keepdim=True), g["accumulation"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_interpolation_matches_reference_hash_encoding(name):
+    """G9c: the oracle's encoder on hashed levels == the reference's own HashEncoding.pytorch_fwd + get_temporal_index (corner order,
+    trilinear weights, hash, channel blending all executed by reference code; oracle/gen_golden_tgrid_interp.py)."""
+    g = load_golden("g9c_tgrid_interp")
+    tdim, C, L, log2T, H = [int(v) for v in g[f"{name}_cfg"]]
+    pls = float(g[f"{name}_per_level_scale"])
+    offs = TO.level_offsets(L, H, pls, log2T, 3)
+    assert offs == g[f"{name}_offsets"].tolist()
+    tab = TO.channel_table(tdim, C)
+    trow = TO.temporal_index(g[f"{name}_times"], tab)
+    torch.testing.assert_close(trow, g[f"{name}_trow"], rtol=0, atol=0)
+    out = TO.encode(g[f"{name}_x"], trow, g[f"{name}_emb"], offs, float(np.log2(pls)), H, gridtype=0, level_dim=C)
+    torch.testing.assert_close(out, g[f"{name}_out"], rtol=1e-5, atol=2e-6)
