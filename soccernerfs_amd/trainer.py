@@ -75,6 +75,7 @@ class KPlanesTrainConfig:
     sorted_scatter_proposals: bool = False
     fuse_reg_into_adam: bool = True   # plane regularisers inside the optimiser sweep (ping-pong parameter buffers)
     shard_optimizer: bool = True      # world > 1: reduce-scatter -> Adam on a 1/world shard -> all-gather (False: one all-reduce)
+    exchange_chunks: int = 2          # world > 1, sharded: 2 = finest scale exchanged on its own, ahead of the rest (1: one exchange)
     grad_transport: str = "fp32"      # world > 1, sharded: "bf16" halves the reduce-scatter bytes (not the reference's fp32 DDP)
     param_transport: str = "fp32"     # world > 1, sharded: "bf16" gathers the parameter UPDATES in bf16
     # fixed-point (int64) gradient accumulation instead of float atomics: sums no longer depend on the order in which wavefronts
@@ -123,7 +124,7 @@ class KPlanesTrainer:
         # opt-in half-width transports of the sharded step: "bf16" rounds the field-plane gradient before the reduce-scatter /
         # gathers the parameter UPDATES in bf16; "fp32" (default) keeps the reference's DDP semantics
         self.grad_transport, self.param_transport = cfg.grad_transport, cfg.param_transport
-        self._delta_pending, self._g16, self._d16_full = False, None, None
+        self._delta_pending = False
         # execution switches (KPlanesTrainConfig); plain attributes so that A-B tools can flip them between steps.
         # async_field_adam: the field planes' optimiser sweep runs on its own stream under the NEXT step's pixel draw / ray generation /
         # proposal levels (which read only the small segments); forward() joins it before the field gather, loss_dict() and
@@ -135,10 +136,11 @@ class KPlanesTrainer:
         self._field_adam_done = None
         self._prop_pending = None
         self._depth = None
+        self._exchange_started = False
         self._grad_scale = 1.0
         self._pipeline_adam, self._early_adam_hi, self._reg_zeroed = False, None, False
         self._dyn_step = 0
-        self._rs_work = self._ar_work = self._ag_work = self._reg_work = None
+        self._ar_work = self._reg_work = None
         self._side = {}  # role -> HIP stream, created on first use
         gen = torch.Generator().manual_seed(cfg.seed)
         a = cfg.aabb_scale
@@ -195,10 +197,7 @@ class KPlanesTrainer:
         # the regulariser-fused optimiser sweep reads neighbours of the OLD parameters: parameters ping-pong between two buffers
         self.fuse_reg_into_adam = cfg.fuse_reg_into_adam
         self._params_alt = torch.zeros_like(self.params)
-        if self.world > 1:
-            shard = self._field_seg[2] // self.world
-            self._g_shard = torch.zeros(shard, dtype=torch.float32, device=self.dev)  # reduce-scatter output
-            self._p_shard = torch.zeros(shard, dtype=torch.float32, device=self.dev)  # all-gather input
+        self._exchange = []  # per exchange chunk: dict(lo, hi, g_shard, p_shard, ...) -- see _plan_exchange
         # ---- work buffers ----
         R = num_rays
         S0, S1 = cfg.num_proposal_samples_per_ray
@@ -239,6 +238,29 @@ class KPlanesTrainer:
         self.lib = _lib.lib()
         self._desc_field = self.field_planes.desc()
         self._desc_prop = [p.desc() for p in self.prop_planes]
+        if self.world > 1:
+            self._plan_exchange()
+
+    def _plan_exchange(self):
+        """Sharded optimiser (world > 1): the field-plane segment is exchanged in CHUNKS so that the reduce-scatter of a chunk starts as soon
+        as its scatter is complete and its shard-Adam + all-gather run while the next chunk is still on the links.  Chunk 0 = the finest
+        scale (the tail of the segment: planes are laid out scale-major; ~72 % of the floats at the preset), scattered first; chunk 1 =
+        everything in front of it.  Inside a chunk rank r owns floats [lo + r * len / world, lo + (r + 1) * len / world).
+        cfg.exchange_chunks = 1 restores the single exchange (A-B)."""
+        _, n, npad = self._field_seg
+        q = 4 * self.world
+        cuts = [0, npad]
+        ns = len(self.cfg.multiscale_res)
+        if self.cfg.exchange_chunks > 1 and ns > 1:
+            b = (self._finest_offset() + q - 1) // q * q  # the boundary rounded UP: chunk 0 lies wholly inside the finest scale
+            if 0 < b < npad:
+                cuts = [0, b, npad]
+        f = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.dev)
+        self._exchange = []
+        for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):  # finest first
+            shard = (hi - lo) // self.world
+            self._exchange.append({"lo": lo, "hi": hi, "shard": shard, "g_shard": f(shard), "p_shard": f(shard), "rs": None, "ag": None,
+                                   "g16": None, "g16_shard": None, "d16_full": None, "d16_shard": None})
 
     def _repoint(self, flat: torch.Tensor):
         """Make `flat` the live parameter buffer: module parameters and self.views alias its segments."""
@@ -456,6 +478,20 @@ class KPlanesTrainer:
                                                           self._p(b["gfeat"]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
             ns = len(self.cfg.multiscale_res)
             early = self._pipeline_adam and ns > 1
+            if self._sharded() and len(self._exchange) == 2:
+                # finest scale first: its reduce-scatter (chunk 0) is on the links while the coarser scales are still being scattered
+                with self._span("kplanes_scatter_sorted.field"):
+                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16,
+                                                                            self._p(ss.sorted_rec), self._p(self.gviews["field.planes"]), ns - 1, ns,
+                                                                            self._st), "scatter_sorted")
+                self._start_field_grad_exchange(0)
+                with self._span("kplanes_scatter_sorted.field"):
+                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16,
+                                                                            self._p(ss.sorted_rec), self._p(self.gviews["field.planes"]), 0, ns - 1,
+                                                                            self._st), "scatter_sorted")
+                self._start_field_grad_exchange(1)
+                self._exchange_started = True
+                return
             with self._span("kplanes_scatter_sorted.field"):
                 # finest scale first: it holds ~3/4 of the plane parameters, so its optimiser sweep (HBM-bound) can start on a side
                 # stream while the other scales are still being scattered (atomic-bound)
@@ -569,7 +605,10 @@ class KPlanesTrainer:
             # hardware queues, and two chains that land on one queue serialise (seen in the rocprofv3 timeline, profiles/r01_kernels.md)
             self._field_backward_chunk(0, R)
             if sharded:
-                self._start_field_grad_exchange()
+                if not self._exchange_started:  # unsorted / deterministic scatter: every chunk is complete only now
+                    for k in range(len(self._exchange)):
+                        self._start_field_grad_exchange(k)
+                self._exchange_started = False
                 if overlap:
                     proposal_chain(after=main.record_event())
             if not overlap:
@@ -630,15 +669,17 @@ class KPlanesTrainer:
     def _wait_params(self):
         """The current stream waits until the field planes of the last optimiser step are complete: the all-gather (sharded
         multi-GPU) or the sweep on the "adam" stream (async_field_adam).  No host block."""
-        if self._ag_work is not None:
-            self._ag_work.wait()
-            self._ag_work = None
-            if self._delta_pending:
-                # bf16 parameter transport: what was gathered are the ranks' parameter UPDATES; every rank (the owner of a shard
-                # included) forms new = old + bf16(update), so the replicas stay bit-identical.  params / _params_alt were swapped since.
-                o, _, npad = self._field_seg
-                torch.add(self._params_alt[o:o + npad], self._d16_full, out=self.params[o:o + npad])
-                self._delta_pending = False
+        for ch in self._exchange:
+            if ch["ag"] is not None:
+                ch["ag"].wait()
+                ch["ag"] = None
+                if self._delta_pending:
+                    # bf16 parameter transport: what was gathered are the ranks' parameter UPDATES; every rank (the owner of a shard
+                    # included) forms new = old + bf16(update), so the replicas stay bit-identical.  params / _params_alt were swapped since.
+                    o = self._field_seg[0]
+                    a, b = o + ch["lo"], o + ch["hi"]
+                    torch.add(self._params_alt[a:b], ch["d16_full"], out=self.params[a:b])
+        self._delta_pending = False
         ev = self._field_adam_done
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -650,24 +691,26 @@ class KPlanesTrainer:
         self._wait_params()
         torch.cuda.synchronize(self.dev)
 
-    def _start_field_grad_exchange(self):
-        """Called on the stream that produced the field-plane gradient, right after the scatter: reduce-scatter(SUM) of the padded
-        segment into this rank's shard buffer, asynchronous on RCCL's stream."""
+    def _start_field_grad_exchange(self, k: int):
+        """Called on the stream that produced the gradient of exchange chunk k, right after its scatter: reduce-scatter(SUM) of the chunk
+        into this rank's shard buffer, asynchronous on RCCL's stream."""
         from . import dist as sdist
 
-        o, _, npad = self._field_seg
-        self._convert_fx(o, o + npad)
+        ch = self._exchange[k]
+        o = self._field_seg[0]
+        a, b = o + ch["lo"], o + ch["hi"]
+        self._convert_fx(a, b)
         with self._span("reduce_scatter.field"):
             if self.grad_transport == "bf16":
                 # opt-in: half the bytes on the links (each rank rounds its own gradient to bf16, the SUM is formed in bf16 by the collective);
                 # NOT the reference's fp32 DDP all-reduce -- the optimiser then sees gradients with ~2^-9 relative rounding
-                if self._g16 is None:
-                    self._g16 = torch.empty(npad, dtype=torch.bfloat16, device=self.dev)
-                    self._g16_shard = torch.empty(npad // self.world, dtype=torch.bfloat16, device=self.dev)
-                self._g16.copy_(self.grads[o:o + npad])
-                self._rs_work = sdist.reduce_scatter_sum(self._g16_shard, self._g16, self.pg, async_op=True)
+                if ch["g16"] is None:
+                    ch["g16"] = torch.empty(b - a, dtype=torch.bfloat16, device=self.dev)
+                    ch["g16_shard"] = torch.empty(ch["shard"], dtype=torch.bfloat16, device=self.dev)
+                ch["g16"].copy_(self.grads[a:b])
+                ch["rs"] = sdist.reduce_scatter_sum(ch["g16_shard"], ch["g16"], self.pg, async_op=True)
             else:
-                self._rs_work = sdist.reduce_scatter_sum(self._g_shard, self.grads[o:o + npad], self.pg, async_op=True)
+                ch["rs"] = sdist.reduce_scatter_sum(ch["g_shard"], self.grads[a:b], self.pg, async_op=True)
 
     def _prepare_group(self, name: str, lr: float):
         """Once per step and parameter group, on the current stream, after the group's gradient producers and before its Adam kernels:
@@ -715,9 +758,6 @@ class KPlanesTrainer:
         gs = 1.0 / self.world
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         o, n, npad = self._field_seg
-        shard = npad // self.world
-        lo = self.rank * shard
-        hi = min(lo + shard, _align4(n))
         new = self._params_alt
         self._convert_fx(0, o)
         self._convert_fx(o + npad, None)
@@ -731,30 +771,35 @@ class KPlanesTrainer:
         if self._reg_work is not None:
             self._reg_work.wait()  # last step's regulariser-value reduction still reads buf["reg"]
         self.buf["reg"].zero_()
-        self._rs_work.wait()
-        self.grads[o + lo:o + lo + shard].copy_(self._g16_shard if self.grad_transport == "bf16" else self._g_shard)
-        with self._span("adam_planes.field"):
-            if hi > lo:
-                ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
-                                     self.vviews["field.planes"], tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
-                                     self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs, zero_grad=False, shard_range=(lo, hi),
-                                     dyn=dyn_f)
-        if self.param_transport == "bf16":
-            # opt-in: gather the shard's UPDATE in bf16 (half the bytes; 2^-9 relative rounding of the update, not of the parameter);
-            # applied in _wait_params.  NOT the reference's semantics (replicas hold old + bf16(update) instead of the fp32 Adam result).
-            if self._d16_full is None:
-                self._d16_full = torch.zeros(npad, dtype=torch.bfloat16, device=self.dev)
-                self._d16_shard = torch.zeros(shard, dtype=torch.bfloat16, device=self.dev)
-            self._d16_shard.zero_()
-            if hi > lo:
-                self._d16_shard[:hi - lo].copy_(new[o + lo:o + hi] - self.params[o + lo:o + hi])
-            with self._span("all_gather.field"):
-                self._ag_work = sdist.all_gather_shards(self._d16_full, self._d16_shard, self.pg, async_op=True)
-            self._delta_pending = True
-        else:
-            self._p_shard.copy_(new[o + lo:o + lo + shard])
-            with self._span("all_gather.field"):
-                self._ag_work = sdist.all_gather_shards(new[o:o + npad], self._p_shard, self.pg, async_op=True)
+        coefs = tuple(co[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss"))
+        n4 = _align4(n)
+        for ch in self._exchange:  # in exchange order: the finest scale's shard is swept and gathered while the rest is still on the links
+            lo = ch["lo"] + self.rank * ch["shard"]
+            hi = min(lo + ch["shard"], n4)
+            ch["rs"].wait()
+            ch["rs"] = None
+            self.grads[o + lo:o + lo + ch["shard"]].copy_(ch["g16_shard"] if self.grad_transport == "bf16" else ch["g_shard"])
+            with self._span("adam_planes.field"):
+                if hi > lo:
+                    ops.adam_planes_step(self.field_planes, self.params[o:o + n], new[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
+                                         self.vviews["field.planes"], coefs, self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=gs,
+                                         zero_grad=False, shard_range=(lo, hi), dyn=dyn_f)
+            if self.param_transport == "bf16":
+                # opt-in: gather the shard's UPDATE in bf16 (half the bytes; 2^-9 relative rounding of the update, not of the parameter);
+                # applied in _wait_params.  NOT the reference's semantics (replicas hold old + bf16(update) instead of the fp32 Adam result).
+                if ch["d16_full"] is None:
+                    ch["d16_full"] = torch.zeros(ch["hi"] - ch["lo"], dtype=torch.bfloat16, device=self.dev)
+                    ch["d16_shard"] = torch.zeros(ch["shard"], dtype=torch.bfloat16, device=self.dev)
+                ch["d16_shard"].zero_()
+                if hi > lo:
+                    ch["d16_shard"][:hi - lo].copy_(new[o + lo:o + hi] - self.params[o + lo:o + hi])
+                with self._span("all_gather.field"):
+                    ch["ag"] = sdist.all_gather_shards(ch["d16_full"], ch["d16_shard"], self.pg, async_op=True)
+                self._delta_pending = True
+            else:
+                ch["p_shard"].copy_(new[o + lo:o + lo + ch["shard"]])
+                with self._span("all_gather.field"):
+                    ch["ag"] = sdist.all_gather_shards(new[o + ch["lo"]:o + ch["hi"]], ch["p_shard"], self.pg, async_op=True)
         for w in self._ar_work:
             w.wait()
         for i in range(2):
@@ -947,14 +992,14 @@ class KPlanesTrainer:
         return names
 
     def _gather_moment_shards(self):
-        """Sharded optimiser: every rank owns 1/world of the field planes' Adam moments; make the full buffers whole on all ranks."""
+        """Sharded optimiser: every rank owns 1/world of each exchange chunk's Adam moments; make the full buffers whole on all ranks."""
         from . import dist as sdist
 
-        off, _, padded = self._field_seg
-        shard = padded // self.world
+        off = self._field_seg[0]
         for buf in (self.exp_avg, self.exp_avg_sq):
-            seg = buf[off:off + padded]
-            sdist.all_gather_shards(seg, seg[self.rank * shard:(self.rank + 1) * shard].clone(), self.pg)
+            for ch in self._exchange:
+                seg = buf[off + ch["lo"]:off + ch["hi"]]
+                sdist.all_gather_shards(seg, seg[self.rank * ch["shard"]:(self.rank + 1) * ch["shard"]].clone(), self.pg)
 
     def save_checkpoint(self, checkpoint_dir: str, save_only_latest_checkpoint: bool = True) -> Optional[str]:
         """Writes `step-%09d.ckpt` (rank 0 only; collective when the optimiser is sharded).  The saved step is the index of the last

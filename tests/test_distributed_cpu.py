@@ -150,6 +150,53 @@ def test_reduce_scatter_shard_all_gather_equals_all_reduce(tmp_path):
         torch.testing.assert_close(s_, w_, rtol=2 ** -8, atol=1e-6)
 
 
+def _chunk_worker(rank, world, port, outdir):
+    """The chunked exchange of trainer._plan_exchange / _sharded_optimizer_step on plain tensors: the segment is cut in two chunks (tail
+    first), each reduce-scattered, stepped on this rank's shard of THAT chunk and all-gathered -- must equal all-reduce + full step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from soccernerfs_amd import dist as sdist
+
+    _, _, pg = sdist.init_from_env(backend="gloo")
+    q = 4 * world
+    n, cut = q * 50, q * 13
+    g = torch.cos(torch.arange(n, dtype=torch.float32) * 0.11 + rank) * (rank + 2)
+    p = torch.linspace(-1, 1, n)
+    new = torch.zeros(n)
+    works = []
+    chunks = [(cut, n), (0, cut)]  # finest (tail) first
+    shards = [torch.empty((hi - lo) // world) for lo, hi in chunks]
+    for (lo, hi), sh in zip(chunks, shards):  # both reduce-scatters in flight before either is consumed
+        works.append(sdist.reduce_scatter_sum(sh, g[lo:hi], pg, async_op=True))
+    owned = torch.zeros(n, dtype=torch.bool)
+    for (lo, hi), sh, w in zip(chunks, shards, works):
+        w.wait()
+        k = (hi - lo) // world
+        a = lo + rank * k
+        owned[a:a + k] = True
+        sdist.all_gather_shards(new[lo:hi], (p[a:a + k] - 0.1 * sh / world).contiguous(), pg, async_op=True).wait()
+    ref = g.clone()
+    sdist.all_reduce_sum_(ref, pg)
+    torch.save((new, p - 0.1 * ref / world, owned), os.path.join(outdir, f"c{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_chunked_exchange_equals_all_reduce(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(rk, 2, port, str(tmp_path))) for rk in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    (n0, r0, o0), (n1, r1, o1) = torch.load(tmp_path / "c0.pt"), torch.load(tmp_path / "c1.pt")
+    assert torch.equal(n0, n1) and torch.equal(n0, r0)
+    assert bool((o0 ^ o1).all())  # the two ranks' shards tile the segment: every float has exactly one owner
+
+
 def test_single_process_is_identity():
     from soccernerfs_amd import dist as sdist
 

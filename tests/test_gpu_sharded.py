@@ -96,6 +96,23 @@ def _reference_two_rank_steps(n_steps, R):
     return tr
 
 
+def _owner_mask(tr, rank, world=2):
+    """Which floats of the field-plane segment rank `rank` owns under the chunked exchange plan (trainer._plan_exchange)."""
+    from soccernerfs_amd.trainer import KPlanesTrainer
+
+    probe = KPlanesTrainer.__new__(KPlanesTrainer)
+    probe.cfg, probe.world, probe.dev = tr.cfg, world, torch.device("cpu")
+    _, n, _ = tr._field_seg
+    q = 4 * world
+    probe._field_seg = (0, n, (n + q - 1) // q * q)
+    probe._desc_field = tr._desc_field
+    probe._plan_exchange()
+    mask = torch.zeros(probe._field_seg[2], dtype=torch.bool)
+    for ch in probe._exchange:
+        mask[ch["lo"] + rank * ch["shard"]:ch["lo"] + (rank + 1) * ch["shard"]] = True
+    return mask
+
+
 def _worker_main():
     """python tests/test_gpu_sharded.py <rank> <world> <port> <steps> <R> <outdir> <shard 0|1|2>   (2 = sharded with bf16 gradient transport)"""
     rank, world, port, n_steps, R = (int(x) for x in sys.argv[1:6])
@@ -175,10 +192,10 @@ def test_two_ranks_on_one_gpu_match_mean_gradient_reference(tmp_path, shard):
         assert float(bad) < 2e-3, (name, float(bad))
         m_ref = ref.mviews[name].cpu()
         m_got = res[0]["m"][name]
-        if shard and name == "field.planes":  # every rank keeps Adam state for its own half only
-            half = (m_ref.numel() + 7) // 8 * 8 // 2
-            assert float(res[0]["m"][name][half:].abs().max()) == 0.0 and float(res[1]["m"][name][:half].abs().max()) == 0.0
-            m_got = torch.cat([res[0]["m"][name][:half], res[1]["m"][name][half:]])
+        if shard and name == "field.planes":  # every rank keeps Adam state for its own half of each exchange chunk only
+            own0 = _owner_mask(ref, rank=0)[:m_ref.numel()]
+            assert float(res[0]["m"][name][~own0].abs().max()) == 0.0 and float(res[1]["m"][name][own0].abs().max()) == 0.0
+            m_got = torch.where(own0, res[0]["m"][name], res[1]["m"][name])
         assert float(m_ref.abs().max()) > 0
         torch.testing.assert_close(m_got, m_ref, rtol=0, atol=2e-3 * float(m_ref.abs().max()))
     want_tv = float(ref.loss_dict()["space_tv_loss"])
@@ -193,8 +210,8 @@ def test_two_ranks_on_one_gpu_match_mean_gradient_reference(tmp_path, shard):
     moments = CK.import_optimizer_states(ref._named_module(), ck["optimizers"])
     m_ck = moments["field.grids.planes"][0].reshape(-1)
     m_ref = ref.mviews["field.planes"].cpu()
-    half = m_ref.numel() // 2
-    assert float(m_ck[:half].abs().max()) > 0 and float(m_ck[half:].abs().max()) > 0
+    own0 = _owner_mask(ref, rank=0)[:m_ref.numel()]
+    assert float(m_ck[own0].abs().max()) > 0 and float(m_ck[~own0].abs().max()) > 0
     torch.testing.assert_close(m_ck, m_ref, rtol=0, atol=2e-3 * float(m_ref.abs().max()))
     resumed = KPlanesTrainerForResume(tmp_path, shard)
     assert resumed.step == n_steps
@@ -214,11 +231,10 @@ def test_sharded_step_through_rccl_world_size_one():
         tr = KPlanesTrainer(_small_cfg(), R, DEV, process_group=dist.group.WORLD)
         assert tr.world == 1 and not tr._sharded()
         tr.world, tr.shard_optimizer = 1, True
-        # force the sharded code path with a single shard
+        # force the sharded code path with a single shard per exchange chunk
         tr._sharded = lambda: True
-        shard = tr._field_seg[2]
-        tr._g_shard = torch.zeros(shard, device=DEV)
-        tr._p_shard = torch.zeros(shard, device=DEV)
+        tr._plan_exchange()
+        assert len(tr._exchange) == 2 and tr._exchange[0]["hi"] == tr._field_seg[2]  # finest scale first
         for k in range(n_steps):
             tr.train_step(*_batch(R, 0, k)[:2], _batch(R, 0, k)[2])
         tr.synchronize()
