@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
+    ap.add_argument("--no-fused-field", action="store_true", help="A-B: gather, sigma_net and color_net as separate kernels (feat / h / gfeat through HBM)")
+    ap.add_argument("--no-fused-backward", action="store_true", help="A-B: fused forward only")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
@@ -127,7 +129,8 @@ def main():
 
     # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
     torch.manual_seed(20231029 + rank)
-    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands)  # the k-planes preset
+    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field,
+                             fused_field_backward=not args.no_fused_backward)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
@@ -199,7 +202,7 @@ def main():
         one_step()
     # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
     CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
-            "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop"]
+            "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_field_bwd"]
     trainer.enable_kernel_timing(CAND)
     elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
@@ -254,6 +257,9 @@ def main():
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),
             "kplanes_gather_fwd.field": ("hbm", gather, "kplanes_gather_fwd_kernel<32,6>: texel reads"),
+            "kplanes_field_fwd": ("hbm", gather + R * S2 * 16, "field_fwd_kernel (gather + sigma_net + color_net fused): texel reads + density / rgb written"),
+            "kplanes_field_bwd": ("hbm", 2 * gather + R * S2 * (16 + 30 * cfg.feature_dim * (2 if args.mlp_operands != "fp32" else 4)),
+                                  "field_bwd_kernel (recomputed forward + both nets' backward + per-plane gradient vectors fused): texel reads x 2 + gvec written"),
             # proposal planes (C = 8, one scale): two launches per updated step (256 and 128 samples per ray) -> mean bytes per launch; runs on
             # its own stream beside the field backward, so its launches are stretched by whatever shares the GPU with them
             "kplanes_gather_bwd.prop": ("hbm", 2 * R * (sum(cfg.num_proposal_samples_per_ray) // 2) * 6 * 4 * cfg.proposal_feature_dim * 4,

@@ -194,6 +194,29 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
                      int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused K-Planes field = KPlanesField.get_density + get_outputs (NS/fields/kplanes_field.py:275-358) in one kernel: plane gather
+ * (interpolate_kplanes :77-126) -> sigma_net (32 n_scales -> 128 -> 16, :249-261) -> density = trunc_exp(column 15) (:308-311) and
+ * color_net on the 15 geometry features (15 -> 64 -> 64 -> 3 Sigmoid, :263-273, disable_viewing_dependent) -> rgb.  The features, the
+ * 16 sigma_net outputs and every MLP activation stay on chip.  Built for 4-D plane sets with C = 32, concatenated scales (<= 5), the two
+ * net shapes above and 16-bit MFMA operands (snerf_mlp_desc.operands = 1 bf16 / 2 fp16, both nets alike): snerf_kplanes_field_supported
+ * tells; the exact-fp32 path composes snerf_kplanes_gather_fwd + snerf_mlp_fwd.  Results are bit-identical to that composition run with the
+ * same 16-bit operands.
+ *   fwd: density [N], rgb [N,3].
+ *   bwd: from g_density [N] and g_rgb [N,3]: recomputes the forward per tile, ACCUMULATES the weight gradients of both nets (flat layouts of
+ *        snerf_mlp_*; float atomics, or fixed-point cells when the *_fx pointers are given instead) and writes the per-plane gradient
+ *        vectors gvec[scale * 6 + plane][N][32] (fp32 or bf16) that snerf_kplanes_scatter_sorted consumes -- i.e. it replaces
+ *        snerf_mlp_bwd x 2 + snerf_kplanes_gradvec; gfeat [N, 32 n_scales] never exists.
+ * ------------------------------------------------------------------------------------------------ */
+int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
+int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                            const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
+                            float* density, float* rgb, snerf_stream_t stream);
+int snerf_kplanes_field_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                            const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
+                            const float* g_density, const float* g_rgb, float* gW_sigma, float* gW_color, int64_t* gW_sigma_fx,
+                            int64_t* gW_color_fx, void* gvec, int32_t gvec_bf16, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Compositing and ray-level losses (one wavefront per ray, S <= 320).
  * ------------------------------------------------------------------------------------------------ */
 

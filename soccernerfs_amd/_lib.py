@@ -193,4 +193,7 @@ EXPORTS = [
     "snerf_mlp_bwd_fx",
     "snerf_adam_prepare",
     "snerf_depth_loss",
+    "snerf_kplanes_field_supported",
+    "snerf_kplanes_field_fwd",
+    "snerf_kplanes_field_bwd",
 ]

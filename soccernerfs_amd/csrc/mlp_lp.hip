@@ -17,96 +17,9 @@
 //             dWO = A1^T dY    A = A1t [H][TS]      B^T = gzot [16][TS]
 // The transposed copies cost nothing extra to write from an accumulator: a lane of the C layout holds 4 consecutive ROWS of one column,
 // i.e. 8 contiguous bytes of the transposed image.  Row stride = K + 8 elements (16-B aligned rows, conflict-free b128 reads).
-#include "common.hpp"
+#include "mlp_lp_common.hpp"
 
 namespace snerf {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16;
-typedef _Float16 fp16;
-
-template <typename T>
-struct Ops;
-template <>
-struct Ops<bf16> {
-  typedef __bf16 v8 __attribute__((ext_vector_type(8)));
-  typedef __bf16 v4 __attribute__((ext_vector_type(4)));
-  static constexpr float GS = 1.f;  // gradient tile scale
-  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ bf16 cvt(float x) { return (bf16)x; }
-  static __device__ __forceinline__ bf16 cvtg(float x) { return (bf16)x; }
-};
-template <>
-struct Ops<fp16> {
-  typedef _Float16 v8 __attribute__((ext_vector_type(8)));
-  typedef _Float16 v4 __attribute__((ext_vector_type(4)));
-  static constexpr float GS = 8192.f;
-  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-  static __device__ __forceinline__ fp16 cvt(float x) { return (fp16)fminf(fmaxf(x, -65504.f), 65504.f); }
-  static __device__ __forceinline__ fp16 cvtg(float x) { return (fp16)fminf(fmaxf(x, -65504.f), 65504.f); }
-};
-
-struct MlpArgs {  // same fields as mlp.hip's (filled there)
-  const float* X; int64_t N; int ldx; int d0;
-  const float* W; int woff[4];
-  int dout;
-  float* Y; int ldy;
-  int hidden_act, out_act;
-  int aux_col; float* aux_out;
-  const float* gY; int ldgy;
-  const float* gaux;
-  float* gX; int ldgx;
-  float* gW;
-  long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
-};
-
-__device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
-  if (a.gWfx) fx_atomic_add(a.gWfx + idx, v); else atomicAdd(a.gW + idx, v);
-}
-
-constexpr int LDS_LIMIT_B = 160 * 1024;
-__host__ __device__ constexpr int ldb(int k) { return k + 8; }
-
-template <typename T>
-__device__ __forceinline__ typename Ops<T>::v8 ld8(const T* p) { return *reinterpret_cast<const typename Ops<T>::v8*>(p); }
-
-// acc[m] (row block m of A, column block nt of the result) += A[., K] * Bt[nt*16 .., K]^T ; both row-major along K
-template <int MT, int K, typename T>
-__device__ __forceinline__ void mma_rr(const T* A, int lda, const T* Bt, int ldbt, int nt, f32x4 (&acc)[MT], int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  const T* bp = Bt + (nt * 16 + lr) * ldbt + lk * 8;
-  const T* ap = A + lr * lda + lk * 8;
-#pragma unroll
-  for (int ks = 0; ks < K / 32; ++ks) {
-    const typename Ops<T>::v8 b = ld8(bp + ks * 32);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8(ap + m * 16 * lda + ks * 32), b, acc[m]);
-  }
-}
-
-// accumulator block (rows mt*16.., cols nt*16..) -> row-major image R[row][col] and/or transposed image T[col][row]
-template <typename T>
-__device__ __forceinline__ void store_rt(T* R, int ldr, T* Tr, int ldt, int mt, int nt, const f32x4& v, int lane) {
-  const int col = nt * 16 + (lane & 15);
-  const int row0 = mt * 16 + (lane >> 4) * 4;
-  const typename Ops<T>::v4 t = {Ops<T>::cvtg(v[0]), Ops<T>::cvtg(v[1]), Ops<T>::cvtg(v[2]), Ops<T>::cvtg(v[3])};
-  if (R) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) R[(row0 + r) * ldr + col] = t[r];
-  }
-  if (Tr) *reinterpret_cast<typename Ops<T>::v4*>(Tr + col * ldt + row0) = t;
-}
-
-// W [rows_act][cols_act] fp32 row-major (global) -> LDS as stored (R [rows_pad][ldr], zero padded) and/or transposed (T [cols_pad][ldt])
-template <typename T>
-__device__ __forceinline__ void stage_w(const float* __restrict__ Wg, int rows_act, int cols_act, int rows_pad, int cols_pad, T* R, int ldr, T* Tr, int ldt) {
-  for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += blockDim.x) {
-    const int r = idx / cols_pad, c = idx - r * cols_pad;
-    const T v = Ops<T>::cvt((r < rows_act && c < cols_act) ? Wg[(int64_t)r * cols_act + c] : 0.f);
-    if (R) R[r * ldr + c] = v;
-    if (Tr) Tr[c * ldt + r] = v;
-  }
-}
 
 // X tile: global fp32 -> registers one tile ahead -> LDS (row-major and, for the backward, transposed)
 template <int TS, int K0, int NT>

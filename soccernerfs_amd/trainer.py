@@ -85,7 +85,11 @@ class KPlanesTrainConfig:
     # reference's GradScaler does (NS/engine/trainer.py:394-408, one found_inf per optimiser); "drop_elements": only the
     # non-finite elements are dropped (round-1 behaviour)
     nonfinite_policy: str = "skip_step"
-    fused_field: bool = False
+    # gather -> sigma_net -> colour net as ONE kernel forward, and recomputed forward -> both nets' backward -> per-plane gradient vectors
+    # as ONE kernel backward (csrc/field_fused.hip): feat / h / gfeat never reach HBM.  Used when the shapes and 16-bit operands allow
+    # (snerf_kplanes_field_supported) and the sorted scatter is on; the exact-fp32 parity path stays unfused
+    fused_field: bool = True
+    fused_field_backward: bool = True  # False: fused forward only; the backward recomputes the gather and runs the unfused kernels (A-B)
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -137,6 +141,7 @@ class KPlanesTrainer:
         self._prop_pending = None
         self._depth = None
         self._exchange_started = False
+        self._fwd_fused = False
         self._grad_scale = 1.0
         self._pipeline_adam, self._early_adam_hi, self._reg_zeroed = False, None, False
         self._dyn_step = 0
@@ -238,6 +243,8 @@ class KPlanesTrainer:
         self.lib = _lib.lib()
         self._desc_field = self.field_planes.desc()
         self._desc_prop = [p.desc() for p in self.prop_planes]
+        self.fused_field = bool(cfg.fused_field and self.sorted_scatter and not cfg.deterministic and self.lib.snerf_kplanes_field_supported(
+            C.byref(self._desc_field), C.byref(self.sigma_net.desc), C.byref(self.color_net.desc)))
         if self.world > 1:
             self._plan_exchange()
 
@@ -397,7 +404,17 @@ class KPlanesTrainer:
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
                 self._wait_params()
-                self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
+                # fused field: always in eval; in training only when the backward will run as ONE chunk over the sorted scatter
+                n_chunks = max(1, min(self.bwd_chunks, R)) if self.overlap and not self._sharded() else 1
+                self._fwd_fused = self.fused_field and (not training or (R == self.R and n_chunks == 1))
+                if self._fwd_fused:
+                    with self._span("kplanes_field_fwd"):
+                        _lib.check(self.lib.snerf_kplanes_field_fwd(C.byref(self._desc_field), self._p(self.field_planes.planes), C.byref(co), C.c_int64(N),
+                                                                    C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), C.byref(self.color_net.desc),
+                                                                    self._p(self.color_net.params), self._p(b["dens"][2]), self._p(b["rgb"]), self._st),
+                                   "kplanes_field_fwd")
+                else:
+                    self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
                 if training and self.sorted_scatter and self.grads_fx is None and R == self.R:
                     # sort the nerf-level samples per (scale, plane) on a side stream.  Started AFTER the (memory-bound) gather so
                     # that it runs under the MFMA-bound MLP forward / backward that follow on the main stream.
@@ -407,8 +424,9 @@ class KPlanesTrainer:
                     with KPlanesTrainer._On(self, st), self._span("kplanes_sort"):
                         self._ss.sort(co, self._st)
                     self._sort_done = st.record_event()
-                self._mlp_fwd(self.sigma_net, b["feat"], self.field_planes.out_dim, N, b["h"], 16, 15, b["dens"][2])
-                self._mlp_fwd(self.color_net, b["h"], 16, N, b["rgb"], 3)
+                if not self._fwd_fused:
+                    self._mlp_fwd(self.sigma_net, b["feat"], self.field_planes.out_dim, N, b["h"], 16, 15, b["dens"][2])
+                    self._mlp_fwd(self.color_net, b["h"], 16, N, b["rgb"], 3)
                 _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, self.S[2], self._p(b["w"][2]), self._st), "weights_fwd")
         a = _lib.RenderArgs()
         a.weights, a.rgb, a.ebins = b["w"][2].data_ptr(), b["rgb"].data_ptr(), b["eb"][2].data_ptr()
@@ -465,15 +483,29 @@ class KPlanesTrainer:
         b, S2, F = self.buf, self.S[2], self.field_planes.out_dim
         n0, N = r0 * S2, (r1 - r0) * S2
         sl = lambda t: t[n0:n0 + N]
-        # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
-        self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
-        self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1], sl(b["gfeat"]), F)
+        fused = self._fwd_fused and self.cfg.fused_field_backward
+        if self._fwd_fused and not fused:  # forward was fused (feat / h never written): recompute them for the unfused backward kernels
+            self._gather(self._desc_field, self.field_planes.planes, self._coords[2], N, b["feat"])
+            self._mlp_fwd(self.sigma_net, b["feat"], F, N, b["h"], 16, -1, None)
+        assert not fused or (r0 == 0 and r1 == self.R and self._sort_done is not None), "fused field backward needs the whole batch and the sorted scatter"
+        if not fused:
+            # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
+            self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
+            self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1], sl(b["gfeat"]), F)
         rays = self.rays
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
         if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:
             torch.cuda.current_stream().wait_event(self._sort_done)
             ss = self._ss
-            with self._span("kplanes_gradvec.field"):
+            if fused:  # recomputed forward -> both nets' backward -> gradient vectors, one kernel
+                with self._span("kplanes_field_bwd"):
+                    _lib.check(self.lib.snerf_kplanes_field_bwd(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
+                                                                C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), C.byref(self.color_net.desc),
+                                                                self._p(self.color_net.params), self._p(b["gdens"][2]), self._p(b["grgb"]),
+                                                                self._p(self.gviews["field.sigma"]), self._p(self.gviews["field.color"]), None, None,
+                                                                self._p(ss.gvec), ss.gvec_bf16, self._st), "kplanes_field_bwd")
+            else:
+              with self._span("kplanes_gradvec.field"):
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
                                                           self._p(b["gfeat"]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
             ns = len(self.cfg.multiscale_res)

@@ -65,7 +65,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     torch.manual_seed(seed)
     random.seed(seed)
     cfg = KPlanesTrainConfig(max_steps=args.schedule_steps, mlp_operands=args.mlp_operands, seed=seed, deterministic=args.deterministic,
-                             nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, gvec_dtype=args.gvec_dtype,
+                             nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, fused_field_backward=not args.no_fused_backward, gvec_dtype=args.gvec_dtype,
                              sigma_operands=args.sigma_operands, color_operands=args.color_operands, proposal_operands=args.proposal_operands)
     R = 4096
     trainer = KPlanesTrainer(cfg, R, dev)
@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="fixed-point gradient accumulation: bit-identical reruns")
     ap.add_argument("--nonfinite-policy", default="skip_step", choices=["skip_step", "drop_elements"])
     ap.add_argument("--no-fused-field", action="store_true")
+    ap.add_argument("--no-fused-backward", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
