@@ -55,15 +55,17 @@ class KPlanesTrainConfig:
     max_steps: int = 30000
     lr_alpha: float = 0.0
     seed: int = 0
-    # MFMA operand type of every net (sigma_net, color_net, proposal sigma nets): "fp32" = exact (parity tests); "fp16" / "bf16" =
-    # 16-bit operands with fp32 accumulation (csrc/mlp_lp.hip; tcnn itself computes these nets in fp16, BASELINE config 2 names bf16).
-    mlp_operands: str = "fp32"
+    # MFMA operand type of every net (sigma_net, color_net, proposal sigma nets): "bf16" (default: what BASELINE config 2 names) / "fp16"
+    # (tcnn's own) = 16-bit operands with fp32 accumulation (csrc/mlp_lp.hip, csrc/field_fused.hip); "fp32" = exact (the parity tests).
+    # 30 k-step novel-view PSNR over 3 seeds: fp32 41.50 dB, bf16 41.49 dB (profiles/r02_psnr_ab.md).
+    mlp_operands: str = "bf16"
     sigma_operands: Optional[str] = None   # per-net overrides of mlp_operands (A-B runs): field sigma_net / color_net / proposal nets
     color_operands: Optional[str] = None
     proposal_operands: Optional[str] = None
-    # element type of the per-plane gradient vectors between the two passes of the sorted scatter: "fp32", "bf16", or "auto" = fp32 with
-    # fp32 MLP operands (the exact parity path), bf16 otherwise
-    gvec_dtype: str = "auto"
+    # element type of the per-plane gradient vectors between the two passes of the sorted scatter: "fp32" (default) or "bf16" (half the
+    # bytes of the step's largest intermediate, ~+1 % throughput; over 3 seeds it costs ~0.4 dB of novel-view PSNR with a +-0.8 dB
+    # run-to-run spread against +-0.2 dB for fp32 vectors -- profiles/r02_psnr_ab.md -- so it stays opt-in)
+    gvec_dtype: str = "fp32"
     # ---- execution switches (defaults = the measured best; bench.py / tools expose them for A-B runs) ----
     overlap: bool = True              # independent kernel chains on role streams (False: everything on the caller's stream)
     async_field_adam: bool = True     # field planes' optimiser sweep on its own stream under the NEXT step's proposal levels
@@ -227,8 +229,7 @@ class KPlanesTrainer:
         self._timing, self._timing_all = None, False
         # sorted plane-gradient scatter for the main field (csrc/kplanes_sorted.hip): ~6x fewer atomic requests
         self.sorted_scatter = cfg.sorted_scatter
-        gv = cfg.gvec_dtype if cfg.gvec_dtype != "auto" else ("fp32" if cfg.mlp_operands == "fp32" else "bf16")
-        self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[gv]
+        self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[cfg.gvec_dtype]
         self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype)
         self._ss.desc = self.field_planes.desc()
         self._sort_done = None

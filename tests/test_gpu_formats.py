@@ -63,7 +63,7 @@ def test_fused_trainer_checkpoint_roundtrip_and_reference_names(tmp_path):
     from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
     def make(seed):
-        cfg = KPlanesTrainConfig(seed=seed, multiscale_res=(1, 2), spacetime_resolution=(8, 8, 8, 4), feature_dim=8, proposal_feature_dim=8,
+        cfg = KPlanesTrainConfig(seed=seed, mlp_operands="fp32", multiscale_res=(1, 2), spacetime_resolution=(8, 8, 8, 4), feature_dim=8, proposal_feature_dim=8,
                             proposal_resolutions=((8, 8, 8, 4), (16, 16, 16, 4)), num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8,
                             sigma_net_hidden_dim=64, rgb_net_hidden_dim=64)
         return KPlanesTrainer(cfg, 256, device=torch.device(DEV))

@@ -87,7 +87,7 @@ def test_config3_fused_train_steps():
     from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
     R = 2048
-    cfg = KPlanesTrainConfig(multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
+    cfg = KPlanesTrainConfig(mlp_operands="fp32", multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
                              proposal_resolutions=((128, 128, 128, 25), (256, 256, 256, 25)))
     tr = KPlanesTrainer(cfg, R, DEV)
     assert tr.params.numel() > 540_000_000

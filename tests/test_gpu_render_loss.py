@@ -207,7 +207,7 @@ def test_trainer_depth_supervision_matches_oracle():
     R = 48
     cfg = KPlanesTrainConfig(aabb_scale=1.5, spacetime_resolution=E["base_res"], multiscale_res=E["multiscale"], feature_dim=32,
                              proposal_resolutions=E["prop_res"], proposal_feature_dim=8, num_proposal_samples_per_ray=(64, 32),
-                             num_nerf_samples_per_ray=16, depth_sigma=0.05)
+                             num_nerf_samples_per_ray=16, depth_sigma=0.05, mlp_operands="fp32")
     tr = KPlanesTrainer(cfg, R, DEV)
     tr.load_oracle_params(P)
     gen = torch.Generator().manual_seed(12)

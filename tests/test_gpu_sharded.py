@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _small_cfg():
     from soccernerfs_amd.trainer import KPlanesTrainConfig
 
-    cfg = KPlanesTrainConfig(spacetime_resolution=(16, 16, 16, 5), multiscale_res=(1, 2), proposal_resolutions=((24, 24, 24, 5), (32, 32, 32, 5)))
+    cfg = KPlanesTrainConfig(spacetime_resolution=(16, 16, 16, 5), multiscale_res=(1, 2), proposal_resolutions=((24, 24, 24, 5), (32, 32, 32, 5)), mlp_operands="fp32")
     cfg.num_proposal_samples_per_ray, cfg.num_nerf_samples_per_ray = (64, 32), 16
     cfg.warm_up_end = 2
     return cfg

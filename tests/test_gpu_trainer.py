@@ -14,7 +14,7 @@ def _cfg_from(E):
 
     return KPlanesTrainConfig(aabb_scale=E["aabb_scale"], spacetime_resolution=E["base_res"], multiscale_res=E["multiscale"],
                               feature_dim=E["feat_dim"], proposal_resolutions=E["prop_res"], proposal_feature_dim=E["prop_feat"],
-                              sigma_net_hidden_dim=E["sigma_hidden"], rgb_net_hidden_dim=E["color_hidden"])
+                              sigma_net_hidden_dim=E["sigma_hidden"], rgb_net_hidden_dim=E["color_hidden"], mlp_operands="fp32")
 
 
 def _name_to_view(tr, name):

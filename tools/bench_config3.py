@@ -9,7 +9,7 @@ from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 steps, warmup, R = 100, 20, 4096
-cfg = KPlanesTrainConfig(multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
+cfg = KPlanesTrainConfig(mlp_operands="fp32", multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
                          proposal_resolutions=((128, 128, 128, 25), (256, 256, 256, 25)))
 tr = KPlanesTrainer(cfg, R, dev)
 tr.step = 6000  # steady-state schedule, IST active (iters_to_start_ist = 2000)

@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--eval-every", type=int, default=10000)
     ap.add_argument("--out", default="gpurun_out/psnr.json")
     ap.add_argument("--mlp-operands", default="bf16", choices=["fp32", "bf16", "fp16"])
-    ap.add_argument("--gvec-dtype", default="auto", choices=["auto", "fp32", "bf16"])
+    ap.add_argument("--gvec-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--sigma-operands", default=None)
     ap.add_argument("--color-operands", default=None)
     ap.add_argument("--proposal-operands", default=None)
