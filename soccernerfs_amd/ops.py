@@ -26,6 +26,19 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def aabb_host(aabb):
+    """[[min x,y,z],[max x,y,z]] as host floats.  A device tensor (the nerfstudio-shaped modules hold scene_box.aabb as an nn.Parameter) is
+    copied to the host ONCE and the copy is kept on the tensor object -- every later call would otherwise be a device-to-host
+    synchronisation in the middle of the stream pipeline (four per model forward).  The cache follows in-place edits through `_version`."""
+    if not isinstance(aabb, torch.Tensor):
+        return aabb
+    cached = getattr(aabb, "_snerf_host", None)
+    if cached is None or cached[0] != aabb._version:
+        cached = (aabb._version, aabb.detach().cpu().tolist())
+        aabb._snerf_host = cached
+    return cached[1]
+
+
 def coords_from_points(pts: torch.Tensor) -> _lib.Coords:
     c = _lib.Coords()
     c.mode = 0
@@ -39,7 +52,7 @@ def coords_from_rays(origins, dirs, times, ebins, aabb, rescale: bool) -> _lib.C
     c.S = ebins.shape[-1] - 1
     c.rescale = int(rescale)
     c.origins, c.dirs, c.times, c.ebins = origins.data_ptr(), dirs.data_ptr(), times.data_ptr(), ebins.data_ptr()
-    a = aabb.detach().cpu().tolist() if isinstance(aabb, torch.Tensor) else aabb
+    a = aabb_host(aabb)
     for k in range(3):
         c.aabb_min[k] = a[0][k]
         c.aabb_max[k] = a[1][k]
@@ -589,7 +602,7 @@ def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_
     a.R = R
     a.origins, a.dirs, a.pixel_area, a.dir_norm, a.times = [out[k].data_ptr() for k in ("origins", "directions", "pixel_area", "directions_norm", "times")]
     if aabb is not None:
-        ab = aabb.detach().cpu().tolist() if isinstance(aabb, torch.Tensor) else aabb
+        ab = aabb_host(aabb)
         a.collide, a.training, a.near_plane = 1, int(training), near_plane
         for k in range(3):
             a.aabb_min[k], a.aabb_max[k] = ab[0][k], ab[1][k]
@@ -622,8 +635,7 @@ def aabb_collide(origins, directions, aabb, near_plane: float = 0.0, training: b
     R = origins.shape[0]
     nears = torch.empty(R, 1, dtype=torch.float32, device=origins.device)
     fars = torch.empty_like(nears)
-    ab = aabb.detach().cpu().reshape(-1).tolist() if isinstance(aabb, torch.Tensor) else [v for row in aabb for v in row]
-    arr = (C.c_float * 6)(*ab)
+    arr = (C.c_float * 6)(*[v for row in aabb_host(aabb) for v in row])
     _lib.check(_lib.lib().snerf_aabb_collide(_ptr(origins), _ptr(directions), R, arr, near_plane, int(training), _ptr(nears), _ptr(fars),
                                              _stream()), "aabb_collide")
     return nears, fars

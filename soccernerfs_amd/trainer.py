@@ -88,9 +88,11 @@ class KPlanesTrainConfig:
     # non-finite elements are dropped (round-1 behaviour)
     nonfinite_policy: str = "skip_step"
     # gather -> sigma_net -> colour net as ONE kernel forward, and recomputed forward -> both nets' backward -> per-plane gradient vectors
-    # as ONE kernel backward (csrc/field_fused.hip): feat / h / gfeat never reach HBM.  Used when the shapes and 16-bit operands allow
-    # (snerf_kplanes_field_supported) and the sorted scatter is on; the exact-fp32 parity path stays unfused
-    fused_field: bool = True
+    # as ONE kernel backward (csrc/field_fused.hip): feat / h / gfeat never reach HBM.  OPT-IN: built and parity-tested (forward bit-identical
+    # to the unfused 16-bit kernels), but measured SLOWER on MI355X at the preset (forward 0.58 vs 0.53 ms, backward 2.5 vs 0.9 ms,
+    # profiles/r02_kernels.md): the gather is latency-bound and wants the 28 waves / CU the stand-alone kernel gets, the MLPs' LDS and
+    # register footprint leaves the fused kernels 16 (forward) and 8 (backward).  Needs 16-bit operands and the sorted scatter.
+    fused_field: bool = False
     fused_field_backward: bool = True  # False: fused forward only; the backward recomputes the gather and runs the unfused kernels (A-B)
 
 
@@ -374,10 +376,23 @@ class KPlanesTrainer:
         assert R <= self.R and (training is False or R == self.R), "training batches must have exactly the configured number of rays"
         self._fwd_rays = R
         self._st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        # the kernels read these buffers through raw pointers: insist on contiguous fp32 device tensors of the expected shapes
+        rays = dict(rays)
+        for k, cols in (("origins", 3), ("directions", 3), ("times", 1)):
+            rays[k] = ops._f32c(rays[k], f"rays[{k!r}]")
+            if rays[k].numel() != R * cols:
+                raise RuntimeError(f"rays[{k!r}] must hold {R} x {cols} values, got {tuple(rays[k].shape)}")
+        if training:
+            rng = dict(rng)
+            rng["t_rand"], rng["bg"] = ops._f32c(rng["t_rand"], "rng['t_rand']"), ops._f32c(rng["bg"], "rng['bg']")
+            rng["u"] = [ops._f32c(u, "rng['u']") for u in rng["u"]]
+            if rng["bg"].numel() != 3 * R or any(u.shape[0] != R for u in rng["u"]) or rng["t_rand"].shape[0] != R:
+                raise RuntimeError("rng draws must have one row per ray")
         o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
         if "nears" not in rays:
-            rays = dict(rays)
             rays["nears"], rays["fars"] = ops.aabb_collide(o, d, self.aabb, cfg.near_plane, training)
+        else:
+            rays["nears"], rays["fars"] = ops._f32c(rays["nears"], "rays['nears']"), ops._f32c(rays["fars"], "rays['fars']")
         self.rays = rays
         t_rand = rng["t_rand"] if training else None
         _lib.check(self.lib.snerf_spaced_bins(self._p(rays["nears"]), self._p(rays["fars"]), self._p(t_rand) if t_rand is not None else None,
@@ -621,7 +636,10 @@ class KPlanesTrainer:
         if overlap and not sharded:
             proposal_chain()
         # MSELoss (kplanes.py:418) folded into the render backward: g_rgb_out = 2 c / (3R) * (rgb_out - target); value lazily from sqerr
-        target = target if target.is_contiguous() else target.contiguous()
+        target = ops._f32c(target, "target")
+        if target.numel() != 3 * R:
+            raise RuntimeError(f"target must be [{R}, 3], got {tuple(target.shape)}")
+        rng = dict(rng, bg=ops._f32c(rng["bg"], "rng['bg']"))
         self.last = {}
         _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
                                                  2.0 * co["rgb_loss"] / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]),
