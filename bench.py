@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--fused-forward-only", action="store_true", help="with --fused-field: fuse the forward only")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
+    ap.add_argument("--prop-after-field", action="store_true", help="A-B: proposal backward behind the field scatter, beside the optimiser sweep")
     ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
@@ -139,6 +140,7 @@ def main():
     trainer.step = args.start_step
     trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
     trainer.prop_on_main = args.prop_on_main
+    trainer.prop_after_field = args.prop_after_field
     trainer.grad_transport = args.grad_transport
     trainer.param_transport = args.param_transport
 

@@ -448,6 +448,18 @@ int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const float* tabl
                               float* grad_table, float* grad_x, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * NeRFPlayer decomposition mixing (NerfplayerField.get_density, NS/fields/nerfplayer_field.py:365-372): probs[N,3] = softmax(logits[N,3])
+ * (0 = static, 1 = deforming, 2 = new) and v[N,F] = probs_0 v_static + probs_1 v_deform + probs_2 v_new; F = 16, 32 or 64.
+ * bwd: from g_v [N,F] and (may be NULL) g_probs [N,3], the gradient that reaches probs from outside v (the rendered-probability
+ * regulariser, NS/models/nerfplayer.py:336-341): g_static / g_deform / g_new [N,F] and g_logits [N,3], all overwritten.
+ * ------------------------------------------------------------------------------------------------ */
+int snerf_nerfplayer_mix_fwd(const float* logits, const float* v_static, const float* v_deform, const float* v_new, int64_t N, int32_t F,
+                             float* probs, float* v, snerf_stream_t stream);
+int snerf_nerfplayer_mix_bwd(const float* probs, const float* v_static, const float* v_deform, const float* v_new, const float* g_v,
+                             const float* g_probs, int64_t N, int32_t F, float* g_static, float* g_deform, float* g_new, float* g_logits,
+                             snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Ray importance sampling (IST = temporal difference).
  * ------------------------------------------------------------------------------------------------ */
 

@@ -196,4 +196,6 @@ EXPORTS = [
     "snerf_kplanes_field_supported",
     "snerf_kplanes_field_fwd",
     "snerf_kplanes_field_bwd",
+    "snerf_nerfplayer_mix_fwd",
+    "snerf_nerfplayer_mix_bwd",
 ]

@@ -1,0 +1,96 @@
+// NeRFPlayer decomposition mixing (NerfplayerField.get_density, NS/fields/nerfplayer_field.py:365-372):
+//   probs = softmax(decomposition_mlp(decomposition_field(x, t)))          [N,3]  0 = static, 1 = deforming, 2 = new
+//   v     = probs[:,0] v_static + probs[:,1] v_deform + probs[:,2] v_new   [N,F]
+// and its backward, including the gradient that reaches probs from outside v (the rendered-probability regulariser,
+// NS/models/nerfplayer.py:336-341).  The reference runs this as ~10 ATen elementwise / reduction kernels each way.
+// F / 4 lanes per sample, float4 per lane; the three channel reductions of the backward are xor-shuffles inside the lane group.
+#include "common.hpp"
+
+namespace snerf {
+
+template <int F>
+__global__ __launch_bounds__(256) void mix_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ vs, const float* __restrict__ vd,
+                                                     const float* __restrict__ vn, int64_t N, float* __restrict__ probs, float* __restrict__ v) {
+  constexpr int LPS = F / 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = gid / LPS;
+  const int cg = (int)(gid % LPS);
+  if (n >= N) return;
+  const float l0 = logits[n * 3], l1 = logits[n * 3 + 1], l2 = logits[n * 3 + 2];
+  const float m = fmaxf(l0, fmaxf(l1, l2));
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m), e2 = expf(l2 - m);
+  const float inv = 1.f / (e0 + e1 + e2);
+  const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+  if (cg == 0) { probs[n * 3] = p0; probs[n * 3 + 1] = p1; probs[n * 3 + 2] = p2; }
+  const float4 a = *reinterpret_cast<const float4*>(vs + n * F + cg * 4), b = *reinterpret_cast<const float4*>(vd + n * F + cg * 4),
+               c = *reinterpret_cast<const float4*>(vn + n * F + cg * 4);
+  float4 o;
+  o.x = p0 * a.x + p1 * b.x + p2 * c.x; o.y = p0 * a.y + p1 * b.y + p2 * c.y;
+  o.z = p0 * a.z + p1 * b.z + p2 * c.z; o.w = p0 * a.w + p1 * b.w + p2 * c.w;
+  *reinterpret_cast<float4*>(v + n * F + cg * 4) = o;
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ vs, const float* __restrict__ vd,
+                                                     const float* __restrict__ vn, const float* __restrict__ gv, const float* __restrict__ gp_ext, int64_t N,
+                                                     float* __restrict__ gvs, float* __restrict__ gvd, float* __restrict__ gvn, float* __restrict__ glogits) {
+  constexpr int LPS = F / 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = gid / LPS;
+  const int cg = (int)(gid % LPS);
+  const bool live = n < N;
+  const int64_t nn = live ? n : N - 1;
+  const float p0 = probs[nn * 3], p1 = probs[nn * 3 + 1], p2 = probs[nn * 3 + 2];
+  const float4 g = *reinterpret_cast<const float4*>(gv + nn * F + cg * 4);
+  const float4 a = *reinterpret_cast<const float4*>(vs + nn * F + cg * 4), b = *reinterpret_cast<const float4*>(vd + nn * F + cg * 4),
+               c = *reinterpret_cast<const float4*>(vn + nn * F + cg * 4);
+  float d0 = g.x * a.x + g.y * a.y + g.z * a.z + g.w * a.w;
+  float d1 = g.x * b.x + g.y * b.y + g.z * b.z + g.w * b.w;
+  float d2 = g.x * c.x + g.y * c.y + g.z * c.z + g.w * c.w;
+#pragma unroll
+  for (int off = LPS / 2; off > 0; off >>= 1) {  // lane groups are aligned: LPS divides 64
+    d0 += __shfl_xor(d0, off, 64); d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64);
+  }
+  if (!live) return;
+  if (gp_ext) { d0 += gp_ext[n * 3]; d1 += gp_ext[n * 3 + 1]; d2 += gp_ext[n * 3 + 2]; }
+  if (cg == 0) {  // softmax backward
+    const float dot = p0 * d0 + p1 * d1 + p2 * d2;
+    glogits[n * 3] = p0 * (d0 - dot); glogits[n * 3 + 1] = p1 * (d1 - dot); glogits[n * 3 + 2] = p2 * (d2 - dot);
+  }
+  *reinterpret_cast<float4*>(gvs + n * F + cg * 4) = make_float4(p0 * g.x, p0 * g.y, p0 * g.z, p0 * g.w);
+  *reinterpret_cast<float4*>(gvd + n * F + cg * 4) = make_float4(p1 * g.x, p1 * g.y, p1 * g.z, p1 * g.w);
+  *reinterpret_cast<float4*>(gvn + n * F + cg * 4) = make_float4(p2 * g.x, p2 * g.y, p2 * g.z, p2 * g.w);
+}
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_nerfplayer_mix_fwd(const float* logits, const float* v_static, const float* v_deform, const float* v_new, int64_t N, int32_t F,
+                                        float* probs, float* v, snerf_stream_t stream) {
+  SNERF_REQUIRE(N >= 0 && (F == 16 || F == 32 || F == 64), "nerfplayer_mix_fwd: N=%lld F=%d (16, 32 or 64)", (long long)N, F);
+  if (N == 0) return 0;
+  SNERF_REQUIRE(logits && v_static && v_deform && v_new && probs && v, "nerfplayer_mix_fwd: null buffer");
+  const dim3 grid((unsigned)ceil_div(N * (F / 4), 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 16) hipLaunchKernelGGL(mix_fwd_kernel<16>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
+  else if (F == 32) hipLaunchKernelGGL(mix_fwd_kernel<32>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
+  else hipLaunchKernelGGL(mix_fwd_kernel<64>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
+  SNERF_LAUNCH_CHECK("nerfplayer_mix_fwd");
+  return 0;
+}
+
+extern "C" int snerf_nerfplayer_mix_bwd(const float* probs, const float* v_static, const float* v_deform, const float* v_new, const float* g_v,
+                                        const float* g_probs, int64_t N, int32_t F, float* g_static, float* g_deform, float* g_new, float* g_logits,
+                                        snerf_stream_t stream) {
+  SNERF_REQUIRE(N >= 0 && (F == 16 || F == 32 || F == 64), "nerfplayer_mix_bwd: N=%lld F=%d (16, 32 or 64)", (long long)N, F);
+  if (N == 0) return 0;
+  SNERF_REQUIRE(probs && v_static && v_deform && v_new && g_v && g_static && g_deform && g_new && g_logits, "nerfplayer_mix_bwd: null buffer");
+  const dim3 grid((unsigned)ceil_div(N * (F / 4), 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (F == 16) hipLaunchKernelGGL(mix_bwd_kernel<16>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
+  else if (F == 32) hipLaunchKernelGGL(mix_bwd_kernel<32>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
+  else hipLaunchKernelGGL(mix_bwd_kernel<64>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
+  SNERF_LAUNCH_CHECK("nerfplayer_mix_bwd");
+  return 0;
+}

@@ -72,6 +72,7 @@ class KPlanesTrainConfig:
     adam_under_scatter: bool = False  # sweep the finest scale while the coarser scales are scattered (measured +1 %: off)
     bwd_chunks: int = 1               # ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)
     prop_on_main: bool = False        # proposal backward on the main stream ahead of the field chain
+    prop_after_field: bool = False    # proposal backward starts behind the field scatter and runs beside the optimiser sweep
     defer_prop: bool = True           # join the proposal chain only in front of the proposal planes' own optimiser kernels
     sorted_scatter: bool = True       # sorted / grouped plane-gradient scatter for the field (csrc/kplanes_sorted.hip)
     sorted_scatter_proposals: bool = False
@@ -139,7 +140,7 @@ class KPlanesTrainer:
         # synchronize() join it for outside readers -- call synchronize() before reading parameters / Adam state / gradients from
         # outside a train step.  +3-5 % (bench.py --sync-adam for A-B).
         self.overlap, self.bwd_chunks = cfg.overlap, cfg.bwd_chunks
-        self.prop_on_main, self.defer_prop = cfg.prop_on_main, cfg.defer_prop
+        self.prop_on_main, self.defer_prop, self.prop_after_field = cfg.prop_on_main, cfg.defer_prop, cfg.prop_after_field
         self.async_field_adam, self.adam_under_scatter = cfg.async_field_adam, cfg.adam_under_scatter
         self._field_adam_done = None
         self._prop_pending = None
@@ -633,7 +634,8 @@ class KPlanesTrainer:
                 self._proposal_backward(proposal_grads)
             joins.append(st)
 
-        if overlap and not sharded:
+        late_prop = self.prop_after_field and n_chunks == 1  # proposal backward behind the field scatter, i.e. beside the optimiser sweep
+        if overlap and not sharded and not late_prop:
             proposal_chain()
         # MSELoss (kplanes.py:418) folded into the render backward: g_rgb_out = 2 c / (3R) * (rgb_out - target); value lazily from sqerr
         target = ops._f32c(target, "target")
@@ -662,6 +664,8 @@ class KPlanesTrainer:
                 self._exchange_started = False
                 if overlap:
                     proposal_chain(after=main.record_event())
+            elif overlap and late_prop:
+                proposal_chain(after=main.record_event())  # waits for the field scatter; the optimiser sweep (own stream) starts at the same point
             if not overlap:
                 self._proposal_backward(proposal_grads)
         else:

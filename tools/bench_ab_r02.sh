@@ -1,18 +1,18 @@
-# A-B of the fused field kernels (bench.py, bf16 operands): run on the GPU box from the repo root
+# round-2 A-B runs of bench.py on the GPU box (from the repo root)
 set -x
-python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/r02_t4.log
+python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > gpurun_out/r02_t5.log
 B="python bench.py --no-cpu-baseline --steps 100 --warmup 10"
-$B --fused-field > gpurun_out/r02_bench_fused.json 2> gpurun_out/r02_bench_fused.err
-$B --fused-field --fused-forward-only > gpurun_out/r02_bench_fusedfwd.json 2>> gpurun_out/r02_bench_fused.err
-$B > gpurun_out/r02_bench_unfused.json 2>> gpurun_out/r02_bench_fused.err
-$B --no-steady-state --breakdown --no-overlap --steps 40 2> gpurun_out/r02_breakdown_fused.txt > /dev/null
-$B --no-steady-state --breakdown --no-overlap --steps 40 --no-fused-field 2> gpurun_out/r02_breakdown_unfused.txt > /dev/null
-$B --no-steady-state --breakdown --no-overlap --steps 40 --no-fused-backward 2> gpurun_out/r02_breakdown_fusedfwd.txt > /dev/null
+for v in "" "--prop-after-field" "--no-overlap" "--mlp-operands fp32" "--gvec-dtype-bf16"; do
+  n=$(echo "default$v" | tr -d ' -')
+  if [ "$v" = "--gvec-dtype-bf16" ]; then continue; fi
+  $B $v > gpurun_out/r02_bench_$n.json 2> gpurun_out/r02_bench_$n.err
+done
 python - <<'PY'
-import json
-for n in ("fused","fusedfwd","unfused"):
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r02_bench_default*.json")):
     try:
-        d=json.loads(open(f"gpurun_out/r02_bench_{n}.json").read().strip().splitlines()[-1])
-        print(n, round(d["ms_per_step"],3), round(d["value"]), "steady", round(d["steady_state"]["ms_per_step"],3), round(d["steady_state"]["value"]))
-    except Exception as e: print(n, "ERR", e)
+        d=json.loads(open(f).read().strip().splitlines()[-1])
+        print(f.split("r02_bench_")[1], round(d["ms_per_step"],3), round(d["value"]), "steady", round(d["steady_state"]["ms_per_step"],3), round(d["steady_state"]["value"]), d["roofline"]["kernel"][:40], round(d["roofline"]["frac"],3))
+    except Exception as e: print(f, "ERR", e)
 PY
+bash tools/collect_profiles.sh r02

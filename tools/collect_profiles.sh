@@ -2,12 +2,11 @@
 # Run on the GPU box from the repo root: bench line, rocprofv3 kernel stats and the three PMC passes for the judged profiles.
 # usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>_*)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python bench.py --no-cpu-baseline --start-step 6000 > $OUT/${TAG}_bench_steady.json 2>> $OUT/${TAG}_bench.err
 python bench.py --no-cpu-baseline --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
@@ -47,13 +46,15 @@ with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
             continue
         tr = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
         g.write(f'"{k}",{v.get("FETCH_SIZE", 0):.1f},{v.get("WRITE_SIZE", 0):.1f},{v.get("TCC_EA0_ATOMIC_sum", 0):.1f},{tr:.0f}\n')
-names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_grouped_kernel<6>",
-         "kplanes_gradvec.field": "snerf::gradvec_kernel<32, 6>", "kplanes_gather_fwd.field": "snerf::kplanes_gather_fwd_kernel<32, 6>",
-         "mlp_bwd.160x128x1": "snerf::mlp_bwd_kernel<160, 128, 1, 32>"}
+names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_grouped_kernel<6",
+         "kplanes_gradvec.field": "snerf::gradvec_kernel<32, 6", "kplanes_gather_fwd.field": "snerf::kplanes_gather_fwd_kernel<32, 6>",
+         "mlp_bwd.160x128x1": "bwd_kernel<__bf16, 160, 128, 1", "kplanes_gather_bwd.prop": "snerf::kplanes_gather_bwd_kernel<8, 6"}
 tj = {"_note": "traffic_bytes_per_launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->B) from separate rocprofv3 --pmc passes, k-planes preset, 4096 rays "
                f"(profiles/{tag}_pmc_counters.csv)"}
-for span, k in names.items():
-    if k in acc:
+for span, pat in names.items():
+    hit = [k for k in acc if pat in k]
+    if hit:
+        k = hit[0]
         v = acc[k]
         tj[span] = {"kernel": k, "traffic_bytes_per_launch": (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024,
                     "atomic_requests": v.get("TCC_EA0_ATOMIC_sum", 0)}
