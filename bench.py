@@ -48,6 +48,8 @@ def parse():
                     "gradient on the links (fp32 = the reference's DDP semantics; bf16 halves the reduce-scatter bytes, opt-in)")
     ap.add_argument("--param-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: fp32 = all-gather the new field planes "
                     "(reference semantics); bf16 = all-gather the parameter UPDATES in bf16 and apply them identically on every rank (opt-in)")
+    ap.add_argument("--cabi-allreduce", action="store_true", help="world > 1 with --no-shard: the flat gradient all-reduce goes through libsnerf's own "
+                    "RCCL communicator (snerf_allreduce_grads) instead of torch.distributed")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
@@ -137,6 +139,10 @@ def main():
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
     if args.no_shard:
         trainer.shard_optimizer = False
+        if args.cabi_allreduce and world > 1 and backend == "nccl":
+            from soccernerfs_amd.dist import CAbiComm
+
+            trainer.cabi_comm = CAbiComm(pg, dev)
     trainer.step = args.start_step
     trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
     trainer.prop_on_main = args.prop_on_main

@@ -331,6 +331,20 @@ int snerf_adam_planes_step_range(const snerf_kplanes_desc* desc, const float* p_
                                  snerf_adam_dyn* dyn, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Gradient exchange (multi-GPU): the reference wraps the model in DistributedDataParallel (NS/pipelines/base_pipeline.py:244-246).
+ * One communicator per process (one process per GPU); snerf_allreduce_grads is ONE in-place RCCL all-reduce (SUM, fp32) of the flat
+ * gradient buffer on `stream` -- the mean over ranks is folded into snerf_adam_step's grad_scale = 1 / world.
+ *   rank 0: snerf_comm_unique_id(id) -> the 128 bytes reach every rank by the launcher's own means (e.g. a torch.distributed broadcast)
+ *   every rank: snerf_comm_create(world, rank, id, &comm) ... snerf_allreduce_grads(comm, grads, n, stream) ... snerf_comm_destroy(comm)
+ * RCCL is resolved with dlopen("librccl.so.1") at the first call (the process's already-loaded copy); errors: code 1000 + ncclResult_t.
+ * ------------------------------------------------------------------------------------------------ */
+#define SNERF_COMM_ID_BYTES 128
+int snerf_comm_unique_id(void* id128);
+int snerf_comm_create(int32_t world, int32_t rank, const void* id128, void** comm_out);
+int snerf_comm_destroy(void* comm);
+int snerf_allreduce_grads(void* comm, float* grads, int64_t n, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Ray generation + collider.
  * ------------------------------------------------------------------------------------------------ */
 

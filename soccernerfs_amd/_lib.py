@@ -198,4 +198,8 @@ EXPORTS = [
     "snerf_kplanes_field_bwd",
     "snerf_nerfplayer_mix_fwd",
     "snerf_nerfplayer_mix_bwd",
+    "snerf_comm_unique_id",
+    "snerf_comm_create",
+    "snerf_comm_destroy",
+    "snerf_allreduce_grads",
 ]

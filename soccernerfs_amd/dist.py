@@ -118,3 +118,36 @@ def max_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if _is_nccl(group) else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+class CAbiComm:
+    """The per-step gradient all-reduce through libsnerf's own RCCL communicator (snerf_comm_* / snerf_allreduce_grads, include/snerf.h)
+    instead of torch.distributed: rank 0 makes the unique id, torch.distributed (any backend) carries its 128 bytes to the other ranks,
+    every rank joins.  `all_reduce_sum_(flat)` enqueues ONE ncclAllReduce(SUM) on the current stream and returns the optimiser's grad_scale."""
+
+    def __init__(self, group, device):
+        import ctypes as C
+
+        from . import _lib
+
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self._lib, self._C = _lib, C
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(_lib.lib().snerf_comm_unique_id(ident), "comm_unique_id")
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=device if _is_nccl(group) else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
+        ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self._comm = C.c_void_p()
+        _lib.check(_lib.lib().snerf_comm_create(self.world, self.rank, ident, C.byref(self._comm)), "comm_create")
+
+    def all_reduce_sum_(self, flat: torch.Tensor) -> float:
+        C = self._C
+        self._lib.check(self._lib.lib().snerf_allreduce_grads(self._comm, C.c_void_p(flat.data_ptr()), C.c_int64(flat.numel()),
+                                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "allreduce_grads")
+        return 1.0 / self.world
+
+    def close(self):
+        if self._comm:
+            self._lib.check(self._lib.lib().snerf_comm_destroy(self._comm), "comm_destroy")
+            self._comm = None

@@ -146,6 +146,7 @@ class KPlanesTrainer:
         self._prop_pending = None
         self._depth = None
         self._exchange_started = False
+        self.cabi_comm = None  # dist.CAbiComm: route the unsharded all-reduce through libsnerf's own RCCL communicator (bench.py --cabi-allreduce)
         self._fwd_fused = False
         self._grad_scale = 1.0
         self._pipeline_adam, self._early_adam_hi, self._reg_zeroed = False, None, False
@@ -920,7 +921,10 @@ class KPlanesTrainer:
             self._join_prop()
             self._convert_fx()
         with self._span("allreduce_grads"):
-            self._grad_scale = sdist.allreduce_flat_(self.grads, self.pg)
+            if self.cabi_comm is not None:  # the exchange behind the C ABI (snerf_allreduce_grads) instead of torch.distributed
+                self._grad_scale = self.cabi_comm.all_reduce_sum_(self.grads)
+            else:
+                self._grad_scale = sdist.allreduce_flat_(self.grads, self.pg)
 
     def optimizer_step(self, fused_reg: bool = False):
         """Adam(lr*cosine, eps 1e-12) over the whole flat buffer + gradient clear (Optimizers.optimizer_step_all/scheduler_step_all)."""

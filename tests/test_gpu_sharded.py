@@ -301,3 +301,28 @@ def test_bf16_gradient_transport_two_ranks(tmp_path):
         want = ref.views[name].cpu()
         bad = ((a - want).abs() > 2e-4).float().mean()
         assert float(bad) < 2e-2, (name, float(bad))
+
+
+def test_cabi_communicator_world_size_one():
+    """snerf_comm_* / snerf_allreduce_grads (the gradient exchange behind the C ABI, include/snerf.h): a one-rank RCCL communicator created from
+    a unique id; the in-place SUM all-reduce of one rank leaves the buffer unchanged and runs on the caller's stream."""
+    import ctypes as C
+
+    from soccernerfs_amd import _lib, ops
+
+    L = _lib.lib()
+    ident = (C.c_ubyte * 128)()
+    _lib.check(L.snerf_comm_unique_id(ident), "comm_unique_id")
+    assert any(ident)  # RCCL filled it
+    comm = C.c_void_p()
+    _lib.check(L.snerf_comm_create(1, 0, ident, C.byref(comm)), "comm_create")
+    try:
+        g = torch.randn(1 << 20, device=DEV)
+        want = g.clone()
+        _lib.check(L.snerf_allreduce_grads(comm, ops._ptr(g), C.c_int64(g.numel()), ops._stream()), "allreduce_grads")
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)
+        assert L.snerf_allreduce_grads(None, ops._ptr(g), C.c_int64(4), ops._stream()) < 0  # argument error, message set
+        assert b"communicator" in L.snerf_last_error()
+    finally:
+        _lib.check(L.snerf_comm_destroy(comm), "comm_destroy")
