@@ -67,6 +67,49 @@ __device__ __forceinline__ void grad_add(float* g, long long* gfx, int64_t idx, 
   if (FX) fx_atomic_add(gfx + idx, v); else atomicAdd(g + idx, v);
 }
 
+// ---- per-ray prefix sums by the whole wavefront, accumulated in double ----
+// The reference's cumsum runs on the CPU in ATen: a sequential double accumulator rounded to fp32 per element (cumsum_cpu_kernel,
+// acc_type<float, false> = double); the sample INDICES of the PDF sampler and the median-depth index depend on those roundings
+// (bit-exact `inds`).  Round 1 reproduced it with one lane walking the ray (63 lanes idle, ~2.5 us per ray and scan).  Here
+// lane l owns the contiguous block [l * PER, (l + 1) * PER) of the ray's n <= 64 * WSCAN_PER elements: a sequential double prefix inside
+// the block, a Hillis-Steele scan of the 64 block totals in double, one add.  Double sums of <= 320 fp32 values differ between the two
+// association orders by ~1e-16 relative, so the value rounded to fp32 is the same unless a sum sits within that distance of an fp32
+// rounding boundary (~1e-9 per element) -- indices stay bit-exact on every fixture and random test of the suite.
+//   in[0..n) (LDS) -> out[i] = (float) sum_{j <= i} in[j]   (EXCLUSIVE: sum_{j < i});  REVERSE: the same from the far end (suffix sums).
+// Returns the total in every lane.  in and out may alias (a lane reads and writes only its own block).
+constexpr int WSCAN_PER = 5;  // 64 * 5 = 320 = the per-ray kernels' MAX_S
+template <bool EXCLUSIVE, bool REVERSE>
+__device__ __forceinline__ double wave_scan_f64(const float* in, float* out, int n, int lane) {
+  const int per = (n + 63) >> 6;
+  const int b0 = lane * per;
+  float v[WSCAN_PER];
+  double local = 0.0;
+#pragma unroll
+  for (int k = 0; k < WSCAN_PER; ++k) {
+    const int i = b0 + k;
+    v[k] = (k < per && i < n) ? in[REVERSE ? n - 1 - i : i] : 0.f;
+    local = local + (double)v[k];
+  }
+  double incl = local;  // inclusive scan of the block totals over the lanes
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl = incl + t;
+  }
+  double run = incl - local;  // sum of all earlier blocks
+  const double total = __shfl(incl, 63, 64);
+#pragma unroll
+  for (int k = 0; k < WSCAN_PER; ++k) {
+    const int i = b0 + k;
+    if (k < per && i < n) {
+      if (EXCLUSIVE) out[REVERSE ? n - 1 - i : i] = (float)run;
+      run = run + (double)v[k];
+      if (!EXCLUSIVE) out[REVERSE ? n - 1 - i : i] = (float)run;
+    }
+  }
+  return total;
+}
+
 // nan_to_num with torch defaults (nan->0, +inf->FLT_MAX, -inf->-FLT_MAX)
 __device__ __forceinline__ float nan_to_num(float v) {
   if (v != v) return 0.f;

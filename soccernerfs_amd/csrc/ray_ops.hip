@@ -1,11 +1,10 @@
 // Per-ray kernels: spaced bins, density->weights (+bwd), PDF (inverse-CDF) resampling.
 //
 // One 64-lane wavefront owns one ray (S <= 320 samples => <= 5 elements per lane); 4 rays per 256-thread
-// workgroup, per-ray scratch in LDS.  Everything order-sensitive (the CDF that decides sample INDICES) is
-// accumulated strictly left-to-right by one lane with a double accumulator rounded to fp32 per element --
-// exactly what torch.cumsum does on the CPU (ATen cumsum_cpu_kernel: acc_type<float,false> = double) -- so
-// indices are a pure function of the inputs and bit-exact against the oracle; FP contraction is disabled in
-// this file for the same reason.  The cost is ~2-3k cycles per ray, <0.5 % of a train step.
+// workgroup, per-ray scratch in LDS.  Everything order-sensitive (the CDF that decides sample INDICES) is a
+// wavefront prefix scan with DOUBLE accumulators rounded to fp32 per element (common.hpp: wave_scan_f64) --
+// the arithmetic of torch.cumsum on the CPU (ATen cumsum_cpu_kernel: acc_type<float,false> = double) -- so
+// indices are bit-exact against the oracle; FP contraction is disabled in this file for the same reason.
 //
 // Reference: NS/model_components/ray_samplers.py (SpacedSampler :79-126, PDFSampler :274-369,
 // ProposalNetworkSampler :584), NS/cameras/rays.py:127-149 (get_weights).
@@ -104,14 +103,7 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
       w[i] = (e1 - e0) * a.density[(int64_t)r * Sp + i];  // delta * sigma
     }
     __syncthreads();
-    if (lane == 0) {  // exclusive cumsum, sequential, double accumulator like ATen's CPU cumsum (rays.py:141-145)
-      double acc = 0.0;
-      for (int i = 0; i < Sp; ++i) {
-        float dd = w[i];
-        cdf[i] = (float)acc;
-        acc = acc + (double)dd;
-      }
-    }
+    wave_scan_f64<true, false>(w, cdf, Sp, lane);  // exclusive cumsum of delta * sigma (rays.py:141-145), double accumulator as ATen's CPU cumsum
     __syncthreads();
     for (int i = lane; i < Sp; i += 64) {
       float dd = w[i];
@@ -135,29 +127,18 @@ __global__ __launch_bounds__(256) void resample_kernel(ResampleArgs a) {
   }
   for (int i = lane; i <= Sp; i += 64) bins[i] = a.sbins_prev[(int64_t)r * (Sp + 1) + i];
   __syncthreads();
-  if (lane == 0) {
-    double sd = 0.0;  // sequential sum == cumsum(w)[-1] (ATen CPU cumsum: double accumulator, float result)
-    for (int i = 0; i < Sp; ++i) sd = sd + (double)w[i];
-    float s = (float)sd;
-    float padding = fmaxf(a.eps - s, 0.f);  // :306
-    cdf[Sp + 1] = padding / (float)Sp;      // stash
-    cdf[0] = s + padding;                   // stash total
-  }
-  __syncthreads();
   {
-    float padd = cdf[Sp + 1], tot = cdf[0];
+    // weights_sum = cumsum(w)[-1] (double accumulator, fp32 result), padding (:305-308)
+    const float s = (float)wave_scan_f64<false, false>(w, cdf + 1, Sp, lane);  // (the prefix sums written to cdf are overwritten below)
+    const float padding = fmaxf(a.eps - s, 0.f);  // :306
+    const float padd = padding / (float)Sp, tot = s + padding;
     __syncthreads();
     for (int i = lane; i < Sp; i += 64) w[i] = (w[i] + padd) / tot;  // pdf (:307-310)
   }
   __syncthreads();
-  if (lane == 0) {
-    double acc = 0.0;
-    cdf[0] = 0.f;
-    for (int i = 0; i < Sp; ++i) {
-      acc = acc + (double)w[i];
-      cdf[i + 1] = fminf(1.f, (float)acc);  // min(ones, cumsum) then leading zero (:311-312)
-    }
-  }
+  wave_scan_f64<false, false>(w, cdf + 1, Sp, lane);  // cumsum(pdf)
+  __syncthreads();
+  for (int i = lane; i <= Sp; i += 64) cdf[i] = i == 0 ? 0.f : fminf(1.f, cdf[i]);  // min(ones, cumsum) then the leading zero (:311-312)
   __syncthreads();
 
   // ---- stage 3: inverse-CDF sampling ----
@@ -218,14 +199,7 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
     dd[i] = (e1 - e0) * density[(int64_t)r * S + i];
   }
   __syncthreads();
-  if (lane == 0) {
-    double acc = 0.0;
-    for (int i = 0; i < S; ++i) {
-      float x = dd[i];
-      aux[i] = (float)acc;  // exclusive cumsum
-      acc = acc + (double)x;
-    }
-  }
+  wave_scan_f64<true, false>(dd, aux, S, lane);  // exclusive cumsum
   __syncthreads();
   // gw_i * w_i (0 where the forward weight was non-finite: nan_to_num passes no gradient there)
   float gwterm[5], Tk[5], ek[5];
@@ -255,14 +229,7 @@ __global__ __launch_bounds__(256) void weights_bwd_kernel(const float* __restric
     if (i < S) aux[i] = gwterm[k];
   }
   __syncthreads();
-  if (lane == 0) {  // suffix sums, right-to-left
-    double acc = 0.0;
-    for (int i = S - 1; i >= 0; --i) {
-      float x = aux[i];
-      aux[i] = (float)acc;  // sum_{j>i}
-      acc = acc + (double)x;
-    }
-  }
+  wave_scan_f64<true, true>(aux, aux, S, lane);  // suffix sums: aux[i] = sum_{j > i}
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 5; ++k) {

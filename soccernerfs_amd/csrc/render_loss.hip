@@ -33,6 +33,7 @@ struct RenderArgs {
 
 __global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
   __shared__ float s_w[RPB][MAXS];
+  __shared__ float s_cum[RPB][MAXS];
   __shared__ int s_med[RPB];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int ray = blockIdx.x * RPB + wv;
@@ -53,16 +54,17 @@ __global__ __launch_bounds__(256) void render_fwd_kernel(RenderArgs a) {
   }
   cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); acc = wave_sum(acc); dsum = wave_sum(dsum);
   __syncthreads();
-  if (lane == 0) {
-    // median: first index with cumsum(w) >= 0.5 (searchsorted left), clamped (renderers.py:264-267)
-    double run = 0.0;
+  {
+    // median: first index with cumsum(w) >= 0.5 (searchsorted left), clamped (renderers.py:264-267); cumsum by wavefront scan in double
+    wave_scan_f64<false, false>(s_w[wv], s_cum[wv], S, lane);
+    __syncthreads();
     int idx = S;
-    for (int i = 0; i < S; ++i) {
-      run = run + (double)s_w[wv][i];
-      if (idx == S && (float)run >= 0.5f) idx = i;
-    }
+    for (int i = lane; i < S; i += 64)
+      if (s_cum[wv][i] >= 0.5f) { idx = i; break; }  // the cumsum of non-negative weights is monotone: the lane's first hit is its smallest
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(idx, off, 64); idx = o < idx ? o : idx; }
     if (idx > S - 1) idx = S - 1;
-    s_med[wv] = idx;
+    if (lane == 0) s_med[wv] = idx;
   }
   __syncthreads();
   if (lane == 0 && live) {
@@ -196,14 +198,8 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
   for (int i = lane; i <= Sp; i += 64) tp[i] = p_bins[(int64_t)r * (Sp + 1) + i];
   for (int i = lane; i < Sp; i += 64) cy[i + 1] = w_prop[(int64_t)r * Sp + i];
   __syncthreads();
-  if (lane == 0) {  // cy = [0, cumsum(wp)] (sequential, double accumulator)
-    double acc = 0.0;
-    cy[0] = 0.f;
-    for (int i = 0; i < Sp; ++i) {
-      acc = acc + (double)cy[i + 1];
-      cy[i + 1] = (float)acc;
-    }
-  }
+  wave_scan_f64<false, false>(cy + 1, cy + 1, Sp, lane);  // cy = [0, cumsum(wp)], double accumulator
+  if (lane == 0) cy[0] = 0.f;
   __syncthreads();
   float total = 0.f;
   for (int i = lane; i < S; i += 64) {
