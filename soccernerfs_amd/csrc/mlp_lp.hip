@@ -403,7 +403,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
 template <typename T, int K0, int H, int NH>
 static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
   if (bwd) {
-    constexpr int TS = 32;
+    constexpr int TS = (H <= 64 && NH == 1) ? 64 : 32;  // proposal nets: 64-sample tiles halve the barriers per sample (0.217 -> 0.153 ms; 128: 0.221)
     using P = PlanB<K0, H, NH, TS>;
     static_assert(P::BYTES <= LDS_LIMIT_B, "bf16 backward tile does not fit LDS");
     const int64_t n_tiles = (a.N + TS - 1) / TS;
@@ -416,7 +416,7 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
   } else {
-    constexpr int TS = 32;
+    constexpr int TS = (H <= 64 && NH == 1) ? 64 : 32;
     using P = PlanF<K0, H, NH, TS>;
     const int64_t n_tiles = (a.N + TS - 1) / TS;
     int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
