@@ -133,3 +133,40 @@ def test_fused_training_reduces_loss_and_keeps_parameters_finite():
         losses.append(float(tr.loss_dict()["rgb_loss"]))
     assert tr.step == 12 and losses[-1] < losses[1], losses
     assert bool(torch.isfinite(tr.params).all()) and float(tr.grads.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tv", [0.0, 1.0])
+def test_optimizer_step_sweeps_every_parameter_exactly_once(tv):
+    """with the temporal-TV term off the sweep used to step the leading segments two and three times.  One optimiser step on a
+    known gradient must equal ONE plain Adam sweep over the whole flat buffer (plus, with TV on, the folded-in TV gradient)."""
+    import dataclasses
+
+    from soccernerfs_amd import ops
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    cfg = dataclasses.replace(_cfg(), temporal_tv_weight=tv)
+    tr = NerfplayerTrainer(cfg, 32, 5, device=DEV, seed=1)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    tr.params.copy_(torch.rand(tr.n_params, device=DEV, generator=gen) - 0.5)
+    tr.grads.copy_(torch.rand(tr.n_params, device=DEV, generator=gen) - 0.5)
+    tr.exp_avg.copy_(torch.rand(tr.n_params, device=DEV, generator=gen) * 0.1)
+    tr.exp_avg_sq.copy_(torch.rand(tr.n_params, device=DEV, generator=gen) * 0.01)
+    tr.step = 700  # past the warm-up: a non-zero learning rate
+    p, g, m, v = tr.params.clone(), tr.grads.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone()
+    if tv > 0:  # the per-row TV steps the sweep folds in: make them explicit in the reference gradient
+        for k, name in enumerate(("field.table", "prop0.table", "prop1.table")):
+            tr._srow[k].copy_(torch.rand(tr._srow[k].shape, device=DEV, generator=gen) - 0.5)
+            o, n = next((o, n) for nm, _, _, o, n in tr.segments if nm == name)
+            ca, cb = tr._tv_cols[k]
+            gv = g[o:o + n].view(tr.views[name].shape)
+            gv[:, ca] += tr._srow[k]
+            gv[:, cb] -= tr._srow[k]
+    from soccernerfs_amd.trainer import cosine_lr_factor
+    lr = tr.lr * cosine_lr_factor(700, tr.warm_up_end, tr.max_steps, 0.0)
+    ops.adam_step(p, g, m, v, 701, lr, eps=tr.adam_eps, zero_grad=True)
+    tr.optimizer_step()
+    torch.cuda.synchronize()
+    assert tr.step == 701 and float(tr.grads.abs().max()) == 0.0
+    torch.testing.assert_close(tr.params, p, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(tr.exp_avg, m, rtol=1e-6, atol=1e-8)
+    torch.testing.assert_close(tr.exp_avg_sq, v, rtol=1e-6, atol=1e-9)
