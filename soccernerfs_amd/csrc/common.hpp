@@ -96,7 +96,10 @@ __device__ __forceinline__ double wave_scan_f64(const float* in, float* out, int
     const double t = __shfl_up(incl, off, 64);
     if (lane >= off) incl = incl + t;
   }
-  double run = incl - local;  // sum of all earlier blocks
+  // sum of all earlier blocks = the previous lane's inclusive value.  (NOT incl - local: an overflowed density makes both +inf, and
+  // inf - inf = NaN would poison the elements in FRONT of the overflow inside the same block, which the sequential cumsum leaves finite.)
+  double run = __shfl_up(incl, 1, 64);
+  if (lane == 0) run = 0.0;
   const double total = __shfl(incl, 63, 64);
 #pragma unroll
   for (int k = 0; k < WSCAN_PER; ++k) {

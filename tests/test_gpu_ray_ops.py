@@ -126,6 +126,52 @@ def test_weights_fwd_bwd_golden_and_oracle():
         close(d2.grad, dens.grad, rtol=1e-4, atol=1e-7)
 
 
+def test_overflowed_densities_behave_as_the_sequential_cumsum():
+    """density = exp(x) overflows to +inf during training (trunc_exp, activations.py:32).  torch.cumsum walks left to right: the samples in
+    FRONT of an infinite one keep finite transmittance and weights, the ones behind get T = 0; a zero-width bin under an infinite density
+    (0 * inf) poisons what follows with NaN, which nan_to_num turns into 0.  The wavefront scan must reproduce exactly that -- inf at the
+    start, in the middle and at the end of a lane's block, next to each other, and in every level's sample count; weights, the resampled bins
+    (indices) and the backward included."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd import ops
+
+    gen = torch.Generator().manual_seed(17)
+    for S in (64, 128, 256, 37):
+        R = 24
+        dens = torch.rand(R, S, generator=gen) ** 3 * 20
+        ebins = torch.cumsum(torch.rand(R, S + 1, generator=gen) * 0.05 + 1e-3, -1)
+        per = (S + 63) // 64
+        for r, pos in enumerate([0, 1, per - 1, per, S // 2, S // 2 + 1, S - 2, S - 1]):
+            dens[r, pos] = float("inf")
+        dens[8, 5] = dens[8, 6] = float("inf")
+        dens[9, 3 * per + 1] = float("inf")
+        ebins[9, 3 * per + 2] = ebins[9, 3 * per + 1]  # zero-width bin: delta * sigma = 0 * inf = NaN from there on
+        dens[10, :] = float("inf")
+        ref = KO.get_weights(ebins[:, 1:] - ebins[:, :-1], dens)
+        got = ops.get_weights(dens.to(DEV), ebins.to(DEV)).cpu()
+        assert bool(torch.isfinite(got).all())
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-7)
+        assert float(got[4, :S // 2].sum()) > 0  # weights in front of the overflow survive
+        # PDF resampling driven by those weights: same bins as the oracle, hence the same indices
+        nears, fars = torch.zeros(R), torch.ones(R) * 3
+        sb = torch.linspace(0, 1, S + 1).expand(R, S + 1).contiguous()
+        u = torch.rand(R, 33, generator=gen)
+        want = KO.pdf_sample(ref, sb, KO.pdf_u(R, 32, u))[0]
+        got_sb, _ = ops.pdf_resample(sb.to(DEV), nears.to(DEV), fars.to(DEV), 32, density=dens.to(DEV), ebins_prev=ebins.to(DEV), rand=u.to(DEV))
+        torch.testing.assert_close(got_sb.cpu(), want, rtol=0, atol=2e-6)
+        # backward: finite everywhere, equal to autograd where autograd is finite
+        d2 = dens.clone().requires_grad_(True)
+        gw = torch.rand(R, S, generator=gen) - 0.3
+        KO.get_weights(ebins[:, 1:] - ebins[:, :-1], d2).backward(gw)
+        d3 = dens.to(DEV).requires_grad_(True)
+        ops.get_weights(d3, ebins.to(DEV)).backward(gw.to(DEV))
+        g3 = d3.grad.cpu()
+        assert bool(torch.isfinite(g3).all())
+        ok = torch.isfinite(d2.grad)
+        rows = ok.all(dim=1)  # rays whose reference gradient is finite throughout
+        torch.testing.assert_close(g3[rows], d2.grad[rows], rtol=1e-4, atol=1e-7)
+
+
 def test_ray_ops_argument_errors():
     from soccernerfs_amd import ops
 
