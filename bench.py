@@ -302,8 +302,8 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.mlp_operands == "fp32" else args.mlp_operands,
             "dtype_note": "exact fp32 everywhere (the parity path)" if args.mlp_operands == "fp32" else
-                          f"{args.mlp_operands} MFMA operands with f32 accumulation in every MLP (sigma_net, color_net, proposal nets) and bf16 per-plane gradient "
-                          "vectors between the two scatter passes; planes, sampling, compositing, losses, gradient accumulation and the optimiser are f32",
+                          f"{args.mlp_operands} MFMA operands with f32 accumulation in every MLP (sigma_net, color_net, proposal nets); per-plane gradient vectors "
+                          f"between the two scatter passes are {cfg.gvec_dtype}; planes, sampling, compositing, losses, gradient accumulation and the optimiser are f32",
             "data": "synthetic",
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",

@@ -147,11 +147,17 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a
 // ---------------------------------------------------------------------------------------------
 // backward (recomputes the forward per tile, as the fp32 kernel)
 // ---------------------------------------------------------------------------------------------
+// 128-wide one-hidden-layer nets (sigma_net): 8 waves x 16 hidden units -- each wave keeps ITS layer-0 B operand (K0 / 32 k-steps x 8
+// values per lane) in registers for the whole persistent loop, so the transposed image W0T (H x K0: 43-51 KB) never enters LDS.  That is what
+// lets the 6-scale field (K0 = 192, BASELINE config 3) fit the backward at all (177 KB with W0T, 126 KB without).
+template <int H, int NH>
+constexpr bool wreg_b() { return H == 128 && NH == 1; }
+
 template <int K0, int H, int NH, int TS>
 struct PlanB {
   static constexpr int LK0 = ldb(K0), LKH = ldb(H), LKO = ldb(32), LKT = ldb(TS);
-  static constexpr int W0T = 0;                    // [H][LK0]   forward
-  static constexpr int W0R = W0T + H * LK0;        // [K0][LKH]  dX
+  static constexpr int W0T = 0;                    // [H][LK0]   forward (absent when register-resident)
+  static constexpr int W0R = W0T + (wreg_b<H, NH>() ? 0 : H * LK0);  // [K0][LKH]  dX
   static constexpr int W1T = W0R + K0 * LKH;       // [H][LKH]   forward, layer 1 (NH == 2)
   static constexpr int W1R = W1T + (NH == 2 ? H * LKH : 0);  // [H][LKH]  dA1 (NH == 2)
   static constexpr int WOT = W1R + (NH == 2 ? H * LKH : 0);  // [16][LKH]  forward
@@ -185,7 +191,22 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
   T *Al = NH == 2 ? smem + P::A2 : A1, *Alt = NH == 2 ? smem + P::A2T : A1t;  // last hidden activations (row-major / transposed)
   T *gz = smem + P::GZ, *gzt = Alt;                                          // gradient of Z_last; its transposed image reuses Alt
   T *gz1 = NH == 2 ? smem + P::GZ1 : gz, *gz1t = NH == 2 ? A1t : gzt;        // gradient of Z1
-  stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, smem + P::W0R, P::LKH, smem + P::W0T, P::LK0);
+  constexpr bool WREG = wreg_b<H, NH>();
+  stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, smem + P::W0R, P::LKH, WREG ? (T*)nullptr : smem + P::W0T, P::LK0);
+  typename Ops<T>::v8 breg[WREG ? K0 / 32 : 1];
+  if (WREG) {  // this wave's hidden units 16 wave .. +15, k = 32 ks + 8 (lane >> 4) .. +8
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < K0 / 32; ++ks) {
+      typename Ops<T>::v8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 32 + lk * 8 + e;
+        b[e] = Ops<T>::cvt(k < a.d0 ? a.W[a.woff[0] + (int64_t)k * H + wave * 16 + lr] : 0.f);
+      }
+      breg[ks] = b;
+    }
+  }
   if (NH == 2) stage_w<T>(a.W + a.woff[1], H, H, H, H, smem + P::W1R, P::LKH, smem + P::W1T, P::LKH);
   stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 32, smem + P::WOR, P::LKO, nullptr, 0);
   stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
@@ -209,7 +230,15 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
       const int nt = wave + NW * j;
       if (nt < HT) {
         f32x4 acc[MT] = {};
-        mma_rr<MT, K0>(Xs, P::LK0, smem + P::W0T, P::LK0, nt, acc, lane);
+        if (WREG) {
+          const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+          for (int ks = 0; ks < K0 / 32; ++ks)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8(Xs + (m * 16 + lr) * P::LK0 + ks * 32 + lk * 8), breg[WREG ? ks : 0], acc[m]);
+        } else {
+          mma_rr<MT, K0>(Xs, P::LK0, smem + P::W0T, P::LK0, nt, acc, lane);
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           f32x4 v = acc[m];
@@ -433,7 +462,7 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
 }
 
 // (input width padded to 32, hidden width, hidden layers)
-#define SNERF_MLP_BF16_SHAPES(X) X(32, 64, 1) X(32, 128, 1) X(64, 128, 1) X(96, 128, 1) X(128, 128, 1) X(160, 128, 1) \
+#define SNERF_MLP_BF16_SHAPES(X) X(32, 64, 1) X(32, 128, 1) X(64, 128, 1) X(96, 128, 1) X(128, 128, 1) X(160, 128, 1) X(192, 128, 1) /* 6 scales: BASELINE config 3 */ \
   X(32, 64, 2) /* K-Planes color_net 15->64->64->3 */ X(64, 64, 2) /* nerfplayer mlp_head 63->64->64->3 */
 
 bool mlp_bf16_supported(const snerf_mlp_desc* d) {

@@ -118,7 +118,8 @@ def test_mlp_unsupported_shape_raises():
 
 
 @pytest.mark.parametrize("operands", ["bf16", "fp16"])
-@pytest.mark.parametrize("shape", [(160, 16, 128, "None"), (8, 1, 64, "None"), (96, 16, 128, "Sigmoid"), (50, 5, 128, "None")])
+@pytest.mark.parametrize("shape", [(160, 16, 128, "None"), (8, 1, 64, "None"), (96, 16, 128, "Sigmoid"), (50, 5, 128, "None"),
+                                   (192, 16, 128, "None")])  # 6 scales x 32: BASELINE config 3 (weights of layer 0 register-resident in the backward)
 def test_16bit_operand_mlp(shape, operands):
     """desc.operands = 1 / 2: bf16 / fp16 MFMA operands, fp32 accumulation.  (a) equals an emulation that rounds exactly the tensors the kernel rounds
     (inputs, weights, hidden activations, upstream gradients) and accumulates in fp32; (b) stays within SURVEY §8d's tolerance for

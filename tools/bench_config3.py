@@ -9,7 +9,7 @@ from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 steps, warmup, R = 100, 20, 4096
-cfg = KPlanesTrainConfig(mlp_operands="fp32", multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
+cfg = KPlanesTrainConfig(mlp_operands=(sys.argv[1] if len(sys.argv) > 1 else "bf16"), multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
                          proposal_resolutions=((128, 128, 128, 25), (256, 256, 256, 25)))
 tr = KPlanesTrainer(cfg, R, dev)
 tr.step = 6000  # steady-state schedule, IST active (iters_to_start_ist = 2000)
@@ -33,5 +33,5 @@ tr.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     step()
 tr.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"config": "K-Planes multiscale 1-32 (6 scales), C=32, 25 frames, IST range 0.75, 15 % importance rays", "params": int(tr.n_params),
+print(json.dumps({"config": "K-Planes multiscale 1-32 (6 scales), C=32, 25 frames, IST range 0.75, 15 % importance rays", "mlp_operands": cfg.mlp_operands, "params": int(tr.n_params),
                   "images": int(M), "ms_per_step": dt / steps * 1e3, "rays_per_s": R * steps / dt}))
