@@ -53,8 +53,8 @@ def parse():
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
-    ap.add_argument("--fused-field", action="store_true", help="opt-in: fused field kernels (csrc/field_fused.hip: gather + sigma_net + color_net in one kernel, forward and backward); measured slower, see profiles/r02_kernels.md")
-    ap.add_argument("--fused-forward-only", action="store_true", help="with --fused-field: fuse the forward only")
+    ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
+    ap.add_argument("--fused-backward", action="store_true", help="opt-in: fused backward kernel as well (recomputed forward + both nets' backward + gradient vectors); measured slower, see profiles/r02_kernels.md")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--prop-after-field", action="store_true", help="A-B: proposal backward behind the field scatter, beside the optimiser sweep")
@@ -132,8 +132,8 @@ def main():
 
     # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
     torch.manual_seed(20231029 + rank)
-    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=args.fused_field,
-                             fused_field_backward=not args.fused_forward_only)  # the k-planes preset
+    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field,
+                             fused_field_backward=args.fused_backward)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks

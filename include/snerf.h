@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 3
+#define SNERF_ABI_VERSION 4
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -189,6 +189,10 @@ int snerf_mlp_fwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * NULL = not needed).  The forward is recomputed tile by tile; nothing is saved between fwd and bwd. */
 int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                   int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* Same with X given in the net's 16-bit operand type (desc.operands = 1: bf16, 2: fp16; row stride ldx in elements) -- the feature tile
+ * snerf_kplanes_field_fwd wrote.  The kernels round X to that type anyway, so results equal snerf_mlp_bwd on the fp32 image of X. */
+int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                      int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
 /* Same with the weight gradients accumulated into fixed-point cells (see snerf_kplanes_gather_bwd_fx). */
 int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                      int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
@@ -201,7 +205,10 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
  * net shapes above and 16-bit MFMA operands (snerf_mlp_desc.operands = 1 bf16 / 2 fp16, both nets alike): snerf_kplanes_field_supported
  * tells; the exact-fp32 path composes snerf_kplanes_gather_fwd + snerf_mlp_fwd.  Results are bit-identical to that composition run with the
  * same 16-bit operands.
- *   fwd: density [N], rgb [N,3].
+ *   fwd: density [N], rgb [N,3].  Optional (NULL = not written), for a training step that runs the UNFUSED backward kernels on what the
+ *        forward already computed: feat16 [N, 32 n_scales] = the feature tile in the operand type (bf16 / fp16: exactly the values the
+ *        MFMA consumed; 2 B per feature instead of the 4 B the unfused gather writes) for snerf_mlp_bwd_x16(sigma_net), and h [N,16] =
+ *        the raw fp32 sigma_net outputs (color_net's input; column 15 = log density) for snerf_mlp_bwd(color_net).
  *   bwd: from g_density [N] and g_rgb [N,3]: recomputes the forward per tile, ACCUMULATES the weight gradients of both nets (flat layouts of
  *        snerf_mlp_*; float atomics, or fixed-point cells when the *_fx pointers are given instead) and writes the per-plane gradient
  *        vectors gvec[scale * 6 + plane][N][32] (fp32 or bf16) that snerf_kplanes_scatter_sorted consumes -- i.e. it replaces
@@ -210,7 +217,7 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
 int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
 int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                             const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
-                            float* density, float* rgb, snerf_stream_t stream);
+                            float* density, float* rgb, void* feat16, float* h, snerf_stream_t stream);
 int snerf_kplanes_field_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                             const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
                             const float* g_density, const float* g_rgb, float* gW_sigma, float* gW_color, int64_t* gW_sigma_fx,

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class KPlanesDesc(C.Structure):
@@ -191,6 +191,7 @@ EXPORTS = [
     "snerf_kplanes_gather_bwd_fx",
     "snerf_fx_to_float",
     "snerf_mlp_bwd_fx",
+    "snerf_mlp_bwd_x16",
     "snerf_adam_prepare",
     "snerf_depth_loss",
     "snerf_kplanes_field_supported",

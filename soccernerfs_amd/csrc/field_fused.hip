@@ -39,6 +39,8 @@ struct FieldArgs {
   const float* Wcol;  // [15 x 64 | 64 x 64 | 64 x 3]
   float* dens;        // [N]   exp(sigma_net(.)[15])
   float* rgb;         // [N,3] sigmoid(color_net(.))
+  void* feat16;       // optional [N, 32 n_scales] in the operand type: the rounded feature tile, for an UNFUSED backward (snerf_mlp_bwd_x16)
+  float* h;           // optional [N,16]: the raw sigma_net outputs (color_net's input, column 15 = log density)
   // backward
   const float* gdens;   // [N]   dL/d density
   const float* grgb;    // [N,3] dL/d rgb
@@ -69,11 +71,9 @@ __device__ __forceinline__ float4 scale_features(const snerf_kplanes_desc& d, co
 #pragma unroll
   for (int k = 0; k < 4; ++k) tap[k] = axis_tap(p[k], d.res[s][k] > 0 ? d.res[s][k] : 1);
   float4 prod = make_float4(1.f, 1.f, 1.f, 1.f);
-  constexpr auto& A = PlanePairs<6>::a;
-  constexpr auto& B = PlanePairs<6>::b;
 #pragma unroll
   for (int q = 0; q < 6; ++q) {
-    const float4 v = plane_sample<32>(planes + d.off[s][q], d.res[s][A[q]], tap[A[q]], tap[B[q]], cg);
+    const float4 v = plane_sample<32>(planes + d.off[s][q], d.res[s][pair_a<6>(q)], tap[pair_a<6>(q)], tap[pair_b<6>(q)], cg);
     if (v_out) (*v_out)[q] = v;
     prod = f4_mul(prod, v);
   }
@@ -190,6 +190,13 @@ __global__ __launch_bounds__(FF_NW * 64, 4) void field_fwd_kernel(FieldArgs a, i
     __syncthreads();  // weights staged / the previous tile's colour layers have read CA1, CA2 (= XS)
     gather_tile<T, NS>(a, n0, XS);
     __syncthreads();
+    if (a.feat16) {  // the tile's rows are contiguous in feat16: one coalesced 16-B store per 8 features
+      T* F16 = reinterpret_cast<T*>(a.feat16);
+      for (int vi = threadIdx.x; vi < FF_TS * (K0 / 8); vi += FF_NW * 64) {
+        const int r = vi / (K0 / 8), c8 = vi - r * (K0 / 8);
+        if (n0 + r < a.N) *reinterpret_cast<typename Ops<T>::v8*>(F16 + (n0 + r) * K0 + c8 * 8) = ld8(XS + r * P::LK0 + c8 * 8);
+      }
+    }
     sigma_layer0<T, NS>(XS, breg, A1, nullptr, 0, wave, lane);
     __syncthreads();
     if (wave < MT) {  // sigma_net output layer: 16 columns; column 15 -> density, columns 0..14 -> colour-net input
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(FF_NW * 64, 4) void field_fwd_kernel(FieldArgs a, i
         const float y = acc[0][r];
         const int64_t n = n0 + row0 + r;
         if (col == FF_GEO && n < a.N) a.dens[n] = expf(y);  // trunc_exp forward (activations.py:32)
+        if (a.h && n < a.N) a.h[n * 16 + col] = y;
         CX[(row0 + r) * P::LKX + col] = col < FF_GEO ? Ops<T>::cvt(y) : (T)0.f;
       }
     }
@@ -666,13 +674,14 @@ extern "C" int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, con
 
 extern "C" int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                                        const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
-                                       float* density, float* rgb, snerf_stream_t stream) {
+                                       float* density, float* rgb, void* feat16, float* h, snerf_stream_t stream) {
   int rc = validate_field(desc, coords, N, sigma, color);
   if (rc) return rc;
   if (N == 0) return 0;
   SNERF_REQUIRE(planes && W_sigma && W_color && density && rgb, "kplanes_field_fwd: null buffer");
   FieldArgs a = {};
   a.d = *desc; a.planes = planes; a.c = *coords; a.N = N; a.Wsig = W_sigma; a.Wcol = W_color; a.dens = density; a.rgb = rgb;
+  a.feat16 = feat16; a.h = h;
   FF_DISPATCH(launch_field_fwd, sigma->operands, desc->n_scales, a, (hipStream_t)stream);
 }
 

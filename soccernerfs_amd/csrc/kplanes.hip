@@ -73,7 +73,7 @@ __device__ __forceinline__ float xor_lanes(float x) {
   }
 }
 
-template <int C, int NP, bool FX>
+template <int C, int NP, bool FX, int U>
 __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_desc d, const float* __restrict__ planes,
                                                                 snerf_coords c, int64_t N, const float* __restrict__ gout,
                                                                 float* __restrict__ gplanes, long long* __restrict__ gplanes_fx, int run) {
@@ -81,14 +81,12 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t group = gid / LPS;
   const int li = (int)(gid % LPS);
-  const int half = li / C;
+  const int hmask = -(li / C);  // all ones for the lanes of the x0 + 1 corner
   const int ch = li % C;
   const int64_t n0 = group * run;
   if (n0 >= N) return;
   const int cnt = (int)((N - n0) < run ? (N - n0) : run);
   const int out_w = d.concat ? C * d.n_scales : C;
-  constexpr auto& A = PlanePairs<NP>::a;
-  constexpr auto& B = PlanePairs<NP>::b;
 
   for (int s = 0; s < d.n_scales; ++s) {
     int pend_key[NP][2];
@@ -102,52 +100,71 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
 #pragma unroll
     for (int k = 0; k < 4; ++k) res[k] = d.res[s][k] > 0 ? d.res[s][k] : 1;
 
-    for (int i = 0; i < cnt; ++i) {
-      const int64_t n = n0 + i;
-      float p[4];
-      load_coords<NP>(c, n, p);
-      AxisTap tap[4];
+    // U samples in flight: their coordinate, texel and upstream-gradient loads are all issued before the first one is consumed
+    for (int i0 = 0; i0 < cnt; i0 += U) {
+      AxisTap tap[U][4];
+      int xsel[U][4];    // this lane's x-corner along each axis (i0 for half 0, i1 for half 1) and its weight: bit-selected once per axis
+      float wsel[U][4];  // (`half ? t.i1 : t.i0` on the structs became an indexed load from a scratch copy of the taps)
+      float ta[U][NP], tb[U][NP], gup[U];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) tap[k] = axis_tap(p[k], res[k]);
-      float v[NP];
-      float wx[NP];
+      for (int u = 0; u < U; ++u) {
+        const int64_t n = n0 + (i0 + u < cnt ? i0 + u : cnt - 1);
+        float p[4];
+        load_coords<NP>(c, n, p);
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const AxisTap& tx = tap[A[q]];
-        const AxisTap& ty = tap[B[q]];
-        const int W = res[A[q]];
-        const int xi = half ? tx.i1 : tx.i0;
-        wx[q] = half ? tx.w1 : tx.w0;
-        const float* base = planes + d.off[s][q] + ch;
-        float a = base[((int64_t)ty.i0 * W + xi) * C];
-        float b = base[((int64_t)ty.i1 * W + xi) * C];
-        float part = wx[q] * (ty.w0 * a + ty.w1 * b);
-        v[q] = part + xor_lanes<C>(part);
+        for (int k = 0; k < 4; ++k) {
+          const AxisTap t = axis_tap(p[k], res[k]);
+          tap[u][k] = t;
+          xsel[u][k] = (t.i1 & hmask) | (t.i0 & ~hmask);
+          wsel[u][k] = __int_as_float((__float_as_int(t.w1) & hmask) | (__float_as_int(t.w0) & ~hmask));
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const AxisTap& ty = tap[u][pair_b<NP>(q)];
+          const int W = res[pair_a<NP>(q)];
+          const int xi = xsel[u][pair_a<NP>(q)];
+          const float* base = planes + d.off[s][q] + ch;
+          ta[u][q] = base[((int64_t)ty.i0 * W + xi) * C];
+          tb[u][q] = base[((int64_t)ty.i1 * W + xi) * C];
+        }
+        gup[u] = gout[n * out_w + (d.concat ? s * C : 0) + ch];
       }
-      const float g = gout[n * out_w + (d.concat ? s * C : 0) + ch];
-      float suf[NP + 1];
-      suf[NP] = 1.f;
 #pragma unroll
-      for (int q = NP - 1; q >= 0; --q) suf[q] = suf[q + 1] * v[q];
-      float pre = g;
+      for (int u = 0; u < U; ++u) {
+        if (i0 + u >= cnt) continue;
+        float v[NP];
+        float wx[NP];
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        const float gq = pre * suf[q + 1] * wx[q];
-        pre *= v[q];
-        const AxisTap& tx = tap[A[q]];
-        const AxisTap& ty = tap[B[q]];
-        const int W = res[A[q]];
-        const int64_t gbase = d.off[s][q] + li;
+        for (int q = 0; q < NP; ++q) {
+          const AxisTap& ty = tap[u][pair_b<NP>(q)];
+          wx[q] = wsel[u][pair_a<NP>(q)];
+          float part = wx[q] * (ty.w0 * ta[u][q] + ty.w1 * tb[u][q]);
+          v[q] = part + xor_lanes<C>(part);
+        }
+        float suf[NP + 1];
+        suf[NP] = 1.f;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          const int key = (r ? ty.i1 : ty.i0) * W + tx.i0;
-          const float val = gq * (r ? ty.w1 : ty.w0);
-          if (key != pend_key[q][r]) {
-            if (pend_val[q][r] != 0.f) grad_add<FX>(gplanes, gplanes_fx, gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
-            pend_key[q][r] = key;
-            pend_val[q][r] = val;
-          } else {
-            pend_val[q][r] += val;
+        for (int q = NP - 1; q >= 0; --q) suf[q] = suf[q + 1] * v[q];
+        float pre = gup[u];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const float gq = pre * suf[q + 1] * wx[q];
+          pre *= v[q];
+          const AxisTap& tx = tap[u][pair_a<NP>(q)];
+          const AxisTap& ty = tap[u][pair_b<NP>(q)];
+          const int W = res[pair_a<NP>(q)];
+          const int64_t gbase = d.off[s][q] + li;
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int key = (r ? ty.i1 : ty.i0) * W + tx.i0;
+            const float val = gq * (r ? ty.w1 : ty.w0);
+            if (key != pend_key[q][r]) {
+              if (pend_val[q][r] != 0.f) grad_add<FX>(gplanes, gplanes_fx, gbase + (int64_t)pend_key[q][r] * C, pend_val[q][r]);
+              pend_key[q][r] = key;
+              pend_val[q][r] = val;
+            } else {
+              pend_val[q][r] += val;
+            }
           }
         }
       }
@@ -191,12 +208,15 @@ static int launch_fwd(const snerf_kplanes_desc* d, const float* planes, const sn
 template <int C, int NP>
 static int launch_bwd(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, float* gp,
                       long long* gp_fx, hipStream_t st) {
-  // consecutive samples walked (and run-length-combined) by one lane group (16 / 32 / 64 / 128 measured: profiles/r01_kernels.md)
-  constexpr int run = 64;
+  // consecutive samples walked (and run-length-combined) by one lane group, and samples in flight per group.  profiles/r02_prop_scatter.md:
+  // with the taps out of scratch the proposal levels (C = 8) take 0.30 ms at run 64 and 0.29 ms at run 32; 2 or 4 samples in flight
+  // change nothing (0.30-0.32 ms) -- the walk is bound by its memory-side atomic requests, not by load latency.
+  constexpr int run = C <= 8 ? 32 : 64;
+  constexpr int U = 1;
   int64_t groups = (N + run - 1) / run;
   int64_t threads = groups * (2 * C);
-  if (gp_fx) hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP, true>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, gp_fx, run);
-  else hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP, false>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, gp_fx, run);
+  if (gp_fx) hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP, true, U>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, gp_fx, run);
+  else hipLaunchKernelGGL((kplanes_gather_bwd_kernel<C, NP, false, U>), dim3(ceil_div(threads, 256)), dim3(256), 0, st, *d, planes, *c, N, gout, gp, gp_fx, run);
   SNERF_LAUNCH_CHECK("kplanes_gather_bwd");
   return 0;
 }

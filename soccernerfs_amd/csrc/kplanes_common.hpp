@@ -60,6 +60,15 @@ template <> struct PlanePairs<3> {  // static scene: XY XZ YZ
   static constexpr int b[3] = {1, 2, 2};
 };
 
+// The same tables as arithmetic on the plane index.  Inside an unrolled plane loop q is a literal and these fold; indexing the constexpr
+// arrays above did not always (kplanes_gather_bwd_kernel, field_fwd_kernel: the taps were kept in scratch and read back through a
+// uniform-but-dynamic index, 16 dwords per sample -- profiles/r02_prop_scatter.md).
+template <int NP> __host__ __device__ constexpr int pair_a(int q) { return NP == 6 ? (q < 3 ? 0 : (q < 5 ? 1 : 2)) : (q < 2 ? 0 : 1); }
+template <int NP> __host__ __device__ constexpr int pair_b(int q) { return NP == 6 ? (q < 3 ? q + 1 : (q < 5 ? q - 1 : 3)) : (q < 1 ? 1 : 2); }
+static_assert(pair_a<6>(0) == 0 && pair_a<6>(2) == 0 && pair_a<6>(3) == 1 && pair_a<6>(4) == 1 && pair_a<6>(5) == 2, "pair_a<6>");
+static_assert(pair_b<6>(0) == 1 && pair_b<6>(1) == 2 && pair_b<6>(2) == 3 && pair_b<6>(3) == 2 && pair_b<6>(4) == 3 && pair_b<6>(5) == 3, "pair_b<6>");
+static_assert(pair_a<3>(0) == 0 && pair_a<3>(1) == 0 && pair_a<3>(2) == 1 && pair_b<3>(0) == 1 && pair_b<3>(1) == 2 && pair_b<3>(2) == 2, "pair_*<3>");
+
 __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

@@ -37,6 +37,7 @@ struct MlpArgs {
   float* gX; int ldgx;
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
+  int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
@@ -896,7 +897,8 @@ extern "C" int snerf_mlp_fwd(const snerf_mlp_desc* d, const float* W, const floa
 }
 
 static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
-                        int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream) {
+                        int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream,
+                        int x16 = 0) {
   MlpArgs a = {};
   int rc = fill(d, a);
   if (rc) return rc;
@@ -909,6 +911,8 @@ static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X,
   SNERF_REQUIRE(!gX || ldgx >= d->d_in, "mlp_bwd: ldgx=%d", ldgx);
   a.X = X; a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
   a.gWfx = gWfx;
+  a.x16 = x16;
+  SNERF_REQUIRE(!x16 || d->operands == 1 || d->operands == 2, "mlp_bwd_x16: a 16-bit input needs 16-bit operands (desc.operands = 1 / 2), got %d", d->operands);
   return dispatch(d, a, true, (hipStream_t)stream);
 }
 
@@ -920,6 +924,11 @@ extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const floa
 extern "C" int snerf_mlp_bwd_fx(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                                 int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream) {
   return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, nullptr, reinterpret_cast<long long*>(gW_fx), stream);
+}
+
+extern "C" int snerf_mlp_bwd_x16(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                 int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+  return mlp_bwd_impl(d, W, reinterpret_cast<const float*>(X16), ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream, 1);
 }
 
 // One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid); K, M <= 128.

@@ -17,6 +17,10 @@
 //             dWO = A1^T dY    A = A1t [H][TS]      B^T = gzot [16][TS]
 // The transposed copies cost nothing extra to write from an accumulator: a lane of the C layout holds 4 consecutive ROWS of one column,
 // i.e. 8 contiguous bytes of the transposed image.  Row stride = K + 8 elements (16-B aligned rows, conflict-free b128 reads).
+#include <stdint.h>
+
+#include <type_traits>
+
 #include "mlp_lp_common.hpp"
 
 namespace snerf {
@@ -26,6 +30,7 @@ template <int TS, int K0, int NT>
 struct XTileB {
   static constexpr int PER = (TS * K0 + NT - 1) / NT;
   float v[PER];
+  template <typename T>
   __device__ __forceinline__ void fetch(const MlpArgs& a, int64_t n0) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -45,6 +50,40 @@ struct XTileB {
         const T b = Ops<T>::cvt(v[i]);
         Xs[r * ldx + c] = b;
         if (Xt) Xt[c * ldt + r] = b;
+      }
+    }
+  }
+};
+
+// X tile that arrives in the operand type already (MlpArgs.x16: the feature tile snerf_kplanes_field_fwd wrote): 16-B loads of 8 elements,
+// no conversion.  Needs d_in == K0, ldx % 8 == 0 and a 16-B aligned base (checked by the launcher).
+template <int TS, int K0, int NT, typename T>
+struct XTile16 {
+  static constexpr int NV = TS * K0 / 8, PER = (NV + NT - 1) / NT, VR = K0 / 8;
+  typename Ops<T>::v8 v[PER];
+  template <typename>
+  __device__ __forceinline__ void fetch(const MlpArgs& a, int64_t n0) {
+    const T* X16 = reinterpret_cast<const T*>(a.X);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int vi = threadIdx.x + i * NT;
+      const int c8 = vi / TS, r = vi - c8 * TS;  // lanes along the rows: the transposed image's stores land in consecutive LDS addresses
+      const int64_t n = n0 + r;
+      typename Ops<T>::v8 z = {};
+      v[i] = (vi < NV && n < a.N) ? *reinterpret_cast<const typename Ops<T>::v8*>(X16 + n * a.ldx + c8 * 8) : z;
+    }
+  }
+  __device__ __forceinline__ void store(T* Xs, int ldx, T* Xt, int ldt) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int vi = threadIdx.x + i * NT;
+      const int c8 = vi / TS, r = vi - c8 * TS;  // lanes along the rows: the transposed image's stores land in consecutive LDS addresses
+      if (vi < NV) {
+        *reinterpret_cast<typename Ops<T>::v8*>(Xs + r * ldx + c8 * 8) = v[i];
+        if (Xt) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) Xt[(c8 * 8 + e) * ldt + r] = v[i][e];
+        }
       }
     }
   }
@@ -82,12 +121,12 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a
   const T* Alast = smem + (NH == 2 ? P::A2 : P::A1);
   const bool relu = a.hidden_act == 1;
   XTileB<TS, K0, NW * 64> xt;
-  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  xt.template fetch<T>(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TS;
     __syncthreads();
     xt.store(smem + P::XS, P::LK0, (T*)nullptr, 0);
-    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
+    if (tile + gridDim.x < n_tiles) xt.template fetch<T>(a, (tile + gridDim.x) * TS);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
@@ -176,7 +215,7 @@ struct PlanB {
   static constexpr size_t BYTES = (size_t)TOTAL * 2;
 };
 
-template <typename T, int K0, int H, int NH, int TS>
+template <typename T, int K0, int H, int NH, int TS, bool X16 = false>
 __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -216,13 +255,13 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
   f32x4 dW0[NB0] = {};
   f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
-  XTileB<TS, K0, NW * 64> xt;
-  xt.fetch(a, (int64_t)blockIdx.x * TS);
+  std::conditional_t<X16, XTile16<TS, K0, NW * 64, T>, XTileB<TS, K0, NW * 64>> xt;
+  xt.template fetch<T>(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * TS;
     __syncthreads();
     xt.store(Xs, P::LK0, Xt, P::LKT);
-    if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
+    if (tile + gridDim.x < n_tiles) xt.template fetch<T>(a, (tile + gridDim.x) * TS);
     __syncthreads();
     // ---- hidden layer: A1 (row-major) and A1t ----
 #pragma unroll
@@ -440,10 +479,25 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
-    auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+    if (a.x16) {
+      // built for the sigma_net shapes (d_in = 32 n_scales -> 128 -> 16): what the fused field forward hands over
+      if constexpr (H == 128 && NH == 1) {
+        SNERF_REQUIRE(a.d0 == K0 && a.ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0,
+                      "mlp_bwd_x16: needs d_in a multiple of 32 (%d), ldx a multiple of 8 (%d) and a 16-byte aligned X", a.d0, a.ldx);
+        auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS, true>;
+        static bool attr_set16 = false;
+        if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+      } else {
+        set_error("mlp_bwd_x16: 16-bit inputs are built for the d_in -> 128 -> d_out one-hidden-layer shapes (sigma_net), got hidden=%d n_hidden=%d", H, NH);
+        return SNERF_ERR_UNSUPPORTED;
+      }
+    } else {
+      auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS>;
+      static bool attr_set = false;
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+    }
   } else {
     constexpr int TS = (H <= 64 && NH == 1) ? 64 : 32;
     using P = PlanF<K0, H, NH, TS>;

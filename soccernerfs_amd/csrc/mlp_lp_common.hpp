@@ -42,6 +42,7 @@ struct MlpArgs {  // same fields as mlp.hip's (filled there)
   float* gX; int ldgx;
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
+  int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {

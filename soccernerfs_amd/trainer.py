@@ -88,13 +88,16 @@ class KPlanesTrainConfig:
     # reference's GradScaler does (NS/engine/trainer.py:394-408, one found_inf per optimiser); "drop_elements": only the
     # non-finite elements are dropped (round-1 behaviour)
     nonfinite_policy: str = "skip_step"
-    # gather -> sigma_net -> colour net as ONE kernel forward, and recomputed forward -> both nets' backward -> per-plane gradient vectors
-    # as ONE kernel backward (csrc/field_fused.hip): feat / h / gfeat never reach HBM.  OPT-IN: built and parity-tested (forward bit-identical
-    # to the unfused 16-bit kernels), but measured SLOWER on MI355X at the preset (forward 0.58 vs 0.53 ms, backward 2.5 vs 0.9 ms,
-    # profiles/r02_kernels.md): the gather is latency-bound and wants the 28 waves / CU the stand-alone kernel gets, the MLPs' LDS and
-    # register footprint leaves the fused kernels 16 (forward) and 8 (backward).  Needs 16-bit operands and the sorted scatter.
-    fused_field: bool = False
-    fused_field_backward: bool = True  # False: fused forward only; the backward recomputes the gather and runs the unfused kernels (A-B)
+    # gather -> sigma_net -> colour net as ONE kernel forward (csrc/field_fused.hip; 16-bit operands, the preset's net shapes): features and
+    # activations stay on chip; for training it also writes the rounded feature tile (2 B / feature) and the 16 sigma_net outputs, which
+    # is all the unfused backward kernels need.  Forward bit-identical to the unfused 16-bit kernels; 0.31 ms against 0.45 ms for
+    # gather + sigma_net + color_net at the preset (profiles/r02_kernels.md).  Falls back to the unfused kernels when the shape / operand
+    # type is outside what the fused kernel is built for (fp32 operands: the parity path).
+    fused_field: bool = True
+    # recomputed forward -> both nets' backward -> per-plane gradient vectors as ONE kernel: feat / h / gfeat never reach HBM.  OPT-IN:
+    # parity-tested but measured SLOWER (2.5 vs 0.9 ms: 256 VGPRs + 0.5 KB of spills per lane leave it 8 waves / CU).  Needs the sorted
+    # scatter and the whole batch in one chunk.
+    fused_field_backward: bool = False
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -248,8 +251,12 @@ class KPlanesTrainer:
         self.lib = _lib.lib()
         self._desc_field = self.field_planes.desc()
         self._desc_prop = [p.desc() for p in self.prop_planes]
-        self.fused_field = bool(cfg.fused_field and self.sorted_scatter and not cfg.deterministic and self.lib.snerf_kplanes_field_supported(
+        self.fused_field = bool(cfg.fused_field and self.lib.snerf_kplanes_field_supported(
             C.byref(self._desc_field), C.byref(self.sigma_net.desc), C.byref(self.color_net.desc)))
+        self.fused_field_backward = bool(self.fused_field and cfg.fused_field_backward and self.sorted_scatter and not cfg.deterministic)
+        if self.fused_field:  # the forward's operand-typed feature tile, kept for the unfused backward (snerf_mlp_bwd_x16)
+            dt16 = torch.bfloat16 if self.sigma_net.desc.operands == 1 else torch.float16
+            self.buf["feat16"] = torch.empty(R * self.S[2], self.field_planes.out_dim, dtype=dt16, device=self.dev)
         if self.world > 1:
             self._plan_exchange()
 
@@ -346,9 +353,11 @@ class KPlanesTrainer:
         _lib.check(self.lib.snerf_mlp_fwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(Y), ldy, aux_col,
                                           self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
 
-    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
+    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, x16=False):
       with self._span(f"mlp_bwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
-        fn = self.lib.snerf_mlp_bwd_fx if self.grads_fx is not None else self.lib.snerf_mlp_bwd
+        fn = self.lib.snerf_mlp_bwd_fx if self.grads_fx is not None else (self.lib.snerf_mlp_bwd_x16 if x16 else self.lib.snerf_mlp_bwd)
+        if x16 and self.grads_fx is not None:  # deterministic mode: the fixed-point kernel takes fp32 inputs (exact image of the 16-bit tile)
+            X = X.float()
         gw = self._fx(self.gviews[gname]) if self.grads_fx is not None else self.gviews[gname]
         _lib.check(fn(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
                       self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
@@ -422,14 +431,18 @@ class KPlanesTrainer:
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
                 self._wait_params()
-                # fused field: always in eval; in training only when the backward will run as ONE chunk over the sorted scatter
+                # fused backward: only when it will run as ONE chunk over the sorted scatter; otherwise the fused forward leaves the
+                # feature tile (16-bit) and the sigma_net outputs behind for the unfused backward kernels
                 n_chunks = max(1, min(self.bwd_chunks, R)) if self.overlap and not self._sharded() else 1
-                self._fwd_fused = self.fused_field and (not training or (R == self.R and n_chunks == 1))
+                self._fwd_fused = self.fused_field
+                self._bwd_fused = training and self.fused_field_backward and R == self.R and n_chunks == 1
+                keep = training and not self._bwd_fused
                 if self._fwd_fused:
                     with self._span("kplanes_field_fwd"):
                         _lib.check(self.lib.snerf_kplanes_field_fwd(C.byref(self._desc_field), self._p(self.field_planes.planes), C.byref(co), C.c_int64(N),
                                                                     C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), C.byref(self.color_net.desc),
-                                                                    self._p(self.color_net.params), self._p(b["dens"][2]), self._p(b["rgb"]), self._st),
+                                                                    self._p(self.color_net.params), self._p(b["dens"][2]), self._p(b["rgb"]),
+                                                                    self._p(b["feat16"]) if keep else None, self._p(b["h"]) if keep else None, self._st),
                                    "kplanes_field_fwd")
                 else:
                     self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
@@ -501,15 +514,13 @@ class KPlanesTrainer:
         b, S2, F = self.buf, self.S[2], self.field_planes.out_dim
         n0, N = r0 * S2, (r1 - r0) * S2
         sl = lambda t: t[n0:n0 + N]
-        fused = self._fwd_fused and self.cfg.fused_field_backward
-        if self._fwd_fused and not fused:  # forward was fused (feat / h never written): recompute them for the unfused backward kernels
-            self._gather(self._desc_field, self.field_planes.planes, self._coords[2], N, b["feat"])
-            self._mlp_fwd(self.sigma_net, b["feat"], F, N, b["h"], 16, -1, None)
+        fused = self._fwd_fused and self._bwd_fused
         assert not fused or (r0 == 0 and r1 == self.R and self._sort_done is not None), "fused field backward needs the whole batch and the sorted scatter"
         if not fused:
             # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
             self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
-            self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1], sl(b["gfeat"]), F)
+            self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
+                          sl(b["gfeat"]), F, x16=self._fwd_fused)
         rays = self.rays
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
         if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:

@@ -60,9 +60,18 @@ def test_fused_field_forward(ms, N, operands):
     co = ops.coords_from_points(pts)
     dens, rgb = torch.full((N,), -1.0, device=DEV), torch.full((N, 3), -1.0, device=DEV)
     _lib.check(L.snerf_kplanes_field_fwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
-                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(dens), ops._ptr(rgb), ops._stream()))
-    _, _, dens_u, rgb_u = _unfused_forward(ps, sigma, color, pts)
+                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(dens), ops._ptr(rgb), None, None, ops._stream()))
+    feat_u, h_u, dens_u, rgb_u = _unfused_forward(ps, sigma, color, pts)
     assert torch.equal(dens, dens_u) and torch.equal(rgb, rgb_u)  # same arithmetic, same order: bit for bit
+    # optional outputs for an unfused backward: the operand-typed feature tile and the raw sigma_net outputs
+    dt = torch.bfloat16 if operands == "bf16" else torch.float16
+    feat16, h = torch.full((N, 32 * len(ms)), -1.0, device=DEV, dtype=dt), torch.full((N, 16), -1.0, device=DEV)
+    dens2, rgb2 = torch.empty_like(dens), torch.empty_like(rgb)
+    _lib.check(L.snerf_kplanes_field_fwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
+                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(dens2), ops._ptr(rgb2), ops._ptr(feat16), ops._ptr(h),
+                                         ops._stream()))
+    assert torch.equal(dens2, dens) and torch.equal(rgb2, rgb)
+    assert torch.equal(feat16, feat_u.to(dt)) and torch.equal(h, h_u)
     # fp32 oracle of the field (kplanes_field.py:275-358)
     grids = [[t.cpu() for t in sc] for sc in ps.to_reference()]
     feat = KO.interpolate_kplanes(pts.cpu(), grids, True)
@@ -122,16 +131,16 @@ def test_fused_field_backward(ms, N, operands, gvec_dtype):
 
 
 def test_fused_and_unfused_training_steps_agree():
-    """Three fused train steps (bf16 operands) against the same steps with cfg.fused_field = False: rendered colours bit for bit at step 0,
-    parameters to atomic-order noise afterwards."""
+    """Three train steps (bf16 operands) with the fused forward + unfused backward (the default), with the fused backward as well, and with
+    cfg.fused_field = False: rendered colours bit for bit at step 0, parameters to atomic-order noise afterwards."""
     from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
     small = dict(aabb_scale=1.5, spacetime_resolution=(16, 16, 16, 4), multiscale_res=(1, 2), feature_dim=32,
                  proposal_resolutions=((24, 24, 24, 4), (32, 32, 32, 4)), proposal_feature_dim=8, num_proposal_samples_per_ray=(64, 32),
                  num_nerf_samples_per_ray=16, warm_up_end=2, mlp_operands="bf16")
     R = 256
-    trs = [KPlanesTrainer(KPlanesTrainConfig(**small, fused_field=f), R, DEV) for f in (True, False)]
-    assert trs[0].fused_field and not trs[1].fused_field
+    trs = [KPlanesTrainer(KPlanesTrainConfig(**small, fused_field=f, fused_field_backward=fb), R, DEV) for f, fb in ((True, False), (False, False), (True, True))]
+    assert trs[0].fused_field and not trs[0].fused_field_backward and not trs[1].fused_field and trs[2].fused_field_backward
     gen = torch.Generator().manual_seed(2)
     g = lambda z: z.to(DEV).contiguous()
     for step in range(3):
@@ -143,15 +152,19 @@ def test_fused_and_unfused_training_steps_agree():
                "bg": g(torch.rand(R, 3, generator=gen))}
         outs = [tr.train_step(rays, target, rng).clone() for tr in trs]
         if step == 0:
-            assert torch.equal(outs[0], outs[1])
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
         else:
             torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=2e-3)
+            torch.testing.assert_close(outs[2], outs[1], rtol=0, atol=2e-3)
     for tr in trs:
         tr.synchronize()
-    assert float((trs[0].params - trs[1].params).abs().mean()) < 2e-5
-    ld0, ld1 = trs[0].loss_dict(), trs[1].loss_dict()
-    for k in ld0:
-        torch.testing.assert_close(ld0[k], ld1[k], rtol=2e-2, atol=1e-7)
+    ld1 = trs[1].loss_dict()
+    for tr in (trs[0], trs[2]):
+        assert float((tr.params - trs[1].params).abs().mean()) < 2e-5
+        ld0 = tr.loss_dict()
+        for k in ld0:
+            torch.testing.assert_close(ld0[k], ld1[k], rtol=2e-2, atol=1e-7)
     # eval forward (no backward): fused as well
     rgb = [tr.forward(rays, None, 1.0, training=False).clone() for tr in trs]
     torch.testing.assert_close(rgb[0], rgb[1], rtol=0, atol=2e-3)
+    torch.testing.assert_close(rgb[2], rgb[1], rtol=0, atol=2e-3)

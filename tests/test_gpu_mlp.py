@@ -238,3 +238,37 @@ def test_16bit_operand_two_hidden_layers(shape, operands):
     rel = lambda u, v: float((u - v).norm() / (v.norm() + 1e-20))
     lim = 1e-1 if operands == "bf16" else 3e-2
     assert rel(xg.grad, xr.grad) < lim and rel(net.params.grad, ref.params.grad) < lim
+
+
+@pytest.mark.parametrize("operands", ["bf16", "fp16"])
+def test_backward_from_16bit_input_equals_backward_from_its_fp32_image(operands):
+    """snerf_mlp_bwd_x16: X handed over in the operand type (the feature tile snerf_kplanes_field_fwd writes) gives the same gX as
+    snerf_mlp_bwd on the fp32 image of those values, and the same gW up to the order of the float atomics."""
+    import ctypes as C
+
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.tcnn_compat import Network
+
+    dt = torch.bfloat16 if operands == "bf16" else torch.float16
+    net = Network(160, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 1},
+                  operands=operands).to(DEV)
+    N = 1000
+    gen = torch.Generator().manual_seed(5)
+    x16 = (torch.rand(N, 160, generator=gen) - 0.3).to(DEV).to(dt)
+    x32 = x16.float()
+    gy = (torch.rand(N, 16, generator=gen) - 0.5).to(DEV)
+    gaux = (torch.rand(N, generator=gen) - 0.5).to(DEV)
+    L = _lib.lib()
+    out = []
+    for fn, x in ((L.snerf_mlp_bwd, x32), (L.snerf_mlp_bwd_x16, x16)):
+        gx, gw = torch.full((N, 160), 7.0, device=DEV), torch.zeros_like(net.params)
+        _lib.check(fn(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x), 160, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux), ops._ptr(gx), 160,
+                      ops._ptr(gw), ops._stream()))
+        out.append((gx, gw))
+    assert torch.equal(out[0][0], out[1][0])
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-4, atol=1e-5 * float(out[0][1].abs().max()))
+    # fp32-operand nets refuse a 16-bit input
+    net32 = Network(160, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 1}).to(DEV)
+    rc = L.snerf_mlp_bwd_x16(C.byref(net32.desc), ops._ptr(net32.params), ops._ptr(x16), 160, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux), None, 160,
+                             ops._ptr(torch.zeros_like(net32.params)), ops._stream())
+    assert rc != 0 and b"16-bit" in L.snerf_last_error()
