@@ -208,7 +208,7 @@ static int launch_fwd(const snerf_kplanes_desc* d, const float* planes, const sn
 template <int C, int NP>
 static int launch_bwd(const snerf_kplanes_desc* d, const float* planes, const snerf_coords* c, int64_t N, const float* gout, float* gp,
                       long long* gp_fx, hipStream_t st) {
-  // consecutive samples walked (and run-length-combined) by one lane group, and samples in flight per group.  profiles/r02_prop_scatter.md:
+  // consecutive samples walked (and run-length-combined) by one lane group, and samples in flight per group.  profiles/r02_kernels.md:
   // with the taps out of scratch the proposal levels (C = 8) take 0.30 ms at run 64 and 0.29 ms at run 32; 2 or 4 samples in flight
   // change nothing (0.30-0.32 ms) -- the walk is bound by its memory-side atomic requests, not by load latency.
   constexpr int run = C <= 8 ? 32 : 64;

@@ -62,7 +62,7 @@ template <> struct PlanePairs<3> {  // static scene: XY XZ YZ
 
 // The same tables as arithmetic on the plane index.  Inside an unrolled plane loop q is a literal and these fold; indexing the constexpr
 // arrays above did not always (kplanes_gather_bwd_kernel, field_fwd_kernel: the taps were kept in scratch and read back through a
-// uniform-but-dynamic index, 16 dwords per sample -- profiles/r02_prop_scatter.md).
+// uniform-but-dynamic index, 16 dwords per sample -- profiles/r02_kernels.md).
 template <int NP> __host__ __device__ constexpr int pair_a(int q) { return NP == 6 ? (q < 3 ? 0 : (q < 5 ? 1 : 2)) : (q < 2 ? 0 : 1); }
 template <int NP> __host__ __device__ constexpr int pair_b(int q) { return NP == 6 ? (q < 3 ? q + 1 : (q < 5 ? q - 1 : 3)) : (q < 1 ? 1 : 2); }
 static_assert(pair_a<6>(0) == 0 && pair_a<6>(2) == 0 && pair_a<6>(3) == 1 && pair_a<6>(4) == 1 && pair_a<6>(5) == 2, "pair_a<6>");
