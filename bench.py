@@ -265,7 +265,8 @@ def main():
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),
             "kplanes_gather_fwd.field": ("hbm", gather, "kplanes_gather_fwd_kernel<32,6>: texel reads"),
-            "kplanes_field_fwd": ("hbm", gather + R * S2 * 16, "field_fwd_kernel (gather + sigma_net + color_net fused): texel reads + density / rgb written"),
+            "kplanes_field_fwd": ("hbm", gather + R * S2 * (16 + 2 * F + 64),
+                                  "field_fwd_kernel (gather + sigma_net + color_net fused): texel reads + density / rgb + the 16-bit feature tile and the 16 sigma_net outputs (kept for the backward) written"),
             "kplanes_field_bwd": ("hbm", 2 * gather + R * S2 * (16 + 30 * cfg.feature_dim * (2 if args.mlp_operands != "fp32" else 4)),
                                   "field_bwd_kernel (recomputed forward + both nets' backward + per-plane gradient vectors fused): texel reads x 2 + gvec written"),
             # proposal planes (C = 8, one scale): two launches per updated step (256 and 128 samples per ray) -> mean bytes per launch; runs on

@@ -48,7 +48,8 @@ with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
         g.write(f'"{k}",{v.get("FETCH_SIZE", 0):.1f},{v.get("WRITE_SIZE", 0):.1f},{v.get("TCC_EA0_ATOMIC_sum", 0):.1f},{tr:.0f}\n')
 names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_grouped_kernel<6",
          "kplanes_gradvec.field": "snerf::gradvec_kernel<32, 6", "kplanes_gather_fwd.field": "snerf::kplanes_gather_fwd_kernel<32, 6>",
-         "mlp_bwd.160x128x1": "bwd_kernel<__bf16, 160, 128, 1", "kplanes_gather_bwd.prop": "snerf::kplanes_gather_bwd_kernel<8, 6"}
+         "mlp_bwd.160x128x1": "bwd_kernel<__bf16, 160, 128, 1", "kplanes_gather_bwd.prop": "snerf::kplanes_gather_bwd_kernel<8, 6",
+         "kplanes_field_fwd": "field_fwd_kernel"}
 tj = {"_note": "traffic_bytes_per_launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->B) from separate rocprofv3 --pmc passes, k-planes preset, 4096 rays "
                f"(profiles/{tag}_pmc_counters.csv)"}
 for span, pat in names.items():
