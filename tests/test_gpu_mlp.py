@@ -272,3 +272,18 @@ def test_backward_from_16bit_input_equals_backward_from_its_fp32_image(operands)
     rc = L.snerf_mlp_bwd_x16(C.byref(net32.desc), ops._ptr(net32.params), ops._ptr(x16), 160, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux), None, 160,
                              ops._ptr(torch.zeros_like(net32.params)), ops._stream())
     assert rc != 0 and b"16-bit" in L.snerf_last_error()
+    # the 16-B loads need ldx % 8 == 0 and an aligned base; ragged N and a padded row stride work
+    rc = L.snerf_mlp_bwd_x16(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x16), 164, C.c_int64(N // 2), ops._ptr(gy), 16, 15, ops._ptr(gaux), None, 160,
+                             ops._ptr(torch.zeros_like(net.params)), ops._stream())
+    assert rc != 0 and b"multiple of 8" in L.snerf_last_error()
+    Nr = 777
+    xp = torch.zeros(Nr, 168, device=DEV, dtype=dt)
+    xp[:, :160] = x16[:Nr]
+    res = []
+    for fn, x, ld in ((L.snerf_mlp_bwd, x32[:Nr].contiguous(), 160), (L.snerf_mlp_bwd_x16, xp, 168)):
+        gx, gw = torch.empty(Nr, 160, device=DEV), torch.zeros_like(net.params)
+        _lib.check(fn(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x), ld, C.c_int64(Nr), ops._ptr(gy), 16, 15, ops._ptr(gaux), ops._ptr(gx), 160,
+                      ops._ptr(gw), ops._stream()))
+        res.append((gx, gw))
+    assert torch.equal(res[0][0], res[1][0])
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * float(res[0][1].abs().max()))
