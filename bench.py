@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
+    ap.add_argument("--no-quotient-scatter", action="store_true", help="A/B: product form of the field's sorted scatter (gradvec + 1 GB of per-plane gradient vectors) instead of the quotient form")
     ap.add_argument("--fused-backward", action="store_true", help="opt-in: fused backward kernel as well (recomputed forward + both nets' backward + gradient vectors); measured slower, see profiles/r02_kernels.md")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
@@ -133,7 +134,7 @@ def main():
     # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
     torch.manual_seed(20231029 + rank)
     cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field,
-                             fused_field_backward=args.fused_backward)  # the k-planes preset
+                             fused_field_backward=args.fused_backward, quotient_scatter=not args.no_quotient_scatter)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
@@ -210,7 +211,7 @@ def main():
         one_step()
     # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
     CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
-            "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_field_bwd"]
+            "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_field_bwd", "kplanes_quotient_prepare"]
     trainer.enable_kernel_timing(CAND)
     elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
@@ -265,6 +266,7 @@ def main():
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),
             "kplanes_gather_fwd.field": ("hbm", gather, "kplanes_gather_fwd_kernel<32,6>: texel reads"),
+            "kplanes_quotient_prepare": ("hbm", 3 * R * S2 * F * 4, "quotient_prepare_kernel: G = gfeat .* feat (two tensors read, one written)"),
             "kplanes_field_fwd": ("hbm", gather + R * S2 * (16 + 2 * F + 64),
                                   "field_fwd_kernel (gather + sigma_net + color_net fused): texel reads + density / rgb + the 16-bit feature tile and the 16 sigma_net outputs (kept for the backward) written"),
             "kplanes_field_bwd": ("hbm", 2 * gather + R * S2 * (16 + 30 * cfg.feature_dim * (2 if args.mlp_operands != "fp32" else 4)),
@@ -303,8 +305,9 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.mlp_operands == "fp32" else args.mlp_operands,
             "dtype_note": "exact fp32 everywhere (the parity path)" if args.mlp_operands == "fp32" else
-                          f"{args.mlp_operands} MFMA operands with f32 accumulation in every MLP (sigma_net, color_net, proposal nets); per-plane gradient vectors "
-                          f"between the two scatter passes are {cfg.gvec_dtype}; planes, sampling, compositing, losses, gradient accumulation and the optimiser are f32",
+                          f"{args.mlp_operands} MFMA operands with f32 accumulation in every MLP (sigma_net, color_net, proposal nets); plane-gradient scatter in "
+                          + ("its quotient form (f32)" if trainer.quotient_scatter else f"its product form with {cfg.gvec_dtype} gradient vectors between the two passes")
+                          + "; planes, sampling, compositing, losses, gradient accumulation and the optimiser are f32",
             "data": "synthetic",
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",

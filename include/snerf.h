@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 4
+#define SNERF_ABI_VERSION 5
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -208,7 +208,8 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
  *   fwd: density [N], rgb [N,3].  Optional (NULL = not written), for a training step that runs the UNFUSED backward kernels on what the
  *        forward already computed: feat16 [N, 32 n_scales] = the feature tile in the operand type (bf16 / fp16: exactly the values the
  *        MFMA consumed; 2 B per feature instead of the 4 B the unfused gather writes) for snerf_mlp_bwd_x16(sigma_net), and h [N,16] =
- *        the raw fp32 sigma_net outputs (color_net's input; column 15 = log density) for snerf_mlp_bwd(color_net).
+ *        the raw fp32 sigma_net outputs (color_net's input; column 15 = log density) for snerf_mlp_bwd(color_net); feat32
+ *        [N, 32 n_scales] = the fp32 features before rounding, for the quotient form of the plane scatter (snerf_kplanes_quotient_*).
  *   bwd: from g_density [N] and g_rgb [N,3]: recomputes the forward per tile, ACCUMULATES the weight gradients of both nets (flat layouts of
  *        snerf_mlp_*; float atomics, or fixed-point cells when the *_fx pointers are given instead) and writes the per-plane gradient
  *        vectors gvec[scale * 6 + plane][N][32] (fp32 or bf16) that snerf_kplanes_scatter_sorted consumes -- i.e. it replaces
@@ -217,7 +218,7 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
 int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
 int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                             const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
-                            float* density, float* rgb, void* feat16, float* h, snerf_stream_t stream);
+                            float* density, float* rgb, void* feat16, float* h, float* feat32, snerf_stream_t stream);
 int snerf_kplanes_field_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                             const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
                             const float* g_density, const float* g_rgb, float* gW_sigma, float* gW_color, int64_t* gW_sigma_fx,
@@ -530,6 +531,28 @@ int snerf_kplanes_gradvec(const snerf_kplanes_desc* desc, const float* planes, c
                           void* gvec, int32_t gvec_bf16, snerf_stream_t stream);
 int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,
                                  float* grad_planes, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Quotient form of the sorted scatter (C = 32, concatenated scales).  interpolate_kplanes multiplies the six planes' values of a scale
+ * (NS/fields/kplanes_field.py:113-120), so the gradient w.r.t. plane q's value at a sample is
+ *     g_q = gfeat .* prod_{p != q} v_p = (gfeat .* feat) ./ v_q          (feat = prod_p v_p, what the forward computed)
+ * Instead of materialising 6 gradient vectors per (sample, scale) (snerf_kplanes_gradvec: a second gather of all 30 planes + 1 GB of
+ * vectors at the preset), ONE tensor G = gfeat .* feat [N, 32 n_scales] is formed and pass B divides by v_q, which it re-interpolates
+ * from the 4 texels of the cell it is adding into (sorted order: the reads stay in cache).  Differs from the product form by a few ulp.
+ * Where a feature is exactly 0 the quotient has lost the other planes' product: _prepare lists those rows (device-side list, capacity
+ * N * n_scales covers the worst case) and _fixup adds their exact gradients; pass B adds 0 there.
+ *   _prepare : G = grad_feat .* feat; fix_count (reset here) / fix_list = rows (sample * n_scales + scale) with a zero feature.
+ *   _scatter_quotient_scales : pass B over scales [scale_begin, scale_end), sorted_rec from snerf_kplanes_sort_samples; ACCUMULATES.
+ *   _fixup   : exact terms of the listed rows for scales [scale_begin, scale_end); ACCUMULATES.  Launch cost only when the list is empty.
+ * ------------------------------------------------------------------------------------------------ */
+int snerf_kplanes_quotient_supported(const snerf_kplanes_desc* desc, int64_t N);
+int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, const float* grad_feat, const float* feat, float* G,
+                                   int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, snerf_stream_t stream);
+int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const float* planes, int64_t N, const float* G, const float* sorted_rec,
+                                          float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
+int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
+                                 const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
+                                 int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
 int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class KPlanesDesc(C.Structure):
@@ -196,6 +196,10 @@ EXPORTS = [
     "snerf_depth_loss",
     "snerf_kplanes_field_supported",
     "snerf_kplanes_field_fwd",
+    "snerf_kplanes_quotient_supported",
+    "snerf_kplanes_quotient_prepare",
+    "snerf_kplanes_scatter_quotient_scales",
+    "snerf_kplanes_quotient_fixup",
     "snerf_kplanes_field_bwd",
     "snerf_nerfplayer_mix_fwd",
     "snerf_nerfplayer_mix_bwd",

@@ -41,6 +41,7 @@ struct FieldArgs {
   float* rgb;         // [N,3] sigmoid(color_net(.))
   void* feat16;       // optional [N, 32 n_scales] in the operand type: the rounded feature tile, for an UNFUSED backward (snerf_mlp_bwd_x16)
   float* h;           // optional [N,16]: the raw sigma_net outputs (color_net's input, column 15 = log density)
+  float* feat32;      // optional [N, 32 n_scales] fp32: the features before rounding, for the quotient form of the plane scatter
   // backward
   const float* gdens;   // [N]   dL/d density
   const float* grgb;    // [N,3] dL/d rgb
@@ -114,6 +115,7 @@ __device__ __forceinline__ void gather_tile(const FieldArgs& a, int64_t n0, T* X
     if (live) f = scale_features(a.d, a.planes, p, s, cg);
     const typename Ops<T>::v4 t = {Ops<T>::cvt(f.x), Ops<T>::cvt(f.y), Ops<T>::cvt(f.z), Ops<T>::cvt(f.w)};
     *reinterpret_cast<typename Ops<T>::v4*>(XS + sample * P::LK0 + s * 32 + cg * 4) = t;
+    if (a.feat32 && live) *reinterpret_cast<float4*>(a.feat32 + n * (32 * NS) + s * 32 + cg * 4) = f;  // 8 lanes x 16 B = one 128-B row segment
   }
 }
 
@@ -674,14 +676,14 @@ extern "C" int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, con
 
 extern "C" int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                                        const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
-                                       float* density, float* rgb, void* feat16, float* h, snerf_stream_t stream) {
+                                       float* density, float* rgb, void* feat16, float* h, float* feat32, snerf_stream_t stream) {
   int rc = validate_field(desc, coords, N, sigma, color);
   if (rc) return rc;
   if (N == 0) return 0;
   SNERF_REQUIRE(planes && W_sigma && W_color && density && rgb, "kplanes_field_fwd: null buffer");
   FieldArgs a = {};
   a.d = *desc; a.planes = planes; a.c = *coords; a.N = N; a.Wsig = W_sigma; a.Wcol = W_color; a.dens = density; a.rgb = rgb;
-  a.feat16 = feat16; a.h = h;
+  a.feat16 = feat16; a.h = h; a.feat32 = feat32;
   FF_DISPATCH(launch_field_fwd, sigma->operands, desc->n_scales, a, (hipStream_t)stream);
 }
 

@@ -73,6 +73,22 @@ __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) { return make_float
 __device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// Bilinear blend of the four texels of a tap with a FIXED evaluation order and explicit roundings (no compiler-chosen contraction):
+// the forward gather and the quotient form of the sorted scatter (kplanes_sorted.hip, QUOT) must produce the SAME bits for a plane's
+// value at a sample -- the quotient G / v_q cancels the forward's v_q exactly only if pass B recomputes that very number (a value that is
+// a small difference of large texels would otherwise come back with a large relative error).
+__device__ __forceinline__ float bilerp4(float nw, float ne, float sw, float se, float w00, float w10, float w01, float w11) {
+  float acc = __fmul_rn(nw, w00);
+  acc = __fmaf_rn(ne, w10, acc);
+  acc = __fmaf_rn(sw, w01, acc);
+  acc = __fmaf_rn(se, w11, acc);
+  return acc;
+}
+// the four corner weights of a tap pair: (x0,y0), (x1,y0), (x0,y1), (x1,y1)
+__device__ __forceinline__ float4 tap_weights(const AxisTap& tx, const AxisTap& ty) {
+  return make_float4(__fmul_rn(tx.w0, ty.w0), __fmul_rn(tx.w1, ty.w0), __fmul_rn(tx.w0, ty.w1), __fmul_rn(tx.w1, ty.w1));
+}
+
 // bilinear value of plane p for this lane's 4 channels
 template <int C>
 __device__ __forceinline__ float4 plane_sample(const float* __restrict__ base, int W, const AxisTap& tx, const AxisTap& ty, int cg) {
@@ -82,11 +98,9 @@ __device__ __forceinline__ float4 plane_sample(const float* __restrict__ base, i
   float4 ne = *reinterpret_cast<const float4*>(r0 + (int64_t)tx.i1 * C);
   float4 sw = *reinterpret_cast<const float4*>(r1 + (int64_t)tx.i0 * C);
   float4 se = *reinterpret_cast<const float4*>(r1 + (int64_t)tx.i1 * C);
-  float4 acc = f4_scale(nw, tx.w0 * ty.w0);
-  acc = f4_add(acc, f4_scale(ne, tx.w1 * ty.w0));
-  acc = f4_add(acc, f4_scale(sw, tx.w0 * ty.w1));
-  acc = f4_add(acc, f4_scale(se, tx.w1 * ty.w1));
-  return acc;
+  const float4 w = tap_weights(tx, ty);
+  return make_float4(bilerp4(nw.x, ne.x, sw.x, se.x, w.x, w.y, w.z, w.w), bilerp4(nw.y, ne.y, sw.y, se.y, w.x, w.y, w.z, w.w),
+                     bilerp4(nw.z, ne.z, sw.z, se.z, w.x, w.y, w.z, w.w), bilerp4(nw.w, ne.w, sw.w, se.w, w.x, w.y, w.z, w.w));
 }
 
 

@@ -395,10 +395,16 @@ struct BitonicK<1> {
   static __device__ __forceinline__ void run(uint32_t (&)[4], int) {}
 };
 
-template <int NP, typename GV>
+// QUOT (the quotient form, snerf_kplanes_scatter_quotient): gvec is ONE tensor G[N][row_stride] = gfeat .* feat (feat = the forward's product
+// over the six planes), and the gradient vector of plane q at an entry is G / v_q with v_q re-interpolated here from the entry's cell --
+// the 4 texels this lane group is about to add into, so the reads follow the sorted order and stay in cache.  lane = (x-corner, channel):
+// each half interpolates its x-column, v_permlane32_swap adds the two halves.  v_q == 0 (then G == 0 as well: the information is gone)
+// yields 0 here and the exact term is added by quotient_fixup_kernel.
+template <int NP, typename GV, bool QUOT = false>
 __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc d, int64_t N, const GV* __restrict__ gvec,
                                                              const float4* __restrict__ sorted_rec, float* __restrict__ gplanes,
-                                                             int64_t groups_per_seg, int seg_begin, int per_scale) {
+                                                             int64_t groups_per_seg, int seg_begin, int per_scale,
+                                                             const float* __restrict__ planes = nullptr, int row_stride = 0) {
   constexpr int C = 32, CH = 256, UNROLL = 16;
   // per wave, per entry (in WALK order) 8 dwords: {gvec row offset (elements), x0 | y0 << 16, -, -, wx0*wy0, wx0*wy1, wx1*wy0, wx1*wy1}.
   // Everything per-entry is prepared lane-parallel (4 entries per lane) so that the walk -- one entry per wave instruction -- costs
@@ -418,8 +424,11 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
   seg_axes<NP>(q, a, b);
   const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
   const float4* rec = sorted_rec + (int64_t)(per_scale ? seg : q) * N + i0;
-  const GV* gseg = gvec + (int64_t)seg * N * C;  // wave-uniform base; rows are addressed with 32-bit element offsets
+  // wave-uniform base; rows are addressed with 32-bit element offsets
+  const GV* gseg = QUOT ? gvec + (int64_t)s * C : gvec + (int64_t)seg * N * C;
+  const uint32_t rstride = QUOT ? (uint32_t)row_stride : (uint32_t)C;
   float* gch = gplanes + d.off[s][q] + ch;
+  const float* pch = QUOT ? planes + d.off[s][q] + ch : nullptr;
   uint32_t* R = s_rec[wave];
   const bool sortable = (int64_t)W * H <= (1 << 23);  // key << 8 | index must fit 31 bits (the launcher guarantees N * C < 2^31)
 
@@ -447,9 +456,10 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
       const float4 rc = rec[word[r] & 255u];
       const AxisTap tx = axis_tap(rc.y, W);
       const AxisTap ty = axis_tap(rc.z, H);
-      hd.x = (uint32_t)__float_as_int(rc.x) * (uint32_t)C;
+      hd.x = (uint32_t)__float_as_int(rc.x) * rstride;
       hd.y = (uint32_t)tx.i0 | ((uint32_t)ty.i0 << 16);
-      wt = make_float4(tx.w0 * ty.w0, tx.w0 * ty.w1, tx.w1 * ty.w0, tx.w1 * ty.w1);  // a clamped second tap has weight 0
+      const float4 tw = tap_weights(tx, ty);                  // (x0y0, x1y0, x0y1, x1y1): the forward's products, bit for bit
+      wt = make_float4(tw.x, tw.z, tw.y, tw.w);               // stored as (x0y0, x0y1 | x1y0, x1y1): one float2 per x-corner; a clamped second tap has weight 0
     }
     *reinterpret_cast<uint4*>(R + e * 8) = hd;
     *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
@@ -466,11 +476,34 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
     float g[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) g[u] = load_g(gseg, (int64_t)(R[(e0 + u) * 8] + ch));  // wave-uniform LDS address: broadcast
+    float t0[QUOT ? UNROLL : 1], t1[QUOT ? UNROLL : 1];  // QUOT: this lane's x-column of the entry's cell, rows y0 and y0 + 1
+    if constexpr (QUOT) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 1]);
+        // clamped like the taps (a clamped corner has weight 0, a null record 0xffffffff has all weights 0): any valid address will do
+        const int x0 = min((int)(pk & 0xffffu), W - 1), y0 = min((int)(pk >> 16), H - 1);
+        const int y1 = min(y0 + 1, H - 1);
+        const int xh = x0 + ((half && x0 + 1 < W) ? 1 : 0);
+        const float* tp = pch + ((int64_t)y0 * W + xh) * C;
+        t0[u] = tp[0];
+        t1[u] = tp[(int64_t)(y1 - y0) * rowC];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 1]);
       const float2 wt = *reinterpret_cast<const float2*>(Rl + (e0 + u) * 8);
-      const float v0 = g[u] * wt.x, v1 = g[u] * wt.y;
+      float gq = g[u];
+      if constexpr (QUOT) {
+        // the plane's value at the entry, with the forward's own formula and order (bilerp4): both x-columns in every lane
+        const float4 w4 = *reinterpret_cast<const float4*>(R + (e0 + u) * 8 + 4);  // wave-uniform address: broadcast
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0[u]), __float_as_uint(t0[u]), false, false);  // row y0: [0] = x0 column, [1] = x1
+        const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1[u]), __float_as_uint(t1[u]), false, false);  // row y0 + 1
+        const float vq = bilerp4(__uint_as_float(s0[0]), __uint_as_float(s0[1]), __uint_as_float(s1[0]), __uint_as_float(s1[1]), w4.x, w4.z, w4.y, w4.w);
+        gq = vq != 0.f ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;
+      }
+      const float v0 = gq * wt.x, v1 = gq * wt.y;
       if (packed == ppk) {
         p0 += v0; p1 += v1;
       } else if (packed == ppk + 1u) {
@@ -495,6 +528,85 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
     float* dst = gch + ((int64_t)(ppk >> 16) * W + (ppk & 0xffffu) + half) * C;
     if (p0 != 0.f) atomicAdd(dst, p0);
     if (p1 != 0.f) atomicAdd(dst + rowC, p1);
+  }
+}
+
+// ---- quotient form, the two small kernels around pass B ----
+// G = gfeat .* feat (C / 4 lanes per (sample, scale) row, float4 each); rows in which a feature is exactly 0 while its gradient is not
+// are listed for quotient_fixup_kernel (G / v_q cannot give plane q's gradient there: v_q == 0 took the other planes' product with it).
+template <int C>
+__global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, const float* __restrict__ gfeat, const float* __restrict__ feat,
+                                                              float* __restrict__ G, int32_t* __restrict__ list, int capacity, int32_t* __restrict__ count) {
+  constexpr int LPR = C / 4;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = gid / LPR;
+  bool bad = false;
+  if (row < rows) {
+    const float4 g = *reinterpret_cast<const float4*>(gfeat + gid * 4);
+    const float4 f = *reinterpret_cast<const float4*>(feat + gid * 4);
+    *reinterpret_cast<float4*>(G + gid * 4) = f4_mul(g, f);
+    bad = (f.x == 0.f && g.x != 0.f) || (f.y == 0.f && g.y != 0.f) || (f.z == 0.f && g.z != 0.f) || (f.w == 0.f && g.w != 0.f);
+  }
+  const unsigned long long m = __ballot(bad);
+  const int lane = threadIdx.x & 63, g0 = lane & ~(LPR - 1);
+  if ((lane & (LPR - 1)) == 0 && ((m >> g0) & ((1ull << LPR) - 1ull))) {
+    const int slot = atomicAdd(count, 1);
+    if (slot < capacity) list[slot] = (int32_t)row;
+  }
+}
+
+// Exact gradient of the listed rows (row = sample * n_scales + scale): where exactly ONE plane's value is 0 at a channel, that plane
+// receives gfeat * (product of the other five); every other case is already right in pass B (it adds 0).  One wave per row,
+// lane = (x-corner, channel) as in the scatter; rare by construction (a trained texel that is exactly 0.0f), so no combining.
+template <int NP>
+__global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c, const float* __restrict__ gfeat,
+                                                            const int32_t* __restrict__ list, const int32_t* __restrict__ count, int capacity,
+                                                            float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end) {
+  constexpr int C = 32;
+  const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
+  int n_list = *count;
+  n_list = n_list < capacity ? n_list : capacity;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n_list; i += gridDim.x * 4) {
+    const int row = list[i];
+    const int64_t n = row / n_scales_total;
+    const int s = row - (int)n * n_scales_total;
+    if (s < scale_begin || s >= scale_end) continue;
+    float p[4];
+    load_coords<NP>(c, n, p);
+    AxisTap tap[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tap[k] = axis_tap(p[k], d.res[s][k] > 0 ? d.res[s][k] : 1);
+    float v[NP];
+    int zeros = 0;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const AxisTap& tx = tap[pair_a<NP>(q)];
+      const AxisTap& ty = tap[pair_b<NP>(q)];
+      const int W = d.res[s][pair_a<NP>(q)];
+      const float* base = planes + d.off[s][q] + ch;
+      const float4 w = tap_weights(tx, ty);
+      // the forward's own number (bilerp4): "exactly zero" must mean the same here, in the forward and in pass B
+      v[q] = bilerp4(base[((int64_t)ty.i0 * W + tx.i0) * C], base[((int64_t)ty.i0 * W + tx.i1) * C], base[((int64_t)ty.i1 * W + tx.i0) * C],
+                     base[((int64_t)ty.i1 * W + tx.i1) * C], w.x, w.y, w.z, w.w);
+      zeros += v[q] == 0.f;
+    }
+    if (zeros != 1) continue;  // per lane (channel): none -> pass B was exact; two or more -> every plane's gradient is 0
+    float prod = gfeat[n * ((int64_t)n_scales_total * C) + s * C + ch];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) prod *= v[q] == 0.f ? 1.f : v[q];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      if (v[q] != 0.f) continue;
+      const AxisTap& tx = tap[pair_a<NP>(q)];
+      const AxisTap& ty = tap[pair_b<NP>(q)];
+      const int W = d.res[s][pair_a<NP>(q)];
+      const float wx = half ? tx.w1 : tx.w0;
+      const int xi = half ? tx.i1 : tx.i0;
+      float* gb = gplanes + d.off[s][q] + ch;
+      const float a0 = prod * wx * ty.w0, a1 = prod * wx * ty.w1;
+      if (a0 != 0.f) atomicAdd(gb + ((int64_t)ty.i0 * W + xi) * C, a0);
+      if (a1 != 0.f) atomicAdd(gb + ((int64_t)ty.i1 * W + xi) * C, a1);
+    }
   }
 }
 
@@ -701,4 +813,83 @@ extern "C" int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int6
                                             float* grad_planes, snerf_stream_t stream) {
   SNERF_REQUIRE(desc, "kplanes_scatter_sorted: null descriptor");
   return snerf_kplanes_scatter_sorted_scales(desc, N, gvec, gvec_bf16, sorted_rec, grad_planes, 0, desc->n_scales, stream);
+}
+
+// ---- quotient form of the sorted scatter (snerf.h) ----
+static int quotient_ok(const snerf_kplanes_desc* d, int64_t N) {
+  SNERF_REQUIRE(d, "kplanes_quotient: null descriptor");
+  SNERF_REQUIRE(d->C == 32 && d->concat == 1 && d->n_scales >= 1 && (int64_t)N * d->C * d->n_scales < (1LL << 31),
+                "kplanes_quotient: built for C = 32, concatenated scales and N * 32 * n_scales < 2^31 (C=%d concat=%d N=%lld)", d->C, d->concat, (long long)N);
+  return 0;
+}
+
+extern "C" int snerf_kplanes_quotient_supported(const snerf_kplanes_desc* desc, int64_t N) {
+  return desc && desc->C == 32 && desc->concat == 1 && desc->n_scales >= 1 && N >= 0 && (int64_t)N * desc->C * desc->n_scales < (1LL << 31) &&
+         (desc->n_coords == 3 || desc->n_coords == 4);
+}
+
+extern "C" int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, const float* grad_feat, const float* feat, float* G,
+                                              int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, snerf_stream_t stream) {
+  int rc = quotient_ok(desc, N);
+  if (rc) return rc;
+  SNERF_REQUIRE(N >= 0 && fix_capacity >= 0, "kplanes_quotient_prepare: N=%lld capacity=%d", (long long)N, fix_capacity);
+  SNERF_REQUIRE(fix_count, "kplanes_quotient_prepare: null counter");
+  hipStream_t st = (hipStream_t)stream;
+  rc = check_hip(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st), "kplanes_quotient_prepare memset");
+  if (rc) return rc;
+  if (N == 0) return 0;
+  SNERF_REQUIRE(grad_feat && feat && G && (fix_list || fix_capacity == 0), "kplanes_quotient_prepare: null buffer");
+  const int64_t rows = N * desc->n_scales;
+  hipLaunchKernelGGL((quotient_prepare_kernel<32>), dim3((unsigned)ceil_div(rows * 8, 256)), dim3(256), 0, st, rows, grad_feat, feat, G, fix_list,
+                     fix_capacity, fix_count);
+  SNERF_LAUNCH_CHECK("kplanes_quotient_prepare");
+  return 0;
+}
+
+extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const float* planes, int64_t N, const float* G, const float* sorted_rec,
+                                                     float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
+  int rc = quotient_ok(desc, N);
+  if (rc) return rc;
+  SNERF_REQUIRE(scale_begin >= 0 && scale_begin <= scale_end && scale_end <= desc->n_scales, "kplanes_scatter_quotient: scales [%d, %d) of %d",
+                scale_begin, scale_end, desc->n_scales);
+  if (N == 0 || scale_begin == scale_end) return 0;
+  SNERF_REQUIRE(planes && G && sorted_rec && grad_planes, "kplanes_scatter_quotient: null buffer");
+  snerf_kplanes_desc dd = *desc;
+  dd.n_scales = scale_end;
+  SegTable stb;
+  rc = build_segs(desc, stb);
+  if (rc) return rc;
+  const int NP = desc->n_coords == 4 ? 6 : 3;
+  const int64_t gps = (N + 255) / 256;
+  const dim3 grid((unsigned)ceil_div(gps * (scale_end - scale_begin) * NP, 4));
+  const float4* rec = reinterpret_cast<const float4*>(sorted_rec);
+  const int stride = desc->C * desc->n_scales;
+  hipStream_t st = (hipStream_t)stream;
+  if (NP == 6) hipLaunchKernelGGL((scatter_grouped_kernel<6, float, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale,
+                                  planes, stride);
+  else hipLaunchKernelGGL((scatter_grouped_kernel<3, float, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale,
+                          planes, stride);
+  SNERF_LAUNCH_CHECK("kplanes_scatter_quotient");
+  return 0;
+}
+
+extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
+                                            const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
+                                            int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
+  int rc = check_desc(desc, coords, N);
+  if (rc) return rc;
+  rc = quotient_ok(desc, N);
+  if (rc) return rc;
+  SNERF_REQUIRE(scale_begin >= 0 && scale_begin <= scale_end && scale_end <= desc->n_scales, "kplanes_quotient_fixup: scales [%d, %d) of %d", scale_begin,
+                scale_end, desc->n_scales);
+  if (N == 0 || fix_capacity == 0 || scale_begin == scale_end) return 0;
+  SNERF_REQUIRE(planes && grad_feat && fix_list && fix_count && grad_planes, "kplanes_quotient_fixup: null buffer");
+  // a fixed small grid that strides over the (device-side) count: an empty list costs one launch
+  hipStream_t st = (hipStream_t)stream;
+  if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, fix_list, fix_count,
+                                              fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end);
+  else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, fix_list, fix_count, fix_capacity,
+                          grad_planes, desc->n_scales, scale_begin, scale_end);
+  SNERF_LAUNCH_CHECK("kplanes_quotient_fixup");
+  return 0;
 }

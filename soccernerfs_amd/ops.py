@@ -84,9 +84,11 @@ class _KPlanesGather(torch.autograd.Function):
 class SortedScatter:
     """Workspace + driver of the sorted plane-gradient scatter (csrc/kplanes_sorted.hip) for a fixed sample count N."""
 
-    def __init__(self, ps: PlaneSet, N: int, device, gvec_dtype: torch.dtype = torch.float32):
+    def __init__(self, ps: PlaneSet, N: int, device, gvec_dtype: torch.dtype = torch.float32, quotient: bool = False):
         """gvec_dtype: element type of the per-plane gradient vectors between pass A and pass B -- float32 (exact) or bfloat16 (half the
-        bytes of the step's largest intermediate; the scatter accumulates in fp32 either way)."""
+        bytes of the step's largest intermediate; the scatter accumulates in fp32 either way).  quotient: the quotient form
+        (scatter_quotient: one [N, C n_scales] tensor instead of the vectors; C = 32, concatenated scales) -- the vector buffer is then
+        not allocated."""
         if gvec_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("gvec_dtype must be torch.float32 or torch.bfloat16")
         self.ps, self.N, self.desc = ps, N, ps.desc()
@@ -96,7 +98,17 @@ class SortedScatter:
         self.hist = torch.empty(hc.value, dtype=torch.int32, device=device)
         self.rank = torch.empty(ie.value, dtype=torch.int32, device=device)
         self.sorted_rec = torch.empty(ie.value, 4, dtype=torch.float32, device=device)  # {sample id bits, pixel x, pixel y, 0}
-        self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=gvec_dtype, device=device)  # [scale*planes+plane][N][C]
+        self.quotient = bool(quotient)
+        if self.quotient:
+            if not _lib.lib().snerf_kplanes_quotient_supported(C.byref(self.desc), C.c_int64(N)):
+                raise ValueError("the quotient scatter is built for C = 32, concatenated scales and N * 32 * n_scales < 2^31")
+            rows = N * len(ps.resolutions)
+            self.G = torch.empty(N, ps.out_dim, dtype=torch.float32, device=device)       # gfeat .* feat
+            self.fix_list = torch.empty(max(rows, 1), dtype=torch.int32, device=device)   # rows (sample * n_scales + scale) with an exactly-zero feature
+            self.fix_count = torch.zeros(1, dtype=torch.int32, device=device)
+            self.gvec = None
+        else:
+            self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=gvec_dtype, device=device)  # [scale*planes+plane][N][C]
 
     def sort(self, coords: _lib.Coords, stream=None):
         _lib.check(_lib.lib().snerf_kplanes_sort_samples(C.byref(self.desc), C.byref(coords), C.c_int64(self.N), _ptr(self.hist), _ptr(self.rank),
@@ -108,6 +120,27 @@ class SortedScatter:
                    "gradvec")
         _lib.check(_lib.lib().snerf_kplanes_scatter_sorted(C.byref(self.desc), C.c_int64(self.N), _ptr(self.gvec), self.gvec_bf16, _ptr(self.sorted_rec), _ptr(gplanes), st),
                    "scatter_sorted")
+
+
+    # ---- quotient form: g_q = (gfeat .* feat) ./ v_q (include/snerf.h) ----
+    def quotient_prepare(self, gfeat, feat, stream=None):
+        st = stream if stream is not None else _stream()
+        _lib.check(_lib.lib().snerf_kplanes_quotient_prepare(C.byref(self.desc), C.c_int64(self.N), _ptr(gfeat), _ptr(feat), _ptr(self.G), _ptr(self.fix_list),
+                                                             self.fix_list.numel(), _ptr(self.fix_count), st), "quotient_prepare")
+
+    def quotient_scatter_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
+        """Pass B + the exact terms of zero-feature rows for scales [scale_begin, scale_end); quotient_prepare must have run."""
+        st = stream if stream is not None else _stream()
+        L = _lib.lib()
+        _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
+                                                           scale_begin, scale_end, st), "scatter_quotient")
+        _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gfeat), _ptr(self.fix_list),
+                                                  _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, st), "quotient_fixup")
+
+    def scatter_quotient(self, planes, coords: _lib.Coords, gfeat, feat, gplanes, stream=None):
+        """gplanes += d(sum gfeat . features)/d planes, with feat = the forward's features [N, C n_scales] (fp32)."""
+        self.quotient_prepare(gfeat, feat, stream)
+        self.quotient_scatter_scales(planes, coords, gfeat, gplanes, 0, len(self.ps.resolutions), stream)
 
 
 def interpolate_kplanes(pts: torch.Tensor, plane_set: PlaneSet) -> torch.Tensor:

@@ -98,6 +98,11 @@ class KPlanesTrainConfig:
     # parity-tested but measured SLOWER (2.5 vs 0.9 ms: 256 VGPRs + 0.5 KB of spills per lane leave it 8 waves / CU).  Needs the sorted
     # scatter and the whole batch in one chunk.
     fused_field_backward: bool = False
+    # Quotient form of the field's sorted scatter (csrc/kplanes_sorted.hip, include/snerf.h): the gradient of plane q is (gfeat .* feat) ./ v_q
+    # with v_q re-interpolated by pass B, so the second gather of all 30 planes and the 1 GB of per-plane gradient vectors (gradvec) go away:
+    # ~1.6 GB less HBM traffic per step.  Equal to the product form to a few ulp (pass B recomputes the forward's v_q bit for bit; rows with an
+    # exactly-zero feature take an exact fix-up).  Needs the sorted scatter, C = 32 and no deterministic mode; False = product form (A-B).
+    quotient_scatter: bool = True
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -237,7 +242,9 @@ class KPlanesTrainer:
         # sorted plane-gradient scatter for the main field (csrc/kplanes_sorted.hip): ~6x fewer atomic requests
         self.sorted_scatter = cfg.sorted_scatter
         self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[cfg.gvec_dtype]
-        self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype)
+        self.quotient_scatter = bool(cfg.quotient_scatter and self.sorted_scatter and not cfg.deterministic and not cfg.fused_field_backward
+                                     and cfg.gvec_dtype == "fp32" and self.lib_quotient_ok(R * S2))
+        self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype, quotient=self.quotient_scatter)
         self._ss.desc = self.field_planes.desc()
         self._sort_done = None
         # sorted scatter for the proposal planes too (opt-in; measured SLOWER at the preset: the planes are small enough that their
@@ -442,7 +449,8 @@ class KPlanesTrainer:
                         _lib.check(self.lib.snerf_kplanes_field_fwd(C.byref(self._desc_field), self._p(self.field_planes.planes), C.byref(co), C.c_int64(N),
                                                                     C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), C.byref(self.color_net.desc),
                                                                     self._p(self.color_net.params), self._p(b["dens"][2]), self._p(b["rgb"]),
-                                                                    self._p(b["feat16"]) if keep else None, self._p(b["h"]) if keep else None, self._st),
+                                                                    self._p(b["feat16"]) if keep else None, self._p(b["h"]) if keep else None,
+                                                                    self._p(b["feat"]) if keep and self.quotient_scatter else None, self._st),
                                    "kplanes_field_fwd")
                 else:
                     self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
@@ -509,6 +517,21 @@ class KPlanesTrainer:
                                                     co["time_smoothness_proposal_loss"], co["sparse_transients_proposal_loss"],
                                                     self._p(b["reg"][1 + lvl]), ops.REG_SLOTS, 1, self._st), "plane_reg")
 
+    def lib_quotient_ok(self, N: int) -> bool:
+        d = self.field_planes.desc()
+        return bool(_lib.lib().snerf_kplanes_quotient_supported(C.byref(d), C.c_int64(N)))
+
+    def _scatter_field_scales(self, co, lo: int, hi: int):
+        """Pass B of the field's sorted scatter for scales [lo, hi): product form (gradient vectors from gradvec / the fused backward) or
+        quotient form (G from quotient_prepare + the exact terms of zero-feature rows)."""
+        ss, b = self._ss, self.buf
+        with self._span("kplanes_scatter_sorted.field"):
+            if self.quotient_scatter:
+                ss.quotient_scatter_scales(self.field_planes.planes, co, b["gfeat"], self.gviews["field.planes"], lo, hi, self._st)
+            else:
+                _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
+                                                                        self._p(self.gviews["field.planes"]), lo, hi, self._st), "scatter_sorted")
+
     def _field_backward_chunk(self, r0: int, r1: int):
         """colour-net bwd -> sigma-net bwd -> plane scatter for rays [r0, r1) of the nerf level."""
         b, S2, F = self.buf, self.S[2], self.field_planes.out_dim
@@ -533,6 +556,9 @@ class KPlanesTrainer:
                                                                 self._p(self.color_net.params), self._p(b["gdens"][2]), self._p(b["grgb"]),
                                                                 self._p(self.gviews["field.sigma"]), self._p(self.gviews["field.color"]), None, None,
                                                                 self._p(ss.gvec), ss.gvec_bf16, self._st), "kplanes_field_bwd")
+            elif self.quotient_scatter:
+                with self._span("kplanes_quotient_prepare"):
+                    ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
             else:
               with self._span("kplanes_gradvec.field"):
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
@@ -541,28 +567,18 @@ class KPlanesTrainer:
             early = self._pipeline_adam and ns > 1
             if self._sharded() and len(self._exchange) == 2:
                 # finest scale first: its reduce-scatter (chunk 0) is on the links while the coarser scales are still being scattered
-                with self._span("kplanes_scatter_sorted.field"):
-                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16,
-                                                                            self._p(ss.sorted_rec), self._p(self.gviews["field.planes"]), ns - 1, ns,
-                                                                            self._st), "scatter_sorted")
+                self._scatter_field_scales(co, ns - 1, ns)
                 self._start_field_grad_exchange(0)
-                with self._span("kplanes_scatter_sorted.field"):
-                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16,
-                                                                            self._p(ss.sorted_rec), self._p(self.gviews["field.planes"]), 0, ns - 1,
-                                                                            self._st), "scatter_sorted")
+                self._scatter_field_scales(co, 0, ns - 1)
                 self._start_field_grad_exchange(1)
                 self._exchange_started = True
                 return
-            with self._span("kplanes_scatter_sorted.field"):
-                # finest scale first: it holds ~3/4 of the plane parameters, so its optimiser sweep (HBM-bound) can start on a side
-                # stream while the other scales are still being scattered (atomic-bound)
-                if early:
-                    _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
-                                                                            self._p(self.gviews["field.planes"]), ns - 1, ns, self._st), "scatter_sorted")
-                    self._adam_field_range(self._finest_offset(), None, side=True)
-                _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
-                                                                        self._p(self.gviews["field.planes"]), 0, ns - 1 if early else ns, self._st),
-                           "scatter_sorted")
+            # finest scale first: it holds ~3/4 of the plane parameters, so its optimiser sweep (HBM-bound) can start on a side
+            # stream while the other scales are still being scattered (atomic-bound)
+            if early:
+                self._scatter_field_scales(co, ns - 1, ns)
+                self._adam_field_range(self._finest_offset(), None, side=True)
+            self._scatter_field_scales(co, 0, ns - 1 if early else ns)
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
 

@@ -60,18 +60,19 @@ def test_fused_field_forward(ms, N, operands):
     co = ops.coords_from_points(pts)
     dens, rgb = torch.full((N,), -1.0, device=DEV), torch.full((N, 3), -1.0, device=DEV)
     _lib.check(L.snerf_kplanes_field_fwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
-                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(dens), ops._ptr(rgb), None, None, ops._stream()))
+                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(dens), ops._ptr(rgb), None, None, None, ops._stream()))
     feat_u, h_u, dens_u, rgb_u = _unfused_forward(ps, sigma, color, pts)
     assert torch.equal(dens, dens_u) and torch.equal(rgb, rgb_u)  # same arithmetic, same order: bit for bit
     # optional outputs for an unfused backward: the operand-typed feature tile and the raw sigma_net outputs
     dt = torch.bfloat16 if operands == "bf16" else torch.float16
     feat16, h = torch.full((N, 32 * len(ms)), -1.0, device=DEV, dtype=dt), torch.full((N, 16), -1.0, device=DEV)
+    feat32 = torch.full((N, 32 * len(ms)), -1.0, device=DEV)
     dens2, rgb2 = torch.empty_like(dens), torch.empty_like(rgb)
     _lib.check(L.snerf_kplanes_field_fwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
                                          C.byref(color.desc), ops._ptr(color.params), ops._ptr(dens2), ops._ptr(rgb2), ops._ptr(feat16), ops._ptr(h),
-                                         ops._stream()))
+                                         ops._ptr(feat32), ops._stream()))
     assert torch.equal(dens2, dens) and torch.equal(rgb2, rgb)
-    assert torch.equal(feat16, feat_u.to(dt)) and torch.equal(h, h_u)
+    assert torch.equal(feat16, feat_u.to(dt)) and torch.equal(h, h_u) and torch.equal(feat32, feat_u)
     # fp32 oracle of the field (kplanes_field.py:275-358)
     grids = [[t.cpu() for t in sc] for sc in ps.to_reference()]
     feat = KO.interpolate_kplanes(pts.cpu(), grids, True)

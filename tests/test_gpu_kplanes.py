@@ -190,3 +190,57 @@ def test_sorted_scatter_equals_direct_scatter_and_oracle(C, ms, concat, N):
         for s in range(len(ms)):
             for p in range(6):
                 torch.testing.assert_close(g[s][p], ref_grids[s][p].grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ms,N,zeros", [((1, 2, 4), 3000, False), ((1, 2), 1500, True), ((1, 2, 4, 8, 16), 100000, False), ((1,), 257, True)])
+def test_quotient_scatter_equals_direct_scatter(ms, N, zeros):
+    """Quotient form of the sorted scatter -- g_q = (gfeat .* feat) ./ v_q with v_q re-interpolated in pass B -- against the sample-major
+    scatter and the product-form sorted scatter.  `zeros`: exact zeros planted in the planes, so that features vanish and the listed rows go
+    through the exact fix-up (where the quotient alone would lose a plane's gradient)."""
+    import ctypes as Ct
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    dev = _dev()
+    gen = torch.Generator().manual_seed(33)
+    base = (11, 9, 7, 5) if N < 20000 else (64, 64, 64, 100)
+    ps = PlaneSet(32, [[r * m for r in base[:3]] + [base[3]] for m in ms], concat=True, generator=gen)
+    with torch.no_grad():
+        ps.planes.copy_(torch.rand(ps.numel, generator=gen) * 1.2 - 0.3)  # both signs, values near zero included
+        if zeros:
+            # whole texels of scale 0 / plane 0 and a sprinkle everywhere: interpolated values that are exactly 0.0f
+            ps.planes[: 32 * 40] = 0.0
+            ps.planes[torch.rand(ps.numel, generator=gen) < 0.02] = 0.0
+    ps = ps.to(dev)
+    pts = torch.rand(N, 4, generator=gen) * 2.2 - 1.1
+    pts[: N // 3, 3] = 0.25
+    pts[: N // 8] = pts[0]
+    if zeros:
+        pts[N // 2: N // 2 + 64] = -1.0  # the all-zero corner texel of plane 0 exactly (weights 1, 0, 0, 0)
+    gout = torch.rand(N, ps.out_dim, generator=gen) - 0.5
+    ptsd, goutd = pts.to(dev), gout.to(dev)
+    co = ops.coords_from_points(ptsd)
+    desc = ps.desc()
+    L = _lib.lib()
+    direct = torch.zeros_like(ps.planes)
+    _lib.check(L.snerf_kplanes_gather_bwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(goutd), ops._ptr(direct), ops._stream()))
+    feat = torch.empty(N, ps.out_dim, device=dev)
+    _lib.check(L.snerf_kplanes_gather_fwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(feat), ops._stream()))
+    ss = ops.SortedScatter(ps, N, dev, quotient=True)
+    assert ss.gvec is None
+    ss.sort(co)
+    got = torch.zeros_like(ps.planes)
+    ss.scatter_quotient(ps.planes, co, goutd, feat, got)
+    n_fix = int(ss.fix_count.item())
+    assert (n_fix > 0) == zeros
+    scale = float(direct.abs().max())
+    torch.testing.assert_close(got, direct, rtol=1e-4, atol=2e-6 * scale)
+    assert float((got - direct).norm() / direct.norm()) < 2e-6
+    # scale ranges (the multi-GPU exchange scatters the finest scale first) add up to the whole
+    if len(ms) > 1:
+        parts = torch.zeros_like(ps.planes)
+        ss.quotient_prepare(goutd, feat)
+        ss.quotient_scatter_scales(ps.planes, co, goutd, parts, len(ms) - 1, len(ms))
+        ss.quotient_scatter_scales(ps.planes, co, goutd, parts, 0, len(ms) - 1)
+        torch.testing.assert_close(parts, got, rtol=1e-4, atol=2e-6 * scale)
