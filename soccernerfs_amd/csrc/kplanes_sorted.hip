@@ -458,6 +458,10 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
       const AxisTap ty = axis_tap(rc.z, H);
       hd.x = (uint32_t)__float_as_int(rc.x) * rstride;
       hd.y = (uint32_t)tx.i0 | ((uint32_t)ty.i0 << 16);
+      if (QUOT) {
+        hd.z = (uint32_t)(ty.i0 * W + tx.i0) * (uint32_t)C;
+        hd.w = (tx.i1 != tx.i0 ? 1u : 0u) | (ty.i1 != ty.i0 ? 2u : 0u);
+      }
       const float4 tw = tap_weights(tx, ty);                  // (x0y0, x1y0, x0y1, x1y1): the forward's products, bit for bit
       wt = make_float4(tw.x, tw.z, tw.y, tw.w);               // stored as (x0y0, x0y1 | x1y0, x1y1): one float2 per x-corner; a clamped second tap has weight 0
     }
@@ -470,6 +474,7 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
   float p0 = 0.f, p1 = 0.f;
   const uint32_t* Rl = R + 4 + half * 2;  // this lane's weight pair of an entry
   const int64_t rowC = (int64_t)W * C;
+  const uint32_t rowC32 = (uint32_t)W * (uint32_t)C;
   for (int e0 = 0; e0 < cnt; e0 += UNROLL) {
     // UNROLL gvec rows in flight per wave (the pass streams 1 GB of them: with 8 in flight it was latency-bound, 0.61 vs 0.56 ms at 16);
     // the small per-entry fields are re-read from LDS when the entry is processed, so only g[] stays in registers
@@ -480,14 +485,13 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
     if constexpr (QUOT) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 1]);
-        // clamped like the taps (a clamped corner has weight 0, a null record 0xffffffff has all weights 0): any valid address will do
-        const int x0 = min((int)(pk & 0xffffu), W - 1), y0 = min((int)(pk >> 16), H - 1);
-        const int y1 = min(y0 + 1, H - 1);
-        const int xh = x0 + ((half && x0 + 1 < W) ? 1 : 0);
-        const float* tp = pch + ((int64_t)y0 * W + xh) * C;
-        t0[u] = tp[0];
-        t1[u] = tp[(int64_t)(y1 - y0) * rowC];
+        // element offset of texel (x0, y0) and the "x0 + 1 / y0 + 1 exist" flags were prepared lane-parallel with the record (a clamped
+        // corner has weight 0 and re-reads the unclamped texel, as the forward's taps do; a null record reads texel 0 with zero weights)
+        const uint32_t toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 2]);
+        const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 3]);
+        const uint32_t o0 = toff + (half ? (fl & 1u) * (uint32_t)C : 0u);
+        t0[u] = pch[o0];
+        t1[u] = pch[o0 + ((fl & 2u) ? rowC32 : 0u)];
       }
     }
 #pragma unroll
@@ -860,6 +864,11 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
   rc = build_segs(desc, stb);
   if (rc) return rc;
   const int NP = desc->n_coords == 4 ? 6 : 3;
+  for (int s = scale_begin; s < scale_end; ++s) {  // pass B addresses a plane's texels with 32-bit element offsets
+    int64_t mx = 1;
+    for (int k = 0; k < desc->n_coords; ++k) mx = mx > desc->res[s][k] ? mx : desc->res[s][k];
+    SNERF_REQUIRE(mx * mx * desc->C < (1LL << 31), "kplanes_scatter_quotient: plane of %lld^2 texels too large for 32-bit offsets", (long long)mx);
+  }
   const int64_t gps = (N + 255) / 256;
   const dim3 grid((unsigned)ceil_div(gps * (scale_end - scale_begin) * NP, 4));
   const float4* rec = reinterpret_cast<const float4*>(sorted_rec);
