@@ -496,8 +496,9 @@ class KPlanesTrainer:
             self.ctx.__exit__(*exc)
 
     def _stream(self, role: str):
-        """Side stream by role, created on first use (so the common path holds main + "sort" + "prop" only: HIP multiplexes
-        streams onto GPU_MAX_HW_QUEUES = 4 hardware queues and chains sharing a queue do not overlap)."""
+        """Side stream by role, created on first use (so the common path holds main + "sort" + "prop" + "adam" only: HIP multiplexes the
+        normal-priority streams onto 3 hardware queues beside the null stream's -- tools/debug_queues.py -- and chains sharing a queue do
+        not overlap; a high-priority stream would get a fifth queue, which made every step slower -- profiles/r02_kernels.md section 8)."""
         if role not in self._side:
             self._side[role] = torch.cuda.Stream(device=self.dev)
         return self._side[role]
@@ -594,31 +595,36 @@ class KPlanesTrainer:
 
     def _proposal_backward(self, proposal_grads: bool):
         """Proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592)."""
+        for lvl in (0, 1):
+            self._proposal_backward_level(lvl, proposal_grads)
+
+    def _proposal_backward_level(self, lvl: int, proposal_grads: bool):
+        """One proposal level: interlevel loss (+ depth term) -> weights backward -> proposal net backward -> plane scatter.  The two levels
+        touch disjoint buffers and parameter segments."""
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
-        S2 = self.S[2]
-        for lvl, Sp in ((0, self.S[0]), (1, self.S[1])):
-            _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
-                                                 co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
-                                                 self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
-            self._depth_loss(lvl, with_grad=proposal_grads)  # adds to the interlevel gradient just written
-            if proposal_grads:
-                N = R * Sp
-                _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp,
-                                                      self._p(b["gdens"][lvl]), 0, self._p(self._dyn["proposal_networks"]), self._st), "weights_bwd")
-                self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
-                              b["gpfeat"][lvl], cfg.proposal_feature_dim)
-                if self.sorted_scatter_proposals and self._sort_done_prop[lvl] is not None:
-                    torch.cuda.current_stream().wait_event(self._sort_done_prop[lvl])
-                    ss = self._ss_prop[lvl]
-                    with self._span("kplanes_gradvec.prop"):
-                        _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.prop_planes[lvl].planes), C.byref(self._coords[lvl]),
-                                                                  C.c_int64(N), self._p(b["gpfeat"][lvl]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
-                    with self._span("kplanes_scatter_sorted.prop"):
-                        _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
-                                                                         self._p(self.gviews[f"prop{lvl}.planes"]), self._st), "scatter_sorted")
-                else:
-                    self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl],
-                                  self.gviews[f"prop{lvl}.planes"])
+        S2, Sp = self.S[2], self.S[lvl]
+        _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
+                                             co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
+                                             self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
+        self._depth_loss(lvl, with_grad=proposal_grads)  # adds to the interlevel gradient just written
+        if proposal_grads:
+            N = R * Sp
+            _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp,
+                                                  self._p(b["gdens"][lvl]), 0, self._p(self._dyn["proposal_networks"]), self._st), "weights_bwd")
+            self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
+                          b["gpfeat"][lvl], cfg.proposal_feature_dim)
+            if self.sorted_scatter_proposals and self._sort_done_prop[lvl] is not None:
+                torch.cuda.current_stream().wait_event(self._sort_done_prop[lvl])
+                ss = self._ss_prop[lvl]
+                with self._span("kplanes_gradvec.prop"):
+                    _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.prop_planes[lvl].planes), C.byref(self._coords[lvl]),
+                                                              C.c_int64(N), self._p(b["gpfeat"][lvl]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
+                with self._span("kplanes_scatter_sorted.prop"):
+                    _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
+                                                                     self._p(self.gviews[f"prop{lvl}.planes"]), self._st), "scatter_sorted")
+            else:
+                self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl],
+                              self.gviews[f"prop{lvl}.planes"])
 
     def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True,
                  defer_prop_join: bool = False, depth: Optional[torch.Tensor] = None):
@@ -658,6 +664,8 @@ class KPlanesTrainer:
             st.wait_stream(main) if after is None else st.wait_event(after)
             if reg_done is not None:
                 st.wait_event(reg_done)
+            # (the two levels' chains are independent, but side by side on two streams they were no faster: 2.78 vs 2.72 ms; on a
+            # high-priority stream -- a fifth hardware queue -- the whole step fell to 3.69 ms: profiles/r02_kernels.md section 8)
             with KPlanesTrainer._On(self, st):
                 self._proposal_backward(proposal_grads)
             joins.append(st)

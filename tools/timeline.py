@@ -4,11 +4,12 @@ import csv, sys, collections
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # consecutive steps to print (the optimiser sweep of step k runs under the head of step k + 1)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("snerf::", "").replace("void ", "")[:60]
 # a step starts at raygen_kernel
 starts = [i for i, r in enumerate(rows) if "raygen_kernel" in r["Kernel_Name"]]
-i0, i1 = starts[-back - 1], starts[-back]
+i0, i1 = starts[-back - 1], starts[-back - 1 + nsteps]
 step = rows[i0:i1]
 t0 = int(step[0]["Start_Timestamp"])
 end = max(int(r["End_Timestamp"]) for r in step)
