@@ -101,6 +101,11 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
     for (int k = 0; k < 4; ++k) res[k] = d.res[s][k] > 0 ? d.res[s][k] : 1;
 
     // U samples in flight: their coordinate, texel and upstream-gradient loads are all issued before the first one is consumed
+    // mode 1: (ray, sample-in-ray) of the run's first sample by one division, then stepped -- the per-sample n / S inside load_coords
+    // was ~100 of the walk's ~350 vector instructions per sample
+    int64_t ray = 0;
+    int sir = 0;
+    if (c.mode == 1) { ray = n0 / c.S; sir = (int)(n0 - ray * c.S); }
     for (int i0 = 0; i0 < cnt; i0 += U) {
       AxisTap tap[U][4];
       int xsel[U][4];    // this lane's x-corner along each axis (i0 for half 0, i1 for half 1) and its weight: bit-selected once per axis
@@ -110,7 +115,12 @@ __global__ __launch_bounds__(256) void kplanes_gather_bwd_kernel(snerf_kplanes_d
       for (int u = 0; u < U; ++u) {
         const int64_t n = n0 + (i0 + u < cnt ? i0 + u : cnt - 1);
         float p[4];
-        load_coords<NP>(c, n, p);
+        if (c.mode == 1) {
+          load_coords_ray(c, ray, sir, p);
+          if (i0 + u + 1 < cnt && ++sir == c.S) { sir = 0; ++ray; }
+        } else {
+          load_coords<NP>(c, n, p);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const AxisTap t = axis_tap(p[k], res[k]);

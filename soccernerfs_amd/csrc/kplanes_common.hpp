@@ -25,6 +25,19 @@ __device__ __forceinline__ AxisTap axis_tap(float x, int size) {
   return t;
 }
 
+// coordinate of sample s of ray r (snerf_coords mode 1: positions derived from rays + euclidean bin edges)
+__device__ __forceinline__ void load_coords_ray(const snerf_coords& c, int64_t r, int s, float p[4]) {
+  const float* eb = c.ebins + r * (c.S + 1) + s;
+  float mid = eb[0] + eb[1];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float pos = c.origins[r * 3 + k] + (c.dirs[r * 3 + k] * mid) / 2.f;
+    float q = (pos - c.aabb_min[k]) / (c.aabb_max[k] - c.aabb_min[k]);
+    p[k] = c.rescale ? q * 2.f - 1.f : q;
+  }
+  p[3] = c.times[r] * 2.f - 1.f;
+}
+
 // coordinate of sample n along x,y,z,t in grid_sample's [-1,1] convention
 template <int NP>
 __device__ __forceinline__ void load_coords(const snerf_coords& c, int64_t n, float p[4]) {
@@ -36,17 +49,9 @@ __device__ __forceinline__ void load_coords(const snerf_coords& c, int64_t n, fl
       p[0] = c.pts[n * 3]; p[1] = c.pts[n * 3 + 1]; p[2] = c.pts[n * 3 + 2]; p[3] = 0.f;
     }
   } else {
-    int64_t r = n / c.S;
+    int64_t r = n / c.S;  // a 64-bit software division (~100 instructions): loops over consecutive samples step (r, s) themselves
     int s = (int)(n - r * c.S);
-    const float* eb = c.ebins + r * (c.S + 1) + s;
-    float mid = eb[0] + eb[1];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float pos = c.origins[r * 3 + k] + (c.dirs[r * 3 + k] * mid) / 2.f;
-      float q = (pos - c.aabb_min[k]) / (c.aabb_max[k] - c.aabb_min[k]);
-      p[k] = c.rescale ? q * 2.f - 1.f : q;
-    }
-    p[3] = c.times[r] * 2.f - 1.f;
+    load_coords_ray(c, r, s, p);
   }
 }
 
