@@ -28,7 +28,7 @@ for step in range(steps):
     tr.forward(rays, rng, anneal, training=True)
     b = tr.buf
     tr.backward(target, rng, proposal_grads=updated, include_reg=False)
-    for i, t in enumerate([b["feat"], b["h"], b["dens"][2], b["w"][2], b["rgb"], b["rgb_out"], b["gw"][2], b["grgb"], b["gh"], b["gfeat"], tr._ss.gvec,
+    for i, t in enumerate([b["feat"], b["h"], b["dens"][2], b["w"][2], b["rgb"], b["rgb_out"], b["gw"][2], b["grgb"], b["gh"], b["gfeat"], tr._ss.G if tr._ss.quotient else tr._ss.gvec,
                            tr.gviews["field.planes"], tr.gviews["field.sigma"], tr.gviews["field.color"], tr.grads[:tr.n_proposal_params]]):
         chk(i, t, step)
     tr.allreduce_grads()
