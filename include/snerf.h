@@ -216,6 +216,8 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
  *        snerf_mlp_bwd x 2 + snerf_kplanes_gradvec; gfeat [N, 32 n_scales] never exists.
  * ------------------------------------------------------------------------------------------------ */
 int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
+/* the forward alone is also built for six scales (d_in = 192) */
+int snerf_kplanes_field_fwd_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
 int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                             const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
                             float* density, float* rgb, void* feat16, float* h, float* feat32, snerf_stream_t stream);

@@ -196,6 +196,7 @@ EXPORTS = [
     "snerf_depth_loss",
     "snerf_kplanes_field_supported",
     "snerf_kplanes_field_fwd",
+    "snerf_kplanes_field_fwd_supported",
     "snerf_kplanes_quotient_supported",
     "snerf_kplanes_quotient_prepare",
     "snerf_kplanes_scatter_quotient_scales",

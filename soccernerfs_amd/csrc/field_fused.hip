@@ -243,11 +243,12 @@ __global__ __launch_bounds__(FF_NW * 64, 4) void field_fwd_kernel(FieldArgs a, i
   }
 }
 
-static int validate_field(const snerf_kplanes_desc* d, const snerf_coords* c, int64_t N, const snerf_mlp_desc* sd, const snerf_mlp_desc* cd) {
+static int validate_field(const snerf_kplanes_desc* d, const snerf_coords* c, int64_t N, const snerf_mlp_desc* sd, const snerf_mlp_desc* cd,
+                          int max_scales = 5) {
   SNERF_REQUIRE(d && c && sd && cd, "kplanes_field: null descriptor");
-  SNERF_REQUIRE(d->C == 32 && d->n_coords == 4 && d->concat == 1 && d->n_scales >= 1 && d->n_scales <= 5,
-                "kplanes_field: the fused kernels are built for 4-D planes, C = 32, concatenated scales (<= 5); got C=%d coords=%d concat=%d scales=%d",
-                d->C, d->n_coords, d->concat, d->n_scales);
+  SNERF_REQUIRE(d->C == 32 && d->n_coords == 4 && d->concat == 1 && d->n_scales >= 1 && d->n_scales <= max_scales,
+                "kplanes_field: the fused kernels are built for 4-D planes, C = 32, concatenated scales (<= %d); got C=%d coords=%d concat=%d scales=%d",
+                max_scales, d->C, d->n_coords, d->concat, d->n_scales);
   SNERF_REQUIRE(sd->d_in == 32 * d->n_scales && sd->hidden == FF_H && sd->n_hidden == 1 && sd->d_out == 16 && sd->hidden_act == 1 && sd->out_act == 0,
                 "kplanes_field: sigma_net must be %d -> 128 (ReLU) -> 16", 32 * d->n_scales);
   SNERF_REQUIRE(cd->d_in == FF_GEO && cd->hidden == FF_HC && cd->n_hidden == 2 && cd->d_out == 3 && cd->hidden_act == 1 && cd->out_act == 1,
@@ -665,6 +666,16 @@ static int launch_field_bwd(const FieldArgs& a, hipStream_t st) {
     }                                                                                        \
   } while (0)
 
+// the forward alone also fits six scales (BASELINE config 3: K0 = 192); the backward's tiles do not
+#define FF_DISPATCH_FWD(FN, operands, ns, ...)                                               \
+  do {                                                                                       \
+    if ((ns) == 6) {                                                                         \
+      if ((operands) == 2) return FN<fp16, 6>(__VA_ARGS__);                                  \
+      return FN<bf16, 6>(__VA_ARGS__);                                                       \
+    }                                                                                        \
+    FF_DISPATCH(FN, operands, ns, __VA_ARGS__);                                              \
+  } while (0)
+
 }  // namespace snerf
 
 using namespace snerf;
@@ -674,17 +685,22 @@ extern "C" int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, con
   return desc && sigma && color && validate_field(desc, &c, 0, sigma, color) == 0 ? 1 : 0;
 }
 
+extern "C" int snerf_kplanes_field_fwd_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color) {
+  snerf_coords c = {};
+  return desc && sigma && color && validate_field(desc, &c, 0, sigma, color, 6) == 0 ? 1 : 0;
+}
+
 extern "C" int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                                        const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
                                        float* density, float* rgb, void* feat16, float* h, float* feat32, snerf_stream_t stream) {
-  int rc = validate_field(desc, coords, N, sigma, color);
+  int rc = validate_field(desc, coords, N, sigma, color, 6);
   if (rc) return rc;
   if (N == 0) return 0;
   SNERF_REQUIRE(planes && W_sigma && W_color && density && rgb, "kplanes_field_fwd: null buffer");
   FieldArgs a = {};
   a.d = *desc; a.planes = planes; a.c = *coords; a.N = N; a.Wsig = W_sigma; a.Wcol = W_color; a.dens = density; a.rgb = rgb;
   a.feat16 = feat16; a.h = h; a.feat32 = feat32;
-  FF_DISPATCH(launch_field_fwd, sigma->operands, desc->n_scales, a, (hipStream_t)stream);
+  FF_DISPATCH_FWD(launch_field_fwd, sigma->operands, desc->n_scales, a, (hipStream_t)stream);
 }
 
 extern "C" int snerf_kplanes_field_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,

@@ -258,9 +258,11 @@ class KPlanesTrainer:
         self.lib = _lib.lib()
         self._desc_field = self.field_planes.desc()
         self._desc_prop = [p.desc() for p in self.prop_planes]
-        self.fused_field = bool(cfg.fused_field and self.lib.snerf_kplanes_field_supported(
+        self.fused_field = bool(cfg.fused_field and self.lib.snerf_kplanes_field_fwd_supported(
             C.byref(self._desc_field), C.byref(self.sigma_net.desc), C.byref(self.color_net.desc)))
-        self.fused_field_backward = bool(self.fused_field and cfg.fused_field_backward and self.sorted_scatter and not cfg.deterministic)
+        self.fused_field_backward = bool(self.fused_field and cfg.fused_field_backward and self.sorted_scatter and not cfg.deterministic
+                                         and self.lib.snerf_kplanes_field_supported(C.byref(self._desc_field), C.byref(self.sigma_net.desc),
+                                                                                    C.byref(self.color_net.desc)))
         if self.fused_field:  # the forward's operand-typed feature tile, kept for the unfused backward (snerf_mlp_bwd_x16)
             dt16 = torch.bfloat16 if self.sigma_net.desc.operands == 1 else torch.float16
             self.buf["feat16"] = torch.empty(R * self.S[2], self.field_planes.out_dim, dtype=dt16, device=self.dev)

@@ -48,7 +48,7 @@ def _unfused_forward(ps, sigma, color, pts):
 
 
 @pytest.mark.parametrize("operands", ["bf16", "fp16"])
-@pytest.mark.parametrize("ms,N", [((1, 2, 4, 8, 16), 5000), ((1, 2), 1031), ((1,), 64), ((1, 2, 4), 33)])
+@pytest.mark.parametrize("ms,N", [((1, 2, 4, 8, 16), 5000), ((1, 2), 1031), ((1,), 64), ((1, 2, 4), 33), ((1, 2, 3, 4, 6, 8), 2100)])
 def test_fused_field_forward(ms, N, operands):
     from oracle import kplanes_oracle as KO
     from soccernerfs_amd import _lib, ops
@@ -56,7 +56,8 @@ def test_fused_field_forward(ms, N, operands):
     ps, sigma, color, pts = _setup(ms, N, operands)
     L = _lib.lib()
     desc = ps.desc()
-    assert L.snerf_kplanes_field_supported(C.byref(desc), C.byref(sigma.desc), C.byref(color.desc)) == 1
+    assert L.snerf_kplanes_field_fwd_supported(C.byref(desc), C.byref(sigma.desc), C.byref(color.desc)) == 1
+    assert L.snerf_kplanes_field_supported(C.byref(desc), C.byref(sigma.desc), C.byref(color.desc)) == int(len(ms) <= 5)  # six scales: forward only
     co = ops.coords_from_points(pts)
     dens, rgb = torch.full((N,), -1.0, device=DEV), torch.full((N, 3), -1.0, device=DEV)
     _lib.check(L.snerf_kplanes_field_fwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
