@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 5
+#define SNERF_ABI_VERSION 6
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -250,6 +250,34 @@ typedef struct {
   int64_t* median_index; /* [R]: searchsorted(cumsum(w), 0.5, left) clamped -- bit-exact vs the oracle */
 } snerf_render_args;
 int snerf_render_fwd(const snerf_render_args* args, snerf_stream_t stream);
+
+/* The nerf level's per-ray work of a TRAINING step in one launch: get_weights (NS/cameras/rays.py:127-149) -> RGB / accumulation / median
+ * depth (renderers.py:58-140,197-223,260-270) -> MSELoss backward (kplanes.py:418) -> distortion loss + gradient (losses.py:125-144) ->
+ * get_weights backward.  Bit-identical to snerf_weights_fwd + snerf_render_fwd + snerf_render_mse_bwd + snerf_distortion(accumulate = 1) +
+ * snerf_weights_bwd(accumulate = 0) run one after the other (same arithmetic, same order).  bg_mode 0 ([R,3]) or 2 ([3]).
+ * go_scale = 2 c_rgb / (3 R), dist_scale = c_distortion / R.  Optional outputs may be NULL: depth_median, sqerr_rays, dist_rays, g_weights
+ * (the gradient w.r.t. the weights, for inspection). */
+typedef struct {
+  const float* density;   /* [R,S] */
+  const float* ebins;     /* [R,S+1] euclidean bin edges */
+  const float* sbins;     /* [R,S+1] s-space bin edges */
+  const float* rgb;       /* [R,S,3] */
+  const float* bg;
+  const float* target;    /* [R,3] */
+  int32_t R, S, bg_mode;
+  float go_scale, dist_scale;
+  float* weights;         /* out [R,S] */
+  float* rgb_out;         /* out [R,3] */
+  float* acc_out;         /* out [R] */
+  float* depth_median;    /* out [R] */
+  float* sqerr_rays;      /* out [R]: sum_c (rgb_out - target)^2 */
+  float* dist_rays;       /* out [R]: unscaled distortion loss per ray */
+  float* g_rgb;           /* out [R,S,3] */
+  float* g_density;       /* out [R,S] */
+  float* g_weights;       /* out [R,S] */
+  int32_t* nonfinite_flag; /* as snerf_weights_bwd */
+} snerf_ray_train_args;
+int snerf_ray_train_fwd_bwd(const snerf_ray_train_args* args, snerf_stream_t stream);
 
 /* Backward of rgb_out (+ optionally accumulation) w.r.t. weights [R,S] and per-sample rgb [R,S,3] (g_rgb may be NULL).
  * bg_mode 0 or 2 only (the training backgrounds).  accumulate_w != 0: g_weights += ... */

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class KPlanesDesc(C.Structure):
@@ -66,6 +66,13 @@ class RenderArgs(C.Structure):
                 ("R", C.c_int32), ("S", C.c_int32), ("bg_mode", C.c_int32), ("training", C.c_int32),
                 ("rgb_out", C.c_void_p), ("acc_out", C.c_void_p), ("depth_median", C.c_void_p), ("depth_expected", C.c_void_p),
                 ("median_rgb", C.c_void_p), ("median_index", C.c_void_p)]
+
+
+class RayTrainArgs(C.Structure):
+    _fields_ = [("density", C.c_void_p), ("ebins", C.c_void_p), ("sbins", C.c_void_p), ("rgb", C.c_void_p), ("bg", C.c_void_p), ("target", C.c_void_p),
+                ("R", C.c_int32), ("S", C.c_int32), ("bg_mode", C.c_int32), ("go_scale", C.c_float), ("dist_scale", C.c_float),
+                ("weights", C.c_void_p), ("rgb_out", C.c_void_p), ("acc_out", C.c_void_p), ("depth_median", C.c_void_p), ("sqerr_rays", C.c_void_p),
+                ("dist_rays", C.c_void_p), ("g_rgb", C.c_void_p), ("g_density", C.c_void_p), ("g_weights", C.c_void_p), ("nonfinite_flag", C.c_void_p)]
 
 
 class RaygenArgs(C.Structure):
@@ -159,6 +166,7 @@ EXPORTS = [
     "snerf_dense_fwd",
     "snerf_dense_bwd",
     "snerf_render_fwd",
+    "snerf_ray_train_fwd_bwd",
     "snerf_render_bwd",
     "snerf_distortion",
     "snerf_interlevel",

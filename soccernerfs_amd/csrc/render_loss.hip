@@ -263,6 +263,164 @@ __global__ __launch_bounds__(256) void depth_loss_kernel(const float* __restrict
   if (lane == 0 && loss_rays) loss_rays[ray] = on ? total : 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch for the nerf level's per-ray work of a TRAINING step: get_weights -> RGB / accumulation / median depth -> MSE backward ->
+// distortion loss + gradient -> get_weights backward.  Same arithmetic, in the same order, as the five kernels it stands for
+// (resample_kernel stage 1, render_fwd_kernel, render_mse_bwd_kernel, distortion_kernel, weights_bwd_kernel: results are bit-identical,
+// tests/test_gpu_render_loss.py); on the step's critical path those five cost ~0.1 ms of launches and barriers for ~20 us of work.
+// ------------------------------------------------------------------------------------------------
+struct RayTrainArgs {
+  const float* density; const float* ebins; const float* sbins; const float* rgb; const float* bg; const float* target;
+  int R, S, bg_mode;
+  float go_scale, dist_scale;
+  float* weights; float* rgb_out; float* acc_out; float* depth_median; float* sqerr_rays; float* dist_rays;
+  float* g_rgb; float* g_density; float* g_weights; int32_t* nonfinite_flag;
+};
+
+__global__ __launch_bounds__(256) void ray_train_kernel(RayTrainArgs a) {
+  __shared__ float s_dd[RPB][MAXS + 1];   // delta * sigma
+  __shared__ float s_aux[RPB][MAXS + 1];  // exclusive cumsum of it; later the suffix sums of the backward
+  __shared__ float s_w[RPB][MAXS + 1];    // weights
+  __shared__ float s_m[RPB][MAXS + 1];    // cumsum of w (median), then the s-space bin midpoints
+  __shared__ float s_g[RPB][MAXS + 1];    // d loss / d weights
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wv;
+  const bool live = ray < a.R;
+  const int r = live ? ray : a.R - 1;
+  const int S = a.S;
+  float *dd = s_dd[wv], *aux = s_aux[wv], *w = s_w[wv], *mm = s_m[wv], *gw = s_g[wv];
+  const float* eb = a.ebins + (int64_t)r * (S + 1);
+
+  // ---- get_weights (resample_kernel stage 1; rays.py:127-149) ----
+  for (int i = lane; i < S; i += 64) {
+    const float e0 = eb[i], e1 = eb[i + 1];
+    dd[i] = (e1 - e0) * a.density[(int64_t)r * S + i];
+  }
+  __syncthreads();
+  wave_scan_f64<true, false>(dd, aux, S, lane);
+  __syncthreads();
+  for (int i = lane; i < S; i += 64) {
+    const float alpha = 1.f - expf(-dd[i]);
+    const float T = expf(-aux[i]);
+    const float wt = nan_to_num(alpha * T);
+    w[i] = wt;
+    if (live) a.weights[(int64_t)r * S + i] = wt;
+  }
+  __syncthreads();
+
+  // ---- render forward, training mode (render_fwd_kernel) ----
+  float cr = 0.f, cg = 0.f, cb = 0.f, acc = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float wi = w[i];
+    const float* c = a.rgb + ((int64_t)r * S + i) * 3;
+    const float x = c[0], y = c[1], z = c[2];
+    cr += wi * x; cg += wi * y; cb += wi * z;
+    acc += wi;
+  }
+  cr = wave_sum(cr); cg = wave_sum(cg); cb = wave_sum(cb); acc = wave_sum(acc);
+  if (a.depth_median) {
+    wave_scan_f64<false, false>(w, mm, S, lane);
+    __syncthreads();
+    int idx = S;
+    for (int i = lane; i < S; i += 64)
+      if (mm[i] >= 0.5f) { idx = i; break; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(idx, off, 64); idx = o < idx ? o : idx; }
+    if (idx > S - 1) idx = S - 1;
+    if (lane == 0 && live) {
+      const float e0 = eb[idx], e1 = eb[idx + 1];
+      a.depth_median[r] = (e0 + e1) / 2.f;
+    }
+    __syncthreads();
+  }
+  float b0, b1, b2;
+  if (a.bg_mode == 0) { b0 = a.bg[(int64_t)r * 3]; b1 = a.bg[(int64_t)r * 3 + 1]; b2 = a.bg[(int64_t)r * 3 + 2]; }
+  else { b0 = a.bg[0]; b1 = a.bg[1]; b2 = a.bg[2]; }
+  const float o0 = cr + b0 * (1.f - acc), o1 = cg + b1 * (1.f - acc), o2 = cb + b2 * (1.f - acc);
+  if (lane == 0 && live) {
+    a.rgb_out[(int64_t)r * 3] = o0; a.rgb_out[(int64_t)r * 3 + 1] = o1; a.rgb_out[(int64_t)r * 3 + 2] = o2;
+    a.acc_out[r] = acc;
+  }
+
+  // ---- MSE folded into the render backward (render_mse_bwd_kernel) ----
+  const float d0 = o0 - a.target[(int64_t)r * 3], d1 = o1 - a.target[(int64_t)r * 3 + 1], d2 = o2 - a.target[(int64_t)r * 3 + 2];
+  if (lane == 0 && live && a.sqerr_rays) a.sqerr_rays[r] = (d0 * d0 + d1 * d1) + d2 * d2;
+  const float go0 = d0 * a.go_scale, go1 = d1 * a.go_scale, go2 = d2 * a.go_scale;
+  for (int i = lane; i < S; i += 64) {
+    const float* c = a.rgb + ((int64_t)r * S + i) * 3;
+    gw[i] = go0 * (c[0] - b0) + go1 * (c[1] - b1) + go2 * (c[2] - b2);
+    if (live) {
+      float* g = a.g_rgb + ((int64_t)r * S + i) * 3;
+      const float wi = w[i];
+      g[0] = go0 * wi; g[1] = go1 * wi; g[2] = go2 * wi;
+    }
+  }
+
+  // ---- distortion loss and its gradient, added to gw (distortion_kernel with accumulate = 1) ----
+  const float* sb = a.sbins + (int64_t)r * (S + 1);
+  for (int i = lane; i < S; i += 64) {
+    const float t0 = sb[i], t1 = sb[i + 1];
+    mm[i] = (t1 + t0) / 2.f;
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float wi = w[i], mi = mm[i];
+    float inner = 0.f;
+    for (int j = 0; j < S; ++j) inner += w[j] * fabsf(mi - mm[j]);
+    const float t0 = sb[i], t1 = sb[i + 1];
+    const float dt = t1 - t0;
+    total += wi * inner + wi * wi * dt / 3.f;
+    const float g = (2.f * inner + 2.f * wi * dt / 3.f) * a.dist_scale;
+    gw[i] += g;
+  }
+  total = wave_sum(total);
+  if (lane == 0 && live && a.dist_rays) a.dist_rays[r] = total;
+  if (a.g_weights && live)
+    for (int i = lane; i < S; i += 64) a.g_weights[(int64_t)r * S + i] = gw[i];
+
+  // ---- get_weights backward (weights_bwd_kernel) ----
+  float gwterm[5], Tk[5], ek[5];
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = lane + 64 * k;
+    gwterm[k] = 0.f; Tk[k] = 0.f; ek[k] = 0.f;
+    if (i < S) {
+      const float T = expf(-aux[i]);
+      const float e = expf(-dd[i]);
+      const float wraw = (1.f - e) * T;
+      const float g = gw[i];
+      const bool fin = (wraw == wraw) && fabsf(wraw) != INFINITY;
+      Tk[k] = T; ek[k] = e;
+      gwterm[k] = fin ? g * wraw : 0.f;
+      if (!fin) { Tk[k] = 0.f; ek[k] = 0.f; bad = bad || live; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = lane + 64 * k;
+    if (i < S) aux[i] = gwterm[k];
+  }
+  __syncthreads();
+  wave_scan_f64<true, true>(aux, aux, S, lane);  // suffix sums: aux[i] = sum_{j > i}
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = lane + 64 * k;
+    if (i < S && live) {
+      const float g = gw[i];
+      const float e0 = eb[i], e1 = eb[i + 1];
+      const float gdd = g * Tk[k] * ek[k] - aux[i];
+      float out = gdd * (e1 - e0);
+      if (!(fabsf(out) <= 3.402823466e+38f)) { out = 0.f; bad = true; }
+      a.g_density[(int64_t)r * S + i] = out;
+    }
+  }
+  if (bad && a.nonfinite_flag) *a.nonfinite_flag = 1;
+}
+
 }  // namespace snerf
 
 using namespace snerf;
@@ -339,5 +497,22 @@ extern "C" int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_
   hipLaunchKernelGGL(interlevel_kernel, dim3(ceil_div(R, RPB)), dim3(256), 0, (hipStream_t)stream, c_bins, w_nerf, S, p_bins, w_prop, Sp, R,
                      grad_scale, loss_rays, g_wprop);
   SNERF_LAUNCH_CHECK("interlevel");
+  return 0;
+}
+
+extern "C" int snerf_ray_train_fwd_bwd(const snerf_ray_train_args* p, snerf_stream_t stream) {
+  SNERF_REQUIRE(p, "ray_train_fwd_bwd: null args");
+  SNERF_REQUIRE(p->R >= 0 && p->S >= 1 && p->S <= MAXS, "ray_train_fwd_bwd: R=%d S=%d (S <= %d)", p->R, p->S, MAXS);
+  SNERF_REQUIRE(p->bg_mode == 0 || p->bg_mode == 2, "ray_train_fwd_bwd: bg_mode %d has no training backward", p->bg_mode);
+  if (p->R == 0) return 0;
+  SNERF_REQUIRE(p->density && p->ebins && p->sbins && p->rgb && p->bg && p->target && p->weights && p->rgb_out && p->acc_out && p->g_rgb && p->g_density,
+                "ray_train_fwd_bwd: null buffer");
+  RayTrainArgs a = {};
+  a.density = p->density; a.ebins = p->ebins; a.sbins = p->sbins; a.rgb = p->rgb; a.bg = p->bg; a.target = p->target;
+  a.R = p->R; a.S = p->S; a.bg_mode = p->bg_mode; a.go_scale = p->go_scale; a.dist_scale = p->dist_scale;
+  a.weights = p->weights; a.rgb_out = p->rgb_out; a.acc_out = p->acc_out; a.depth_median = p->depth_median; a.sqerr_rays = p->sqerr_rays;
+  a.dist_rays = p->dist_rays; a.g_rgb = p->g_rgb; a.g_density = p->g_density; a.g_weights = p->g_weights; a.nonfinite_flag = p->nonfinite_flag;
+  hipLaunchKernelGGL(ray_train_kernel, dim3(ceil_div(p->R, RPB)), dim3(256), 0, (hipStream_t)stream, a);
+  SNERF_LAUNCH_CHECK("ray_train_fwd_bwd");
   return 0;
 }

@@ -242,3 +242,60 @@ def test_trainer_depth_supervision_matches_oracle():
             torch.testing.assert_close(gp[p].cpu(), want, rtol=5e-3, atol=2e-3 * float(want.abs().max()) + 1e-9)
     # without depths the term is absent and the gradient differs
     assert "depth_loss" in got
+
+
+@pytest.mark.parametrize("R,S", [(37, 64), (5, 48), (130, 320), (4, 1)])
+def test_ray_train_kernel_equals_the_five_kernels(R, S):
+    """snerf_ray_train_fwd_bwd (the fused trainer's one launch for the nerf level's per-ray work) against snerf_weights_fwd + snerf_render_fwd +
+    snerf_render_mse_bwd + snerf_distortion(accumulate) + snerf_weights_bwd run one after the other: every output bit for bit, including rays
+    whose densities overflow (non-finite weights -> the skip-step flag) and zero-width bins."""
+    import ctypes as C
+
+    from soccernerfs_amd import _lib
+
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(R * 1000 + S)
+    g = lambda *sh: torch.rand(*sh, generator=gen)
+    dens = (g(R, S) ** 4 * 60).to(DEV)
+    if R > 3:
+        dens[1, S // 2] = float("inf")   # exp overflow in the field
+        dens[2] = 0.0
+        dens[3, : max(1, S // 3)] = 3e38
+    eb = torch.cumsum(g(R, S + 1) * 0.05 + 1e-3, -1)
+    if R > 3 and S > 4:
+        eb[1, S // 2 + 1] = eb[1, S // 2]  # a zero-width bin under the infinite density: 0 * inf
+    eb = eb.to(DEV)
+    sb = torch.sort(g(R, S + 1), -1).values.to(DEV)
+    rgb, bg, target = g(R, S, 3).to(DEV), g(R, 3).to(DEV), g(R, 3).to(DEV)
+    go_scale, dist_scale = 2.0 / (3 * R), 1e-3 / R
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    new = lambda *sh: torch.full(sh, -7.0, device=DEV)
+    # ---- the five kernels ----
+    w, rgb_out, acc, depth = new(R, S), new(R, 3), new(R), new(R)
+    gw, grgb, sqerr, dist, gdens = new(R, S), new(R, S, 3), new(R), new(R), new(R, S)
+    flag = torch.zeros(4, dtype=torch.int32, device=DEV)
+    _lib.check(L.snerf_weights_fwd(p(dens), p(eb), R, S, p(w), st))
+    a = _lib.RenderArgs()
+    a.weights, a.rgb, a.ebins, a.bg, a.R, a.S, a.bg_mode, a.training = w.data_ptr(), rgb.data_ptr(), eb.data_ptr(), bg.data_ptr(), R, S, 0, 1
+    a.rgb_out, a.acc_out, a.depth_median = rgb_out.data_ptr(), acc.data_ptr(), depth.data_ptr()
+    _lib.check(L.snerf_render_fwd(C.byref(a), st))
+    _lib.check(L.snerf_render_mse_bwd(p(w), p(rgb), p(bg), 0, p(rgb_out), p(target), go_scale, R, S, p(gw), p(grgb), p(sqerr), st))
+    _lib.check(L.snerf_distortion(p(w), p(sb), R, S, dist_scale, p(dist), p(gw), 1, st))
+    _lib.check(L.snerf_weights_bwd(p(dens), p(eb), p(gw), R, S, p(gdens), 0, p(flag), st))
+    # ---- one launch ----
+    w2, rgb_out2, acc2, depth2 = new(R, S), new(R, 3), new(R), new(R)
+    gw2, grgb2, sqerr2, dist2, gdens2 = new(R, S), new(R, S, 3), new(R), new(R), new(R, S)
+    flag2 = torch.zeros(4, dtype=torch.int32, device=DEV)
+    ra = _lib.RayTrainArgs()
+    ra.density, ra.ebins, ra.sbins, ra.rgb, ra.bg, ra.target = dens.data_ptr(), eb.data_ptr(), sb.data_ptr(), rgb.data_ptr(), bg.data_ptr(), target.data_ptr()
+    ra.R, ra.S, ra.bg_mode, ra.go_scale, ra.dist_scale = R, S, 0, go_scale, dist_scale
+    ra.weights, ra.rgb_out, ra.acc_out, ra.depth_median = w2.data_ptr(), rgb_out2.data_ptr(), acc2.data_ptr(), depth2.data_ptr()
+    ra.sqerr_rays, ra.dist_rays, ra.g_rgb, ra.g_density = sqerr2.data_ptr(), dist2.data_ptr(), grgb2.data_ptr(), gdens2.data_ptr()
+    ra.g_weights, ra.nonfinite_flag = gw2.data_ptr(), flag2.data_ptr()
+    _lib.check(L.snerf_ray_train_fwd_bwd(C.byref(ra), st))
+    eq = lambda x, y: torch.equal(torch.nan_to_num(x, nan=12345.0), torch.nan_to_num(y, nan=12345.0))
+    for name, x, y in (("weights", w, w2), ("rgb_out", rgb_out, rgb_out2), ("acc", acc, acc2), ("depth", depth, depth2), ("g_weights", gw, gw2),
+                       ("g_rgb", grgb, grgb2), ("sqerr", sqerr, sqerr2), ("dist", dist, dist2), ("g_density", gdens, gdens2)):
+        assert eq(x, y), name
+    assert int(flag[0]) == int(flag2[0]) and (int(flag[0]) == 1) == (R > 3 and S > 4)
