@@ -571,13 +571,15 @@ int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, cons
  * from the 4 texels of the cell it is adding into (sorted order: the reads stay in cache).  Differs from the product form by a few ulp.
  * Where a feature is exactly 0 the quotient has lost the other planes' product: _prepare lists those rows (device-side list, capacity
  * N * n_scales covers the worst case) and _fixup adds their exact gradients; pass B adds 0 there.
- *   _prepare : G = grad_feat .* feat; fix_count (reset here) / fix_list = rows (sample * n_scales + scale) with a zero feature.
+ *   _prepare : G = grad_feat .* feat; fix_count / fix_list = rows (sample * n_scales + scale) with a zero feature.  fix_count must be 0 on
+ *              entry: with fix_count_next == NULL it is reset here (one memset); a caller that alternates between two counters passes the
+ *              other one as fix_count_next and the kernel resets THAT one for the next step (no extra launch).
  *   _scatter_quotient_scales : pass B over scales [scale_begin, scale_end), sorted_rec from snerf_kplanes_sort_samples; ACCUMULATES.
  *   _fixup   : exact terms of the listed rows for scales [scale_begin, scale_end); ACCUMULATES.  Launch cost only when the list is empty.
  * ------------------------------------------------------------------------------------------------ */
 int snerf_kplanes_quotient_supported(const snerf_kplanes_desc* desc, int64_t N);
 int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, const float* grad_feat, const float* feat, float* G,
-                                   int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, snerf_stream_t stream);
+                                   int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, int32_t* fix_count_next, snerf_stream_t stream);
 int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const float* planes, int64_t N, const float* G, const float* sorted_rec,
                                           float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,

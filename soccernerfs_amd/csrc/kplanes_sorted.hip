@@ -540,7 +540,11 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
 // are listed for quotient_fixup_kernel (G / v_q cannot give plane q's gradient there: v_q == 0 took the other planes' product with it).
 template <int C>
 __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, const float* __restrict__ gfeat, const float* __restrict__ feat,
-                                                              float* __restrict__ G, int32_t* __restrict__ list, int capacity, int32_t* __restrict__ count) {
+                                                              float* __restrict__ G, int32_t* __restrict__ list, int capacity, int32_t* __restrict__ count,
+                                                              int32_t* __restrict__ count_next) {
+  // two counters, used alternately: this launch resets the OTHER one (its last reader, the previous step's fix-up, is behind us in stream
+  // order), so no memset launch sits between the MLP backward and this kernel
+  if (blockIdx.x == 0 && threadIdx.x == 0 && count_next) *count_next = 0;
   constexpr int LPR = C / 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / LPR;
@@ -833,19 +837,24 @@ extern "C" int snerf_kplanes_quotient_supported(const snerf_kplanes_desc* desc, 
 }
 
 extern "C" int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, const float* grad_feat, const float* feat, float* G,
-                                              int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, snerf_stream_t stream) {
+                                              int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, int32_t* fix_count_next, snerf_stream_t stream) {
   int rc = quotient_ok(desc, N);
   if (rc) return rc;
   SNERF_REQUIRE(N >= 0 && fix_capacity >= 0, "kplanes_quotient_prepare: N=%lld capacity=%d", (long long)N, fix_capacity);
   SNERF_REQUIRE(fix_count, "kplanes_quotient_prepare: null counter");
   hipStream_t st = (hipStream_t)stream;
-  rc = check_hip(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st), "kplanes_quotient_prepare memset");
-  if (rc) return rc;
-  if (N == 0) return 0;
+  if (!fix_count_next) {  // single counter: reset it here
+    rc = check_hip(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st), "kplanes_quotient_prepare memset");
+    if (rc) return rc;
+  }
+  if (N == 0) {
+    if (fix_count_next) return check_hip(hipMemsetAsync(fix_count_next, 0, sizeof(int32_t), st), "kplanes_quotient_prepare memset");
+    return 0;
+  }
   SNERF_REQUIRE(grad_feat && feat && G && (fix_list || fix_capacity == 0), "kplanes_quotient_prepare: null buffer");
   const int64_t rows = N * desc->n_scales;
   hipLaunchKernelGGL((quotient_prepare_kernel<32>), dim3((unsigned)ceil_div(rows * 8, 256)), dim3(256), 0, st, rows, grad_feat, feat, G, fix_list,
-                     fix_capacity, fix_count);
+                     fix_capacity, fix_count, fix_count_next);
   SNERF_LAUNCH_CHECK("kplanes_quotient_prepare");
   return 0;
 }

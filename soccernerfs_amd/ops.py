@@ -105,7 +105,9 @@ class SortedScatter:
             rows = N * len(ps.resolutions)
             self.G = torch.empty(N, ps.out_dim, dtype=torch.float32, device=device)       # gfeat .* feat
             self.fix_list = torch.empty(max(rows, 1), dtype=torch.int32, device=device)   # rows (sample * n_scales + scale) with an exactly-zero feature
-            self.fix_count = torch.zeros(1, dtype=torch.int32, device=device)
+            self.fix_counts = torch.zeros(2, dtype=torch.int32, device=device)  # used alternately: a prepare resets the other one for the next step
+            self._fix_parity = 0
+            self.fix_count = self.fix_counts[0:1]
             self.gvec = None
         else:
             self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=gvec_dtype, device=device)  # [scale*planes+plane][N][C]
@@ -125,8 +127,12 @@ class SortedScatter:
     # ---- quotient form: g_q = (gfeat .* feat) ./ v_q (include/snerf.h) ----
     def quotient_prepare(self, gfeat, feat, stream=None):
         st = stream if stream is not None else _stream()
+        k = self._fix_parity
+        self._fix_parity = 1 - k
+        self.fix_count = self.fix_counts[k:k + 1]
         _lib.check(_lib.lib().snerf_kplanes_quotient_prepare(C.byref(self.desc), C.c_int64(self.N), _ptr(gfeat), _ptr(feat), _ptr(self.G), _ptr(self.fix_list),
-                                                             self.fix_list.numel(), _ptr(self.fix_count), st), "quotient_prepare")
+                                                             self.fix_list.numel(), _ptr(self.fix_count), _ptr(self.fix_counts[1 - k:2 - k]), st),
+                   "quotient_prepare")
 
     def quotient_scatter_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
         """Pass B + the exact terms of zero-feature rows for scales [scale_begin, scale_end); quotient_prepare must have run."""

@@ -153,6 +153,7 @@ class KPlanesTrainer:
         self.prop_on_main, self.defer_prop, self.prop_after_field = cfg.prop_on_main, cfg.defer_prop, cfg.prop_after_field
         self.async_field_adam, self.adam_under_scatter = cfg.async_field_adam, cfg.adam_under_scatter
         self._field_adam_done = None
+        self._reg_in_adam = False
         self._render_deferred = False
         self._prop_pending = None
         self._depth = None
@@ -572,6 +573,14 @@ class KPlanesTrainer:
             elif self.quotient_scatter:
                 with self._span("kplanes_quotient_prepare"):
                     ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
+                if self.world == 1 and self._reg_in_adam and not self._pipeline_adam:
+                    # the optimiser sweep's two tiny forerunners (skip decision of the group, zeroed regulariser slots) depend on nothing pass B
+                    # produces: issued here they are off the scatter -> sweep hand-over
+                    cfgl = self.cfg
+                    self._prepare_group("fields", cfgl.lr * cosine_lr_factor(self.step, cfgl.warm_up_end, cfgl.max_steps, cfgl.lr_alpha))
+                    if not self._reg_zeroed:
+                        b["reg"].zero_()
+                        self._reg_zeroed = True
             else:
               with self._span("kplanes_gradvec.field"):
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
@@ -649,6 +658,7 @@ class KPlanesTrainer:
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
         S2 = self.S[2]
         main = torch.cuda.current_stream()
+        self._reg_in_adam = not include_reg  # train_step: the regularisers' values and gradients come out of the optimiser sweep
         # depth supervision: termination depths [R] (batch["depth_image"]); None or a zero coefficient switches the term off
         self._depth = ops._f32c(depth, "depth").reshape(-1) if depth is not None and co.get("depth_loss", 0) > 0 else None
         overlap = self.overlap
