@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--prop-after-field", action="store_true", help="A-B: proposal backward behind the field scatter, beside the optimiser sweep")
+    ap.add_argument("--quotient-in-epilogue", action="store_true", help="A-B: G = gfeat .* feat in the sigma_net backward's epilogue instead of a pass of its own (measured slower)")
     ap.add_argument("--no-fused-ray-loss", action="store_true", help="A-B: the nerf level's weights / render / MSE / distortion / weights-backward as five kernels instead of one")
     ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
@@ -136,7 +137,7 @@ def main():
     torch.manual_seed(20231029 + rank)
     cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field,
                              fused_field_backward=args.fused_backward, quotient_scatter=not args.no_quotient_scatter,
-                             fused_ray_loss=not args.no_fused_ray_loss)  # the k-planes preset
+                             fused_ray_loss=not args.no_fused_ray_loss, quotient_in_epilogue=args.quotient_in_epilogue)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks

@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 6
+#define SNERF_ABI_VERSION 7
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -193,6 +193,23 @@ int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * snerf_kplanes_field_fwd wrote.  The kernels round X to that type anyway, so results equal snerf_mlp_bwd on the fp32 image of X. */
 int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                       int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* snerf_mlp_bwd_x16 with the quotient scatter's preparation folded into its epilogue (sigma_net of the K-Planes field: X16 = the feature
+ * tile, d_in = 32 n_scales): beside gX it writes G = gX .* feat and lists every (sample, scale) row with an exactly-zero feature once --
+ * what snerf_kplanes_quotient_prepare does in a pass of its own (see "Quotient form" below).  row_flags [N * d_in / 32] must be zero on
+ * entry; snerf_kplanes_quotient_fixup clears the flags of the rows it handles, so the buffer is zeroed once, at allocation.  fix_count
+ * must be 0 on entry; fix_count_next (may be NULL) is reset for the next step. */
+typedef struct {
+  const float* feat;        /* [N, d_in] fp32 features of the forward, row stride ldgx */
+  float* G;                 /* out [N, d_in], row stride ldgx */
+  int32_t* fix_list;
+  int32_t fix_capacity;
+  int32_t* fix_count;
+  int32_t* fix_count_next;
+  int32_t* row_flags;
+} snerf_quotient_epilogue;
+int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                               int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, const snerf_quotient_epilogue* q,
+                               snerf_stream_t stream);
 /* Same with the weight gradients accumulated into fixed-point cells (see snerf_kplanes_gather_bwd_fx). */
 int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                      int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
@@ -584,7 +601,8 @@ int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const 
                                           float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
                                  const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
-                                 int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
+                                 int32_t scale_begin, int32_t scale_end, int32_t* row_flags /* may be NULL: cleared for the handled rows */,
+                                 snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
 int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,

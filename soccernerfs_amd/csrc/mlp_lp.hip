@@ -252,6 +252,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
   // columns 16..31 of gzo (the padded half of the K = 32 contraction) stay zero for the whole kernel
   for (int idx = threadIdx.x; idx < TS * 16; idx += blockDim.x) gzo[(idx / 16) * P::LKO + 16 + (idx % 16)] = (T)0.f;
   const bool relu = a.hidden_act == 1;
+  if (a.qcount_next && blockIdx.x == 0 && threadIdx.x == 0) *a.qcount_next = 0;  // the other of the two alternating counters, for the next step
   f32x4 dW0[NB0] = {};
   f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
@@ -425,7 +426,21 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
             const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[m][r] * (1.f / GS);
+              if (row0 + r < a.N && col < a.d0) {
+                const float gx = acc[m][r] * (1.f / GS);
+                a.gX[(row0 + r) * a.ldgx + col] = gx;
+                if (a.qG) {  // quotient form of the plane scatter: G = gfeat .* feat formed here instead of by a pass of its own
+                  const float f = a.qfeat[(row0 + r) * a.ldgx + col];
+                  a.qG[(row0 + r) * a.ldgx + col] = gx * f;
+                  if (f == 0.f && gx != 0.f) {  // (sample, scale) row with a vanished feature: listed ONCE (two column blocks share a row)
+                    const int64_t rs = (row0 + r) * (a.d0 / 32) + col / 32;
+                    if (atomicExch(a.qflags + rs, 1) == 0) {
+                      const int slot = atomicAdd(a.qcount, 1);
+                      if (slot < a.qcap) a.qlist[slot] = (int32_t)rs;
+                    }
+                  }
+                }
+              }
           }
         }
       }

@@ -105,6 +105,8 @@ class KPlanesTrainConfig:
     # ~1.6 GB less HBM traffic per step.  Equal to the product form to a few ulp (pass B recomputes the forward's v_q bit for bit; rows with an
     # exactly-zero feature take an exact fix-up).  Needs the sorted scatter, C = 32 and no deterministic mode; False = product form (A-B).
     quotient_scatter: bool = True
+    quotient_in_epilogue: bool = False  # opt-in (A-B): G and the zero-feature list from the sigma_net backward's epilogue instead of a pass of
+    #                                     their own -- measured SLOWER (3.06 vs 2.92 ms: the epilogue's 64-B row segments against a float4 stream)
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -153,6 +155,7 @@ class KPlanesTrainer:
         self.prop_on_main, self.defer_prop, self.prop_after_field = cfg.prop_on_main, cfg.defer_prop, cfg.prop_after_field
         self.async_field_adam, self.adam_under_scatter = cfg.async_field_adam, cfg.adam_under_scatter
         self._field_adam_done = None
+        self._q_in_epilogue = False
         self._reg_in_adam = False
         self._render_deferred = False
         self._prop_pending = None
@@ -366,8 +369,13 @@ class KPlanesTrainer:
         _lib.check(self.lib.snerf_mlp_fwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(Y), ldy, aux_col,
                                           self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
 
-    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, x16=False):
+    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, x16=False, quotient=None):
       with self._span(f"mlp_bwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
+        if quotient is not None:  # sigma_net with the quotient scatter's preparation in its epilogue (G, zero-feature rows)
+            _lib.check(self.lib.snerf_mlp_bwd_x16_quotient(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
+                                                           self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
+                                                           self._p(gX), ldgx, self._p(self.gviews[gname]), C.byref(quotient), self._st), "mlp_bwd_x16_quotient")
+            return
         fn = self.lib.snerf_mlp_bwd_fx if self.grads_fx is not None else (self.lib.snerf_mlp_bwd_x16 if x16 else self.lib.snerf_mlp_bwd)
         if x16 and self.grads_fx is not None:  # deterministic mode: the fixed-point kernel takes fp32 inputs (exact image of the 16-bit tile)
             X = X.float()
@@ -556,8 +564,11 @@ class KPlanesTrainer:
         if not fused:
             # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
             self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
+            # quotient scatter behind a fused forward: G = gfeat .* feat and the zero-feature list come out of this kernel's epilogue
+            self._q_in_epilogue = bool(self.quotient_scatter and self._fwd_fused and self.grads_fx is None and r0 == 0 and r1 == self.R
+                                       and self.sorted_scatter and self._sort_done is not None and self.cfg.quotient_in_epilogue)
             self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
-                          sl(b["gfeat"]), F, x16=self._fwd_fused)
+                          sl(b["gfeat"]), F, x16=self._fwd_fused, quotient=self._ss.quotient_epilogue(b["feat"]) if self._q_in_epilogue else None)
         rays = self.rays
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
         if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:
@@ -571,8 +582,9 @@ class KPlanesTrainer:
                                                                 self._p(self.gviews["field.sigma"]), self._p(self.gviews["field.color"]), None, None,
                                                                 self._p(ss.gvec), ss.gvec_bf16, self._st), "kplanes_field_bwd")
             elif self.quotient_scatter:
-                with self._span("kplanes_quotient_prepare"):
-                    ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
+                if not self._q_in_epilogue:
+                    with self._span("kplanes_quotient_prepare"):
+                        ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
                 if self.world == 1 and self._reg_in_adam and not self._pipeline_adam:
                     # the optimiser sweep's two tiny forerunners (skip decision of the group, zeroed regulariser slots) depend on nothing pass B
                     # produces: issued here they are off the scatter -> sweep hand-over
