@@ -106,7 +106,7 @@ class KPlanesTrainConfig:
     # exactly-zero feature take an exact fix-up).  Needs the sorted scatter, C = 32 and no deterministic mode; False = product form (A-B).
     quotient_scatter: bool = True
     quotient_in_epilogue: bool = False  # opt-in (A-B): G and the zero-feature list from the sigma_net backward's epilogue instead of a pass of
-    #                                     their own -- measured SLOWER (3.06 vs 2.92 ms: the epilogue's 64-B row segments against a float4 stream)
+    #                                     their own -- measured SLOWER (2.84 vs 2.63 ms: that instantiation needs 256 VGPRs + spills; profiles/r02_kernels.md section 10)
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
