@@ -66,6 +66,16 @@ def test_config3_gather_and_scatter_full_size():
     got = torch.zeros_like(ps.planes)
     ss.scatter(ps.planes, co, gout, got)
     torch.testing.assert_close(got, direct, rtol=1e-4, atol=2e-5)
+    del ss
+    # the quotient form (g_q = (gout .* features) ./ v_q, v_q recomputed in pass B) at the same size: features from the forward above
+    ssq = ops.SortedScatter(ps, N, DEV, quotient=True)
+    ssq.sort(co)
+    got.zero_()
+    ssq.scatter_quotient(ps.planes, co, gout, out, got)
+    assert int(ssq.fix_count.item()) == 0  # positive planes: no feature vanishes
+    torch.testing.assert_close(got, direct, rtol=1e-4, atol=2e-5)
+    assert float((got - direct).norm() / direct.norm()) < 2e-6
+    del ssq
     # conservation on the finest scale: sum over texels of dL/dplane = sum_n gout * prod(other planes), checked against autograd of the torch restatement
     s = 5
     grids = [[ps.plane_view(s, p).detach().permute(2, 0, 1)[None].contiguous().requires_grad_(True) for p in range(6)]]
