@@ -46,8 +46,11 @@ class KPlanesField(nn.Module):
                  sigma_net_hidden_dim: int = 64, rgb_net_layers: int = 2, rgb_net_hidden_dim: int = 64, use_appearance_embedding: bool = False,
                  spatial_distortion=None, **_unused) -> None:
         super().__init__()
-        if linear_decoder or not disable_viewing_dependent or use_appearance_embedding or spatial_distortion is not None:
-            raise NotImplementedError("only the k-planes preset decoder (MLP, view-independent, bounded scene) is built")
+        if linear_decoder or use_appearance_embedding or spatial_distortion is not None:
+            # (the reference's appearance-embedding branch, kplanes_field.py:325-346, cannot run with per-sample camera indices: see
+            # oracle/gen_golden_field_options.py)
+            raise NotImplementedError("built: the MLP decoder on a bounded scene, view-independent (the k-planes preset) or view-dependent")
+        self.disable_viewing_dependent = disable_viewing_dependent
         self.aabb = nn.Parameter(aabb, requires_grad=False)
         mult = list(multiscale_res or [1])
         base = list(spacetime_resolution)
@@ -57,7 +60,13 @@ class KPlanesField(nn.Module):
         cfg = {"otype": "FullyFusedMLP", "activation": "ReLU"}
         self.sigma_net = Network(self.feature_dim, self.geo_feat_dim + 1,
                                  {**cfg, "output_activation": "None", "n_neurons": sigma_net_hidden_dim, "n_hidden_layers": sigma_net_layers})
-        self.color_net = Network(self.geo_feat_dim, 3,
+        self.in_dim_color = self.geo_feat_dim
+        if not disable_viewing_dependent:
+            # kplanes_field.py:206-216: tcnn SphericalHarmonics degree 4 on the directions shifted to [0, 1]; 16 values in FRONT of the features
+            from .tcnn_compat import Encoding
+            self.direction_encoder = Encoding(3, {"otype": "SphericalHarmonics", "degree": 4})
+            self.in_dim_color += self.direction_encoder.n_output_dims
+        self.color_net = Network(self.in_dim_color, 3,
                                  {**cfg, "output_activation": "Sigmoid", "n_neurons": rgb_net_hidden_dim, "n_hidden_layers": rgb_net_layers})
 
     def _features(self, ray_samples: RaySamples):
@@ -77,7 +86,12 @@ class KPlanesField(nn.Module):
         """kplanes_field.py:314-358."""
         assert density_embedding is not None
         n_rays, n_samples = ray_samples.frustums.shape[:2]
-        return self.color_net(density_embedding).view(n_rays, n_samples, 3)
+        if self.disable_viewing_dependent:
+            return self.color_net(density_embedding).view(n_rays, n_samples, 3)
+        # kplanes_field.py:318-323: get_normalized_directions = (d + 1) / 2 (base_field.py:131-137), SH encoding, [encoded directions | features]
+        directions = ray_samples.frustums.directions.reshape(-1, 3)
+        enc = self.direction_encoder((directions + 1.0) / 2.0)
+        return self.color_net(torch.cat([enc, density_embedding], dim=-1).contiguous()).view(n_rays, n_samples, 3)
 
     def forward(self, ray_samples: RaySamples, compute_normals: bool = False, mask=None, bg_color=None):
         density, feats = self.get_density(ray_samples)

@@ -117,3 +117,28 @@ def test_eval_image_chunked_and_ray_generator():
     out = model.get_outputs_for_camera_ray_bundle(img)
     assert out["rgb"].shape == (54, 96, 3) and out["depth"].shape == (54, 96, 1)
     assert float(out["rgb"].min()) >= 0.0 and float(out["rgb"].max()) <= 1.0
+
+
+def test_view_dependent_field_matches_reference_golden():
+    """KPlanesField(disable_viewing_dependent=False): spherical harmonics of the direction in front of the 15 geometry features as color_net's
+    input (NS/fields/kplanes_field.py:206-216, :314-323) -- G6b, the reference's own class evaluated through the shims, training and eval mode."""
+    from soccernerfs_amd.kplanes_field import FieldHeadNames, KPlanesField
+    from soccernerfs_amd.rays import Frustums, RaySamples
+
+    g = load_golden("g6b_field_options")
+    f = KPlanesField(g["aabb"], spacetime_resolution=[6, 5, 4, 3], feat_dim=32, multiscale_res=[1, 2], concat_features_across_scales=True,
+                     disable_viewing_dependent=False, sigma_net_layers=1, sigma_net_hidden_dim=128, rgb_net_layers=2, rgb_net_hidden_dim=64).to(DEV)
+    assert f.color_net.n_input_dims == 31
+    f.grids.load_reference([[g[f"vd_plane_{s}_{q}"] for q in range(6)] for s in range(2)])
+    f.sigma_net.load_linear_weights([g[f"vd_sigma_{i}"].to(DEV) for i in range(2)])
+    f.color_net.load_linear_weights([g[f"vd_color_{i}"].to(DEV) for i in range(3)])
+    pos, dirs, tms = g["vd_positions"].to(DEV), g["vd_directions"].to(DEV), g["vd_times"].to(DEV)
+    R, S = pos.shape[:2]
+    rs = RaySamples(frustums=Frustums(origins=pos, directions=dirs, starts=torch.zeros(R, S, 1, device=DEV), ends=torch.zeros(R, S, 1, device=DEV),
+                                      pixel_area=torch.ones(R, S, 1, device=DEV)), times=tms[:, None])
+    for mode in ("train", "eval"):
+        f.train(mode == "train")
+        with torch.no_grad():
+            o = f(rs)
+        torch.testing.assert_close(o[FieldHeadNames.DENSITY][..., 0].cpu(), g[f"vd_{mode}_density"], rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(o[FieldHeadNames.RGB].cpu(), g[f"vd_{mode}_rgb"], rtol=2e-5, atol=2e-6)
