@@ -227,6 +227,7 @@ int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X,
  *        MFMA consumed; 2 B per feature instead of the 4 B the unfused gather writes) for snerf_mlp_bwd_x16(sigma_net), and h [N,16] =
  *        the raw fp32 sigma_net outputs (color_net's input; column 15 = log density) for snerf_mlp_bwd(color_net); feat32
  *        [N, 32 n_scales] = the fp32 features before rounding, for the quotient form of the plane scatter (snerf_kplanes_quotient_*).
+ *        The three come as a set: feat16 and h together (or neither), feat32 only with them.
  *   bwd: from g_density [N] and g_rgb [N,3]: recomputes the forward per tile, ACCUMULATES the weight gradients of both nets (flat layouts of
  *        snerf_mlp_*; float atomics, or fixed-point cells when the *_fx pointers are given instead) and writes the per-plane gradient
  *        vectors gvec[scale * 6 + plane][N][32] (fp32 or bf16) that snerf_kplanes_scatter_sorted consumes -- i.e. it replaces

@@ -100,7 +100,7 @@ __device__ __forceinline__ void load_breg(const float* __restrict__ W0, int wave
 }
 
 // gather phase: 16 lanes per sample = (4-channel group cg) x (scale parity sg); rounds the features into the A-operand image XS
-template <typename T, int NS>
+template <typename T, int NS, bool F32OUT = false>
 __device__ __forceinline__ void gather_tile(const FieldArgs& a, int64_t n0, T* XS) {
   using P = PlanFF<NS>;
   // waves 0-3 take the even scales, waves 4-7 the odd ones: the scale index is wave-uniform, so the descriptor reads stay scalar
@@ -115,7 +115,8 @@ __device__ __forceinline__ void gather_tile(const FieldArgs& a, int64_t n0, T* X
     if (live) f = scale_features(a.d, a.planes, p, s, cg);
     const typename Ops<T>::v4 t = {Ops<T>::cvt(f.x), Ops<T>::cvt(f.y), Ops<T>::cvt(f.z), Ops<T>::cvt(f.w)};
     *reinterpret_cast<typename Ops<T>::v4*>(XS + sample * P::LK0 + s * 32 + cg * 4) = t;
-    if (a.feat32 && live) *reinterpret_cast<float4*>(a.feat32 + n * (32 * NS) + s * 32 + cg * 4) = f;  // 8 lanes x 16 B = one 128-B row segment
+    if constexpr (F32OUT)
+      if (live) *reinterpret_cast<float4*>(a.feat32 + n * (32 * NS) + s * 32 + cg * 4) = f;  // 8 lanes x 16 B = one 128-B row segment
   }
 }
 
@@ -172,7 +173,9 @@ __device__ __forceinline__ void store_gq(__bf16* gv, int64_t idx, float4 g) {
   *reinterpret_cast<ff_bf16x4*>(gv + idx) = b;
 }
 
-template <typename T, int NS>
+// KEEP: what a training step leaves behind for its backward -- 0 nothing (eval), 1 the 16-bit feature tile + the sigma_net outputs,
+// 2 those + the fp32 features (quotient scatter).  Compile-time: as run-time pointer tests these cost every variant registers.
+template <typename T, int NS, int KEEP = 0>
 __global__ __launch_bounds__(FF_NW * 64, 4) void field_fwd_kernel(FieldArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -190,9 +193,9 @@ __global__ __launch_bounds__(FF_NW * 64, 4) void field_fwd_kernel(FieldArgs a, i
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t n0 = tile * FF_TS;
     __syncthreads();  // weights staged / the previous tile's colour layers have read CA1, CA2 (= XS)
-    gather_tile<T, NS>(a, n0, XS);
+    gather_tile<T, NS, KEEP == 2>(a, n0, XS);
     __syncthreads();
-    if (a.feat16) {  // the tile's rows are contiguous in feat16: one coalesced 16-B store per 8 features
+    if constexpr (KEEP >= 1) {  // the tile's rows are contiguous in feat16: one coalesced 16-B store per 8 features
       T* F16 = reinterpret_cast<T*>(a.feat16);
       for (int vi = threadIdx.x; vi < FF_TS * (K0 / 8); vi += FF_NW * 64) {
         const int r = vi / (K0 / 8), c8 = vi - r * (K0 / 8);
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(FF_NW * 64, 4) void field_fwd_kernel(FieldArgs a, i
         const float y = acc[0][r];
         const int64_t n = n0 + row0 + r;
         if (col == FF_GEO && n < a.N) a.dens[n] = expf(y);  // trunc_exp forward (activations.py:32)
-        if (a.h && n < a.N) a.h[n * 16 + col] = y;
+        if constexpr (KEEP >= 1)
+          if (n < a.N) a.h[n * 16 + col] = y;
         CX[(row0 + r) * P::LKX + col] = col < FF_GEO ? Ops<T>::cvt(y) : (T)0.f;
       }
     }
@@ -261,20 +265,26 @@ static int validate_field(const snerf_kplanes_desc* d, const snerf_coords* c, in
   return 0;
 }
 
-template <typename T, int NS>
-static int launch_field_fwd(const FieldArgs& a, hipStream_t st) {
+template <typename T, int NS, int KEEP>
+static int launch_field_fwd_k(const FieldArgs& a, hipStream_t st) {
   using P = PlanFF<NS>;
   const int64_t n_tiles = (a.N + FF_TS - 1) / FF_TS;
   int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
   per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);  // 125 VGPRs: two 8-wave workgroups per CU
   int64_t grid = 256 * per_cu;
   if (grid > n_tiles) grid = n_tiles;
-  auto k = field_fwd_kernel<T, NS>;
+  auto k = field_fwd_kernel<T, NS, KEEP>;
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(FF_NW * 64), P::BYTES, st, a, n_tiles);
   SNERF_LAUNCH_CHECK("kplanes_field_fwd");
   return 0;
+}
+template <typename T, int NS>
+static int launch_field_fwd(const FieldArgs& a, hipStream_t st) {
+  if (a.feat16 && a.feat32) return launch_field_fwd_k<T, NS, 2>(a, st);
+  if (a.feat16) return launch_field_fwd_k<T, NS, 1>(a, st);
+  return launch_field_fwd_k<T, NS, 0>(a, st);
 }
 
 
@@ -699,6 +709,8 @@ extern "C" int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const flo
   SNERF_REQUIRE(planes && W_sigma && W_color && density && rgb, "kplanes_field_fwd: null buffer");
   FieldArgs a = {};
   a.d = *desc; a.planes = planes; a.c = *coords; a.N = N; a.Wsig = W_sigma; a.Wcol = W_color; a.dens = density; a.rgb = rgb;
+  SNERF_REQUIRE((feat16 != nullptr) == (h != nullptr) && (!feat32 || feat16),
+                "kplanes_field_fwd: the training outputs come as a set: feat16 and h together, feat32 only with them");
   a.feat16 = feat16; a.h = h; a.feat32 = feat32;
   FF_DISPATCH_FWD(launch_field_fwd, sigma->operands, desc->n_scales, a, (hipStream_t)stream);
 }
