@@ -586,7 +586,9 @@ int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, cons
  *     g_q = gfeat .* prod_{p != q} v_p = (gfeat .* feat) ./ v_q          (feat = prod_p v_p, what the forward computed)
  * Instead of materialising 6 gradient vectors per (sample, scale) (snerf_kplanes_gradvec: a second gather of all 30 planes + 1 GB of
  * vectors at the preset), ONE tensor G = gfeat .* feat [N, 32 n_scales] is formed and pass B divides by v_q, which it re-interpolates
- * from the 4 texels of the cell it is adding into (sorted order: the reads stay in cache).  Differs from the product form by a few ulp.
+ * from the 4 texels of the cell it is adding into (sorted order: the reads stay in cache) -- with the forward's own arithmetic, bit for
+ * bit, so that the division cancels the forward's v_q exactly even where v_q is a small difference of large texels.  Differs from the
+ * product form by a few ulp.
  * Where a feature is exactly 0 the quotient has lost the other planes' product: _prepare lists those rows (device-side list, capacity
  * N * n_scales covers the worst case) and _fixup adds their exact gradients; pass B adds 0 there.
  *   _prepare : G = grad_feat .* feat; fix_count / fix_list = rows (sample * n_scales + scale) with a zero feature.  fix_count must be 0 on
