@@ -148,6 +148,7 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
         if (a.zero_grad) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
       } else {
       float4 gg = ldnt4(a.grad + o), mm = ldnt4(a.m + o), vv = ldnt4(a.v + o), pp = t;
+      const float4 gz = gg;
       float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* RG = &g.x;
       int ndrop = 0;
 #pragma unroll
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
       stnt4(a.p_out + o, pp);
       stnt4(a.m + o, mm);
       stnt4(a.v + o, vv);
-      if (a.zero_grad) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
+      // clear only what is not zero already: at the finest scale about half of the texels receive no sample in a step (gg was read before
+      // the loop changed it: compare the loaded value)
+      if (a.zero_grad && (gz.x != 0.f || gz.y != 0.f || gz.z != 0.f || gz.w != 0.f)) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
       }
     } else if (a.grad) {
       float* gp = a.grad + a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
