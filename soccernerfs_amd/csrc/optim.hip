@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void adam_kernel(const float* p, float* p_out,
     stnt4(p_out + i * 4, pp);
     stnt4(m + i * 4, mm);
     stnt4(v + i * 4, vv);
-    if (zero_grad) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+    // clear only what is not zero already (hash / temporal tables: most of a row's columns receive nothing in a step)
+    if (zero_grad && (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f)) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
   }
   // tail (n % 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256) void adam_tv_kernel(float* p, float* __restric
   stnt4(p + i * 4, pp);
   stnt4(m + i * 4, mm);
   stnt4(v + i * 4, vv);
-  if (zero_grad) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
+  if (zero_grad && (gg.x != 0.f || gg.y != 0.f || gg.z != 0.f || gg.w != 0.f)) stnt4(g + i * 4, make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
 }  // namespace snerf
