@@ -395,6 +395,10 @@ struct BitonicK<1> {
   static __device__ __forceinline__ void run(uint32_t (&)[4], int) {}
 };
 
+// a plane value below the smallest normal float counts as zero in the quotient form: pass B adds nothing for it and the fix-up supplies the exact
+// term (v_rcp_f32 may flush a subnormal operand, which would turn 0 * inf into a NaN gradient)
+constexpr float QUOT_TINY = 1.17549435e-38f;
+
 // QUOT (the quotient form, snerf_kplanes_scatter_quotient): gvec is ONE tensor G[N][row_stride] = gfeat .* feat (feat = the forward's product
 // over the six planes), and the gradient vector of plane q at an entry is G / v_q with v_q re-interpolated here from the entry's cell --
 // the 4 texels this lane group is about to add into, so the reads follow the sorted order and stay in cache.  lane = (x-corner, channel):
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
         const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0[u]), __float_as_uint(t0[u]), false, false);  // row y0: [0] = x0 column, [1] = x1
         const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1[u]), __float_as_uint(t1[u]), false, false);  // row y0 + 1
         const float vq = bilerp4(__uint_as_float(s0[0]), __uint_as_float(s0[1]), __uint_as_float(s1[0]), __uint_as_float(s1[1]), w4.x, w4.z, w4.y, w4.w);
-        gq = vq != 0.f ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;
+        gq = fabsf(vq) >= QUOT_TINY ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;  // zero or subnormal (v_rcp_f32 may flush it): left to the fix-up
       }
       const float v0 = gq * wt.x, v1 = gq * wt.y;
       if (packed == ppk) {
@@ -553,7 +557,8 @@ __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, con
     const float4 g = *reinterpret_cast<const float4*>(gfeat + gid * 4);
     const float4 f = *reinterpret_cast<const float4*>(feat + gid * 4);
     *reinterpret_cast<float4*>(G + gid * 4) = f4_mul(g, f);
-    bad = (f.x == 0.f && g.x != 0.f) || (f.y == 0.f && g.y != 0.f) || (f.z == 0.f && g.z != 0.f) || (f.w == 0.f && g.w != 0.f);
+    bad = (fabsf(f.x) < QUOT_TINY && g.x != 0.f) || (fabsf(f.y) < QUOT_TINY && g.y != 0.f) || (fabsf(f.z) < QUOT_TINY && g.z != 0.f) ||
+          (fabsf(f.w) < QUOT_TINY && g.w != 0.f);
   }
   const unsigned long long m = __ballot(bad);
   const int lane = threadIdx.x & 63, g0 = lane & ~(LPR - 1);
@@ -598,15 +603,15 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc 
       // the forward's own number (bilerp4): "exactly zero" must mean the same here, in the forward and in pass B
       v[q] = bilerp4(base[((int64_t)ty.i0 * W + tx.i0) * C], base[((int64_t)ty.i0 * W + tx.i1) * C], base[((int64_t)ty.i1 * W + tx.i0) * C],
                      base[((int64_t)ty.i1 * W + tx.i1) * C], w.x, w.y, w.z, w.w);
-      zeros += v[q] == 0.f;
+      zeros += fabsf(v[q]) < QUOT_TINY;
     }
     if (zeros != 1) continue;  // per lane (channel): none -> pass B was exact; two or more -> every plane's gradient is 0
     float prod = gfeat[n * ((int64_t)n_scales_total * C) + s * C + ch];
 #pragma unroll
-    for (int q = 0; q < NP; ++q) prod *= v[q] == 0.f ? 1.f : v[q];
+    for (int q = 0; q < NP; ++q) prod *= fabsf(v[q]) < QUOT_TINY ? 1.f : v[q];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      if (v[q] != 0.f) continue;
+      if (fabsf(v[q]) >= QUOT_TINY) continue;
       const AxisTap& tx = tap[pair_a<NP>(q)];
       const AxisTap& ty = tap[pair_b<NP>(q)];
       const int W = d.res[s][pair_a<NP>(q)];

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
                 if constexpr (QEP) {  // quotient form of the plane scatter: G = gfeat .* feat formed here instead of by a pass of its own
                   const float f = a.qfeat[(row0 + r) * a.ldgx + col];
                   a.qG[(row0 + r) * a.ldgx + col] = gx * f;
-                  if (f == 0.f && gx != 0.f) {  // (sample, scale) row with a vanished feature: listed ONCE (two column blocks share a row)
+                  if (fabsf(f) < 1.17549435e-38f && gx != 0.f) {  // (sample, scale) row with a vanished feature (zero or subnormal, as quotient_prepare_kernel): listed ONCE (two column blocks share a row)
                     const int64_t rs = (row0 + r) * (a.d0 / 32) + col / 32;
                     if (atomicExch(a.qflags + rs, 1) == 0) {
                       const int slot = atomicAdd(a.qcount, 1);

@@ -212,12 +212,15 @@ def test_quotient_scatter_equals_direct_scatter(ms, N, zeros):
             # whole texels of scale 0 / plane 0 and a sprinkle everywhere: interpolated values that are exactly 0.0f
             ps.planes[: 32 * 40] = 0.0
             ps.planes[torch.rand(ps.numel, generator=gen) < 0.02] = 0.0
+        if zeros:
+            ps.plane_view(0, 2)[-1, -1, :] = 3e-39  # a SUBNORMAL texel: counts as zero in the quotient form (v_rcp_f32 may flush it)
     ps = ps.to(dev)
     pts = torch.rand(N, 4, generator=gen) * 2.2 - 1.1
     pts[: N // 3, 3] = 0.25
     pts[: N // 8] = pts[0]
     if zeros:
         pts[N // 2: N // 2 + 64] = -1.0  # the all-zero corner texel of plane 0 exactly (weights 1, 0, 0, 0)
+        pts[N // 2 + 64: N // 2 + 96] = 1.0  # the subnormal last texel of plane 2 exactly
     gout = torch.rand(N, ps.out_dim, generator=gen) - 0.5
     ptsd, goutd = pts.to(dev), gout.to(dev)
     co = ops.coords_from_points(ptsd)
