@@ -554,7 +554,8 @@ int snerf_isg_maps(const void* images, int32_t image_dtype, int32_t M, int32_t H
  * by inverse-CDF on cdf[M, H*W] (fp32 inclusive prefix sums of the maps) with the uniform draws u[n].  As torch.multinomial with the
  * reference's replacement flag (:400-402): WITHOUT replacement inside a slot when nonzero_counts[image] >= the slot's draws (a drawn
  * pixel's weight leaves the distribution of the slot's later draws), with replacement otherwise (or always, if nonzero_counts is NULL).
- * per_image <= 1024.  indices [n,3] int64 = (image, row, col).  oracle/ist_oracle.py::sample restates the loop: identical indices for
+ * min(per_image, n) <= 13000 (the slot's removed-pixel list lives in LDS; the search costs O(draws^2) per slot -- the preset draws 10).
+ * indices [n,3] int64 = (image, row, col).  oracle/ist_oracle.py::sample restates the loop: identical indices for
  * identical (cdf, chosen, u). */
 int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, const int32_t* nonzero_counts, int32_t per_image,
                      const float* u, int32_t n, int64_t* indices, snerf_stream_t stream);

@@ -97,12 +97,16 @@ __global__ void isg_weights_kernel(const T* __restrict__ images, const T* __rest
 // One wavefront per slot (~62 slots x 10 draws per step); the removed pixels of a slot sit in LDS and every probe of the search
 // subtracts their mass.  The order-sensitive arithmetic is in double, where it is EXACT (weights are fp32 differences of the
 // prefix sums: sums of <= 1024 of them fit 53 bits), so kernel and oracle agree bit for bit whatever the summation order.
-constexpr int IST_MAX_PER_IMAGE = 1024;
+// The removed list lives in dynamic LDS, sized by the launcher for the largest slot (min(per_image, n) entries x 12 B): the preset draws
+// 10 per slot; few images with a large batch (per_image = 10 * ceil(0.15 R / M), pixel_samplers.py:369) need thousands -- up to
+// IST_MAX_DRAWS_PER_SLOT fit a CU's 160 KB.  The probe loop is O(draws^2) per slot: beyond ~1000 draws per slot it costs milliseconds.
+constexpr int IST_MAX_DRAWS_PER_SLOT = 13000;
 __global__ __launch_bounds__(64) void ist_sample_kernel(const float* __restrict__ cdf, int64_t HW, int W, const int64_t* __restrict__ chosen,
                                                         const int32_t* __restrict__ nnz, int per_image, const float* __restrict__ u, int n,
-                                                        int64_t* __restrict__ indices) {
-  __shared__ int32_t rem_idx[IST_MAX_PER_IMAGE];
-  __shared__ double rem_w[IST_MAX_PER_IMAGE];
+                                                        int64_t* __restrict__ indices, int list_cap) {
+  extern __shared__ __align__(16) unsigned char ist_lds[];
+  double* rem_w = reinterpret_cast<double*>(ist_lds);                  // [list_cap]
+  int32_t* rem_idx = reinterpret_cast<int32_t*>(rem_w + list_cap);     // [list_cap]
   const int slot = blockIdx.x, lane = threadIdx.x;
   const int d0 = slot * per_image;
   if (d0 >= n) return;
@@ -195,14 +199,21 @@ extern "C" int snerf_isg_maps(const void* images, int32_t image_dtype, int32_t M
 
 extern "C" int snerf_ist_sample(const float* cdf, int32_t H, int32_t W, const int64_t* chosen_images, const int32_t* nonzero_counts, int32_t per_image,
                                 const float* u, int32_t n, int64_t* indices, snerf_stream_t stream) {
-  SNERF_REQUIRE(n >= 0 && per_image >= 1 && per_image <= IST_MAX_PER_IMAGE && H >= 1 && W >= 1, "ist_sample: n=%d per_image=%d (<= %d)", n, per_image,
-                IST_MAX_PER_IMAGE);
+  SNERF_REQUIRE(n >= 0 && per_image >= 1 && H >= 1 && W >= 1, "ist_sample: n=%d per_image=%d", n, per_image);
   if (n == 0) return 0;
+  const int list_cap = per_image < n ? per_image : n;  // the largest slot's draws: what the without-replacement list must hold
+  SNERF_REQUIRE(list_cap <= IST_MAX_DRAWS_PER_SLOT, "ist_sample: %d draws in one image slot (at most %d: the removed-pixel list lives in LDS)", list_cap,
+                IST_MAX_DRAWS_PER_SLOT);
   SNERF_REQUIRE(cdf && chosen_images && u && indices, "ist_sample: null buffer");
   SNERF_REQUIRE((int64_t)H * W < (1LL << 31), "ist_sample: image too large");
   const int slots = ceil_div(n, per_image);
-  hipLaunchKernelGGL(ist_sample_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, cdf, (int64_t)H * W, W, chosen_images, nonzero_counts,
-                     per_image, u, n, indices);
+  const size_t lds = (size_t)list_cap * (sizeof(double) + sizeof(int32_t));
+  if (lds > 48 * 1024) {
+    int rc = check_hip(hipFuncSetAttribute((const void*)ist_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "ist_sample LDS size");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(ist_sample_kernel, dim3(slots), dim3(64), lds, (hipStream_t)stream, cdf, (int64_t)H * W, W, chosen_images, nonzero_counts,
+                     per_image, u, n, indices, list_cap);
   SNERF_LAUNCH_CHECK("ist_sample");
   return 0;
 }

@@ -176,7 +176,21 @@ class KPlanesTrainer:
         def mlp(din, dout, h, nh, act, operands):
             ncfg = {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": h, "n_hidden_layers": nh}
             seed = int(torch.randint(0, 2**31, (1,), generator=gen))
-            return Network(din, dout, ncfg, seed=seed, operands=operands or cfg.mlp_operands)
+            ops_ = operands or cfg.mlp_operands
+            if operands is None and ops_ != "fp32":
+                # the model-wide default applies where the 16-bit kernels are built for the shape; other shapes (e.g. the reference field's
+                # own sigma_net_hidden_dim = 64 behind >= 2 scales) keep training with exact fp32 operands.  An explicit per-net
+                # override (sigma / color / proposal_operands) is taken literally and raises in Network if unsupported.
+                probe = _lib.MlpDesc()
+                probe.d_in, probe.d_out, probe.hidden, probe.n_hidden = din, dout, h, nh
+                probe.hidden_act, probe.out_act = 1, {"None": 0, "Sigmoid": 1}[act]
+                probe.operands = {"bf16": 1, "fp16": 2}[ops_]
+                if not _lib.lib().snerf_mlp_supported(C.byref(probe)):
+                    import warnings
+
+                    warnings.warn(f"{ops_} MFMA operands are not built for the {din} -> {h} x {nh} -> {dout} net: it runs with fp32 operands")
+                    ops_ = "fp32"
+            return Network(din, dout, ncfg, seed=seed, operands=ops_)
 
         self.field_planes = PlaneSet(cfg.feature_dim, reso, concat=True, a=0.1, b=0.5, generator=gen)
         self.sigma_net = mlp(cfg.feature_dim * len(reso), 16, cfg.sigma_net_hidden_dim, 1, "None", cfg.sigma_operands)

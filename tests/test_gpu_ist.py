@@ -137,6 +137,47 @@ def test_ist_draws_match_oracle_and_do_not_repeat_pixels():
         assert float(((emp - ref) ** 2 / ref).sum() * T) < 25.0  # chi-square, 3 dof: P(> 25) ~ 1.5e-5
 
 
+def test_ist_sampler_with_few_images_and_more_than_1024_draws_per_slot():
+    """per_image = 10 * ceil(0.15 R / M) (pixel_samplers.py:369) exceeds 1024 with few images or large batches (R = 4096 with M <= 5): the
+    slot's removed-pixel list is sized for the draws it really makes.  Kernel == oracle index for index beyond 1024 draws in one slot, no
+    repeats; and the sampler itself with M = 3."""
+    import ctypes as C
+
+    from oracle import ist_oracle as IO
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.pixel_samplers import DynamicBasedPixelSampler
+
+    gen = torch.Generator().manual_seed(8)
+    M, H, W = 2, 36, 40
+    w = (torch.rand(M, H, W, generator=gen) * 0.85 + 0.15).half().float()
+    w[1, :, ::3] = 0.0
+    cdf = torch.cumsum(w.reshape(M, -1), dim=1).contiguous()
+    nnz = (w.reshape(M, -1) > 0).sum(1).to(torch.int32)
+    chosen = torch.tensor([0, 1], dtype=torch.int64)
+    per_image, n = 1100, 1100 + 37  # slot 0: 1100 draws of 1440 pixels without replacement; slot 1: 37
+    u = torch.rand(n, generator=gen)
+    idx = torch.empty(n, 3, dtype=torch.int64, device=DEV)
+    keep = [cdf.to(DEV), chosen.to(DEV), nnz.to(DEV), u.to(DEV)]
+    _lib.check(_lib.lib().snerf_ist_sample(ops._ptr(keep[0]), H, W, ops._ptr(keep[1]), ops._ptr(keep[2]), per_image, ops._ptr(keep[3]), n, ops._ptr(idx),
+                                           ops._stream()))
+    idx = idx.cpu()
+    pix, img = IO.sample(cdf.numpy(), chosen.tolist(), nnz.numpy(), per_image, u.numpy())
+    assert torch.equal(idx[:, 0], torch.from_numpy(img)) and torch.equal(idx[:, 1] * W + idx[:, 2], torch.from_numpy(pix))
+    p0 = (idx[:per_image, 1] * W + idx[:per_image, 2]).tolist()
+    assert len(set(p0)) == per_image and torch.all(w[idx[:, 0], idx[:, 1], idx[:, 2]] > 0)
+    # the sampler with three images and the preset's batch: per_image = 2050, one slot of 614 draws
+    M, H, W, R = 3, 54, 96, 4096
+    maps = (torch.rand(M, H, W, generator=gen) > 0.5).half().to(DEV)
+    batch = {"image": torch.zeros(M, H, W, 3, dtype=torch.uint8, device=DEV), "image_idx": torch.arange(M, device=DEV), "ist_weights": maps,
+             "iter_steps": 5000}
+    smp = DynamicBasedPixelSampler(R, is_pixel_ratio=0.15, iters_to_start_ist=2000)
+    ind = smp.sample_method(R, M, H, W, batch=batch, device=DEV).cpu()
+    assert ind.shape == (R, 3)
+    ist = ind[:614]
+    assert len(set(ist[:, 0].tolist())) == 1 and bool((maps.cpu()[ist[:, 0], ist[:, 1], ist[:, 2]] > 0).all())
+    assert len(set((ist[:, 1] * W + ist[:, 2]).tolist())) == 614  # without replacement inside the image
+
+
 @pytest.mark.parametrize("tag,gamma", [("0_05", 5e-2), ("0_2", 2e-1)])
 @pytest.mark.parametrize("as_float", [False, True])
 def test_isg_maps_match_reference_golden(tag, gamma, as_float):

@@ -80,6 +80,21 @@ def test_g4_pdf_indices_exact(tag):
     close(bins_e, g[f"{tag}_eval_sbins"], atol=1e-6)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g4e_pdf_indices_exact_at_preset_sizes(tag):
+    """G4e (oracle/gen_golden_pdf_preset.py): the reference's PDFSampler on 512 rays at the preset's two levels (256 -> 128 -> 64), weights
+    from its own get_weights, annealed.  99 328 indices: the oracle's cumsum-normalised CDF (a documented deviation from the reference's
+    torch.sum, ray_samplers.py:305) flips none of them."""
+    g = load_golden("g4e_pdf_preset")
+    w, prev, rand = g[f"{tag}_weights"], g[f"{tag}_prev_sbins"], g[f"{tag}_rand"]
+    S, R = rand.shape[1] - 1, w.shape[0]
+    assert (R, w.shape[1], S) == ((512, 256, 128) if tag == "a" else (512, 128, 64))
+    bins, inds, _ = KO.pdf_sample(w, prev, KO.pdf_u(R, S, rand))
+    ref = g[f"{tag}_inds"].long()
+    assert int((inds != ref).sum()) == 0, f"{int((inds != ref).sum())} of {ref.numel()} indices differ from the reference's"
+    close(bins, g[f"{tag}_new_sbins"], rtol=0, atol=3e-6)
+
+
 def _g5_case(g, tag):
     C, n_scales, concat = [int(v) for v in g[f"{tag}_meta"]]
     grids = [[g[f"{tag}_plane_{s}_{p}"].clone().requires_grad_(True) for p in range(6)] for s in range(n_scales)]
