@@ -38,11 +38,11 @@ def parse():
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (k-planes preset: 4096)")
     ap.add_argument("--images", type=int, default=0, help="override the number of synthetic training images (default 19 cams x 33 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-standin", action="store_true", help="skip the stock-PyTorch-ROCm stand-in of the reference rate (N = 1 only; ~10 s)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel time table to stderr after the timed run")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (debug / A-B)")
     ap.add_argument("--start-step", type=int, default=0, help="pretend this many optimiser steps are done: >= 5000 gives the steady-state "
                     "schedule (proposal networks updated every 5th step, kplanes.py:254-259) instead of the every-step schedule of early training")
-    ap.add_argument("--adam-under-scatter", action="store_true", help="A-B: sweep the finest scale's planes while the coarser scales are scattered")
     ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
     ap.add_argument("--grad-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
                     "gradient on the links (fp32 = the reference's DDP semantics; bf16 halves the reduce-scatter bytes, opt-in)")
@@ -55,52 +55,65 @@ def parse():
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="A/B: product form of the field's sorted scatter (gradvec + 1 GB of per-plane gradient vectors) instead of the quotient form")
-    ap.add_argument("--fused-backward", action="store_true", help="opt-in: fused backward kernel as well (recomputed forward + both nets' backward + gradient vectors); measured slower, see profiles/r02_kernels.md")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
-    ap.add_argument("--prop-after-field", action="store_true", help="A-B: proposal backward behind the field scatter, beside the optimiser sweep")
-    ap.add_argument("--quotient-in-epilogue", action="store_true", help="A-B: G = gfeat .* feat in the sigma_net backward's epilogue instead of a pass of its own (measured slower)")
     ap.add_argument("--no-fused-ray-loss", action="store_true", help="A-B: the nerf level's weights / render / MSE / distortion / weights-backward as five kernels instead of one")
     ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
     ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(rays_per_step=256, steps=4):
-    """The oracle's K-Planes train step (fwd + autograd bwd + Adam) at the preset's plane sizes, on the host cores."""
-    from oracle import kplanes_oracle as KO  # the checker; only timed here, never on the product path
+    """The stock-PyTorch restatement of the reference's K-Planes train step (oracle/torch_standin.py: F.grid_sample per plane, Linear
+    stacks, autograd, torch.optim.Adam) on the host cores: a 256-ray slice of config 2 (the preset's planes) and config 1 itself
+    (BASELINE.md section 3)."""
+    from oracle import torch_standin as TS  # baseline / checker code; only timed here, never on the product path
 
     torch.manual_seed(0)
     # many small ops: beyond ~16 intra-op threads torch only adds synchronisation overhead (256 threads: 2000x slower)
     n_threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(n_threads)
-    P = KO.make_kplanes_params(base_res=(64, 64, 64, 100), multiscale=(1, 2, 4, 8, 16),
-                               prop_res=((128, 128, 128, 100), (256, 256, 256, 100)))
-    leaves = KO.all_param_tensors(P)
-    for x in leaves:
-        x.requires_grad_(True)
-    ms = [torch.zeros_like(x) for x in leaves]
-    vs = [torch.zeros_like(x) for x in leaves]
-    R = rays_per_step
-    dt = 0.0
-    for step in range(steps):
-        o = (torch.rand(R, 3) * 2 - 1) * 0.9
-        d = torch.nn.functional.normalize(torch.rand(R, 3) * 2 - 1, dim=-1)
-        rays = {"origins": o, "directions": d, "times": torch.rand(R, 1)}
-        rng = {"t_rand": torch.rand(R, 257), "u": [torch.rand(R, 129), torch.rand(R, 65)], "bg": torch.rand(R, 3)}
-        target = torch.rand(R, 3)
-        t0 = time.perf_counter()
-        out = KO.kplanes_forward(P, rays, rng, anneal=KO.anneal_value(step))
-        loss = sum(KO.kplanes_loss_dict(P, out, target).values())
-        for x in leaves:
-            x.grad = None
-        loss.backward()
-        with torch.no_grad():
-            for x, m, v in zip(leaves, ms, vs):
-                KO.adam_step(x, x.grad if x.grad is not None else torch.zeros_like(x), m, v, step + 1, 1e-2 * KO.cosine_lr_factor(step))
-        dt += time.perf_counter() - t0
-    return {"value": R * steps / dt, "unit": "rays/s", "cores": n_threads, "kind": "port",
-            "sample": f"{steps} full train steps (fwd+bwd+Adam, k-planes preset planes, fp32) of {R} rays each on the CPU oracle"}
+    c2 = TS.time_train_steps("cpu", rays_per_step, steps=steps, warmup=1, model=TS.PRESET)
+    c1 = TS.time_train_steps("cpu", 256, steps=20, warmup=2, model=TS.CONFIG1)
+    return {"value": c2["rays_per_s"], "unit": "rays/s", "cores": n_threads, "kind": "port",
+            "sample": f"{steps} full train steps (fwd + autograd bwd + torch.optim.Adam, k-planes preset planes = config 2, fp32) of {rays_per_step} rays each, "
+                      "stock PyTorch on the host cores (oracle/torch_standin.py)",
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch_threads": n_threads, "torch": torch.__version__,
+            "config1": {"value": c1["rays_per_s"], "unit": "rays/s", "ms_per_step": c1["seconds_per_step"] * 1e3,
+                        "sample": "BASELINE.json configs[0]: single scale (64,64,64,8), C=32, proposals (128^3,8)/(256^3,8), samples 256/128/64, 256 rays/step, "
+                                  "fp32, 20 full train steps after 2 warm-up"}}
+
+
+def reference_standin(dev, rays, hip_rays_per_s):
+    """BASELINE.md section 2's stand-in for the unpublished reference rate: the same algorithm in stock PyTorch-ROCm ops on THIS MI355X
+    (oracle/torch_standin.py), a handful of steps outside the HIP path's timed region.  fp32 and with the MLP matmuls under bf16 autocast
+    (the reference trains with mixed_precision=True); the ratio uses the FASTER of the two."""
+    from oracle import torch_standin as TS  # baseline code, never the product path
+
+    runs = {}
+    for name, ac in (("fp32", None), ("autocast_bf16", torch.bfloat16)):
+        try:
+            r = TS.time_train_steps(dev, rays, steps=8, warmup=3, model=TS.PRESET, autocast=ac)
+            runs[name] = {"rays_per_s": r["rays_per_s"], "ms_per_step": r["seconds_per_step"] * 1e3, "steps": r["steps"]}
+        except Exception as e:  # the stand-in must not take the bench line down
+            runs[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        torch.cuda.empty_cache()
+    ok = [v["rays_per_s"] for v in runs.values() if "rays_per_s" in v]
+    best = max(ok) if ok else None
+    return {"what": "stock PyTorch-ROCm K-Planes train step on the same MI355X: F.grid_sample per plane + Linear stacks + autograd + torch.optim.Adam, "
+                    f"k-planes preset, {rays} rays/step (BASELINE.md section 2: the stand-in for the reference's unpublished CUDA rate)",
+            "runs": runs, "value": best, "unit": "rays/s", "hip_over_standin": (hip_rays_per_s / best) if best else None,
+            "note": "vs_baseline stays null: BASELINE.md holds no published number for this metric; this ratio is the measured stand-in for north_star's >= 10x"}
 
 
 def main():
@@ -133,11 +146,20 @@ def main():
     from soccernerfs_amd import ops, synthetic
     from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
+    # what the collectives actually run on: read back from the live communicator (a SCALE record can check N ranks against it)
+    comm_info = {"backend": None, "world_size": 1, "note": "single process: no communicator"}
+    if world > 1:
+        import torch.distributed as dist
+
+        probe = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(probe)  # SUM of ones over the communicator = the number of ranks that really take part
+        comm_info = {"backend": dist.get_backend(pg) + (" (RCCL over xGMI)" if backend == "nccl" else ""), "world_size": dist.get_world_size(pg),
+                     "ranks_counted_by_all_reduce": int(probe.item()), "devices_visible": torch.cuda.device_count()}
+
     # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
     torch.manual_seed(20231029 + rank)
-    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field,
-                             fused_field_backward=args.fused_backward, quotient_scatter=not args.no_quotient_scatter,
-                             fused_ray_loss=not args.no_fused_ray_loss, quotient_in_epilogue=args.quotient_in_epilogue)  # the k-planes preset
+    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter,
+                             fused_ray_loss=not args.no_fused_ray_loss)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
@@ -148,9 +170,8 @@ def main():
 
             trainer.cabi_comm = CAbiComm(pg, dev)
     trainer.step = args.start_step
-    trainer.adam_under_scatter, trainer.async_field_adam = args.adam_under_scatter, not args.sync_adam
+    trainer.async_field_adam = not args.sync_adam
     trainer.prop_on_main = args.prop_on_main
-    trainer.prop_after_field = args.prop_after_field
     trainer.grad_transport = args.grad_transport
     trainer.param_transport = args.param_transport
 
@@ -214,7 +235,7 @@ def main():
         one_step()
     # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
     CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
-            "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_field_bwd", "kplanes_quotient_prepare"]
+            "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_quotient_prepare"]
     trainer.enable_kernel_timing(CAND)
     elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
@@ -272,8 +293,6 @@ def main():
             "kplanes_quotient_prepare": ("hbm", 3 * R * S2 * F * 4, "quotient_prepare_kernel: G = gfeat .* feat (two tensors read, one written)"),
             "kplanes_field_fwd": ("hbm", gather + R * S2 * (16 + 2 * F + 64),
                                   "field_fwd_kernel (gather + sigma_net + color_net fused): texel reads + density / rgb + the 16-bit feature tile and the 16 sigma_net outputs (kept for the backward) written"),
-            "kplanes_field_bwd": ("hbm", 2 * gather + R * S2 * (16 + 30 * cfg.feature_dim * (2 if args.mlp_operands != "fp32" else 4)),
-                                  "field_bwd_kernel (recomputed forward + both nets' backward + per-plane gradient vectors fused): texel reads x 2 + gvec written"),
             # proposal planes (C = 8, one scale): two launches per updated step (256 and 128 samples per ray) -> mean bytes per launch; runs on
             # its own stream beside the field backward, so its launches are stretched by whatever shares the GPU with them
             "kplanes_gather_bwd.prop": ("hbm", 2 * R * (sum(cfg.num_proposal_samples_per_ray) // 2) * 6 * 4 * cfg.proposal_feature_dim * 4,
@@ -312,6 +331,7 @@ def main():
                           + ("its quotient form (f32)" if trainer.quotient_scatter else f"its product form with {cfg.gvec_dtype} gradient vectors between the two passes")
                           + "; planes, sampling, compositing, losses, gradient accumulation and the optimiser are f32",
             "data": "synthetic",
+            "comm": comm_info,
             "config": {"workload": "K-Planes default multiscale-res 1-16 on synthetic Broadcast-style (k-planes preset: 4096 rays/GPU/step, "
                                    "samples 256/128/64, 5 scales x 6 planes C=32, 156.0 M params), full train step incl. Adam",
                        "schedule": "early training: proposal networks updated every 2nd step (every step for the first 10)" if args.start_step < 10 else
@@ -355,6 +375,9 @@ def main():
                     psnr[op] = {"source": os.path.basename(f), "error": str(e)}
         if psnr:
             line["psnr_30k"] = psnr
+        if world == 1 and not args.no_standin:
+            trainer.synchronize()
+            line["reference_standin"] = reference_standin(dev, R, line["value"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps)
         if breakdown:

@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 7
+#define SNERF_ABI_VERSION 8
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -193,56 +193,30 @@ int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * snerf_kplanes_field_fwd wrote.  The kernels round X to that type anyway, so results equal snerf_mlp_bwd on the fp32 image of X. */
 int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                       int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
-/* snerf_mlp_bwd_x16 with the quotient scatter's preparation folded into its epilogue (sigma_net of the K-Planes field: X16 = the feature
- * tile, d_in = 32 n_scales): beside gX it writes G = gX .* feat and lists every (sample, scale) row with an exactly-zero feature once --
- * what snerf_kplanes_quotient_prepare does in a pass of its own (see "Quotient form" below).  row_flags [N * d_in / 32] must be zero on
- * entry; snerf_kplanes_quotient_fixup clears the flags of the rows it handles, so the buffer is zeroed once, at allocation.  fix_count
- * must be 0 on entry; fix_count_next (may be NULL) is reset for the next step. */
-typedef struct {
-  const float* feat;        /* [N, d_in] fp32 features of the forward, row stride ldgx */
-  float* G;                 /* out [N, d_in], row stride ldgx */
-  int32_t* fix_list;
-  int32_t fix_capacity;
-  int32_t* fix_count;
-  int32_t* fix_count_next;
-  int32_t* row_flags;
-} snerf_quotient_epilogue;
-int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
-                               int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, const snerf_quotient_epilogue* q,
-                               snerf_stream_t stream);
 /* Same with the weight gradients accumulated into fixed-point cells (see snerf_kplanes_gather_bwd_fx). */
 int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                      int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Fused K-Planes field = KPlanesField.get_density + get_outputs (NS/fields/kplanes_field.py:275-358) in one kernel: plane gather
+ * Fused K-Planes field forward = KPlanesField.get_density + get_outputs (NS/fields/kplanes_field.py:275-358) in one kernel: plane gather
  * (interpolate_kplanes :77-126) -> sigma_net (32 n_scales -> 128 -> 16, :249-261) -> density = trunc_exp(column 15) (:308-311) and
  * color_net on the 15 geometry features (15 -> 64 -> 64 -> 3 Sigmoid, :263-273, disable_viewing_dependent) -> rgb.  The features, the
- * 16 sigma_net outputs and every MLP activation stay on chip.  Built for 4-D plane sets with C = 32, concatenated scales (<= 5), the two
- * net shapes above and 16-bit MFMA operands (snerf_mlp_desc.operands = 1 bf16 / 2 fp16, both nets alike): snerf_kplanes_field_supported
+ * 16 sigma_net outputs and every MLP activation stay on chip.  Built for 4-D plane sets with C = 32, concatenated scales (<= 6), the two
+ * net shapes above and 16-bit MFMA operands (snerf_mlp_desc.operands = 1 bf16 / 2 fp16, both nets alike): snerf_kplanes_field_fwd_supported
  * tells; the exact-fp32 path composes snerf_kplanes_gather_fwd + snerf_mlp_fwd.  Results are bit-identical to that composition run with the
- * same 16-bit operands.
+ * same 16-bit operands.  The backward runs unfused on what this kernel leaves behind (snerf_mlp_bwd, snerf_mlp_bwd_x16, the sorted scatter);
+ * a fused backward kernel existed in ABI v3-v7 and was removed in v8 (slower than the unfused kernels).
  *   fwd: density [N], rgb [N,3].  Optional (NULL = not written), for a training step that runs the UNFUSED backward kernels on what the
  *        forward already computed: feat16 [N, 32 n_scales] = the feature tile in the operand type (bf16 / fp16: exactly the values the
  *        MFMA consumed; 2 B per feature instead of the 4 B the unfused gather writes) for snerf_mlp_bwd_x16(sigma_net), and h [N,16] =
  *        the raw fp32 sigma_net outputs (color_net's input; column 15 = log density) for snerf_mlp_bwd(color_net); feat32
  *        [N, 32 n_scales] = the fp32 features before rounding, for the quotient form of the plane scatter (snerf_kplanes_quotient_*).
  *        The three come as a set: feat16 and h together (or neither), feat32 only with them.
- *   bwd: from g_density [N] and g_rgb [N,3]: recomputes the forward per tile, ACCUMULATES the weight gradients of both nets (flat layouts of
- *        snerf_mlp_*; float atomics, or fixed-point cells when the *_fx pointers are given instead) and writes the per-plane gradient
- *        vectors gvec[scale * 6 + plane][N][32] (fp32 or bf16) that snerf_kplanes_scatter_sorted consumes -- i.e. it replaces
- *        snerf_mlp_bwd x 2 + snerf_kplanes_gradvec; gfeat [N, 32 n_scales] never exists.
  * ------------------------------------------------------------------------------------------------ */
-int snerf_kplanes_field_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
-/* the forward alone is also built for six scales (d_in = 192) */
 int snerf_kplanes_field_fwd_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* sigma, const snerf_mlp_desc* color);
 int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                             const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
                             float* density, float* rgb, void* feat16, float* h, float* feat32, snerf_stream_t stream);
-int snerf_kplanes_field_bwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
-                            const snerf_mlp_desc* sigma, const float* W_sigma, const snerf_mlp_desc* color, const float* W_color,
-                            const float* g_density, const float* g_rgb, float* gW_sigma, float* gW_color, int64_t* gW_sigma_fx,
-                            int64_t* gW_color_fx, void* gvec, int32_t gvec_bf16, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Compositing and ray-level losses (one wavefront per ray, S <= 320).
@@ -605,8 +579,7 @@ int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const 
                                           float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
                                  const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
-                                 int32_t scale_begin, int32_t scale_end, int32_t* row_flags /* may be NULL: cleared for the handled rows */,
-                                 snerf_stream_t stream);
+                                 int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
 int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,

@@ -186,6 +186,12 @@ def get_weights(deltas, densities):
 COO_COMBS = list(itertools.combinations(range(4), 2))  # kplanes_field.py:61-65: XY XZ XT YZ YT ZT
 
 
+# True: `bilinear_plane` calls torch.nn.functional.grid_sample exactly as the reference's grid_sample_wrapper does
+# (NS/utils/interpolation.py:5-33) instead of the explicit restatement below.  Used by oracle/torch_standin.py (the stock-PyTorch
+# stand-in timed by bench.py) and by tests/test_oracle_golden.py, which checks the two routes against each other.
+USE_GRID_SAMPLE = False
+
+
 def bilinear_plane(plane, coords):
     """Bilinear, align_corners=True, padding 'border' sample of one plane.
 
@@ -194,6 +200,9 @@ def bilinear_plane(plane, coords):
     ix = ((x+1)/2)*(W-1) clipped to [0,W-1]; corners floor/floor+1; out-of-range corners add 0.
     Returns [N,C].
     """
+    if USE_GRID_SAMPLE:
+        out = torch.nn.functional.grid_sample(plane, coords.view(1, -1, 1, 2), align_corners=True, mode="bilinear", padding_mode="border")
+        return out[0, :, :, 0].t()  # [1,C,N,1] -> [N,C]
     _, C, H, W = plane.shape
     ix = ((coords[:, 0] + 1) / 2) * (W - 1)
     iy = ((coords[:, 1] + 1) / 2) * (H - 1)

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class KPlanesDesc(C.Structure):
@@ -66,11 +66,6 @@ class RenderArgs(C.Structure):
                 ("R", C.c_int32), ("S", C.c_int32), ("bg_mode", C.c_int32), ("training", C.c_int32),
                 ("rgb_out", C.c_void_p), ("acc_out", C.c_void_p), ("depth_median", C.c_void_p), ("depth_expected", C.c_void_p),
                 ("median_rgb", C.c_void_p), ("median_index", C.c_void_p)]
-
-
-class QuotientEpilogue(C.Structure):
-    _fields_ = [("feat", C.c_void_p), ("G", C.c_void_p), ("fix_list", C.c_void_p), ("fix_capacity", C.c_int32), ("fix_count", C.c_void_p),
-                ("fix_count_next", C.c_void_p), ("row_flags", C.c_void_p)]
 
 
 class RayTrainArgs(C.Structure):
@@ -205,17 +200,14 @@ EXPORTS = [
     "snerf_fx_to_float",
     "snerf_mlp_bwd_fx",
     "snerf_mlp_bwd_x16",
-    "snerf_mlp_bwd_x16_quotient",
     "snerf_adam_prepare",
     "snerf_depth_loss",
-    "snerf_kplanes_field_supported",
     "snerf_kplanes_field_fwd",
     "snerf_kplanes_field_fwd_supported",
     "snerf_kplanes_quotient_supported",
     "snerf_kplanes_quotient_prepare",
     "snerf_kplanes_scatter_quotient_scales",
     "snerf_kplanes_quotient_fixup",
-    "snerf_kplanes_field_bwd",
     "snerf_nerfplayer_mix_fwd",
     "snerf_nerfplayer_mix_bwd",
     "snerf_comm_unique_id",

@@ -8,6 +8,7 @@
 // the copy the host process has already loaded (PyTorch ships one with that SONAME) and keeps the library loadable on machines without a
 // GPU runtime (the CPU-side build / ABI checks).
 #include <dlfcn.h>
+#include <stdio.h>
 #include <rccl/rccl.h>
 
 #include "common.hpp"
@@ -21,6 +22,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   const char* (*GetErrorString)(ncclResult_t);
   bool ok;
+  char why[256];  // dlopen / dlsym diagnosis, captured once (dlerror() clears itself when read)
 };
 
 static RcclApi* rccl() {
@@ -28,13 +30,18 @@ static RcclApi* rccl() {
     RcclApi a = {};
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return a;
+    if (!h) {
+      const char* e = dlerror();
+      snprintf(a.why, sizeof(a.why), "%s", e ? e : "dlopen failed");
+      return a;
+    }
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+    if (!a.ok) snprintf(a.why, sizeof(a.why), "librccl is missing one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclGetErrorString");
     return a;
   }();
   return &api;
@@ -57,7 +64,7 @@ using namespace snerf;
 
 #define SNERF_NEED_RCCL(r)                                                                              \
   RcclApi* r = rccl();                                                                                  \
-  SNERF_REQUIRE(r->ok, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols")
+  SNERF_REQUIRE(r->ok, "RCCL (librccl.so.1) could not be loaded: %s", r->why)
 
 extern "C" int snerf_comm_unique_id(void* id128) {
   SNERF_REQUIRE(id128, "comm_unique_id: null buffer");

@@ -574,8 +574,7 @@ __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, con
 template <int NP>
 __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c, const float* __restrict__ gfeat,
                                                             const int32_t* __restrict__ list, const int32_t* __restrict__ count, int capacity,
-                                                            float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end,
-                                                            int32_t* __restrict__ row_flags) {
+                                                            float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end) {
   constexpr int C = 32;
   const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
   int n_list = *count;
@@ -585,7 +584,6 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc 
     const int64_t n = row / n_scales_total;
     const int s = row - (int)n * n_scales_total;
     if (s < scale_begin || s >= scale_end) continue;
-    if (row_flags && lane == 0) row_flags[row] = 0;  // the "already listed" mark of snerf_mlp_bwd_x16_quotient: handled exactly once, here
     float p[4];
     load_coords<NP>(c, n, p);
     AxisTap tap[4];
@@ -900,7 +898,7 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
 
 extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
                                             const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
-                                            int32_t scale_begin, int32_t scale_end, int32_t* row_flags, snerf_stream_t stream) {
+                                            int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
   int rc = check_desc(desc, coords, N);
   if (rc) return rc;
   rc = quotient_ok(desc, N);
@@ -912,9 +910,9 @@ extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, cons
   // a fixed small grid that strides over the (device-side) count: an empty list costs one launch
   hipStream_t st = (hipStream_t)stream;
   if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, fix_list, fix_count,
-                                              fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end, row_flags);
+                                              fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end);
   else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, fix_list, fix_count, fix_capacity,
-                          grad_planes, desc->n_scales, scale_begin, scale_end, row_flags);
+                          grad_planes, desc->n_scales, scale_begin, scale_end);
   SNERF_LAUNCH_CHECK("kplanes_quotient_fixup");
   return 0;
 }

@@ -38,8 +38,6 @@ struct MlpArgs {
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
   int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
-  // quotient epilogue (snerf_mlp_bwd_x16_quotient): G = gX .* qfeat written beside gX, rows with a zero feature listed once
-  const float* qfeat; float* qG; int32_t* qlist; int qcap; int32_t* qcount; int32_t* qcount_next; int32_t* qflags;
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
@@ -900,7 +898,7 @@ extern "C" int snerf_mlp_fwd(const snerf_mlp_desc* d, const float* W, const floa
 
 static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                         int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream,
-                        int x16 = 0, const snerf_quotient_epilogue* q = nullptr) {
+                        int x16 = 0) {
   MlpArgs a = {};
   int rc = fill(d, a);
   if (rc) return rc;
@@ -914,15 +912,6 @@ static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X,
   a.X = X; a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
   a.gWfx = gWfx;
   a.x16 = x16;
-  if (q) {
-    SNERF_REQUIRE(x16 && gX && d->d_in % 32 == 0, "mlp_bwd_x16_quotient: needs the 16-bit input form, gX and d_in a multiple of 32 (%d)", d->d_in);
-    SNERF_REQUIRE(q->feat && q->G && q->fix_count && q->row_flags && (q->fix_list || q->fix_capacity == 0) && q->fix_capacity >= 0,
-                  "mlp_bwd_x16_quotient: null epilogue buffer");
-    a.qfeat = q->feat; a.qG = q->G; a.qlist = q->fix_list; a.qcap = q->fix_capacity; a.qcount = q->fix_count; a.qcount_next = q->fix_count_next;
-    a.qflags = q->row_flags;
-    SNERF_REQUIRE((int64_t)q->fix_capacity >= N * (d->d_in / 32), "mlp_bwd_x16_quotient: fix_capacity %d < N * n_scales (a dropped row would keep its flag)",
-                  q->fix_capacity);
-  }
   SNERF_REQUIRE(!x16 || d->operands == 1 || d->operands == 2, "mlp_bwd_x16: a 16-bit input needs 16-bit operands (desc.operands = 1 / 2), got %d", d->operands);
   return dispatch(d, a, true, (hipStream_t)stream);
 }
@@ -940,13 +929,6 @@ extern "C" int snerf_mlp_bwd_fx(const snerf_mlp_desc* d, const float* W, const f
 extern "C" int snerf_mlp_bwd_x16(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                                  int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
   return mlp_bwd_impl(d, W, reinterpret_cast<const float*>(X16), ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream, 1);
-}
-
-extern "C" int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
-                                          int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, const snerf_quotient_epilogue* q,
-                                          snerf_stream_t stream) {
-  SNERF_REQUIRE(q, "mlp_bwd_x16_quotient: null epilogue");
-  return mlp_bwd_impl(d, W, reinterpret_cast<const float*>(X16), ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream, 1, q);
 }
 
 // One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid); K, M <= 128.

@@ -215,9 +215,10 @@ struct PlanB {
   static constexpr size_t BYTES = (size_t)TOTAL * 2;
 };
 
-// QEP: the quotient scatter's preparation in the gX epilogue (snerf_mlp_bwd_x16_quotient).  A template parameter, not a run-time branch: with
-// `if (a.qG)` in the unrolled epilogue EVERY instantiation paid for it (proposal nets 158 -> 256 VGPRs, sigma_net 196 -> 256 + spills).
-template <typename T, int K0, int H, int NH, int TS, bool X16 = false, bool QEP = false>
+// (Round 2 also formed the quotient scatter's G = gX .* feat in this kernel's gX epilogue: that instantiation needed 256 VGPRs + spills and the
+// step got slower -- profiles/r02_kernels.md section 10 -- so the separate quotient_prepare pass stayed and the variant was removed.  A lesson
+// kept: an optional epilogue must be a template parameter; as a run-time `if` EVERY instantiation paid its registers.)
+template <typename T, int K0, int H, int NH, int TS, bool X16 = false>
 __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -254,8 +255,6 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
   // columns 16..31 of gzo (the padded half of the K = 32 contraction) stay zero for the whole kernel
   for (int idx = threadIdx.x; idx < TS * 16; idx += blockDim.x) gzo[(idx / 16) * P::LKO + 16 + (idx % 16)] = (T)0.f;
   const bool relu = a.hidden_act == 1;
-  if constexpr (QEP)
-    if (a.qcount_next && blockIdx.x == 0 && threadIdx.x == 0) *a.qcount_next = 0;  // the other of the two alternating counters, for the next step
   f32x4 dW0[NB0] = {};
   f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
@@ -432,17 +431,6 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
               if (row0 + r < a.N && col < a.d0) {
                 const float gx = acc[m][r] * (1.f / GS);
                 a.gX[(row0 + r) * a.ldgx + col] = gx;
-                if constexpr (QEP) {  // quotient form of the plane scatter: G = gfeat .* feat formed here instead of by a pass of its own
-                  const float f = a.qfeat[(row0 + r) * a.ldgx + col];
-                  a.qG[(row0 + r) * a.ldgx + col] = gx * f;
-                  if (fabsf(f) < 1.17549435e-38f && gx != 0.f) {  // (sample, scale) row with a vanished feature (zero or subnormal, as quotient_prepare_kernel): listed ONCE (two column blocks share a row)
-                    const int64_t rs = (row0 + r) * (a.d0 / 32) + col / 32;
-                    if (atomicExch(a.qflags + rs, 1) == 0) {
-                      const int slot = atomicAdd(a.qcount, 1);
-                      if (slot < a.qcap) a.qlist[slot] = (int32_t)rs;
-                    }
-                  }
-                }
               }
           }
         }
@@ -502,17 +490,10 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
       if constexpr (H == 128 && NH == 1) {
         SNERF_REQUIRE(a.d0 == K0 && a.ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0,
                       "mlp_bwd_x16: needs d_in a multiple of 32 (%d), ldx a multiple of 8 (%d) and a 16-byte aligned X", a.d0, a.ldx);
-        if (a.qG) {
-          auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS, true, true>;
-          static bool attr_setq = false;
-          if (!attr_setq) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_setq = true; }
-          hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
-        } else {
-          auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS, true>;
-          static bool attr_set16 = false;
-          if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
-          hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
-        }
+        auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS, true>;
+        static bool attr_set16 = false;
+        if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
       } else {
         set_error("mlp_bwd_x16: 16-bit inputs are built for the d_in -> 128 -> d_out one-hidden-layer shapes (sigma_net), got hidden=%d n_hidden=%d", H, NH);
         return SNERF_ERR_UNSUPPORTED;

@@ -43,8 +43,6 @@ struct MlpArgs {  // same fields as mlp.hip's (filled there)
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
   int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
-  // quotient epilogue (snerf_mlp_bwd_x16_quotient): G = gX .* qfeat written beside gX, rows with a zero feature listed once
-  const float* qfeat; float* qG; int32_t* qlist; int qcap; int32_t* qcount; int32_t* qcount_next; int32_t* qflags;
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {

@@ -108,7 +108,6 @@ class SortedScatter:
             self.fix_counts = torch.zeros(2, dtype=torch.int32, device=device)  # used alternately: a prepare resets the other one for the next step
             self._fix_parity = 0
             self.fix_count = self.fix_counts[0:1]
-            self.row_flags = torch.zeros(max(rows, 1), dtype=torch.int32, device=device)  # "listed" marks of the epilogue form; the fix-up clears them
             self.gvec = None
         else:
             self.gvec = torch.empty(len(ps.resolutions) * ie.value * ps.C, dtype=gvec_dtype, device=device)  # [scale*planes+plane][N][C]
@@ -135,17 +134,6 @@ class SortedScatter:
                                                              self.fix_list.numel(), _ptr(self.fix_count), _ptr(self.fix_counts[1 - k:2 - k]), st),
                    "quotient_prepare")
 
-    def quotient_epilogue(self, feat) -> "_lib.QuotientEpilogue":
-        """Arguments for snerf_mlp_bwd_x16_quotient, which then stands for quotient_prepare (G and the zero-feature list come out of the
-        sigma_net backward's epilogue).  Call once per step, before that backward."""
-        k = self._fix_parity
-        self._fix_parity = 1 - k
-        self.fix_count = self.fix_counts[k:k + 1]
-        q = _lib.QuotientEpilogue()
-        q.feat, q.G, q.fix_list, q.fix_capacity = feat.data_ptr(), self.G.data_ptr(), self.fix_list.data_ptr(), self.fix_list.numel()
-        q.fix_count, q.fix_count_next, q.row_flags = self.fix_count.data_ptr(), self.fix_counts[1 - k:2 - k].data_ptr(), self.row_flags.data_ptr()
-        return q
-
     def quotient_scatter_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
         """Pass B + the exact terms of zero-feature rows for scales [scale_begin, scale_end); quotient_prepare must have run."""
         st = stream if stream is not None else _stream()
@@ -153,7 +141,7 @@ class SortedScatter:
         _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
                                                            scale_begin, scale_end, st), "scatter_quotient")
         _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gfeat), _ptr(self.fix_list),
-                                                  _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, _ptr(self.row_flags), st),
+                                                  _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, st),
                    "quotient_fixup")
 
     def scatter_quotient(self, planes, coords: _lib.Coords, gfeat, feat, gplanes, stream=None):

@@ -69,10 +69,8 @@ class KPlanesTrainConfig:
     # ---- execution switches (defaults = the measured best; bench.py / tools expose them for A-B runs) ----
     overlap: bool = True              # independent kernel chains on role streams (False: everything on the caller's stream)
     async_field_adam: bool = True     # field planes' optimiser sweep on its own stream under the NEXT step's proposal levels
-    adam_under_scatter: bool = False  # sweep the finest scale while the coarser scales are scattered (measured +1 %: off)
     bwd_chunks: int = 1               # ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)
     prop_on_main: bool = False        # proposal backward on the main stream ahead of the field chain
-    prop_after_field: bool = False    # proposal backward starts behind the field scatter and runs beside the optimiser sweep
     defer_prop: bool = True           # join the proposal chain only in front of the proposal planes' own optimiser kernels
     fused_ray_loss: bool = True       # train_step: the nerf level's weights / render / MSE / distortion / weights-backward as ONE launch
     #                                   (snerf_ray_train_fwd_bwd: bit-identical to the five kernels, ~0.08 ms less on the critical path)
@@ -96,17 +94,11 @@ class KPlanesTrainConfig:
     # gather + sigma_net + color_net at the preset (profiles/r02_kernels.md).  Falls back to the unfused kernels when the shape / operand
     # type is outside what the fused kernel is built for (fp32 operands: the parity path).
     fused_field: bool = True
-    # recomputed forward -> both nets' backward -> per-plane gradient vectors as ONE kernel: feat / h / gfeat never reach HBM.  OPT-IN:
-    # parity-tested but measured SLOWER (2.5 vs 0.9 ms: 256 VGPRs + 0.5 KB of spills per lane leave it 8 waves / CU).  Needs the sorted
-    # scatter and the whole batch in one chunk.
-    fused_field_backward: bool = False
     # Quotient form of the field's sorted scatter (csrc/kplanes_sorted.hip, include/snerf.h): the gradient of plane q is (gfeat .* feat) ./ v_q
     # with v_q re-interpolated by pass B, so the second gather of all 30 planes and the 1 GB of per-plane gradient vectors (gradvec) go away:
     # ~1.6 GB less HBM traffic per step.  Equal to the product form to a few ulp (pass B recomputes the forward's v_q bit for bit; rows with an
     # exactly-zero feature take an exact fix-up).  Needs the sorted scatter, C = 32 and no deterministic mode; False = product form (A-B).
     quotient_scatter: bool = True
-    quotient_in_epilogue: bool = False  # opt-in (A-B): G and the zero-feature list from the sigma_net backward's epilogue instead of a pass of
-    #                                     their own -- measured SLOWER (2.84 vs 2.63 ms: that instantiation needs 256 VGPRs + spills; profiles/r02_kernels.md section 10)
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -152,10 +144,9 @@ class KPlanesTrainer:
         # synchronize() join it for outside readers -- call synchronize() before reading parameters / Adam state / gradients from
         # outside a train step.  +3-5 % (bench.py --sync-adam for A-B).
         self.overlap, self.bwd_chunks = cfg.overlap, cfg.bwd_chunks
-        self.prop_on_main, self.defer_prop, self.prop_after_field = cfg.prop_on_main, cfg.defer_prop, cfg.prop_after_field
-        self.async_field_adam, self.adam_under_scatter = cfg.async_field_adam, cfg.adam_under_scatter
+        self.prop_on_main, self.defer_prop = cfg.prop_on_main, cfg.defer_prop
+        self.async_field_adam = cfg.async_field_adam
         self._field_adam_done = None
-        self._q_in_epilogue = False
         self._reg_in_adam = False
         self._render_deferred = False
         self._prop_pending = None
@@ -164,7 +155,7 @@ class KPlanesTrainer:
         self.cabi_comm = None  # dist.CAbiComm: route the unsharded all-reduce through libsnerf's own RCCL communicator (bench.py --cabi-allreduce)
         self._fwd_fused = False
         self._grad_scale = 1.0
-        self._pipeline_adam, self._early_adam_hi, self._reg_zeroed = False, None, False
+        self._reg_zeroed = False
         self._dyn_step = 0
         self._ar_work = self._reg_work = None
         self._side = {}  # role -> HIP stream, created on first use
@@ -263,7 +254,7 @@ class KPlanesTrainer:
         # sorted plane-gradient scatter for the main field (csrc/kplanes_sorted.hip): ~6x fewer atomic requests
         self.sorted_scatter = cfg.sorted_scatter
         self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[cfg.gvec_dtype]
-        self.quotient_scatter = bool(cfg.quotient_scatter and self.sorted_scatter and not cfg.deterministic and not cfg.fused_field_backward
+        self.quotient_scatter = bool(cfg.quotient_scatter and self.sorted_scatter and not cfg.deterministic
                                      and cfg.gvec_dtype == "fp32" and self.lib_quotient_ok(R * S2))
         self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype, quotient=self.quotient_scatter)
         self._ss.desc = self.field_planes.desc()
@@ -281,9 +272,6 @@ class KPlanesTrainer:
         self._desc_prop = [p.desc() for p in self.prop_planes]
         self.fused_field = bool(cfg.fused_field and self.lib.snerf_kplanes_field_fwd_supported(
             C.byref(self._desc_field), C.byref(self.sigma_net.desc), C.byref(self.color_net.desc)))
-        self.fused_field_backward = bool(self.fused_field and cfg.fused_field_backward and self.sorted_scatter and not cfg.deterministic
-                                         and self.lib.snerf_kplanes_field_supported(C.byref(self._desc_field), C.byref(self.sigma_net.desc),
-                                                                                    C.byref(self.color_net.desc)))
         if self.fused_field:  # the forward's operand-typed feature tile, kept for the unfused backward (snerf_mlp_bwd_x16)
             dt16 = torch.bfloat16 if self.sigma_net.desc.operands == 1 else torch.float16
             self.buf["feat16"] = torch.empty(R * self.S[2], self.field_planes.out_dim, dtype=dt16, device=self.dev)
@@ -383,13 +371,8 @@ class KPlanesTrainer:
         _lib.check(self.lib.snerf_mlp_fwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(Y), ldy, aux_col,
                                           self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
 
-    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, x16=False, quotient=None):
+    def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, x16=False):
       with self._span(f"mlp_bwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
-        if quotient is not None:  # sigma_net with the quotient scatter's preparation in its epilogue (G, zero-feature rows)
-            _lib.check(self.lib.snerf_mlp_bwd_x16_quotient(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
-                                                           self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
-                                                           self._p(gX), ldgx, self._p(self.gviews[gname]), C.byref(quotient), self._st), "mlp_bwd_x16_quotient")
-            return
         fn = self.lib.snerf_mlp_bwd_fx if self.grads_fx is not None else (self.lib.snerf_mlp_bwd_x16 if x16 else self.lib.snerf_mlp_bwd)
         if x16 and self.grads_fx is not None:  # deterministic mode: the fixed-point kernel takes fp32 inputs (exact image of the 16-bit tile)
             X = X.float()
@@ -469,12 +452,10 @@ class KPlanesTrainer:
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
                 self._wait_params()
-                # fused backward: only when it will run as ONE chunk over the sorted scatter; otherwise the fused forward leaves the
-                # feature tile (16-bit) and the sigma_net outputs behind for the unfused backward kernels
-                n_chunks = max(1, min(self.bwd_chunks, R)) if self.overlap and not self._sharded() else 1
+                # a training step's fused forward leaves the feature tile (16-bit), the sigma_net outputs and (quotient scatter) the fp32 features
+                # behind for the unfused backward kernels
                 self._fwd_fused = self.fused_field
-                self._bwd_fused = training and self.fused_field_backward and R == self.R and n_chunks == 1
-                keep = training and not self._bwd_fused
+                keep = training
                 if self._fwd_fused:
                     with self._span("kplanes_field_fwd"):
                         _lib.check(self.lib.snerf_kplanes_field_fwd(C.byref(self._desc_field), self._p(self.field_planes.planes), C.byref(co), C.c_int64(N),
@@ -573,33 +554,19 @@ class KPlanesTrainer:
         b, S2, F = self.buf, self.S[2], self.field_planes.out_dim
         n0, N = r0 * S2, (r1 - r0) * S2
         sl = lambda t: t[n0:n0 + N]
-        fused = self._fwd_fused and self._bwd_fused
-        assert not fused or (r0 == 0 and r1 == self.R and self._sort_done is not None), "fused field backward needs the whole batch and the sorted scatter"
-        if not fused:
-            # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
-            self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
-            # quotient scatter behind a fused forward: G = gfeat .* feat and the zero-feature list come out of this kernel's epilogue
-            self._q_in_epilogue = bool(self.quotient_scatter and self._fwd_fused and self.grads_fx is None and r0 == 0 and r1 == self.R
-                                       and self.sorted_scatter and self._sort_done is not None and self.cfg.quotient_in_epilogue)
-            self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
-                          sl(b["gfeat"]), F, x16=self._fwd_fused, quotient=self._ss.quotient_epilogue(b["feat"]) if self._q_in_epilogue else None)
+        # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
+        self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
+        self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
+                      sl(b["gfeat"]), F, x16=self._fwd_fused)
         rays = self.rays
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
         if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:
             torch.cuda.current_stream().wait_event(self._sort_done)
             ss = self._ss
-            if fused:  # recomputed forward -> both nets' backward -> gradient vectors, one kernel
-                with self._span("kplanes_field_bwd"):
-                    _lib.check(self.lib.snerf_kplanes_field_bwd(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
-                                                                C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), C.byref(self.color_net.desc),
-                                                                self._p(self.color_net.params), self._p(b["gdens"][2]), self._p(b["grgb"]),
-                                                                self._p(self.gviews["field.sigma"]), self._p(self.gviews["field.color"]), None, None,
-                                                                self._p(ss.gvec), ss.gvec_bf16, self._st), "kplanes_field_bwd")
-            elif self.quotient_scatter:
-                if not self._q_in_epilogue:
-                    with self._span("kplanes_quotient_prepare"):
-                        ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
-                if self.world == 1 and self._reg_in_adam and not self._pipeline_adam:
+            if self.quotient_scatter:
+                with self._span("kplanes_quotient_prepare"):
+                    ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
+                if self.world == 1 and self._reg_in_adam:
                     # the optimiser sweep's two tiny forerunners (skip decision of the group, zeroed regulariser slots) depend on nothing pass B
                     # produces: issued here they are off the scatter -> sweep hand-over
                     cfgl = self.cfg
@@ -612,7 +579,6 @@ class KPlanesTrainer:
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
                                                           self._p(b["gfeat"]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
             ns = len(self.cfg.multiscale_res)
-            early = self._pipeline_adam and ns > 1
             if self._sharded() and len(self._exchange) == 2:
                 # finest scale first: its reduce-scatter (chunk 0) is on the links while the coarser scales are still being scattered
                 self._scatter_field_scales(co, ns - 1, ns)
@@ -621,12 +587,7 @@ class KPlanesTrainer:
                 self._start_field_grad_exchange(1)
                 self._exchange_started = True
                 return
-            # finest scale first: it holds ~3/4 of the plane parameters, so its optimiser sweep (HBM-bound) can start on a side
-            # stream while the other scales are still being scattered (atomic-bound)
-            if early:
-                self._scatter_field_scales(co, ns - 1, ns)
-                self._adam_field_range(self._finest_offset(), None, side=True)
-            self._scatter_field_scales(co, 0, ns - 1 if early else ns)
+            self._scatter_field_scales(co, 0, ns)
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
 
@@ -718,7 +679,6 @@ class KPlanesTrainer:
                 self._proposal_backward(proposal_grads)
             joins.append(st)
 
-        late_prop = self.prop_after_field and n_chunks == 1  # proposal backward behind the field scatter, i.e. beside the optimiser sweep
         target = ops._f32c(target, "target")
         if target.numel() != 3 * R:
             raise RuntimeError(f"target must be [{R}, 3], got {tuple(target.shape)}")
@@ -738,10 +698,10 @@ class KPlanesTrainer:
             ra.g_weights, ra.nonfinite_flag = None, self._dyn["fields"].data_ptr()
             with self._span("ray_train_fwd_bwd"):
                 _lib.check(self.lib.snerf_ray_train_fwd_bwd(C.byref(ra), self._st), "ray_train_fwd_bwd")
-            if overlap and not sharded and not late_prop:
+            if overlap and not sharded:
                 proposal_chain()
         else:
-            if overlap and not sharded and not late_prop:
+            if overlap and not sharded:
                 proposal_chain()
             # MSELoss (kplanes.py:418) folded into the render backward: g_rgb_out = 2 c / (3R) * (rgb_out - target); value lazily from sqerr
             _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
@@ -765,8 +725,6 @@ class KPlanesTrainer:
                 self._exchange_started = False
                 if overlap:
                     proposal_chain(after=main.record_event())
-            elif overlap and late_prop:
-                proposal_chain(after=main.record_event())  # waits for the field scatter; the optimiser sweep (own stream) starts at the same point
             if not overlap:
                 self._proposal_backward(proposal_grads)
         else:
@@ -1010,7 +968,6 @@ class KPlanesTrainer:
         st.wait_stream(cur)
         with KPlanesTrainer._On(self, st), self._span("adam_planes.field"):
             ops.adam_planes_step(*args, **kw)
-        self._early_adam_hi = lo  # optimizer_step still owes [0, lo)
 
     def allreduce_grads(self):
         """One all-reduce (SUM) over the flat gradient buffer; the mean (DDP semantics, base_pipeline.py:244-246) is folded
@@ -1049,21 +1006,14 @@ class KPlanesTrainer:
         new = self._params_alt
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         sl = lambda t, name: t[off[name][0]:off[name][0] + off[name][1]]
-        early_hi = self._early_adam_hi
-        self._early_adam_hi = None
         async_field = self.async_field_adam and self.overlap
-        if early_hi is None:
-            if not self._reg_zeroed:
-                self.buf["reg"].zero_()
-            # async: the big sweep goes to the "adam" stream and is NOT joined here -- the next step's pixel draw, ray generation and
-            # proposal levels (which read only the small segments updated below) run under it; forward() joins before the field gather
-            self._adam_field_range(0, None, side=async_field)
-            self._early_adam_hi = None
-            if async_field:
-                self._field_adam_done = self._stream("adam").record_event()
-        else:  # the finest scale is already being swept on the "adam" stream (train_step pipelining): the coarser scales remain
-            self._adam_field_range(0, early_hi, side=False)
-            torch.cuda.current_stream().wait_stream(self._stream("adam"))
+        if not self._reg_zeroed:
+            self.buf["reg"].zero_()
+        # async: the big sweep goes to the "adam" stream and is NOT joined here -- the next step's pixel draw, ray generation and
+        # proposal levels (which read only the small segments updated below) run under it; forward() joins before the field gather
+        self._adam_field_range(0, None, side=async_field)
+        if async_field:
+            self._field_adam_done = self._stream("adam").record_event()
         self._reg_zeroed = False
         self._join_prop()  # the proposal gradients are needed from here on
         self._prepare_group("fields", lr)
@@ -1107,16 +1057,8 @@ class KPlanesTrainer:
         defer = bool(cfg.fused_ray_loss and (depth is None or co.get("depth_loss", 0) <= 0))
         out = self.forward(rays, rng, anneal, training=True, defer_render=defer)
         fuse = self.fuse_reg_into_adam
-        # single GPU: no gradient exchange between scatter and optimiser, so the optimiser sweep of the finest scale overlaps the scatter
-        # of the coarser ones
-        self._pipeline_adam = (fuse and self.world == 1 and not self._sharded() and self.sorted_scatter and self.overlap
-                               and self.adam_under_scatter)
-        if self._pipeline_adam:
-            self.buf["reg"].zero_()
-            self._reg_zeroed = True
         self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
                       defer_prop_join=fuse and self.world == 1 and self.defer_prop, depth=depth)
-        self._pipeline_adam = False
         if self._sharded():
             self._sharded_optimizer_step()
         else:

@@ -1,8 +1,7 @@
-"""GPU parity of the fused K-Planes field kernels (csrc/field_fused.hip: gather -> sigma_net -> colour net in one kernel, and the
-recomputed forward -> both nets' backward -> per-plane gradient vectors in one kernel) against
+"""GPU parity of the fused K-Planes field forward (csrc/field_fused.hip: gather -> sigma_net -> colour net in one kernel) against
 
-* the UNFUSED composition with the same 16-bit MFMA operands (snerf_kplanes_gather_fwd + snerf_mlp_fwd x 2; snerf_mlp_bwd x 2 +
-  snerf_kplanes_gradvec): density / rgb bit for bit, gradient vectors and weight gradients to accumulation-order noise;
+* the UNFUSED composition with the same 16-bit MFMA operands (snerf_kplanes_gather_fwd + snerf_mlp_fwd x 2): density / rgb and the
+  tensors left behind for the unfused backward bit for bit;
 * the fp32 CPU oracle restating KPlanesField (NS/fields/kplanes_field.py:275-358) within SURVEY 8d's bf16 tolerance
   (density rtol 2e-2, rgb atol 4e-3);
 * whole training steps: the fused trainer path against the unfused one."""
@@ -57,7 +56,6 @@ def test_fused_field_forward(ms, N, operands):
     L = _lib.lib()
     desc = ps.desc()
     assert L.snerf_kplanes_field_fwd_supported(C.byref(desc), C.byref(sigma.desc), C.byref(color.desc)) == 1
-    assert L.snerf_kplanes_field_supported(C.byref(desc), C.byref(sigma.desc), C.byref(color.desc)) == int(len(ms) <= 5)  # six scales: forward only
     co = ops.coords_from_points(pts)
     dens, rgb = torch.full((N,), -1.0, device=DEV), torch.full((N, 3), -1.0, device=DEV)
     _lib.check(L.snerf_kplanes_field_fwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
@@ -84,65 +82,17 @@ def test_fused_field_forward(ms, N, operands):
     torch.testing.assert_close(rgb.cpu(), want_rgb, rtol=0, atol=4e-3)
 
 
-@pytest.mark.parametrize("operands,gvec_dtype", [("bf16", torch.float32), ("bf16", torch.bfloat16), ("fp16", torch.float32)])
-@pytest.mark.parametrize("ms,N", [((1, 2, 4, 8, 16), 4099), ((1, 2), 777)])
-def test_fused_field_backward(ms, N, operands, gvec_dtype):
-    from soccernerfs_amd import _lib, ops
-
-    ps, sigma, color, pts = _setup(ms, N, operands, seed=3)
-    L = _lib.lib()
-    desc = ps.desc()
-    co = ops.coords_from_points(pts)
-    gen = torch.Generator().manual_seed(9)
-    gdens = ((torch.rand(N, generator=gen) - 0.5) * 1e-2).to(DEV)
-    grgb = ((torch.rand(N, 3, generator=gen) - 0.5) * 1e-2).to(DEV)
-    NSP = len(ms) * 6
-    bf = int(gvec_dtype == torch.bfloat16)
-    # ---- unfused reference with the same operand type ----
-    feat, h, _, _ = _unfused_forward(ps, sigma, color, pts)
-    gh, gfeat = torch.zeros(N, 16, device=DEV), torch.empty(N, ps.out_dim, device=DEV)
-    gws_u, gwc_u = torch.zeros_like(sigma.params), torch.zeros_like(color.params)
-    _lib.check(L.snerf_mlp_bwd(C.byref(color.desc), ops._ptr(color.params), ops._ptr(h), 16, C.c_int64(N), ops._ptr(grgb), 3, -1, None, ops._ptr(gh), 16,
-                               ops._ptr(gwc_u), ops._stream()))
-    _lib.check(L.snerf_mlp_bwd(C.byref(sigma.desc), ops._ptr(sigma.params), ops._ptr(feat), ps.out_dim, C.c_int64(N), ops._ptr(gh), 16, 15, ops._ptr(gdens),
-                               ops._ptr(gfeat), ps.out_dim, ops._ptr(gws_u), ops._stream()))
-    gvec_u = torch.empty(NSP * N * 32, dtype=gvec_dtype, device=DEV)
-    _lib.check(L.snerf_kplanes_gradvec(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), ops._ptr(gfeat), ops._ptr(gvec_u), bf, ops._stream()))
-    # ---- fused ----
-    gws, gwc = torch.zeros_like(sigma.params), torch.zeros_like(color.params)
-    gvec = torch.full((NSP * N * 32,), 7.0, dtype=gvec_dtype, device=DEV)
-    _lib.check(L.snerf_kplanes_field_bwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
-                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(gdens), ops._ptr(grgb), ops._ptr(gws), ops._ptr(gwc), None, None,
-                                         ops._ptr(gvec), bf, ops._stream()))
-    torch.cuda.synchronize()
-    rel = lambda u, v: float((u.float() - v.float()).norm() / (v.float().norm() + 1e-30))
-    # gradient vectors: the unfused path rounds gh (colour-net dX) to fp32 in HBM and back to 16 bits when the sigma backward stages it, the
-    # fused one keeps the 16-bit tile: identical values; the feature gradient itself goes through fp32 in both
-    assert rel(gvec, gvec_u) < (2e-3 if bf else 2e-4), rel(gvec, gvec_u)
-    torch.testing.assert_close(gvec.float(), gvec_u.float(), rtol=2e-2 if bf else 1e-3, atol=1e-3 * float(gvec_u.float().abs().max()))
-    # weight gradients: same products, different tile -> workgroup assignment and flush order
-    assert rel(gws, gws_u) < 1e-4 and rel(gwc, gwc_u) < 1e-4, (rel(gws, gws_u), rel(gwc, gwc_u))
-    # deterministic (fixed-point) accumulation of the weight gradients gives the same sums
-    gws_fx, gwc_fx = torch.zeros(gws.numel(), dtype=torch.int64, device=DEV), torch.zeros(gwc.numel(), dtype=torch.int64, device=DEV)
-    _lib.check(L.snerf_kplanes_field_bwd(C.byref(desc), ops._ptr(ps.planes), C.byref(co), C.c_int64(N), C.byref(sigma.desc), ops._ptr(sigma.params),
-                                         C.byref(color.desc), ops._ptr(color.params), ops._ptr(gdens), ops._ptr(grgb), None, None, ops._ptr(gws_fx),
-                                         ops._ptr(gwc_fx), ops._ptr(gvec), bf, ops._stream()))
-    out = torch.zeros_like(gws)
-    ops.fx_to_float(gws_fx, out)
-    assert rel(out, gws_u) < 1e-4
-
-
 def test_fused_and_unfused_training_steps_agree():
-    """Three train steps (bf16 operands) with the fused forward + unfused backward (the default), with the fused backward as well, and with
-    cfg.fused_field = False: rendered colours bit for bit at step 0, parameters to atomic-order noise afterwards."""
+    """Three train steps (bf16 operands) with the fused forward + unfused backward (the default) and with cfg.fused_field = False:
+    rendered colours bit for bit at step 0, parameters to atomic-order noise afterwards."""
     from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
     small = dict(aabb_scale=1.5, spacetime_resolution=(16, 16, 16, 4), multiscale_res=(1, 2), feature_dim=32,
                  proposal_resolutions=((24, 24, 24, 4), (32, 32, 32, 4)), proposal_feature_dim=8, num_proposal_samples_per_ray=(64, 32),
                  num_nerf_samples_per_ray=16, warm_up_end=2, mlp_operands="bf16")
     R = 256
-    trs = [KPlanesTrainer(KPlanesTrainConfig(**small, fused_field=f, fused_field_backward=fb), R, DEV) for f, fb in ((True, False), (False, False), (True, True))]
-    assert trs[0].fused_field and not trs[0].fused_field_backward and not trs[1].fused_field and trs[2].fused_field_backward
+    trs = [KPlanesTrainer(KPlanesTrainConfig(**small, fused_field=f), R, DEV) for f in (True, False)]
+    assert trs[0].fused_field and not trs[1].fused_field
     gen = torch.Generator().manual_seed(2)
     g = lambda z: z.to(DEV).contiguous()
     for step in range(3):
@@ -154,14 +104,13 @@ def test_fused_and_unfused_training_steps_agree():
                "bg": g(torch.rand(R, 3, generator=gen))}
         outs = [tr.train_step(rays, target, rng).clone() for tr in trs]
         if step == 0:
-            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[1])
+            assert torch.equal(outs[0], outs[1])
         else:
             torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=2e-3)
-            torch.testing.assert_close(outs[2], outs[1], rtol=0, atol=2e-3)
     for tr in trs:
         tr.synchronize()
     ld1 = trs[1].loss_dict()
-    for tr in (trs[0], trs[2]):
+    for tr in (trs[0],):
         assert float((tr.params - trs[1].params).abs().mean()) < 2e-5
         ld0 = tr.loss_dict()
         for k in ld0:
@@ -169,4 +118,3 @@ def test_fused_and_unfused_training_steps_agree():
     # eval forward (no backward): fused as well
     rgb = [tr.forward(rays, None, 1.0, training=False).clone() for tr in trs]
     torch.testing.assert_close(rgb[0], rgb[1], rtol=0, atol=2e-3)
-    torch.testing.assert_close(rgb[2], rgb[1], rtol=0, atol=2e-3)

@@ -287,52 +287,3 @@ def test_backward_from_16bit_input_equals_backward_from_its_fp32_image(operands)
         res.append((gx, gw))
     assert torch.equal(res[0][0], res[1][0])
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * float(res[0][1].abs().max()))
-
-
-def test_sigma_backward_with_quotient_epilogue_equals_backward_plus_prepare():
-    """snerf_mlp_bwd_x16_quotient = snerf_mlp_bwd_x16 + snerf_kplanes_quotient_prepare: same gX and weight gradients, G bit for bit, the same
-    set of zero-feature rows (each listed once although two column blocks share a (sample, scale) row); the fix-up clears the row marks."""
-    import ctypes as C
-
-    from soccernerfs_amd import _lib, ops
-    from soccernerfs_amd.plane_set import PlaneSet
-    from soccernerfs_amd.tcnn_compat import Network
-
-    ns, N = 5, 3001
-    gen = torch.Generator().manual_seed(9)
-    net = Network(32 * ns, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 1},
-                  operands="bf16").to(DEV)
-    ps = PlaneSet(32, [[6 * m, 5 * m, 4 * m, 3] for m in (1, 2, 3, 4, 6)], concat=True, generator=gen).to(DEV)
-    feat = (torch.rand(N, 32 * ns, generator=gen) - 0.3).to(DEV)
-    feat[torch.rand(N, 32 * ns, generator=gen).to(DEV) < 0.01] = 0.0  # vanished features
-    feat[7] = 0.0
-    x16 = feat.to(torch.bfloat16)
-    gy = (torch.rand(N, 16, generator=gen) - 0.5).to(DEV)
-    gaux = (torch.rand(N, generator=gen) - 0.5).to(DEV)
-    L = _lib.lib()
-    pts = (torch.rand(N, 4, generator=gen) * 2 - 1).to(DEV)
-    co = ops.coords_from_points(pts)
-    # reference: backward, then the prepare pass
-    ssA = ops.SortedScatter(ps, N, DEV, quotient=True)
-    gxA, gwA = torch.empty(N, 32 * ns, device=DEV), torch.zeros_like(net.params)
-    _lib.check(L.snerf_mlp_bwd_x16(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x16), 32 * ns, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux),
-                                   ops._ptr(gxA), 32 * ns, ops._ptr(gwA), ops._stream()))
-    ssA.quotient_prepare(gxA, feat)
-    nA = int(ssA.fix_count.item())
-    # epilogue form, twice (the two counters alternate; the second call must start from a clean count)
-    ssB = ops.SortedScatter(ps, N, DEV, quotient=True)
-    for rep in range(2):
-        gxB, gwB = torch.empty(N, 32 * ns, device=DEV), torch.zeros_like(net.params)
-        q = ssB.quotient_epilogue(feat)
-        _lib.check(L.snerf_mlp_bwd_x16_quotient(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x16), 32 * ns, C.c_int64(N), ops._ptr(gy), 16, 15,
-                                                ops._ptr(gaux), ops._ptr(gxB), 32 * ns, ops._ptr(gwB), C.byref(q), ops._stream()))
-        nB = int(ssB.fix_count.item())
-        assert torch.equal(gxA, gxB) and torch.equal(ssA.G, ssB.G)
-        torch.testing.assert_close(gwA, gwB, rtol=1e-4, atol=1e-5 * float(gwA.abs().max()))
-        assert nA == nB and nA > N // 10
-        assert torch.equal(torch.sort(ssA.fix_list[:nA]).values, torch.sort(ssB.fix_list[:nB]).values)
-        assert int(ssB.row_flags.sum()) == nB
-        # the fix-up (any planes: only its bookkeeping is looked at here) clears the marks of what it handled
-        ssB.sort(co)
-        ssB.quotient_scatter_scales(ps.planes, co, gxB, torch.zeros_like(ps.planes), 0, ns)
-        assert int(ssB.row_flags.sum()) == 0

@@ -102,6 +102,24 @@ def _g5_case(g, tag):
 
 
 @pytest.mark.parametrize("tag", ["single", "multi", "prop"])
+def test_g5_through_the_grid_sample_route(tag):
+    """oracle/torch_standin.py (the stock-PyTorch stand-in bench.py times) switches `bilinear_plane` to torch's own grid_sample, the call the
+    reference makes (NS/utils/interpolation.py:5-33): same features and plane gradients as the reference's G5 output."""
+    g = load_golden("g5_interp")
+    grids, concat = _g5_case(g, tag)
+    KO.USE_GRID_SAMPLE = True
+    try:
+        feats = KO.interpolate_kplanes(g[f"{tag}_pts"], grids, concat)
+    finally:
+        KO.USE_GRID_SAMPLE = False
+    close(feats, g[f"{tag}_feats"], rtol=1e-5, atol=1e-6)
+    feats.backward(g[f"{tag}_gout"])
+    for s, pl in enumerate(grids):
+        for p, t in enumerate(pl):
+            close(t.grad, g[f"{tag}_grad_{s}_{p}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["single", "multi", "prop"])
 def test_g5_interpolate_kplanes(tag):
     g = load_golden("g5_interp")
     grids, concat = _g5_case(g, tag)

@@ -7,11 +7,11 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python bench.py --no-cpu-baseline --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null
+python bench.py --no-cpu-baseline --no-standin --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --images 38 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 > /dev/null 2>&1
 done
 cd $ROOT
 python - <<PY

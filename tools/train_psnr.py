@@ -65,7 +65,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     torch.manual_seed(seed)
     random.seed(seed)
     cfg = KPlanesTrainConfig(max_steps=args.schedule_steps, mlp_operands=args.mlp_operands, seed=seed, deterministic=args.deterministic,
-                             nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, fused_field_backward=args.fused_backward, quotient_scatter=not args.no_quotient_scatter, gvec_dtype=args.gvec_dtype,
+                             nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter, gvec_dtype=args.gvec_dtype,
                              sigma_operands=args.sigma_operands, color_operands=args.color_operands, proposal_operands=args.proposal_operands)
     R = 4096
     trainer = KPlanesTrainer(cfg, R, dev)
@@ -130,7 +130,6 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="fixed-point gradient accumulation: bit-identical reruns")
     ap.add_argument("--nonfinite-policy", default="skip_step", choices=["skip_step", "drop_elements"])
     ap.add_argument("--no-fused-field", action="store_true", help="unfused forward kernels")
-    ap.add_argument("--fused-backward", action="store_true", help="fused backward kernel as well")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="product form of the field's sorted scatter")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
     args = ap.parse_args()
@@ -151,7 +150,7 @@ def main():
     log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps,
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
            "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
-           "fused_field": not args.no_fused_field, "fused_field_backward": args.fused_backward, "quotient_scatter": not args.no_quotient_scatter,
+           "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
            "eval_sets": {"camera_20": "20th arc camera (reference 'all' split eval camera; extrapolated view), %d frames" % len(sets["camera_20"][1]),
                          "novel": "3 evaluation-only cameras between training cameras (interpolated views), %d images" % len(sets["novel"][1]),
                          "train": "4 training images"},
