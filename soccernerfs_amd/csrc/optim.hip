@@ -6,39 +6,9 @@
 // torch.optim.Adam as configured at NS/configs/method_configs.py:546-557 (lr 1e-2, eps 1e-12).
 // Both are HBM-bound streaming passes over every parameter: float4 per lane, channel-last planes so the
 // +-1 row/column neighbours are other lanes' lines (L2 hits).
-#include "common.hpp"
+#include "plane_adam_common.hpp"
 
 namespace snerf {
-
-struct RegArgs {
-  snerf_kplanes_desc d;
-  int blk_off[SNERF_MAX_SCALES][6];  // first workgroup of each plane (prefix sum), 256 float4-lanes per workgroup
-  int n_planes;                      // 6 or 3
-  const float* planes;
-  float* grad;                       // may be null (values only)
-  float c_tv, c_smooth, c_l1;        // loss coefficients folded into the gradient
-  float* losses;                     // [n_slots][16]: per-slot partial sums (cols 0..2), UNSCALED
-  int n_slots;
-  // fused Adam (adam_planes_kernel): the regulariser gradient never touches HBM; parameters ping-pong p_in -> p_out because the
-  // sweep reads +-1/+-2 neighbours of the OLD parameters
-  float* p_out; float* m; float* v;
-  float step_size, b1, b2, inv_sqrt_bc2, eps, grad_scale;
-  int zero_grad;
-  int overwrite;                     // 1: grad = reg gradient (buffer known to be zero), 0: grad += reg gradient
-  // optimiser sharding (one rank updates floats [range_lo, range_hi) of the segment): the grid starts at workgroup blk_base
-  int blk_base;
-  int64_t range_lo, range_hi;
-  snerf_adam_dyn* dyn;               // device-side step state (snerf_adam_prepare); null: step_size / inv_sqrt_bc2 above are used
-};
-
-// Device-side optimiser state of one parameter group (snerf.h: snerf_adam_dyn).  The kernels read {step_size, inv_sqrt_bc2, skip} from
-// it when given, so that a step can be skipped (the reference's GradScaler semantics) without the host ever reading the flag.
-struct DynConsts { float step_size, inv_sqrt_bc2; int skip; };
-__device__ __forceinline__ DynConsts load_dyn(const snerf_adam_dyn* dyn, float step_size, float inv_sqrt_bc2) {
-  DynConsts c = {step_size, inv_sqrt_bc2, 0};
-  if (dyn) { c.step_size = dyn->step_size; c.inv_sqrt_bc2 = dyn->inv_sqrt_bc2; c.skip = dyn->skip; }
-  return c;
-}
 
 __global__ void adam_prepare_kernel(snerf_adam_dyn* dyn, float lr, float b1, float b2, int policy, int force_nonfinite) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -54,22 +24,6 @@ __global__ void adam_prepare_kernel(snerf_adam_dyn* dyn, float lr, float b1, flo
   dyn->inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
 }
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ldnt4(const float* p) {
-  const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ void stnt4(float* p, float4 v) {
-  nt_f4 w = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(w, reinterpret_cast<nt_f4*>(p));
-}
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 mul4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
-__device__ __forceinline__ float sq4(float4 a) { return a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w; }
-__device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
-
 template <int C, bool ADAM>
 __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
   // locate this workgroup's plane
@@ -82,10 +36,8 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
       for (int pp = a.n_planes - 1; pp >= 0; --pp)
         if (b >= a.blk_off[ss][pp]) { s = ss; p = pp; found = true; break; }
   }
-  constexpr int PA6[6] = {0, 0, 0, 1, 1, 2}, PB6[6] = {1, 2, 3, 2, 3, 3};
-  constexpr int PA3[3] = {0, 0, 1}, PB3[3] = {1, 2, 2};
-  const int ax = a.n_planes == 6 ? PA6[p] : PA3[p];
-  const int bx = a.n_planes == 6 ? PB6[p] : PB3[p];
+  int ax, bx;
+  plane_axes(a.n_planes, p, ax, bx);
   const int W = a.d.res[s][ax], H = a.d.res[s][bx];
   const bool time_plane = (a.n_planes == 6) && (bx == 3);  // planes 2,4,5: H = time
   constexpr int C4 = C / 4;
@@ -102,42 +54,7 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
     const float* base = a.planes + a.d.off[s][p] + c4 * 4;
     auto at = [&](int hh, int ww) { return ld4(base + ((int64_t)hh * W + ww) * C); };
     const float4 t = at(h, w);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    // ---- total variation: w direction always; h direction only on space-only planes ----
-    const float n_w = (float)C * (float)H * (float)(W - 1);
-    if (W > 1) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (w + 1 < W) { float4 d = sub4(at(h, w + 1), t); l_tv += sq4(d) / n_w; acc = sub4(acc, d); }
-      if (w > 0) { float4 d = sub4(t, at(h, w - 1)); acc = add4(acc, d); }
-      g = add4(g, mul4(acc, 2.f * a.c_tv / n_w));
-    }
-    if (!time_plane && H > 1) {
-      const float n_h = (float)C * (float)(H - 1) * (float)W;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (h + 1 < H) { float4 d = sub4(at(h + 1, w), t); l_tv += sq4(d) / n_h; acc = sub4(acc, d); }
-      if (h > 0) { float4 d = sub4(t, at(h - 1, w)); acc = add4(acc, d); }
-      g = add4(g, mul4(acc, 2.f * a.c_tv / n_h));
-    }
-    if (time_plane) {
-      // ---- smoothness: second difference along h (= time); d2[k] = t[k+2] - 2 t[k+1] + t[k], k in [0, H-3] ----
-      if (H > 2) {
-        const float n_s = (float)C * (float)(H - 2) * (float)W;
-        auto d2 = [&](int k) {  // valid for 0 <= k <= H-3
-          float4 x0 = at(k, w), x1 = at(k + 1, w), x2 = at(k + 2, w);
-          return make_float4(x2.x - 2.f * x1.x + x0.x, x2.y - 2.f * x1.y + x0.y, x2.z - 2.f * x1.z + x0.z, x2.w - 2.f * x1.w + x0.w);
-        };
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (h <= H - 3) { float4 v = d2(h); l_sm += sq4(v) / n_s; acc = add4(acc, v); }          // t[h] enters d2[h] with +1
-        if (h >= 1 && h - 1 <= H - 3) { float4 v = d2(h - 1); acc = add4(acc, mul4(v, -2.f)); }  // d2[h-1] with -2
-        if (h >= 2) { float4 v = d2(h - 2); acc = add4(acc, v); }                                 // d2[h-2] with +1
-        g = add4(g, mul4(acc, 2.f * a.c_smooth / n_s));
-      }
-      // ---- sparse transients: mean |1 - t| ----
-      const float n_a = (float)C * (float)H * (float)W;
-      l_l1 += (fabsf(1.f - t.x) + fabsf(1.f - t.y) + fabsf(1.f - t.z) + fabsf(1.f - t.w)) / n_a;
-      const float k = -a.c_l1 / n_a;
-      g = add4(g, make_float4(k * sgn(1.f - t.x), k * sgn(1.f - t.y), k * sgn(1.f - t.z), k * sgn(1.f - t.w)));
-    }
+    const float4 g = plane_reg_grad<C>(at, t, h, w, H, W, time_plane, a.c_tv, a.c_smooth, a.c_l1, l_tv, l_sm, l_l1);
     if (ADAM) {
       const int64_t o = a.d.off[s][p] + ((int64_t)h * W + w) * C + c4 * 4;
       // g, m, v are touched exactly once per step: stream them past the caches (nontemporal) so that L2 keeps the parameter lines
@@ -147,18 +64,9 @@ __global__ __launch_bounds__(256) void plane_reg_kernel(RegArgs a) {
         stnt4(a.p_out + o, t);
         if (a.zero_grad) stnt4(a.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));
       } else {
-      float4 gg = ldnt4(a.grad + o), mm = ldnt4(a.m + o), vv = ldnt4(a.v + o), pp = t;
-      const float4 gz = gg;
-      float* P = &pp.x; float* G = &gg.x; float* M = &mm.x; float* V = &vv.x; const float* RG = &g.x;
-      int ndrop = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float gk = G[k] * a.grad_scale + RG[k];
-        if (!(fabsf(gk) <= 3.402823466e+38f)) { gk = 0.f; ++ndrop; }  // a non-finite gradient element is dropped (and counted), never written into m / v / p
-        M[k] = a.b1 * M[k] + (1.f - a.b1) * gk;
-        V[k] = a.b2 * V[k] + (1.f - a.b2) * gk * gk;
-        P[k] = P[k] - dc.step_size * (M[k] / (sqrtf(V[k]) * dc.inv_sqrt_bc2 + a.eps));
-      }
+      float4 mm = ldnt4(a.m + o), vv = ldnt4(a.v + o), pp = t;
+      const float4 gz = ldnt4(a.grad + o);
+      const int ndrop = adam_float4(pp, mm, vv, gz, g, a.grad_scale, a.b1, a.b2, a.eps, dc);
       if (ndrop && a.dyn) atomicAdd(&a.dyn->dropped, ndrop);
       stnt4(a.p_out + o, pp);
       stnt4(a.m + o, mm);
@@ -326,7 +234,7 @@ extern "C" int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* plan
   return 0;
 }
 
-static void adam_consts(float lr, float beta1, float beta2, int step, float& step_size, float& inv_sqrt_bc2) {
+void snerf::adam_consts(float lr, float beta1, float beta2, int step, float& step_size, float& inv_sqrt_bc2) {
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   step_size = (float)((double)lr / bc1);
   inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));

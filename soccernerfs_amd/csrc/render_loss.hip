@@ -223,10 +223,20 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const float* __restrict
   if (lane == 0 && live && loss_rays) loss_rays[r] = total;
   __syncthreads();
   if (g_wprop) {
+    // d loss / d w_prop[j] = sum of g_i over the nerf intervals whose envelope [lo_i, hi_i] holds j.  Both bounds are searchsorted results of
+    // ascending queries, i.e. non-decreasing in i, so those intervals are ONE contiguous range [a_j, b_j]: a_j = first i with hi_i >= j,
+    // b_j = last i with lo_i <= j (two binary searches), summed in ascending i -- the order (and therefore the bits) of the dense
+    // "for every i: if (lo_i <= j <= hi_i)" loop this replaces, in O(S + Sp) instead of O(S Sp) LDS reads per ray.
+    const int* slo = s_lo[wv];
+    const int* shi = s_hi[wv];
     for (int j = lane; j < Sp; j += 64) {
+      int a = 0, e = S;
+      while (a < e) { const int mid = (a + e) >> 1; if (shi[mid] < j) a = mid + 1; else e = mid; }   // a = first i with hi_i >= j
+      int b = 0;
+      e = S;
+      while (b < e) { const int mid = (b + e) >> 1; if (slo[mid] <= j) b = mid + 1; else e = mid; }  // b = first i with lo_i > j
       float acc = 0.f;
-      for (int i = 0; i < S; ++i)
-        if (s_lo[wv][i] <= j && j <= s_hi[wv][i]) acc += s_g[wv][i];
+      for (int i = a; i < b; ++i) acc += s_g[wv][i];
       if (live) g_wprop[(int64_t)r * Sp + j] = acc * grad_scale;
     }
   }
