@@ -591,7 +591,7 @@ int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* pl
  *   fix_count (may be NULL): device counter of snerf_kplanes_quotient_prepare; when > 0, snerf_kplanes_quotient_fixup must have run for this scale
  *   into g -- the kernel adds g where it is non-zero and clears it.  g is not read otherwise (may be NULL with fix_count NULL).
  *   losses / n_slots, the coefficients, lr .. dyn: as snerf_adam_planes_step (the regulariser VALUES of this scale's planes are added to losses).
- *   tile_shape: 0 = 16 x 8 texels (default), 1 = 32 x 8, 2 = 16 x 16, 3 = 16 x 4.
+ *   tile_shape (texels x threads per workgroup): 0 = 16 x 8 x 512 (default); A-B: 1 = 16 x 4 x 512, 2 = 16 x 4 x 256, 3 = 32 x 4 x 512, 4 = 16 x 8 x 256.
  * ------------------------------------------------------------------------------------------------ */
 int snerf_kplanes_scatter_adam_supported(const snerf_kplanes_desc* desc, int32_t scale, int64_t N);
 int snerf_kplanes_scatter_adam_scale(const snerf_kplanes_desc* desc, int32_t scale, int64_t N, const float* G, const float* sorted_rec,

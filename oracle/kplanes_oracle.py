@@ -113,7 +113,7 @@ def spaced_bins(num_rays: int, num_samples: int, t_rand: Optional[torch.Tensor])
 
     t_rand None = eval (no jitter); else [R,S+1] or [R,1] (single_jitter) uniform draws.
     """
-    bins = torch.linspace(0.0, 1.0, num_samples + 1)[None, :]
+    bins = torch.linspace(0.0, 1.0, num_samples + 1, device=t_rand.device if t_rand is not None else None)[None, :]
     if t_rand is not None:
         centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
         upper = torch.cat([centers, bins[..., -1:]], -1)
@@ -162,7 +162,7 @@ def pdf_sample(weights, existing_bins, u, histogram_padding: float = 0.01, eps: 
 def pdf_u(num_rays: int, num_samples: int, rand: Optional[torch.Tensor]):
     """u for the PDF sampler: ray_samplers.py:316-327. rand None = eval; else [R,S+1] or [R,1]."""
     nb = num_samples + 1
-    u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb)
+    u = torch.linspace(0.0, 1.0 - (1.0 / nb), steps=nb, device=rand.device if rand is not None else None)
     if rand is not None:
         u = u.expand(num_rays, nb) + rand / nb
     else:
@@ -338,7 +338,7 @@ def render_accumulation(weights):
 def median_index(weights):
     """searchsorted(cumsum(w), 0.5, left) clamped; renderers.py:264-267 and :312-315."""
     cw = torch.cumsum(weights, dim=-1)
-    split = torch.full((weights.shape[0], 1), 0.5)
+    split = torch.full((weights.shape[0], 1), 0.5, device=weights.device)
     idx = torch.searchsorted(cw, split, side="left")
     return torch.clamp(idx, 0, weights.shape[-1] - 1)
 

@@ -81,6 +81,11 @@ class KPlanesTrainConfig:
     exchange_chunks: int = 2          # world > 1, sharded: 2 = finest scale exchanged on its own, ahead of the rest (1: one exchange)
     grad_transport: str = "fp32"      # world > 1, sharded: "bf16" halves the reduce-scatter bytes (not the reference's fp32 DDP)
     param_transport: str = "fp32"     # world > 1, sharded: "bf16" gathers the parameter UPDATES in bf16
+    # Single-GPU EMULATION of the two half-width transports' numerics (tools/train_psnr.py --emulate-transports; PSNR studies without a
+    # multi-GPU node): "grad" rounds the field-plane gradient to bf16 before Adam (what a bf16 reduce-scatter hands the optimiser; one
+    # rounding, where W ranks' ring sum makes ~log W of them), "param" applies new = old + bf16(new - old) to the field planes (exactly the bf16
+    # update gather), "both".  Slow path: the plain sweep, no tile kernel.
+    emulate_transports: str = ""
     # fixed-point (int64) gradient accumulation instead of float atomics: sums no longer depend on the order in which wavefronts
     # arrive, so two runs from one seed are bit-identical (debugging / reproducibility; ~2x slower steps)
     deterministic: bool = False
@@ -102,7 +107,7 @@ class KPlanesTrainConfig:
     # Owner-computes scatter + optimiser sweep for the FINEST scale (csrc/kplanes_tile_adam.hip; 72 % of the preset's parameters): a workgroup owns
     # a tile of texels, sums the sorted entries of the cells that touch it in LDS and applies regularisers + Adam from there -- that scale's
     # gradient plane never reaches HBM (24 instead of 32 B / parameter) and needs no float atomics.  Single GPU, quotient scatter, regularisers
-    # inside the sweep (train_step); anything else takes pass B + the plain sweep.  tile_adam_shape: 0 = 16 x 8 texels (A-B: 1, 2, 3).
+    # inside the sweep (train_step); anything else takes pass B + the plain sweep.  tile_adam_shape: 0 = 16 x 8 texels x 512 threads (A-B: 1 .. 4, include/snerf.h).
     tile_adam: bool = True
     tile_adam_shape: int = 0
 
@@ -265,7 +270,9 @@ class KPlanesTrainer:
                                      and cfg.gvec_dtype == "fp32" and self.lib_quotient_ok(R * S2))
         self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype, quotient=self.quotient_scatter)
         self._ss.desc = self.field_planes.desc()
-        self.tile_adam = bool(cfg.tile_adam and self.quotient_scatter and self.world == 1 and cfg.fuse_reg_into_adam
+        if cfg.emulate_transports not in ("", "grad", "param", "both"):
+            raise ValueError(f"emulate_transports must be '', 'grad', 'param' or 'both', got {cfg.emulate_transports!r}")
+        self.tile_adam = bool(cfg.tile_adam and self.quotient_scatter and self.world == 1 and cfg.fuse_reg_into_adam and not cfg.emulate_transports
                               and self._ss.scatter_adam_supported(len(cfg.multiscale_res) - 1))
         self._sort_done = None
         # sorted scatter for the proposal planes too (opt-in; measured SLOWER at the preset: the planes are small enough that their
@@ -992,9 +999,9 @@ class KPlanesTrainer:
         """First float of the finest scale's planes inside the field-plane segment (planes are laid out scale-major)."""
         return int(self._desc_field.off[len(self.cfg.multiscale_res) - 1][0])
 
-    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool):
+    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool, role: str = "adam"):
         """Fused Adam + regularisers over floats [lo, hi) of the field planes, old -> other half of the ping-pong pair.  side=True:
-        on the "adam" stream, ordered after everything issued so far on the current stream (the scatter of those planes)."""
+        on the side stream `role`, ordered after everything issued so far on the current stream (the scatter of those planes)."""
         cfg, co = self.cfg, self.cfg.loss_coefficients
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
         n4 = _align4(self.field_planes.numel)
@@ -1010,7 +1017,7 @@ class KPlanesTrainer:
                 ops.adam_planes_step(*args, **kw)
             return
         cur = torch.cuda.current_stream()
-        st = self._stream("adam")
+        st = self._stream(role)
         st.wait_stream(cur)
         with KPlanesTrainer._On(self, st), self._span("adam_planes.field"):
             ops.adam_planes_step(*args, **kw)
@@ -1057,12 +1064,25 @@ class KPlanesTrainer:
             self.buf["reg"].zero_()
         # async: the big sweep goes to the "adam" stream and is NOT joined here -- the next step's pixel draw, ray generation and
         # proposal levels (which read only the small segments updated below) run under it; forward() joins before the field gather
+        emu = self.cfg.emulate_transports if self.world == 1 else ""
+        if emu in ("grad", "both"):
+            gv = self.gviews["field.planes"]
+            gv.copy_(gv.to(torch.bfloat16))
         if self._tile_adam_issued:  # the finest scale's planes are already being updated by the owner-computes kernel: the coarser scales remain
             self._tile_adam_issued = False
             if self._finest_offset() > 0:
-                self._adam_field_range(0, self._finest_offset(), side=async_field)
+                # the coarser scales' sweep must not queue up behind the tile kernel (same "adam" stream): it goes to the "sort" stream, idle
+                # since the counting sort finished under the MLP backward, and the "adam" stream -- whose event forward() waits for -- joins it
+                self._adam_field_range(0, self._finest_offset(), side=async_field, role="sort")
+                if async_field:
+                    self._stream("adam").wait_stream(self._stream("sort"))
         else:
             self._adam_field_range(0, None, side=async_field)
+        if emu in ("param", "both"):  # new = old + bf16(new - old) on the field planes, on the stream that ran the sweep
+            o_, n_ = next((o, n) for name, _, _, o, n in self.segments if name == "field.planes")
+            with KPlanesTrainer._On(self, self._stream("adam") if async_field else torch.cuda.current_stream()):
+                old_, new_ = self.params[o_:o_ + n_], self._params_alt[o_:o_ + n_]
+                new_.copy_(old_ + (new_ - old_).to(torch.bfloat16).float())
         if async_field:
             self._field_adam_done = self._stream("adam").record_event()
         self._reg_zeroed = False

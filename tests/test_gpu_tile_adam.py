@@ -27,12 +27,12 @@ def _setup(base, ms, N, seed=0, spread=1.05, zero_texels=False):
     if zero_texels:
         s = len(ms) - 1
         res = ps.resolutions[s]
-        with torch.no_grad():  # exact zeros at the finest scale, with samples placed exactly on them (one zero plane per sample: the fix-up's case)
-            ps.plane_view(s, 0)[1, 2, :] = 0.0   # XY plane: y texel 1, x texel 2
-            ps.plane_view(s, 2)[1, 3, :] = 0.0   # XT plane: t texel 1, x texel 3
+        with torch.no_grad():  # exact zeros at the finest scale: all four texels of a cell, so every sample inside it sees v = 0 exactly
+            ps.plane_view(s, 0)[1:3, 2:4, :] = 0.0   # XY plane: y texels 1-2, x texels 2-3 (one zero plane per sample: the fix-up's case)
+            ps.plane_view(s, 2)[1:3, 4:6, :] = 0.0   # XT plane: t texels 1-2, x texels 4-5
         tex = lambda i, n: 2.0 * i / (n - 1) - 1.0
-        pts[0, 0], pts[0, 1] = tex(2, res[0]), tex(1, res[1])
-        pts[1, 0], pts[1, 3] = tex(3, res[0]), tex(1, res[3])
+        pts[0, 0], pts[0, 1] = tex(2.5, res[0]), tex(1.5, res[1])
+        pts[1, 0], pts[1, 3] = tex(4.5, res[0]), tex(1.5, res[3])
     gfeat = (torch.rand(N, ps.out_dim, device=DEV, generator=gen) - 0.5) * 1e-2
     feat = ops.interpolate_kplanes(pts.contiguous(), ps).detach()
     return ps, pts.contiguous(), gfeat, feat
@@ -69,7 +69,7 @@ def _tile_path(ps, ss, co, gfeat, m0, v0, step, lr, tile_shape, dyn=None):
     return p_out, m, v, losses, g
 
 
-@pytest.mark.parametrize("tile_shape", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile_shape", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("base,ms,N", [((12, 10, 9, 6), (1, 2, 4), 20000), ((33, 17, 40, 7), (1,), 9000), ((16, 16, 16, 5), (1, 2), 257)])
 def test_tile_kernel_equals_pass_b_plus_sweep(base, ms, N, tile_shape):
     from soccernerfs_amd import ops

@@ -89,13 +89,16 @@ def main():
     res["sweep_all_ms"] = timeit(lambda: ops.adam_planes_step(ps, p_in, p_alt, g, m, v, coefs, losses, tr.step + 1, lr, eps=cfg.adam_eps))
     res["sweep_coarse_ms"] = timeit(lambda: ops.adam_planes_step(ps, p_in, p_alt, g, m, v, coefs, losses, tr.step + 1, lr, eps=cfg.adam_eps, shard_range=(0, lo)))
     res["sweep_finest_ms"] = timeit(lambda: ops.adam_planes_step(ps, p_in, p_alt, g, m, v, coefs, losses, tr.step + 1, lr, eps=cfg.adam_eps, shard_range=(lo, n + 3 & ~3)))
-    for shape in (0, 1, 2, 3):
+    for shape in (0, 1, 2, 3, 4):
         m.copy_(m0), v.copy_(v0)
         res[f"tile_adam_shape{shape}_ms"] = timeit(lambda: ss.scatter_adam_scale(fin, p_in, p_alt, g, m, v, coefs, losses, tr.step + 1, lr, eps=cfg.adam_eps, tile_shape=shape))
+    for dbg in (1, 2, 3):  # timing bisection of the default shape (results are wrong in these modes): no walk / records only / walk without LDS adds
+        m.copy_(m0), v.copy_(v0)
+        res[f"tile_adam_shape0_debug{dbg}_ms"] = timeit(lambda: ss.scatter_adam_scale(fin, p_in, p_alt, g, m, v, coefs, losses, tr.step + 1, lr, eps=cfg.adam_eps, tile_shape=dbg << 8))
     # the same kernel on an EMPTY batch (every tile takes the streaming path): the kernel's floor
     hist0 = ss.hist.clone()
     ss.hist.fill_(ss.N * 6)  # every cell starts at the end of the records: all counts are zero
-    for shape in (0, 3):
+    for shape in (0, 1, 2):
         res[f"tile_adam_shape{shape}_empty_ms"] = timeit(lambda: _empty(ss, fin, p_in, p_alt, g, m, v, coefs, losses, tr, lr, cfg, shape))
     ss.hist.copy_(hist0)
     gb = lambda ms, b: round(b / (ms * 1e-3) / 1e12, 2)
