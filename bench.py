@@ -234,7 +234,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
-    CAND = ["adam_planes.field", "kplanes_tile_adam.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
+    CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
             "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_quotient_prepare"]
     trainer.enable_kernel_timing(CAND)
     elapsed = timed(one_step, args.steps)
@@ -260,7 +260,7 @@ def main():
     alone = None
     if trainer.async_field_adam and not trainer._sharded():
         trainer.async_field_adam = False
-        trainer.enable_kernel_timing(["adam_planes.field", "kplanes_tile_adam.field"])
+        trainer.enable_kernel_timing(["adam_planes.field"])
         for _ in range(20):
             one_step()
         torch.cuda.synchronize()
@@ -284,14 +284,8 @@ def main():
         F = cfg.feature_dim * len(cfg.multiscale_res)
         alg = {
             "adam_step": ("hbm", 32 * trainer.n_params, "adam_kernel: p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
-            "adam_planes.field": ("hbm", 32 * (trainer._field_seg[2] // world if trainer._sharded() else
-                                               (trainer._finest_offset() if trainer.tile_adam else trainer.field_planes.numel)),
+            "adam_planes.field": ("hbm", 32 * (trainer._field_seg[2] // world if trainer._sharded() else trainer.field_planes.numel),
                                   "plane_reg_kernel<32,true> (Adam + K-Planes regularisers fused, field planes): p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
-            # owner-computes scatter + Adam of the finest scale: its data gradient never exists in HBM, so what the formulation must move is p, m, v
-            # read + written (24 B / parameter) and the scatter's inputs (per plane and sample one 128-B row of G and one 16-B sorted record)
-            "kplanes_tile_adam.field": ("hbm", 24 * (trainer.field_planes.numel - trainer._finest_offset()) + 6 * R * S2 * (4 * cfg.feature_dim + 16),
-                                        "tile_scatter_adam_kernel<6,16,8> (pass B of the finest scale + plane regularisers + Adam, gradient tile in LDS): p,m,v read + "
-                                        "p,m,v written = 24 B/param of the finest scale + 144 B per (sample, plane) of scatter input"),
             "kplanes_scatter_sorted.field": ("hbm", 2 * gather, "scatter_sorted_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),

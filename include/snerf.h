@@ -580,25 +580,6 @@ int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const 
 int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
                                  const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
                                  int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
-/* ------------------------------------------------------------------------------------------------
- * Owner-computes scatter + optimiser sweep for ONE scale (csrc/kplanes_tile_adam.hip): pass B of the quotient scatter, the plane
- * regularisers' gradient and Adam in one kernel, for the scale whose resolutions equal the sort grid (the finest scale: 72 % of the k-planes
- * preset's parameters).  A workgroup owns a tile of texels, finds the cells that touch it in the sort's scanned histogram (sort_hist as
- * snerf_kplanes_sort_samples left it: the entries of cell k are sorted_rec[hist[k] .. hist[k+1])), sums their contributions G / v_q in LDS
- * and updates p, m, v from there: this scale's data gradient never reaches HBM (24 B / parameter instead of the sweep's 32; no float atomics).
- * Same arithmetic as snerf_kplanes_scatter_quotient_scales + snerf_adam_planes_step_range on that scale, up to the order of the gradient sums.
- *   p_in / p_out / g / m / v: the plane SET's buffers (segment base, as snerf_adam_planes_step); only the scale's planes are touched.
- *   fix_count (may be NULL): device counter of snerf_kplanes_quotient_prepare; when > 0, snerf_kplanes_quotient_fixup must have run for this scale
- *   into g -- the kernel adds g where it is non-zero and clears it.  g is not read otherwise (may be NULL with fix_count NULL).
- *   losses / n_slots, the coefficients, lr .. dyn: as snerf_adam_planes_step (the regulariser VALUES of this scale's planes are added to losses).
- *   tile_shape (texels x threads per workgroup): 0 = 16 x 8 x 512 (default); A-B: 1 = 16 x 4 x 512, 2 = 16 x 4 x 256, 3 = 32 x 4 x 512, 4 = 16 x 8 x 256.
- * ------------------------------------------------------------------------------------------------ */
-int snerf_kplanes_scatter_adam_supported(const snerf_kplanes_desc* desc, int32_t scale, int64_t N);
-int snerf_kplanes_scatter_adam_scale(const snerf_kplanes_desc* desc, int32_t scale, int64_t N, const float* G, const float* sorted_rec,
-                                     const int32_t* sort_hist, const int32_t* fix_count, const float* p_in, float* p_out, float* g, float* m, float* v,
-                                     float c_space_tv, float c_time_smooth, float c_sparse, float* losses, int32_t n_slots, float lr, float beta1,
-                                     float beta2, float eps, int32_t step, float grad_scale, snerf_adam_dyn* dyn, int32_t tile_shape,
-                                     snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
 int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,

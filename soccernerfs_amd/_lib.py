@@ -123,8 +123,6 @@ def lib():
     l.snerf_adam_planes_step.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, P, P]
     l.snerf_adam_planes_step_range.argtypes = [P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, I, L, L, P, P]
     l.snerf_adam_prepare.argtypes = [P, F, F, F, I, I, P]
-    l.snerf_kplanes_scatter_adam_scale.argtypes = [P, I, L, P, P, P, P, P, P, P, P, P, F, F, F, P, I, F, F, F, F, I, F, P, I, P]
-    l.snerf_kplanes_scatter_adam_supported.argtypes = [P, I, L]
     l.snerf_weights_bwd.argtypes = [P, P, P, I, I, P, I, P, P]
     l.snerf_fx_to_float.argtypes = [P, P, L, I, P]
     l.snerf_aabb_collide.argtypes = [P, P, I, P, F, I, P, P, P]
@@ -210,8 +208,6 @@ EXPORTS = [
     "snerf_kplanes_quotient_prepare",
     "snerf_kplanes_scatter_quotient_scales",
     "snerf_kplanes_quotient_fixup",
-    "snerf_kplanes_scatter_adam_supported",
-    "snerf_kplanes_scatter_adam_scale",
     "snerf_nerfplayer_mix_fwd",
     "snerf_nerfplayer_mix_bwd",
     "snerf_comm_unique_id",

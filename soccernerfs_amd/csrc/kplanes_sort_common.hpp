@@ -1,5 +1,6 @@
-// The sort order of the sorted plane-gradient scatter, shared by kplanes_sorted.hip (counting sort + pass B) and kplanes_tile_adam.hip
-// (owner-computes scatter + Adam, which looks cells up in the sort's scanned histogram).
+// The sort order of the sorted plane-gradient scatter (kplanes_sorted.hip: counting sort + pass B): segment table, Morton keys, the zero
+// threshold of the quotient form.  (Split out in round 3 for an owner-computes scatter + Adam kernel that looked cells up in the sort's scanned
+// histogram; that kernel measured slower than pass B + sweep and was removed -- profiles/r03_tile_adam_experiment.md.)
 #pragma once
 #include "kplanes_common.hpp"
 

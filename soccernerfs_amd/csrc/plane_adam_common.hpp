@@ -1,5 +1,4 @@
-// Per-float4 pieces of the dense optimiser sweep, shared by plane_reg_kernel (optim.hip) and the owner-computes scatter + Adam kernel
-// (kplanes_tile_adam.hip): the K-Planes plane regularisers' analytic gradient (NS/model_components/losses.py:356-452) and torch.optim.Adam
+// Per-float4 pieces of the dense optimiser sweep (plane_reg_kernel, optim.hip): the K-Planes plane regularisers' analytic gradient (NS/model_components/losses.py:356-452) and torch.optim.Adam
 // (NS/configs/method_configs.py:546-557) on one float4 of a channel-last plane.
 #pragma once
 #include "common.hpp"

@@ -144,27 +144,6 @@ class SortedScatter:
                                                   _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, st),
                    "quotient_fixup")
 
-    def quotient_fixup_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
-        """Only the exact terms of zero-feature rows for scales [scale_begin, scale_end) (added into gplanes): what must run in front of
-        scatter_adam_scale, which takes the place of pass B for its scale."""
-        st = stream if stream is not None else _stream()
-        _lib.check(_lib.lib().snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gfeat), _ptr(self.fix_list),
-                                                           _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, st), "quotient_fixup")
-
-    def scatter_adam_supported(self, scale: int) -> bool:
-        return bool(self.quotient and _lib.lib().snerf_kplanes_scatter_adam_supported(C.byref(self.desc), scale, C.c_int64(self.N)))
-
-    def scatter_adam_scale(self, scale: int, p_in, p_out, g, m, v, coefs, losses, step: int, lr: float, betas=(0.9, 0.999), eps: float = 1e-12,
-                           grad_scale: float = 1.0, dyn: Optional[torch.Tensor] = None, tile_shape: int = 0, stream=None):
-        """Owner-computes pass B + regularisers + Adam for `scale` (csrc/kplanes_tile_adam.hip): sort() and quotient_prepare() must have run, and
-        quotient_fixup_scales(scale, scale + 1) into g.  All tensors are the plane set's whole segments (ping-pong p_in -> p_out)."""
-        st = stream if stream is not None else _stream()
-        _lib.check(_lib.lib().snerf_kplanes_scatter_adam_scale(C.byref(self.desc), scale, C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(self.hist),
-                                                               _ptr(self.fix_count), _ptr(p_in), _ptr(p_out), _ptr(g), _ptr(m), _ptr(v), coefs[0], coefs[1], coefs[2],
-                                                               _ptr(losses) if losses is not None else None, REG_SLOTS if losses is not None else 0, lr,
-                                                               betas[0], betas[1], eps, step, grad_scale, _ptr(dyn) if dyn is not None else None, tile_shape, st),
-                   "scatter_adam_scale")
-
     def scatter_quotient(self, planes, coords: _lib.Coords, gfeat, feat, gplanes, stream=None):
         """gplanes += d(sum gfeat . features)/d planes, with feat = the forward's features [N, C n_scales] (fp32)."""
         self.quotient_prepare(gfeat, feat, stream)

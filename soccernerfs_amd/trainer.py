@@ -104,12 +104,6 @@ class KPlanesTrainConfig:
     # ~1.6 GB less HBM traffic per step.  Equal to the product form to a few ulp (pass B recomputes the forward's v_q bit for bit; rows with an
     # exactly-zero feature take an exact fix-up).  Needs the sorted scatter, C = 32 and no deterministic mode; False = product form (A-B).
     quotient_scatter: bool = True
-    # Owner-computes scatter + optimiser sweep for the FINEST scale (csrc/kplanes_tile_adam.hip; 72 % of the preset's parameters): a workgroup owns
-    # a tile of texels, sums the sorted entries of the cells that touch it in LDS and applies regularisers + Adam from there -- that scale's
-    # gradient plane never reaches HBM (24 instead of 32 B / parameter) and needs no float atomics.  Single GPU, quotient scatter, regularisers
-    # inside the sweep (train_step); anything else takes pass B + the plain sweep.  tile_adam_shape: 0 = 16 x 8 texels x 512 threads (A-B: 1 .. 4, include/snerf.h).
-    tile_adam: bool = True
-    tile_adam_shape: int = 0
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -167,7 +161,6 @@ class KPlanesTrainer:
         self._fwd_fused = False
         self._grad_scale = 1.0
         self._reg_zeroed = False
-        self._tile_adam_issued = False
         self._dyn_step = 0
         self._ar_work = self._reg_work = None
         self._side = {}  # role -> HIP stream, created on first use
@@ -272,8 +265,6 @@ class KPlanesTrainer:
         self._ss.desc = self.field_planes.desc()
         if cfg.emulate_transports not in ("", "grad", "param", "both"):
             raise ValueError(f"emulate_transports must be '', 'grad', 'param' or 'both', got {cfg.emulate_transports!r}")
-        self.tile_adam = bool(cfg.tile_adam and self.quotient_scatter and self.world == 1 and cfg.fuse_reg_into_adam and not cfg.emulate_transports
-                              and self._ss.scatter_adam_supported(len(cfg.multiscale_res) - 1))
         self._sort_done = None
         # sorted scatter for the proposal planes too (opt-in; measured SLOWER at the preset: the planes are small enough that their
         # atomics are served by L2 -- 0.5 M of 19 M requests reach memory -- while sorting 1.5 M samples x 6 planes costs ~0.6 ms)
@@ -595,12 +586,6 @@ class KPlanesTrainer:
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
                                                           self._p(b["gfeat"]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
             ns = len(self.cfg.multiscale_res)
-            if self.tile_adam and self.quotient_scatter and self._reg_in_adam and not self._sharded():
-                # finest scale: scatter + regularisers + Adam in one owner-computes kernel, beside pass B of the coarser scales (its inputs -- G, the
-                # sort, the group's step constants, the zeroed regulariser slots -- are all complete here)
-                self._tile_adam_finest(co, ns - 1)
-                self._scatter_field_scales(co, 0, ns - 1)
-                return
             if self._sharded() and len(self._exchange) == 2:
                 # finest scale first: its reduce-scatter (chunk 0) is on the links while the coarser scales are still being scattered
                 self._scatter_field_scales(co, ns - 1, ns)
@@ -612,37 +597,6 @@ class KPlanesTrainer:
             self._scatter_field_scales(co, 0, ns)
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
-
-    def _tile_adam_finest(self, co, scale: int):
-        """snerf_kplanes_scatter_adam_scale for `scale` (old -> other half of the ping-pong pair), on the "adam" stream when the sweep is
-        asynchronous; optimizer_step then only owes the coarser scales."""
-        cfg, lc = self.cfg, self.cfg.loss_coefficients
-        lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
-        self._prepare_group("fields", lr)
-        if not self._reg_zeroed:
-            self.buf["reg"].zero_()
-            self._reg_zeroed = True
-        o, n = next((o, n) for name, _, _, o, n in self.segments if name == "field.planes")
-        side = self.async_field_adam and self.overlap
-        cur = torch.cuda.current_stream()
-
-        def run():
-            ss = self._ss
-            ss.quotient_fixup_scales(self.field_planes.planes, co, self.buf["gfeat"], self.gviews["field.planes"], scale, scale + 1, self._st)
-            with self._span("kplanes_tile_adam.field"):
-                ss.scatter_adam_scale(scale, self.params[o:o + n], self._params_alt[o:o + n], self.gviews["field.planes"], self.mviews["field.planes"],
-                                      self.vviews["field.planes"], tuple(lc[k] for k in ("space_tv_loss", "time_smoothness_loss", "sparse_transients_loss")),
-                                      self.buf["reg"][0], self.step + 1, lr, eps=cfg.adam_eps, grad_scale=self._grad_scale, dyn=self._dyn["fields"],
-                                      tile_shape=cfg.tile_adam_shape, stream=self._st)
-
-        if side:
-            st = self._stream("adam")
-            st.wait_stream(cur)
-            with KPlanesTrainer._On(self, st):
-                run()
-        else:
-            run()
-        self._tile_adam_issued = True
 
     def _depth_loss(self, lvl: int, with_grad: bool):
         """ds_nerf depth loss of one sampling level (kplanes.py:395-409: every level, weight 1/3); its gradient is ADDED to gw[lvl]."""
@@ -999,7 +953,7 @@ class KPlanesTrainer:
         """First float of the finest scale's planes inside the field-plane segment (planes are laid out scale-major)."""
         return int(self._desc_field.off[len(self.cfg.multiscale_res) - 1][0])
 
-    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool, role: str = "adam"):
+    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool, role: str = "adam", span: str = "adam_planes.field"):
         """Fused Adam + regularisers over floats [lo, hi) of the field planes, old -> other half of the ping-pong pair.  side=True:
         on the side stream `role`, ordered after everything issued so far on the current stream (the scatter of those planes)."""
         cfg, co = self.cfg, self.cfg.loss_coefficients
@@ -1013,13 +967,13 @@ class KPlanesTrainer:
         self._prepare_group("fields", lr)
         kw = dict(eps=cfg.adam_eps, grad_scale=self._grad_scale, zero_grad=True, shard_range=rng_, dyn=self._dyn["fields"])
         if not side:
-            with self._span("adam_planes.field"):
+            with self._span(span):
                 ops.adam_planes_step(*args, **kw)
             return
         cur = torch.cuda.current_stream()
         st = self._stream(role)
         st.wait_stream(cur)
-        with KPlanesTrainer._On(self, st), self._span("adam_planes.field"):
+        with KPlanesTrainer._On(self, st), self._span(span):
             ops.adam_planes_step(*args, **kw)
 
     def allreduce_grads(self):
@@ -1068,16 +1022,7 @@ class KPlanesTrainer:
         if emu in ("grad", "both"):
             gv = self.gviews["field.planes"]
             gv.copy_(gv.to(torch.bfloat16))
-        if self._tile_adam_issued:  # the finest scale's planes are already being updated by the owner-computes kernel: the coarser scales remain
-            self._tile_adam_issued = False
-            if self._finest_offset() > 0:
-                # the coarser scales' sweep must not queue up behind the tile kernel (same "adam" stream): it goes to the "sort" stream, idle
-                # since the counting sort finished under the MLP backward, and the "adam" stream -- whose event forward() waits for -- joins it
-                self._adam_field_range(0, self._finest_offset(), side=async_field, role="sort")
-                if async_field:
-                    self._stream("adam").wait_stream(self._stream("sort"))
-        else:
-            self._adam_field_range(0, None, side=async_field)
+        self._adam_field_range(0, None, side=async_field)
         if emu in ("param", "both"):  # new = old + bf16(new - old) on the field planes, on the stream that ran the sweep
             o_, n_ = next((o, n) for name, _, _, o, n in self.segments if name == "field.planes")
             with KPlanesTrainer._On(self, self._stream("adam") if async_field else torch.cuda.current_stream()):

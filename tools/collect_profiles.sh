@@ -49,8 +49,7 @@ with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
 names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_grouped_kernel<6",
          "kplanes_gradvec.field": "snerf::gradvec_kernel<32, 6", "kplanes_gather_fwd.field": "snerf::kplanes_gather_fwd_kernel<32, 6>",
          "mlp_bwd.160x128x1": "bwd_kernel<__bf16, 160, 128, 1", "kplanes_gather_bwd.prop": "snerf::kplanes_gather_bwd_kernel<8, 6",
-         "kplanes_field_fwd": "field_fwd_kernel", "kplanes_quotient_prepare": "quotient_prepare_kernel",
-         "kplanes_tile_adam.field": "tile_scatter_adam_kernel"}
+         "kplanes_field_fwd": "field_fwd_kernel", "kplanes_quotient_prepare": "quotient_prepare_kernel"}
 tj = {"_note": "traffic_bytes_per_launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->B) from separate rocprofv3 --pmc passes, k-planes preset, 4096 rays "
                f"(profiles/{tag}_pmc_counters.csv)"}
 for span, pat in names.items():

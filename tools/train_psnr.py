@@ -66,7 +66,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     random.seed(seed)
     cfg = KPlanesTrainConfig(max_steps=args.schedule_steps, mlp_operands=args.mlp_operands, seed=seed, deterministic=args.deterministic,
                              nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter, gvec_dtype=args.gvec_dtype,
-                             emulate_transports=args.emulate_transports, tile_adam=not args.no_tile_adam,
+                             emulate_transports=args.emulate_transports,
                              sigma_operands=args.sigma_operands, color_operands=args.color_operands, proposal_operands=args.proposal_operands)
     R = 4096
     trainer = KPlanesTrainer(cfg, R, dev)
@@ -134,7 +134,6 @@ def main():
     ap.add_argument("--no-quotient-scatter", action="store_true", help="product form of the field's sorted scatter")
     ap.add_argument("--emulate-transports", default="", choices=["", "grad", "param", "both"],
                     help="single-GPU emulation of the bf16 gradient / parameter-update transports of the sharded multi-GPU step (KPlanesTrainConfig.emulate_transports)")
-    ap.add_argument("--no-tile-adam", action="store_true", help="A-B: pass B + plain sweep for the finest scale instead of the owner-computes kernel")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -154,7 +153,7 @@ def main():
     log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps,
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
            "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
-           "emulate_transports": args.emulate_transports, "tile_adam": not args.no_tile_adam, "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
+           "emulate_transports": args.emulate_transports, "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
            "eval_sets": {"camera_20": "20th arc camera (reference 'all' split eval camera; extrapolated view), %d frames" % len(sets["camera_20"][1]),
                          "novel": "3 evaluation-only cameras between training cameras (interpolated views), %d images" % len(sets["novel"][1]),
                          "train": "4 training images"},
