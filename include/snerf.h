@@ -493,7 +493,7 @@ int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const float* tabl
 
 /* ------------------------------------------------------------------------------------------------
  * NeRFPlayer decomposition mixing (NerfplayerField.get_density, NS/fields/nerfplayer_field.py:365-372): probs[N,3] = softmax(logits[N,3])
- * (0 = static, 1 = deforming, 2 = new) and v[N,F] = probs_0 v_static + probs_1 v_deform + probs_2 v_new; F = 16, 32 or 64.
+ * (0 = static, 1 = deforming, 2 = new) and v[N,F] = probs_0 v_static + probs_1 v_deform + probs_2 v_new; F = 4, 8, 16, 32 or 64.
  * bwd: from g_v [N,F] and (may be NULL) g_probs [N,3], the gradient that reaches probs from outside v (the rendered-probability
  * regulariser, NS/models/nerfplayer.py:336-341): g_static / g_deform / g_new [N,F] and g_logits [N,3], all overwritten.
  * ------------------------------------------------------------------------------------------------ */
@@ -564,8 +564,10 @@ int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, cons
  * from the 4 texels of the cell it is adding into (sorted order: the reads stay in cache) -- with the forward's own arithmetic, bit for
  * bit, so that the division cancels the forward's v_q exactly even where v_q is a small difference of large texels.  Differs from the
  * product form by a few ulp.
- * Where a feature is exactly 0 the quotient has lost the other planes' product: _prepare lists those rows (device-side list, capacity
- * N * n_scales covers the worst case) and _fixup adds their exact gradients; pass B adds 0 there.
+ * Where a feature vanished (exactly 0, or below the smallest normal float -- also as the underflowing product of six normal plane values) the
+ * quotient has lost the other planes' product: _prepare writes G = 0 for such a channel and lists the row (device-side list, capacity
+ * N * n_scales covers the worst case); pass B then adds exactly 0 there and _fixup -- which recognises the channel by G == 0 with a non-zero
+ * feature gradient -- adds the exact product-form terms (one vanished plane: that plane's; none, i.e. an underflowed product: every plane's).
  *   _prepare : G = grad_feat .* feat; fix_count / fix_list = rows (sample * n_scales + scale) with a zero feature.  fix_count must be 0 on
  *              entry: with fix_count_next == NULL it is reset here (one memset); a caller that alternates between two counters passes the
  *              other one as fix_count_next and the kernel resets THAT one for the next step (no extra launch).
@@ -578,7 +580,7 @@ int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, co
 int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const float* planes, int64_t N, const float* G, const float* sorted_rec,
                                           float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
-                                 const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
+                                 const float* G, const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
                                  int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */

@@ -528,9 +528,13 @@ __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, con
   if (row < rows) {
     const float4 g = *reinterpret_cast<const float4*>(gfeat + gid * 4);
     const float4 f = *reinterpret_cast<const float4*>(feat + gid * 4);
-    *reinterpret_cast<float4*>(G + gid * 4) = f4_mul(g, f);
-    bad = (fabsf(f.x) < QUOT_TINY && g.x != 0.f) || (fabsf(f.y) < QUOT_TINY && g.y != 0.f) || (fabsf(f.z) < QUOT_TINY && g.z != 0.f) ||
-          (fabsf(f.w) < QUOT_TINY && g.w != 0.f);
+    // a vanished feature (zero, or a subnormal product -- of six normal plane values as well) carries no usable quotient: G = 0 there, so that
+    // pass B adds exactly nothing for the channel and the fix-up, which recognises the channel by G == 0 with a non-zero gradient, adds the exact term
+    const bool zx = fabsf(f.x) < QUOT_TINY, zy = fabsf(f.y) < QUOT_TINY, zz = fabsf(f.z) < QUOT_TINY, zw = fabsf(f.w) < QUOT_TINY;
+    float4 Gv = f4_mul(g, f);
+    Gv.x = zx ? 0.f : Gv.x; Gv.y = zy ? 0.f : Gv.y; Gv.z = zz ? 0.f : Gv.z; Gv.w = zw ? 0.f : Gv.w;
+    *reinterpret_cast<float4*>(G + gid * 4) = Gv;
+    bad = (zx && g.x != 0.f) || (zy && g.y != 0.f) || (zz && g.z != 0.f) || (zw && g.w != 0.f);
   }
   const unsigned long long m = __ballot(bad);
   const int lane = threadIdx.x & 63, g0 = lane & ~(LPR - 1);
@@ -540,13 +544,16 @@ __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, con
   }
 }
 
-// Exact gradient of the listed rows (row = sample * n_scales + scale): where exactly ONE plane's value is 0 at a channel, that plane
-// receives gfeat * (product of the other five); every other case is already right in pass B (it adds 0).  One wave per row,
-// lane = (x-corner, channel) as in the scatter; rare by construction (a trained texel that is exactly 0.0f), so no combining.
+// Exact gradient of the listed rows (row = sample * n_scales + scale), channel by channel (lane = (x-corner, channel)), for the channels pass B
+// could not serve: G == 0 there (quotient_prepare_kernel) while the feature's gradient is not.  With v_p the six planes' values at the sample:
+//   exactly ONE |v_z| below QUOT_TINY -> plane z receives gfeat * prod_{p != z} v_p (the others' terms contain v_z: zero);
+//   none (the product of six normal values underflowed)  -> EVERY plane q receives gfeat * prod_{p != q} v_p;
+//   two or more -> every term contains a vanished factor: nothing to add.
+// Rare by construction (a trained texel that is exactly 0.0f, or an underflowing product), so no run-length combining.
 template <int NP>
 __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c, const float* __restrict__ gfeat,
-                                                            const int32_t* __restrict__ list, const int32_t* __restrict__ count, int capacity,
-                                                            float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end) {
+                                                            const float* __restrict__ G, const int32_t* __restrict__ list, const int32_t* __restrict__ count,
+                                                            int capacity, float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end) {
   constexpr int C = 32;
   const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
   int n_list = *count;
@@ -556,6 +563,9 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc 
     const int64_t n = row / n_scales_total;
     const int s = row - (int)n * n_scales_total;
     if (s < scale_begin || s >= scale_end) continue;
+    const int64_t fo = n * ((int64_t)n_scales_total * C) + s * C + ch;
+    const float g = gfeat[fo];
+    if (g == 0.f || G[fo] != 0.f) continue;  // per lane (channel): nothing to add, or pass B was exact
     float p[4];
     load_coords<NP>(c, n, p);
     AxisTap tap[4];
@@ -570,25 +580,29 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc 
       const int W = d.res[s][pair_a<NP>(q)];
       const float* base = planes + d.off[s][q] + ch;
       const float4 w = tap_weights(tx, ty);
-      // the forward's own number (bilerp4): "exactly zero" must mean the same here, in the forward and in pass B
+      // the forward's own number (bilerp4): "vanished" must mean the same here, in the forward and in pass B
       v[q] = bilerp4(base[((int64_t)ty.i0 * W + tx.i0) * C], base[((int64_t)ty.i0 * W + tx.i1) * C], base[((int64_t)ty.i1 * W + tx.i0) * C],
                      base[((int64_t)ty.i1 * W + tx.i1) * C], w.x, w.y, w.z, w.w);
       zeros += fabsf(v[q]) < QUOT_TINY;
     }
-    if (zeros != 1) continue;  // per lane (channel): none -> pass B was exact; two or more -> every plane's gradient is 0
-    float prod = gfeat[n * ((int64_t)n_scales_total * C) + s * C + ch];
+    if (zeros >= 2) continue;
+    float suf[NP + 1];
+    suf[NP] = 1.f;
 #pragma unroll
-    for (int q = 0; q < NP; ++q) prod *= fabsf(v[q]) < QUOT_TINY ? 1.f : v[q];
+    for (int q = NP - 1; q >= 0; --q) suf[q] = suf[q + 1] * v[q];
+    float pre = g;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      if (fabsf(v[q]) >= QUOT_TINY) continue;
+      const float term = pre * suf[q + 1];  // gfeat * prod_{p != q} v_p
+      pre *= v[q];
+      if (zeros == 1 && fabsf(v[q]) >= QUOT_TINY) continue;  // one vanished plane: only IT has a non-zero gradient
       const AxisTap& tx = tap[pair_a<NP>(q)];
       const AxisTap& ty = tap[pair_b<NP>(q)];
       const int W = d.res[s][pair_a<NP>(q)];
       const float wx = half ? tx.w1 : tx.w0;
       const int xi = half ? tx.i1 : tx.i0;
       float* gb = gplanes + d.off[s][q] + ch;
-      const float a0 = prod * wx * ty.w0, a1 = prod * wx * ty.w1;
+      const float a0 = term * wx * ty.w0, a1 = term * wx * ty.w1;
       if (a0 != 0.f) atomicAdd(gb + ((int64_t)ty.i0 * W + xi) * C, a0);
       if (a1 != 0.f) atomicAdd(gb + ((int64_t)ty.i1 * W + xi) * C, a1);
     }
@@ -804,7 +818,7 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
 }
 
 extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
-                                            const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
+                                            const float* G, const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
                                             int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
   int rc = check_desc(desc, coords, N);
   if (rc) return rc;
@@ -813,12 +827,12 @@ extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, cons
   SNERF_REQUIRE(scale_begin >= 0 && scale_begin <= scale_end && scale_end <= desc->n_scales, "kplanes_quotient_fixup: scales [%d, %d) of %d", scale_begin,
                 scale_end, desc->n_scales);
   if (N == 0 || fix_capacity == 0 || scale_begin == scale_end) return 0;
-  SNERF_REQUIRE(planes && grad_feat && fix_list && fix_count && grad_planes, "kplanes_quotient_fixup: null buffer");
+  SNERF_REQUIRE(planes && grad_feat && G && fix_list && fix_count && grad_planes, "kplanes_quotient_fixup: null buffer");
   // a fixed small grid that strides over the (device-side) count: an empty list costs one launch
   hipStream_t st = (hipStream_t)stream;
-  if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, fix_list, fix_count,
+  if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, G, fix_list, fix_count,
                                               fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end);
-  else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, fix_list, fix_count, fix_capacity,
+  else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, G, fix_list, fix_count, fix_capacity,
                           grad_planes, desc->n_scales, scale_begin, scale_end);
   SNERF_LAUNCH_CHECK("kplanes_quotient_fixup");
   return 0;

@@ -68,12 +68,14 @@ using namespace snerf;
 
 extern "C" int snerf_nerfplayer_mix_fwd(const float* logits, const float* v_static, const float* v_deform, const float* v_new, int64_t N, int32_t F,
                                         float* probs, float* v, snerf_stream_t stream) {
-  SNERF_REQUIRE(N >= 0 && (F == 16 || F == 32 || F == 64), "nerfplayer_mix_fwd: N=%lld F=%d (16, 32 or 64)", (long long)N, F);
+  SNERF_REQUIRE(N >= 0 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64), "nerfplayer_mix_fwd: N=%lld F=%d (4, 8, 16, 32 or 64)", (long long)N, F);
   if (N == 0) return 0;
   SNERF_REQUIRE(logits && v_static && v_deform && v_new && probs && v, "nerfplayer_mix_fwd: null buffer");
   const dim3 grid((unsigned)ceil_div(N * (F / 4), 256));
   hipStream_t st = (hipStream_t)stream;
-  if (F == 16) hipLaunchKernelGGL(mix_fwd_kernel<16>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
+  if (F == 4) hipLaunchKernelGGL(mix_fwd_kernel<4>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
+  else if (F == 8) hipLaunchKernelGGL(mix_fwd_kernel<8>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
+  else if (F == 16) hipLaunchKernelGGL(mix_fwd_kernel<16>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
   else if (F == 32) hipLaunchKernelGGL(mix_fwd_kernel<32>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
   else hipLaunchKernelGGL(mix_fwd_kernel<64>, grid, dim3(256), 0, st, logits, v_static, v_deform, v_new, N, probs, v);
   SNERF_LAUNCH_CHECK("nerfplayer_mix_fwd");
@@ -83,12 +85,14 @@ extern "C" int snerf_nerfplayer_mix_fwd(const float* logits, const float* v_stat
 extern "C" int snerf_nerfplayer_mix_bwd(const float* probs, const float* v_static, const float* v_deform, const float* v_new, const float* g_v,
                                         const float* g_probs, int64_t N, int32_t F, float* g_static, float* g_deform, float* g_new, float* g_logits,
                                         snerf_stream_t stream) {
-  SNERF_REQUIRE(N >= 0 && (F == 16 || F == 32 || F == 64), "nerfplayer_mix_bwd: N=%lld F=%d (16, 32 or 64)", (long long)N, F);
+  SNERF_REQUIRE(N >= 0 && (F == 4 || F == 8 || F == 16 || F == 32 || F == 64), "nerfplayer_mix_bwd: N=%lld F=%d (4, 8, 16, 32 or 64)", (long long)N, F);
   if (N == 0) return 0;
   SNERF_REQUIRE(probs && v_static && v_deform && v_new && g_v && g_static && g_deform && g_new && g_logits, "nerfplayer_mix_bwd: null buffer");
   const dim3 grid((unsigned)ceil_div(N * (F / 4), 256));
   hipStream_t st = (hipStream_t)stream;
-  if (F == 16) hipLaunchKernelGGL(mix_bwd_kernel<16>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
+  if (F == 4) hipLaunchKernelGGL(mix_bwd_kernel<4>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
+  else if (F == 8) hipLaunchKernelGGL(mix_bwd_kernel<8>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
+  else if (F == 16) hipLaunchKernelGGL(mix_bwd_kernel<16>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
   else if (F == 32) hipLaunchKernelGGL(mix_bwd_kernel<32>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
   else hipLaunchKernelGGL(mix_bwd_kernel<64>, grid, dim3(256), 0, st, probs, v_static, v_deform, v_new, g_v, g_probs, N, g_static, g_deform, g_new, g_logits);
   SNERF_LAUNCH_CHECK("nerfplayer_mix_bwd");

@@ -140,7 +140,7 @@ class SortedScatter:
         L = _lib.lib()
         _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
                                                            scale_begin, scale_end, st), "scatter_quotient")
-        _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gfeat), _ptr(self.fix_list),
+        _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gfeat), _ptr(self.G), _ptr(self.fix_list),
                                                   _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, st),
                    "quotient_fixup")
 

@@ -247,3 +247,45 @@ def test_quotient_scatter_equals_direct_scatter(ms, N, zeros):
         ss.quotient_scatter_scales(ps.planes, co, goutd, parts, len(ms) - 1, len(ms))
         ss.quotient_scatter_scales(ps.planes, co, goutd, parts, 0, len(ms) - 1)
         torch.testing.assert_close(parts, got, rtol=1e-4, atol=2e-6 * scale)
+
+
+@pytest.mark.gpu
+def test_quotient_scatter_when_the_product_of_six_normal_values_underflows():
+    """A feature can vanish although no plane value does: six values of 2e-7 multiply to 6.4e-41, below the smallest normal float.  The
+    quotient G / v_q has lost (almost) all bits there; quotient_prepare zeroes G for the channel, lists the row, and the fix-up adds the exact
+    product-form term to EVERY plane (these gradients used to be dropped or mangled)."""
+    import ctypes as Ct
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    dev = _dev()
+    gen = torch.Generator().manual_seed(4)
+    ps = PlaneSet(32, [[11, 9, 7, 5], [22, 18, 14, 5]], concat=True, generator=gen)
+    with torch.no_grad():
+        ps.planes.copy_(torch.rand(ps.numel, generator=gen) * 0.8 + 0.2)
+        for q in range(6):
+            ps.plane_view(0, q)[0:2, 0:2, :] = 2e-7  # the first cell of every plane of scale 0
+    ps = ps.to(dev)
+    N = 600
+    pts = torch.rand(N, 4, generator=gen) * 2 - 1
+    pts[:64] = -1.0 + 0.04 + 0.1 * torch.rand(64, 4, generator=gen)  # inside the first cell of every axis (cell widths 0.2 .. 0.5)
+    gout = torch.rand(N, ps.out_dim, generator=gen) + 0.5
+    ptsd, goutd = pts.to(dev), gout.to(dev)
+    co = ops.coords_from_points(ptsd)
+    desc = ps.desc()
+    L = _lib.lib()
+    direct = torch.zeros_like(ps.planes)
+    _lib.check(L.snerf_kplanes_gather_bwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(goutd), ops._ptr(direct), ops._stream()))
+    feat = torch.empty(N, ps.out_dim, device=dev)
+    _lib.check(L.snerf_kplanes_gather_fwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(feat), ops._stream()))
+    assert float(feat[:64, :32].abs().max()) < 1.2e-38  # the features of scale 0 underflowed ...
+    ss = ops.SortedScatter(ps, N, dev, quotient=True)
+    ss.sort(co)
+    got = torch.zeros_like(ps.planes)
+    ss.scatter_quotient(ps.planes, co, goutd, feat, got)
+    assert int(ss.fix_count.item()) >= 64
+    torch.testing.assert_close(got, direct, rtol=1e-4, atol=2e-6 * float(direct.abs().max()))
+    for q in range(6):  # ... but every plane's gradient there (g * (2e-7)^5 ~ 3e-34 per sample) arrives, to fp32 accuracy
+        a, b = ps.plane_view(0, q, got)[0:2, 0:2, :], ps.plane_view(0, q, direct)[0:2, 0:2, :]
+        assert float(b.abs().min()) > 1e-36
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=0)
