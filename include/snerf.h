@@ -301,6 +301,13 @@ int snerf_interlevel(const float* c_bins, const float* w_nerf, int32_t S, const 
 int snerf_depth_loss(const float* weights, const float* ebins, const float* termination_depth, const float* directions_norm, float sigma,
                      int32_t R, int32_t S, float grad_scale, float* loss_rays, float* g_weights, int32_t accumulate, snerf_stream_t stream);
 
+/* urban_radiance_field_depth_loss behind depth_loss (DepthLossType.URF, NS/model_components/losses.py:238-274,308-309), one sampling level:
+ * loss_rays[R] = [D > 0] * ((D - predicted_depth)^2 + sum over bins within +-sigma of D of (w - N(t - D; 0, sigma / 3))^2 + sum over bins in front
+ * of D - sigma of w^2); D, t, grad_scale, g_weights as snerf_depth_loss.  g_predicted_depth [R] (may be NULL) = grad_scale * d loss_r / d depth. */
+int snerf_urf_depth_loss(const float* weights, const float* ebins, const float* termination_depth, const float* directions_norm,
+                         const float* predicted_depth, float sigma, int32_t R, int32_t S, float grad_scale, float* loss_rays, float* g_weights,
+                         float* g_predicted_depth, int32_t accumulate, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense per-step sweeps.
  * ------------------------------------------------------------------------------------------------ */

@@ -1,6 +1,7 @@
 """G8b: depth supervision vectors captured from the REFERENCE itself (TEST INFRASTRUCTURE; runs only where /root/reference exists).
 
-Calls nerfstudio.model_components.losses.depth_loss (DS_NERF branch -> ds_nerf_depth_loss, losses.py:213-235,261-311) on explicit
+Calls nerfstudio.model_components.losses.depth_loss (DS_NERF branch -> ds_nerf_depth_loss, losses.py:213-235,261-311, and the URF branch ->
+urban_radiance_field_depth_loss, :238-274) on explicit
 weights / bins / termination depths, for Euclidean and z-distance depth maps, and stores values and gradients w.r.t. the weights.
 
     python -m oracle.gen_golden_depth        ->  tests/golden/g8b_depth.npz
@@ -41,6 +42,16 @@ def main():
                          directions_norm=dnorm, is_euclidean=eucl, depth_loss_type=DepthLossType.DS_NERF)
         val.backward()
         g[f"loss_{tag}"], g[f"grad_{tag}"], g[f"sigma_{tag}"] = val.detach(), w.grad[..., 0], torch.tensor(sigma)
+    # Urban Radiance Fields variant (losses.py:238-274): values + gradients w.r.t. the weights AND the predicted depth
+    pred = term + (torch.rand(R, 1, generator=gen) - 0.5) * 0.3
+    g["predicted_depth"] = pred[:, 0]
+    for tag, sigma, eucl in (("urf_eucl_s02", 0.2, True), ("urf_z_s05", 0.5, False), ("urf_eucl_s001", 0.01, True)):
+        w = weights.clone().requires_grad_(True)
+        pd = pred.clone().requires_grad_(True)
+        val = depth_loss(weights=w, ray_samples=rs, termination_depth=term, predicted_depth=pd, sigma=torch.tensor([sigma]), directions_norm=dnorm,
+                         is_euclidean=eucl, depth_loss_type=DepthLossType.URF)
+        val.backward()
+        g[f"loss_{tag}"], g[f"grad_{tag}"], g[f"gpred_{tag}"], g[f"sigma_{tag}"] = val.detach(), w.grad[..., 0], pd.grad[:, 0], torch.tensor(sigma)
     np.savez_compressed(OUT, **{k: v.numpy() for k, v in g.items()})
     print("wrote", OUT, {k: tuple(v.shape) for k, v in g.items()})
 

@@ -273,6 +273,13 @@ def mlp(x, weights: Sequence[torch.Tensor], out_act: str = "None", hidden_act: s
     return x
 
 
+def scene_contraction_inf(x):
+    """SceneContraction(order=inf), NS/field_components/spatial_distortions.py:62-69: identity inside the unit cube, (2 - 1/m) x/m with
+    m = max |x_k| outside; the K-Planes fields halve the result into [-1, 1] (kplanes_field.py:278-280)."""
+    mag = torch.linalg.norm(x, ord=float("inf"), dim=-1)[..., None]
+    return torch.where(mag < 1, x, (2 - (1 / mag)) * (x / mag))
+
+
 def normalize_positions(positions, aabb):
     """SceneBox.get_normalized_positions, NS/data/scene_box.py:55-65."""
     return (positions - aabb[0]) / (aabb[1] - aabb[0])
@@ -414,6 +421,22 @@ def ds_nerf_depth_loss(weights, termination_depth, steps, lengths, sigma):
     mask = (termination_depth > 0).to(weights.dtype)
     loss = -torch.log(weights + EPS) * torch.exp(-((steps - termination_depth[:, None]) ** 2) / (2 * sigma)) * lengths
     return torch.mean(loss.sum(-1) * mask)
+
+
+def urf_depth_loss(weights, ebins, termination_depth, predicted_depth, sigma, directions_norm=None, is_euclidean: bool = True):
+    """depth_loss, URF branch = urban_radiance_field_depth_loss (NS/model_components/losses.py:238-274,308-309).  weights [R,S], ebins
+    [R,S+1], termination_depth / predicted_depth [R]."""
+    D = termination_depth if is_euclidean else termination_depth * directions_norm
+    steps = (ebins[:, :-1] + ebins[:, 1:]) / 2
+    mask = (D > 0).to(weights.dtype)
+    expected = (D - predicted_depth) ** 2
+    sd = sigma / 3.0  # URF_SIGMA_SCALE_FACTOR, losses.py:36
+    x = steps - D[:, None]
+    pdf = torch.exp(-(x**2) / (2 * sd**2) - math.log(sd) - 0.5 * math.log(2 * math.pi))
+    near = ((steps <= D[:, None] + sigma) & (steps >= D[:, None] - sigma)).to(weights.dtype)
+    empty = (steps < D[:, None] - sigma).to(weights.dtype)
+    los = (near * (weights - pdf) ** 2).sum(-1) + (empty * weights**2).sum(-1)
+    return torch.mean((expected + los) * mask)
 
 
 def depth_loss(weights, ebins, termination_depth, sigma, directions_norm=None, is_euclidean: bool = True):

@@ -117,6 +117,7 @@ def lib():
     F, I, L, P = C.c_float, C.c_int32, C.c_int64, C.c_void_p
     l.snerf_distortion.argtypes = [P, P, I, I, F, P, P, I, P]
     l.snerf_depth_loss.argtypes = [P, P, P, P, F, I, I, F, P, P, I, P]
+    l.snerf_urf_depth_loss.argtypes = [P, P, P, P, P, F, I, I, F, P, P, P, I, P]
     l.snerf_interlevel.argtypes = [P, P, I, P, P, I, I, F, P, P, P]
     l.snerf_plane_reg.argtypes = [P, P, P, F, F, F, P, I, I, P]
     l.snerf_adam_step.argtypes = [P, P, P, P, P, L, F, F, F, F, I, F, I, P, P]
@@ -202,6 +203,7 @@ EXPORTS = [
     "snerf_mlp_bwd_x16",
     "snerf_adam_prepare",
     "snerf_depth_loss",
+    "snerf_urf_depth_loss",
     "snerf_kplanes_field_fwd",
     "snerf_kplanes_field_fwd_supported",
     "snerf_kplanes_quotient_supported",

@@ -274,6 +274,55 @@ __global__ __launch_bounds__(256) void depth_loss_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// urban_radiance_field_depth_loss (losses.py:238-274) behind depth_loss (:261-311, URF branch) for one sampling level, D as above:
+//   loss_r = [D_r > 0] * ( (D_r - d_r)^2                                          d_r = the level's predicted depth
+//                        + sum_{|t_s - D_r| <= sigma} (w_s - N(t_s - D_r; 0, sigma / 3))^2   "line of sight", near the surface
+//                        + sum_{t_s < D_r - sigma} w_s^2 )                                   ... and in front of it
+// with N the normal density (torch.distributions.Normal.log_prob, exponentiated).  g_weights (+)= grad_scale * d loss_r / d w,
+// g_pred (may be NULL) = grad_scale * d loss_r / d d_r.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void urf_depth_loss_kernel(const float* __restrict__ weights, const float* __restrict__ ebins, const float* __restrict__ term,
+                                                            const float* __restrict__ dir_norm, const float* __restrict__ pred, float sigma, int R, int S,
+                                                            float grad_scale, float* __restrict__ loss_rays, float* __restrict__ g_weights,
+                                                            float* __restrict__ g_pred, int accumulate) {
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * RPB + wv;
+  if (ray >= R) return;
+  float D = term[ray];
+  if (dir_norm) D = D * dir_norm[ray];
+  const bool on = D > 0.f;
+  const float sd = sigma / 3.0f;  // URF_SIGMA_SCALE_FACTOR (losses.py:36)
+  const float log_norm = -logf(sd) - 0.918938533204672742f;  // - log(sd) - log(sqrt(2 pi))
+  float total = 0.f;
+  for (int i = lane; i < S; i += 64) {
+    const float e0 = ebins[(int64_t)ray * (S + 1) + i], e1 = ebins[(int64_t)ray * (S + 1) + i + 1];
+    const float w = weights[(int64_t)ray * S + i];
+    const float t = (e0 + e1) / 2.f;
+    const float x = t - D;
+    float term_i = 0.f, g = 0.f;
+    if (t <= D + sigma && t >= D - sigma) {
+      const float pdf = expf(-(x * x) / (2.f * sd * sd) + log_norm);
+      term_i = (w - pdf) * (w - pdf);
+      g = 2.f * (w - pdf);
+    } else if (t < D - sigma) {
+      term_i = w * w;
+      g = 2.f * w;
+    }
+    total += term_i;
+    if (g_weights) {
+      const float gv = on ? grad_scale * g : 0.f;
+      if (accumulate) g_weights[(int64_t)ray * S + i] += gv; else g_weights[(int64_t)ray * S + i] = gv;
+    }
+  }
+  total = wave_sum(total);
+  if (lane == 0) {
+    const float d = pred[ray];
+    if (loss_rays) loss_rays[ray] = on ? total + (D - d) * (D - d) : 0.f;
+    if (g_pred) g_pred[ray] = on ? grad_scale * -2.f * (D - d) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One launch for the nerf level's per-ray work of a TRAINING step: get_weights -> RGB / accumulation / median depth -> MSE backward ->
 // distortion loss + gradient -> get_weights backward.  Same arithmetic, in the same order, as the five kernels it stands for
 // (resample_kernel stage 1, render_fwd_kernel, render_mse_bwd_kernel, distortion_kernel, weights_bwd_kernel: results are bit-identical,
@@ -443,6 +492,18 @@ extern "C" int snerf_depth_loss(const float* weights, const float* ebins, const 
   hipLaunchKernelGGL(depth_loss_kernel, dim3(ceil_div(R, RPB)), dim3(256), 0, (hipStream_t)stream, weights, ebins, termination_depth, directions_norm, sigma,
                      R, S, grad_scale, loss_rays, g_weights, accumulate);
   SNERF_LAUNCH_CHECK("depth_loss");
+  return 0;
+}
+
+extern "C" int snerf_urf_depth_loss(const float* weights, const float* ebins, const float* termination_depth, const float* directions_norm,
+                                    const float* predicted_depth, float sigma, int32_t R, int32_t S, float grad_scale, float* loss_rays, float* g_weights,
+                                    float* g_predicted_depth, int32_t accumulate, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && S >= 1 && S <= MAXS && sigma > 0.f, "urf_depth_loss: R=%d S=%d sigma=%g", R, S, (double)sigma);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(weights && ebins && termination_depth && predicted_depth, "urf_depth_loss: null buffer");
+  hipLaunchKernelGGL(urf_depth_loss_kernel, dim3(ceil_div(R, RPB)), dim3(256), 0, (hipStream_t)stream, weights, ebins, termination_depth, directions_norm,
+                     predicted_depth, sigma, R, S, grad_scale, loss_rays, g_weights, g_predicted_depth, accumulate);
+  SNERF_LAUNCH_CHECK("urf_depth_loss");
   return 0;
 }
 

@@ -11,10 +11,11 @@ from torch import nn
 from .kplanes_field import FieldHeadNames, KPlanesDensityField, KPlanesField
 from .losses import (MSELoss, depth_loss, distortion_loss, interlevel_loss, plane_regularizer_terms, space_tv_loss, sparse_transients_loss,
                      time_smoothness_loss)
-from .ray_samplers import ProposalNetworkSampler, UniformSampler
+from .ray_samplers import ProposalNetworkSampler, UniformLinDispPiecewiseSampler, UniformSampler
 from .rays import RayBundle
 from .renderers import render_all
 from .scene_colliders import AABBBoxCollider, NearFarCollider, SceneBox
+from .spatial_distortions import SceneContraction
 
 
 @dataclass
@@ -86,9 +87,9 @@ class KPlanesModel(nn.Module):
     def populate_modules(self):
         """kplanes.py:188-309."""
         cfg = self.config
-        if not cfg.bounded:
-            raise NotImplementedError("unbounded scenes (SceneContraction) are not used by the soccer datasets")
-        self.field = KPlanesField(self.scene_box.aabb, feat_dim=cfg.feature_dim, spacetime_resolution=cfg.spacetime_resolution,
+        # unbounded scenes: L-inf scene contraction in every field, near / far collider, piecewise initial sampler (kplanes.py:194,260-281)
+        scene_contraction = None if cfg.bounded else SceneContraction(order=float("inf"))
+        self.field = KPlanesField(self.scene_box.aabb, spatial_distortion=scene_contraction, feat_dim=cfg.feature_dim, spacetime_resolution=cfg.spacetime_resolution,
                                   concat_features_across_scales=cfg.concat_features_across_scales, multiscale_res=cfg.multiscale_res,
                                   linear_decoder=cfg.linear_decoder, disable_viewing_dependent=cfg.disable_viewing_dependent,
                                   sigma_net_layers=cfg.sigma_net_layers, sigma_net_hidden_dim=cfg.sigma_net_hidden_dim,
@@ -97,13 +98,13 @@ class KPlanesModel(nn.Module):
         n = cfg.num_proposal_iterations
         if cfg.use_same_proposal_network:
             assert len(cfg.proposal_net_args_list) == 1, "Only one proposal network is allowed."
-            net = KPlanesDensityField(self.scene_box.aabb, **cfg.proposal_net_args_list[0])
+            net = KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, **cfg.proposal_net_args_list[0])
             self.proposal_networks.append(net)
             self.density_fns = [net.density_fn for _ in range(n)]
         else:
             for i in range(n):
                 args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
-                self.proposal_networks.append(KPlanesDensityField(self.scene_box.aabb, **args))
+                self.proposal_networks.append(KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, **args))
             self.density_fns = [net.density_fn for net in self.proposal_networks]
 
         def update_schedule(step):
@@ -112,8 +113,8 @@ class KPlanesModel(nn.Module):
         self.proposal_sampler = ProposalNetworkSampler(
             num_nerf_samples_per_ray=cfg.num_nerf_samples_per_ray, num_proposal_samples_per_ray=cfg.num_proposal_samples_per_ray,
             num_proposal_network_iterations=cfg.num_proposal_iterations, single_jitter=cfg.use_single_jitter, update_sched=update_schedule,
-            initial_sampler=UniformSampler(single_jitter=cfg.use_single_jitter))
-        self.collider = AABBBoxCollider(scene_box=self.scene_box)
+            initial_sampler=(UniformSampler if cfg.bounded else UniformLinDispPiecewiseSampler)(single_jitter=cfg.use_single_jitter))
+        self.collider = AABBBoxCollider(scene_box=self.scene_box) if cfg.bounded else NearFarCollider(near_plane=cfg.near_plane, far_plane=cfg.far_plane)
         self.rgb_loss = MSELoss()
         self.rand_fn = None  # parity hook: (shape, device) -> uniform draws; None = torch.rand
 

@@ -29,10 +29,13 @@ def interpolate_kplanes(pts: torch.Tensor, ms_grids: PlaneSet, concat_features: 
     return ops.interpolate_kplanes(pts, ms_grids)
 
 
-def _pts_from_positions(positions, times, aabb, rescale: bool):
-    p = SceneBox.get_normalized_positions(positions, aabb)
-    if rescale:
-        p = p * 2.0 - 1.0
+def _pts_from_positions(positions, times, aabb, rescale: bool, spatial_distortion=None):
+    if spatial_distortion is not None:  # unbounded scene: contraction onto [-2, 2]^3, halved (kplanes_field.py:278-280, :438-440)
+        p = spatial_distortion(positions) / 2.0
+    else:
+        p = SceneBox.get_normalized_positions(positions, aabb)
+        if rescale:
+            p = p * 2.0 - 1.0
     t = (times * 2) - 1
     if t.dim() == 2:
         t = t[:, None, :]
@@ -46,10 +49,11 @@ class KPlanesField(nn.Module):
                  sigma_net_hidden_dim: int = 64, rgb_net_layers: int = 2, rgb_net_hidden_dim: int = 64, use_appearance_embedding: bool = False,
                  spatial_distortion=None, **_unused) -> None:
         super().__init__()
-        if linear_decoder or use_appearance_embedding or spatial_distortion is not None:
+        if linear_decoder or use_appearance_embedding:
             # (the reference's appearance-embedding branch, kplanes_field.py:325-346, cannot run with per-sample camera indices: see
             # oracle/gen_golden_field_options.py)
-            raise NotImplementedError("built: the MLP decoder on a bounded scene, view-independent (the k-planes preset) or view-dependent")
+            raise NotImplementedError("built: the MLP decoder, view-independent (the k-planes preset) or view-dependent, bounded or contracted scenes")
+        self.spatial_distortion = spatial_distortion
         self.disable_viewing_dependent = disable_viewing_dependent
         self.aabb = nn.Parameter(aabb, requires_grad=False)
         mult = list(multiscale_res or [1])
@@ -71,9 +75,9 @@ class KPlanesField(nn.Module):
 
     def _features(self, ray_samples: RaySamples):
         c = ray_samples._compact
-        if c is not None and c["times"] is not None:
+        if c is not None and c["times"] is not None and self.spatial_distortion is None:
             return ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=True)
-        pts = _pts_from_positions(ray_samples.frustums.get_positions(), ray_samples.times, self.aabb, True)
+        pts = _pts_from_positions(ray_samples.frustums.get_positions(), ray_samples.times, self.aabb, True, self.spatial_distortion)
         return ops.interpolate_kplanes(pts, self.grids)
 
     def get_density(self, ray_samples: RaySamples):
@@ -101,8 +105,9 @@ class KPlanesField(nn.Module):
 class KPlanesDensityField(nn.Module):
     def __init__(self, aabb, resolution, feature_dim, spatial_distortion=None, linear_decoder: bool = False, **_unused) -> None:
         super().__init__()
-        if linear_decoder or spatial_distortion is not None:
-            raise NotImplementedError("only the k-planes preset proposal field is built")
+        if linear_decoder:
+            raise NotImplementedError("the linear decoder of the proposal field is not built")
+        self.spatial_distortion = spatial_distortion
         self.aabb = nn.Parameter(aabb, requires_grad=False)
         self.grids = PlaneSet(feature_dim, [list(resolution)], concat=False, a=0.1, b=0.15)
         self.sigma_net = Network(feature_dim, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
@@ -113,7 +118,7 @@ class KPlanesDensityField(nn.Module):
         shape = positions.shape[:-1]
         if positions.dim() == 2:
             positions, times = positions[:, None, :], times
-        pts = _pts_from_positions(positions, times, self.aabb, rescale=False)  # [0,1] coordinates: reference quirk (:440)
+        pts = _pts_from_positions(positions, times, self.aabb, rescale=False, spatial_distortion=self.spatial_distortion)  # bounded: [0,1] coordinates, reference quirk (:440)
         _, dens = self.sigma_net.forward_with_exp_head(ops.interpolate_kplanes(pts, self.grids), 0)
         return dens.view(*shape, 1)
 
@@ -126,7 +131,7 @@ class KPlanesDensityField(nn.Module):
         return dens.view(n_rays, n_samples, 1)
 
     def get_density(self, ray_samples: RaySamples):
-        if ray_samples._compact is not None:
+        if ray_samples._compact is not None and self.spatial_distortion is None:
             return self.density_from_ray_samples(ray_samples), None
         return self.density_fn(ray_samples.frustums.get_positions(), ray_samples.times), None
 

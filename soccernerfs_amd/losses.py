@@ -42,7 +42,10 @@ def _ebins_of(ray_samples) -> torch.Tensor:
 
 def depth_loss(weights, ray_samples, termination_depth, predicted_depth, sigma, directions_norm, is_euclidean: bool,
                depth_loss_type=DepthLossType.DS_NERF) -> torch.Tensor:
-    """losses.py:261-311 with the argument list of the reference.  Only the DS-NeRF loss (the K-Planes default, kplanes.py:172) is built."""
+    """losses.py:261-311 with the argument list of the reference: DS-NeRF (the K-Planes default, kplanes.py:172) or Urban Radiance Fields."""
+    dn = None if is_euclidean else directions_norm.reshape(-1)
+    if depth_loss_type == DepthLossType.URF:
+        return ops.urf_depth_loss(weights[..., 0], _ebins_of(ray_samples), termination_depth.reshape(-1), predicted_depth, float(sigma), dn)
     if depth_loss_type != DepthLossType.DS_NERF:
         raise NotImplementedError("Provided depth loss type not implemented.")
     return ops.ds_nerf_depth_loss(weights[..., 0], _ebins_of(ray_samples), termination_depth.reshape(-1), float(sigma),

@@ -552,6 +552,32 @@ def ds_nerf_depth_loss(weights, ebins, termination_depth, sigma: float, directio
                             float(sigma))
 
 
+class _UrfDepthLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, ebins, term, dnorm, pred, sigma: float):
+        R, S = weights.shape
+        loss_rays = torch.empty(R, dtype=torch.float32, device=weights.device)
+        gw, gp = torch.empty_like(weights), torch.empty(R, dtype=torch.float32, device=weights.device)
+        _lib.check(_lib.lib().snerf_urf_depth_loss(_ptr(weights), _ptr(ebins), _ptr(term), _ptr(dnorm) if dnorm is not None else None, _ptr(pred), sigma, R, S,
+                                                   1.0 / R, _ptr(loss_rays), _ptr(gw), _ptr(gp), 0, _stream()), "urf_depth_loss")
+        ctx.save_for_backward(gw, gp)
+        ctx.pred_shape = pred.shape
+        return loss_rays.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        gw, gp = ctx.saved_tensors
+        return gw * g, None, None, None, (gp * g).view(ctx.pred_shape), None
+
+
+def urf_depth_loss(weights, ebins, termination_depth, predicted_depth, sigma: float, directions_norm=None):
+    """depth_loss with DepthLossType.URF for one sampling level (losses.py:238-274): arguments as ds_nerf_depth_loss + the level's predicted
+    depth [R] (differentiable: the expected-depth term)."""
+    dn = _f32c(directions_norm, "directions_norm").reshape(-1) if directions_norm is not None else None
+    return _UrfDepthLoss.apply(_f32c(weights, "weights"), _f32c(ebins.detach(), "ebins"), _f32c(termination_depth, "termination_depth").reshape(-1), dn,
+                               _f32c(predicted_depth, "predicted_depth").reshape(-1), float(sigma))
+
+
 REG_SLOTS = 1024  # partial-sum slots of the regulariser values (one 64-B line each)
 
 

@@ -170,6 +170,6 @@ def _call_density(fn, ray_samples: RaySamples):
     package's density fields the sample coordinates are derived in-kernel instead of materialising positions."""
     base = getattr(fn, "func", fn)
     owner = getattr(base, "__self__", None)
-    if owner is not None and hasattr(owner, "density_from_ray_samples"):
+    if owner is not None and hasattr(owner, "density_from_ray_samples") and getattr(owner, "spatial_distortion", None) is None:
         return owner.density_from_ray_samples(ray_samples)
     return fn(ray_samples.frustums.get_positions())

@@ -142,3 +142,57 @@ def test_view_dependent_field_matches_reference_golden():
             o = f(rs)
         torch.testing.assert_close(o[FieldHeadNames.DENSITY][..., 0].cpu(), g[f"vd_{mode}_density"], rtol=2e-5, atol=1e-6)
         torch.testing.assert_close(o[FieldHeadNames.RGB].cpu(), g[f"vd_{mode}_rgb"], rtol=2e-5, atol=2e-6)
+
+
+def test_unbounded_scene_contraction_matches_reference_golden():
+    """KPlanesModelConfig.bounded = False (NS/models/kplanes.py:194,260-281): L-inf SceneContraction in front of KPlanesField and
+    KPlanesDensityField, near / far collider, piecewise initial sampler.  Field values vs the reference's own classes on positions inside and far
+    outside the unit cube (G6c); then the unbounded model runs a training forward + loss + backward."""
+    from soccernerfs_amd.kplanes import KPlanesModel, KPlanesModelConfig
+    from soccernerfs_amd.kplanes_field import FieldHeadNames, KPlanesDensityField, KPlanesField
+    from soccernerfs_amd.ray_samplers import UniformLinDispPiecewiseSampler
+    from soccernerfs_amd.rays import Frustums, RayBundle, RaySamples
+    from soccernerfs_amd.scene_colliders import NearFarCollider, SceneBox
+    from soccernerfs_amd.spatial_distortions import SceneContraction
+
+    g = load_golden("g6c_contraction")
+    sc = SceneContraction(order=float("inf"))
+    pos, dirs, tms = g["positions"].to(DEV), g["directions"].to(DEV), g["times"].to(DEV)
+    torch.testing.assert_close(sc(pos).cpu(), g["contracted"], rtol=0, atol=1e-7)
+    f = KPlanesField(g["aabb"], spacetime_resolution=[6, 5, 4, 3], feat_dim=32, multiscale_res=[1, 2], concat_features_across_scales=True,
+                     spatial_distortion=sc, disable_viewing_dependent=True, sigma_net_layers=1, sigma_net_hidden_dim=128, rgb_net_layers=2,
+                     rgb_net_hidden_dim=64).to(DEV)
+    f.grids.load_reference([[g[f"plane_{s}_{q}"] for q in range(6)] for s in range(2)])
+    f.sigma_net.load_linear_weights([g[f"sigma_{i}"].to(DEV) for i in range(2)])
+    f.color_net.load_linear_weights([g[f"color_{i}"].to(DEV) for i in range(3)])
+    R, S = pos.shape[:2]
+    rs = RaySamples(frustums=Frustums(origins=pos, directions=dirs, starts=torch.zeros(R, S, 1, device=DEV), ends=torch.zeros(R, S, 1, device=DEV),
+                                      pixel_area=torch.ones(R, S, 1, device=DEV)), times=tms[:, None])
+    with torch.no_grad():
+        o = f(rs)
+    torch.testing.assert_close(o[FieldHeadNames.DENSITY][..., 0].cpu(), g["density"], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(o[FieldHeadNames.RGB].cpu(), g["rgb"], rtol=2e-5, atol=2e-6)
+    df = KPlanesDensityField(g["aabb"], resolution=[8, 7, 6, 3], feature_dim=8, spatial_distortion=sc).to(DEV)
+    df.grids.load_reference([[g[f"prop_plane_{q}"] for q in range(6)]])
+    df.sigma_net.load_linear_weights([g[f"prop_sigma_{i}"].to(DEV) for i in range(2)])
+    with torch.no_grad():
+        torch.testing.assert_close(df.density_fn(pos, tms)[..., 0].cpu(), g["prop_density"], rtol=2e-5, atol=1e-6)
+    # the unbounded model end to end
+    cfg = KPlanesModelConfig(bounded=False, multiscale_res=(1, 2), spacetime_resolution=(16, 16, 16, 4), feature_dim=32, concat_features_across_scales=True,
+                             proposal_net_args_list=[{"feature_dim": 8, "resolution": (24, 24, 24, 4)}, {"feature_dim": 8, "resolution": (32, 32, 32, 4)}],
+                             sigma_net_hidden_dim=128, num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    model = KPlanesModel(cfg, SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3]))).to(DEV).train()
+    assert isinstance(model.collider, NearFarCollider) and isinstance(model.proposal_sampler.initial_sampler, UniformLinDispPiecewiseSampler)
+    assert model.field.spatial_distortion is not None and all(p.spatial_distortion is not None for p in model.proposal_networks)
+    gen = torch.Generator().manual_seed(3)
+    R = 64
+    rb = RayBundle(origins=((torch.rand(R, 3, generator=gen) * 2 - 1) * 0.5).to(DEV), directions=torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1).to(DEV),
+                   pixel_area=torch.ones(R, 1, device=DEV), camera_indices=torch.zeros(R, 1, dtype=torch.long, device=DEV), times=torch.rand(R, 1, generator=gen).to(DEV))
+    out = model(rb)
+    batch = {"image": torch.rand(R, 3, generator=gen).to(DEV)}
+    ld = model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
+    sum(ld.values()).backward()
+    assert out["rgb"].shape == (R, 3) and bool(torch.isfinite(out["rgb"]).all())
+    far = float(out["ray_samples_list"][-1].frustums.ends.max())
+    assert far > 10.0  # the piecewise sampler reaches far beyond the unit cube; those samples are contracted onto [-2, 2]^3
+    assert float(model.field.grids.planes.grad.abs().sum()) > 0 and all(float(p.grids.planes.grad.abs().sum()) > 0 for p in model.proposal_networks)

@@ -193,6 +193,30 @@ def test_depth_loss_golden():
         torch.testing.assert_close(w.grad.cpu() / 2.0, g["grad_" + tag], rtol=2e-5, atol=1e-9)
 
 
+def test_urf_depth_loss_golden():
+    """snerf_urf_depth_loss (Urban Radiance Fields lidar losses, losses.py:238-274) through the reference-shaped losses.depth_loss vs the
+    reference's own values and gradients w.r.t. weights and predicted depth (G8b)."""
+    from soccernerfs_amd import losses
+    from soccernerfs_amd.rays import Frustums, RaySamples
+
+    g = load_golden("g8b_depth")
+    d = lambda k: g[k].to(DEV).contiguous()
+    bins = d("bins")
+    R, S = g["weights"].shape
+    o = torch.zeros(R, S, 3, device=DEV)
+    rs = RaySamples(frustums=Frustums(origins=o, directions=torch.ones_like(o), starts=bins[:, :-1, None], ends=bins[:, 1:, None],
+                                      pixel_area=torch.ones(R, S, 1, device=DEV)))
+    for tag, eucl in (("urf_eucl_s02", True), ("urf_z_s05", False), ("urf_eucl_s001", True)):
+        w = d("weights")[..., None].clone().requires_grad_(True)
+        pd = d("predicted_depth")[:, None].clone().requires_grad_(True)
+        val = losses.depth_loss(w, rs, d("termination_depth")[:, None], pd, float(g["sigma_" + tag]), d("directions_norm")[:, None], eucl,
+                                losses.DepthLossType.URF)
+        (val * 3.0).backward()
+        torch.testing.assert_close(val.detach().cpu(), torch.as_tensor(g["loss_" + tag]), rtol=2e-5, atol=1e-8)
+        torch.testing.assert_close(w.grad[..., 0].cpu() / 3.0, g["grad_" + tag], rtol=2e-5, atol=1e-8)
+        torch.testing.assert_close(pd.grad[:, 0].cpu() / 3.0, g["gpred_" + tag], rtol=2e-5, atol=1e-8)
+
+
 def test_trainer_depth_supervision_matches_oracle():
     """Fused trainer with termination depths: loss value and every gradient segment equal the oracle with the depth term on all three levels."""
     from oracle import kplanes_oracle as KO

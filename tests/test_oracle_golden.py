@@ -282,3 +282,34 @@ def test_g8b_depth_loss():
         val.backward()
         torch.testing.assert_close(val.detach(), torch.as_tensor(g["loss_" + tag]), rtol=1e-6, atol=1e-8)
         torch.testing.assert_close(w.grad, g["grad_" + tag], rtol=1e-5, atol=1e-9)
+
+
+def test_g8b_urf_depth_loss():
+    """oracle urf_depth_loss vs the reference's own depth_loss(depth_loss_type=URF): values, gradients w.r.t. weights and predicted depth (G8b)."""
+    g = load_golden("g8b_depth")
+    for tag, eucl in (("urf_eucl_s02", True), ("urf_z_s05", False), ("urf_eucl_s001", True)):
+        w = g["weights"].clone().requires_grad_(True)
+        pd = g["predicted_depth"].clone().requires_grad_(True)
+        val = KO.urf_depth_loss(w, g["bins"], g["termination_depth"], pd, float(g["sigma_" + tag]), g["directions_norm"], eucl)
+        val.backward()
+        torch.testing.assert_close(val.detach(), torch.as_tensor(g["loss_" + tag]), rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(w.grad, g["grad_" + tag], rtol=1e-5, atol=1e-8)
+        torch.testing.assert_close(pd.grad, g["gpred_" + tag], rtol=1e-5, atol=1e-8)
+
+
+def test_g6c_scene_contraction_fields():
+    """G6c (oracle/gen_golden_contraction.py): the reference's SceneContraction(order=inf) and its K-Planes fields behind it.  The oracle's
+    contraction equals the reference's; its field functions fed contracted / 2 positions (aabb [-1,1]^3: the normalisation is then the
+    identity; the density field's [0,1] quirk undone by 2x - 1 -> x) reproduce the reference's densities and colours."""
+    g = load_golden("g6c_contraction")
+    pos = g["positions"]
+    c = KO.scene_contraction_inf(pos)
+    close(c, g["contracted"], rtol=0, atol=0)
+    assert float(c.abs().max()) <= 2.0 and float(c[5:].abs().amax(-1).min()) > 1.9  # far samples sit next to the cube's faces
+    grids = [[g[f"plane_{s}_{q}"] for q in range(6)] for s in range(2)]
+    dens, rgb = KO.field_forward(c / 2.0, g["times"], g["aabb"], grids, [g["sigma_0"], g["sigma_1"]], [g["color_0"], g["color_1"], g["color_2"]])
+    close(dens, g["density"], rtol=2e-5, atol=1e-6)
+    close(rgb, g["rgb"], rtol=2e-5, atol=2e-6)
+    # KPlanesDensityField: contracted / 2 goes to the planes as is; the oracle's bounded branch would map x -> (x + 1) / 2, so feed 2 (c/2) - ... = c - 1
+    pd = KO.density_field_forward(c - 1.0, g["times"], g["aabb"], [g[f"prop_plane_{q}"] for q in range(6)], [g["prop_sigma_0"], g["prop_sigma_1"]])
+    close(pd, g["prop_density"], rtol=2e-5, atol=1e-6)
