@@ -424,7 +424,7 @@ int snerf_aabb_collide(const float* origins, const float* dirs, int32_t R, const
  * `nerfstudio_field_components_cuda` (NS/field_components/cuda/csrc/include/temporal_gridencoder.h:24-60, pybind.cu:11-13):
  *   temporal_grid_encode_forward (inputs, temporal_row_index, embeddings, offsets, outputs, B, D, grid_C, C, L, S, H, dy_dx, gridtype, align_corners)
  *   temporal_grid_encode_backward(grad, inputs, temporal_row_index, embeddings, offsets, grad_embeddings, B, D, grid_C, C, L, S, H, dy_dx, grad_inputs, gridtype, align_corners)
- * dy_dx / grad_inputs (gradient w.r.t. coordinates) are not provided: xyz never requires grad on this path (camera optimiser off).
+ * dy_dx / grad_inputs (the gradient w.r.t. the coordinates, calc_grad_inputs): snerf_tgrid_encode_fwd_dydx + snerf_tgrid_input_bwd below.
  * ------------------------------------------------------------------------------------------------ */
 typedef struct {
   int32_t D;             /* input dims (1..3) */
@@ -446,6 +446,14 @@ typedef struct {
 int snerf_tgrid_encode_fwd(const snerf_tgrid_desc* desc, const float* embeddings, const snerf_coords* coords,
                            const float* temporal_row_index, const float* times, int32_t samples_per_row, int64_t B, float* out,
                            snerf_stream_t stream);
+/* Forward that also writes dy_dx [B, L, D, C] = d out[b, l*C + ch] / d x[b, d] (temporal_gridencoder.cu:204-273; zero for out-of-range inputs),
+ * and the coordinate gradient built from it: grad_inputs[B, D] = sum_{l, ch} grad_out[b, l*C + ch] * dy_dx[b, l, d, ch] (kernel_input_backward,
+ * .cu:373-398).  The reference allocates dy_dx only when the inputs require a gradient (temporal_grid.py:82-87). */
+int snerf_tgrid_encode_fwd_dydx(const snerf_tgrid_desc* desc, const float* embeddings, const snerf_coords* coords,
+                                const float* temporal_row_index, const float* times, int32_t samples_per_row, int64_t B, float* out, float* dy_dx,
+                                snerf_stream_t stream);
+int snerf_tgrid_input_bwd(const float* grad_out, const float* dy_dx, int64_t B, int32_t D, int32_t C, int32_t L, float* grad_inputs,
+                          snerf_stream_t stream);
 /* ACCUMULATES (atomic fp32) into grad_embeddings [rows, grid_C]; the caller zeroes it when needed (the reference allocates a
  * zeros_like(embeddings) every backward, temporal_grid.py:126). */
 int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,

@@ -191,6 +191,8 @@ EXPORTS = [
     "snerf_hashgrid_encode_fwd",
     "snerf_hashgrid_encode_bwd",
     "snerf_tgrid_encode_bwd",
+    "snerf_tgrid_encode_fwd_dydx",
+    "snerf_tgrid_input_bwd",
     "snerf_ist_maps",
     "snerf_ist_sample",
     "snerf_kplanes_sort_workspace",

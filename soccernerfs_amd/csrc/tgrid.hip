@@ -25,6 +25,7 @@ struct TgridArgs {
   int spr;             // samples per row of trow/times (1 = per sample; S = per ray)
   int64_t B;
   float* out;          // fwd: [B, L*C]
+  float* dy_dx;        // fwd, optional: [B, L, D, C] d out / d x (temporal_gridencoder.cu:204-273, calc_grad_inputs)
   const float* gout;   // bwd
   float* gemb;         // bwd
 };
@@ -45,7 +46,7 @@ __device__ __forceinline__ void tg_slot_from_time(float t, int C, int n_rows, in
   }
 }
 
-template <bool BWD>
+template <bool BWD, bool DYDX = false>
 __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
   const int C = a.d.C, D = a.d.D;
   const int LPG = 2 * C;  // lanes per (sample, level)
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
   if (BWD) g = a.gout[bb * (a.d.L * C) + level * C + ch] * wt;
   const bool active = live && !oob && wt != 0.f;
   float acc = 0.f;
+  float dacc[3] = {0.f, 0.f, 0.f};  // DYDX: d (this lane's column share of the output) / d x_d
   const int ncorner = 1 << D;
   // Row index of a corner = get_grid_index (.cu:62-88): fast_hash (XOR of coordinate * prime, .cu:46-59) on hashed levels, the
   // strided sum on dense ones, modulo the level's table size.  Per-axis terms, shared by the 2^D corners: t[d][bit] = (pg[d] + bit) * (prime[d] | dense stride[d]); a corner's row is
@@ -140,13 +142,32 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
         float v = w * g;
         if (v != 0.f) atomicAdd(a.gemb + e, v);
       } else {
-        acc += w * (a.emb[e] * wt);
+        const float val = a.emb[e] * wt;
+        acc += w * val;
+        if (DYDX) {
+          // d/d x_gd of the D-linear interpolation: scale * sum over the corners of (+1 on the far side, -1 on the near side of axis gd) x the
+          // other axes' weights x the corner's value (.cu:211-267 pairs the corners up as right - left)
+          for (int gd = 0; gd < D; ++gd) {
+            float wo = scale;
+            for (int d = 0; d < D; ++d)
+              if (d != gd) wo *= ((idx >> d) & 1) ? pos[d] : 1.f - pos[d];
+            dacc[gd] += (((idx >> gd) & 1) ? wo : -wo) * val;
+          }
+        }
       }
     }
   }
   if (!BWD) {
     acc += __shfl_xor(acc, 1, 64);  // column a + column b of this channel
     if (live && ab == 0) a.out[b * (a.d.L * C) + level * C + ch] = oob ? 0.f : acc;
+    if (DYDX) {
+      for (int gd = 0; gd < D; ++gd) {
+        float v = dacc[gd];
+        v += __shfl_xor(v, 1, 64);
+        // out-of-range inputs: the reference returns before dy_dx is written (.cu:119-124) into a zero-initialised buffer
+        if (live && ab == 0) a.dy_dx[((b * a.d.L + level) * D + gd) * C + ch] = oob ? 0.f : v;
+      }
+    }
   }
 }
 
@@ -165,11 +186,25 @@ static int validate(const snerf_tgrid_desc* d, const snerf_coords* c, const floa
   return 0;
 }
 
+// coordinate gradient (kernel_input_backward, .cu:373-398): grad_inputs[b, d] = sum_{l, ch} grad[b, l, ch] * dy_dx[b, l, d, ch]; one lane per (b, d)
+__global__ __launch_bounds__(256) void tgrid_input_bwd_kernel(const float* __restrict__ grad, const float* __restrict__ dy_dx, int64_t B, int D, int C, int L,
+                                                             float* __restrict__ grad_inputs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * D) return;
+  const int64_t b = t / D;
+  const int d = (int)(t - b * D);
+  float r = 0.f;
+  for (int l = 0; l < L; ++l)
+    for (int ch = 0; ch < C; ++ch) r += grad[(b * L + l) * C + ch] * dy_dx[((b * L + l) * D + d) * C + ch];
+  grad_inputs[t] = r;
+}
+
 template <bool BWD>
 static int launch(const TgridArgs& a, hipStream_t st) {
   const int64_t threads = a.B * 2 * a.d.C;
   dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)a.d.L);
-  hipLaunchKernelGGL(tgrid_kernel<BWD>, grid, dim3(256), 0, st, a);
+  if (!BWD && a.dy_dx) hipLaunchKernelGGL((tgrid_kernel<false, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(tgrid_kernel<BWD>, grid, dim3(256), 0, st, a);
   SNERF_LAUNCH_CHECK(BWD ? "tgrid_encode_bwd" : "tgrid_encode_fwd");
   return 0;
 }
@@ -281,6 +316,29 @@ extern "C" int snerf_tgrid_encode_fwd(const snerf_tgrid_desc* desc, const float*
   TgridArgs a = {};
   a.d = *desc; a.c = *coords; a.emb = embeddings; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.out = out;
   return launch<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int snerf_tgrid_encode_fwd_dydx(const snerf_tgrid_desc* desc, const float* embeddings, const snerf_coords* coords,
+                                           const float* temporal_row_index, const float* times, int32_t samples_per_row, int64_t B, float* out,
+                                           float* dy_dx, snerf_stream_t stream) {
+  int rc = validate(desc, coords, temporal_row_index, times, samples_per_row, B);
+  if (rc) return rc;
+  if (B == 0) return 0;
+  SNERF_REQUIRE(embeddings && out && dy_dx, "tgrid_encode_fwd_dydx: null buffer");
+  TgridArgs a = {};
+  a.d = *desc; a.c = *coords; a.emb = embeddings; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.out = out;
+  a.dy_dx = dy_dx;
+  return launch<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int snerf_tgrid_input_bwd(const float* grad_out, const float* dy_dx, int64_t B, int32_t D, int32_t C, int32_t L, float* grad_inputs,
+                                     snerf_stream_t stream) {
+  SNERF_REQUIRE(B >= 0 && D >= 1 && D <= 3 && C >= 1 && L >= 1, "tgrid_input_bwd: B=%lld D=%d C=%d L=%d", (long long)B, D, C, L);
+  if (B == 0) return 0;
+  SNERF_REQUIRE(grad_out && dy_dx && grad_inputs, "tgrid_input_bwd: null buffer");
+  hipLaunchKernelGGL(tgrid_input_bwd_kernel, dim3((unsigned)ceil_div(B * D, 256)), dim3(256), 0, (hipStream_t)stream, grad_out, dy_dx, B, D, C, L, grad_inputs);
+  SNERF_LAUNCH_CHECK("tgrid_input_bwd");
+  return 0;
 }
 
 extern "C" int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,

@@ -37,11 +37,19 @@ class _Encode(torch.autograd.Function):
     table, profiles/r01_kernels.md)."""
 
     @staticmethod
-    def forward(ctx, embeddings, enc, coords_keep, coords, trow, times, spr, B, tv_a, tv_b):
+    def forward(ctx, embeddings, enc, coords_keep, coords, trow, times, spr, B, tv_a, tv_b, xyz=None):
         out = torch.empty(B, enc.output_dim, dtype=torch.float32, device=embeddings.device)
-        _lib.check(_lib.lib().snerf_tgrid_encode_fwd(C.byref(enc.desc), ops._ptr(embeddings), C.byref(coords),
-                                                     ops._ptr(trow) if trow is not None else None, ops._ptr(times) if times is not None else None,
-                                                     spr, C.c_int64(B), ops._ptr(out), ops._stream()), "tgrid_encode_fwd")
+        ctx.dy_dx = None
+        if xyz is not None and xyz.requires_grad:
+            # calc_grad_inputs (temporal_grid.py:82-87): d out / d xyz is kept for the backward, [B, L, D, C]
+            ctx.dy_dx = torch.empty(B, enc.num_levels, enc.input_dim, enc.level_dim, dtype=torch.float32, device=embeddings.device)
+            _lib.check(_lib.lib().snerf_tgrid_encode_fwd_dydx(C.byref(enc.desc), ops._ptr(embeddings), C.byref(coords),
+                                                              ops._ptr(trow) if trow is not None else None, ops._ptr(times) if times is not None else None,
+                                                              spr, C.c_int64(B), ops._ptr(out), ops._ptr(ctx.dy_dx), ops._stream()), "tgrid_encode_fwd_dydx")
+        else:
+            _lib.check(_lib.lib().snerf_tgrid_encode_fwd(C.byref(enc.desc), ops._ptr(embeddings), C.byref(coords),
+                                                         ops._ptr(trow) if trow is not None else None, ops._ptr(times) if times is not None else None,
+                                                         spr, C.c_int64(B), ops._ptr(out), ops._stream()), "tgrid_encode_fwd")
         ctx.enc, ctx.coords, ctx.keep, ctx.trow, ctx.times, ctx.spr, ctx.B = enc, coords, coords_keep, trow, times, spr, B
         ctx.shape, ctx.tv = embeddings.shape, None
         if tv_a is None:
@@ -58,8 +66,13 @@ class _Encode(torch.autograd.Function):
         enc = ctx.enc
         acc = enc.embeddings.grad if getattr(enc, "accumulate_into_grad", False) else None
         gemb = acc if acc is not None else torch.zeros(ctx.shape, dtype=torch.float32, device=enc.embeddings.device)
+        gxyz = None
         if g is not None:
             g = g.contiguous()
+            if ctx.dy_dx is not None:  # kernel_input_backward (temporal_gridencoder.cu:373-398)
+                gxyz = torch.empty(ctx.B, enc.input_dim, dtype=torch.float32, device=g.device)
+                _lib.check(_lib.lib().snerf_tgrid_input_bwd(ops._ptr(g), ops._ptr(ctx.dy_dx), C.c_int64(ctx.B), enc.input_dim, enc.level_dim, enc.num_levels,
+                                                            ops._ptr(gxyz), ops._stream()), "tgrid_input_bwd")
             _lib.check(_lib.lib().snerf_tgrid_encode_bwd(C.byref(enc.desc), C.byref(ctx.coords), ops._ptr(ctx.trow) if ctx.trow is not None else None,
                                                          ops._ptr(ctx.times) if ctx.times is not None else None, ctx.spr, C.c_int64(ctx.B), ops._ptr(g),
                                                          ops._ptr(gemb), ops._stream()), "tgrid_encode_bwd")
@@ -70,7 +83,7 @@ class _Encode(torch.autograd.Function):
                                                      ops._stream()), "tgrid_tv_bwd")
         # accumulate_into_grad (set by optimizers.FusedAdam): the scatter went straight into the persistent, optimiser-cleared
         # .grad buffer; returning None keeps autograd from allocating / adding a second dense tensor
-        return (None if acc is not None else gemb), None, None, None, None, None, None, None, None, None
+        return (None if acc is not None else gemb), None, None, None, None, None, None, None, None, None, gxyz
 
 
 class TemporalGridEncoder(nn.Module):
@@ -125,7 +138,9 @@ class TemporalGridEncoder(nn.Module):
 
     def forward(self, xyz: torch.Tensor, time: torch.Tensor, explicit_rows: bool = False) -> torch.Tensor:
         """xyz [B, input_dim] in [0,1]; time [B,1] in [0,1] -> [B, num_levels*level_dim].  explicit_rows=True passes the
-        reference's temporal_row_index tensor to the kernel; default derives it in-kernel from `time` (same values)."""
+        reference's temporal_row_index tensor to the kernel; default derives it in-kernel from `time` (same values).  When xyz requires a
+        gradient (deformed positions, camera optimisation) the forward also keeps d out / d xyz and the backward returns the coordinate gradient
+        (calc_grad_inputs of TemporalGridEncodeFunc, temporal_grid.py:82-87,139-150)."""
         xyz = ops._f32c(xyz, "xyz")
         t = ops._f32c(time, "time").reshape(-1)
         B = xyz.shape[0]
@@ -133,9 +148,9 @@ class TemporalGridEncoder(nn.Module):
         tv_a, tv_b = self._draw_tv_columns()
         if explicit_rows:
             rows = self.get_temporal_index(t).contiguous()
-            out, tv = _Encode.apply(self.embeddings, self, (xyz, rows), co, rows, None, 1, B, tv_a, tv_b)
+            out, tv = _Encode.apply(self.embeddings, self, (xyz, rows), co, rows, None, 1, B, tv_a, tv_b, xyz)
         else:
-            out, tv = _Encode.apply(self.embeddings, self, (xyz, t), co, None, t, 1, B, tv_a, tv_b)
+            out, tv = _Encode.apply(self.embeddings, self, (xyz, t), co, None, t, 1, B, tv_a, tv_b, xyz)
         self._tv_cached = tv
         return out
 

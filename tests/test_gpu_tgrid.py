@@ -72,6 +72,20 @@ def test_encode_fwd_bwd_matches_oracle(kw):
         out.backward(go.to(DEV))
         torch.testing.assert_close(enc.embeddings.grad.cpu(), emb.grad, rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(enc.get_temporal_index(t[:, 0].to(DEV)).cpu(), TO.temporal_index(t[:, 0], ed["table"]), rtol=0, atol=0)
+    # coordinate gradient (calc_grad_inputs: dy_dx in the forward, kernel_input_backward, temporal_gridencoder.cu:204-273,373-398) against autograd
+    # through the oracle's interpolation weights (floor has no gradient: the same piecewise-linear derivative); zero for the out-of-range point
+    xo = x.clone().requires_grad_(True)
+    ref2 = TO.encode(xo, TO.temporal_index(t[:, 0], ed["table"]), emb.detach(), ed["offsets"], ed["log2_scale"], ed["base_res"], ed["gridtype"], ed["level_dim"])
+    ref2.backward(go)
+    for explicit in (False, True):
+        xd = x.to(DEV).requires_grad_(True)
+        enc.embeddings.grad = None
+        out = enc(xd, t.to(DEV), explicit_rows=explicit)
+        torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+        out.backward(go.to(DEV))
+        torch.testing.assert_close(xd.grad.cpu(), xo.grad, rtol=2e-4, atol=1e-5 * float(xo.grad.abs().max()))
+        assert torch.all(xd.grad[2] == 0)
+        torch.testing.assert_close(enc.embeddings.grad.cpu(), emb.grad, rtol=1e-4, atol=1e-6)  # the table's gradient is unchanged by it
 
 
 def _make_model(num_images=5):
