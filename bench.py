@@ -44,10 +44,11 @@ def parse():
     ap.add_argument("--start-step", type=int, default=0, help="pretend this many optimiser steps are done: >= 5000 gives the steady-state "
                     "schedule (proposal networks updated every 5th step, kplanes.py:254-259) instead of the every-step schedule of early training")
     ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
-    ap.add_argument("--grad-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
-                    "gradient on the links (fp32 = the reference's DDP semantics; bf16 halves the reduce-scatter bytes, opt-in)")
-    ap.add_argument("--param-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: fp32 = all-gather the new field planes "
-                    "(reference semantics); bf16 = all-gather the parameter UPDATES in bf16 and apply them identically on every rank (opt-in)")
+    ap.add_argument("--grad-transport", default="bf16", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
+                    "gradient on the links.  bf16 (the bench default since round 3: half the reduce-scatter bytes; 10 paired 30 k-step seeds of the single-GPU "
+                    "emulation: PSNR -0.03 +- 0.12 dB, profiles/r03_psnr_30k_bf16_emulated_bf16_transports.json); fp32 = the reference's DDP arithmetic")
+    ap.add_argument("--param-transport", default="bf16", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: bf16 (bench default) = all-gather the "
+                    "parameter UPDATES in bf16 and apply them identically on every rank; fp32 = all-gather the new field planes (reference arithmetic)")
     ap.add_argument("--cabi-allreduce", action="store_true", help="world > 1 with --no-shard: the flat gradient all-reduce goes through libsnerf's own "
                     "RCCL communicator (snerf_allreduce_grads) instead of torch.distributed")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
@@ -338,8 +339,9 @@ def main():
                                    f"from optimiser step {args.start_step} (proposal networks updated every {cfg.proposal_update_every}th step past step {cfg.proposal_warmup})",
                        "rays_per_gpu": R, "images": int(M), "image_hw": [int(H), int(W)], "params": int(trainer.n_params),
                        "parallelism": "single GPU" if world == 1 else (
-                           f"ray-sharded x{world}; field-plane gradients: RCCL reduce-scatter -> Adam on a 1/{world} shard -> all-gather of the new "
-                           "planes (= one all-reduce's bytes), small segments: all-reduce" if trainer._sharded() else
+                           f"ray-sharded x{world}; field-plane gradients: RCCL reduce-scatter ({trainer.grad_transport}) -> Adam on a 1/{world} shard -> all-gather of "
+                           f"the {'parameter updates (bf16)' if trainer.param_transport == 'bf16' else 'new planes (fp32)'} (= one all-reduce's worth of "
+                           "traffic, halved by the bf16 transports), small segments: fp32 all-reduce" if trainer._sharded() else
                            f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step")},
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": alg_bytes,
