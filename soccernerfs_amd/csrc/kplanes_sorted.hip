@@ -458,25 +458,18 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) g[u] = load_g(gseg, (int64_t)(R[(e0 + u) * 8] + ch));  // wave-uniform LDS address: broadcast
     float t0[QUOT ? UNROLL : 1], t1[QUOT ? UNROLL : 1];  // QUOT: this lane's x-column of the entry's cell, rows y0 and y0 + 1
-    bool same[QUOT ? UNROLL : 1];                         // the entry sits in its predecessor's cell (same texels, same clamping): nothing to fetch
     if constexpr (QUOT) {
-      uint32_t ptoff = 0xffffffffu, pfl = 0u;
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
         // element offset of texel (x0, y0) and the "x0 + 1 / y0 + 1 exist" flags were prepared lane-parallel with the record (a clamped
         // corner has weight 0 and re-reads the unclamped texel, as the forward's taps do; a null record reads texel 0 with zero weights)
         const uint32_t toff = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 2]);
         const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 3]);
-        same[u] = u > 0 && toff == ptoff && fl == pfl;  // wave-uniform
-        if (!same[u]) {
-          const uint32_t o0 = toff + (half ? (fl & 1u) * (uint32_t)C : 0u);
-          t0[u] = pch[o0];
-          t1[u] = pch[o0 + ((fl & 2u) ? rowC32 : 0u)];
-        }
-        ptoff = toff; pfl = fl;
+        const uint32_t o0 = toff + (half ? (fl & 1u) * (uint32_t)C : 0u);
+        t0[u] = pch[o0];
+        t1[u] = pch[o0 + ((fl & 2u) ? rowC32 : 0u)];
       }
     }
-    float c00 = 0.f, c10 = 0.f, c01 = 0.f, c11 = 0.f;  // QUOT: the current cell's four texels (this lane's channel), both x-columns in every lane
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t packed = (uint32_t)__builtin_amdgcn_readfirstlane((int)R[(e0 + u) * 8 + 1]);
@@ -485,12 +478,9 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
       if constexpr (QUOT) {
         // the plane's value at the entry, with the forward's own formula and order (bilerp4): both x-columns in every lane
         const float4 w4 = *reinterpret_cast<const float4*>(R + (e0 + u) * 8 + 4);  // wave-uniform address: broadcast
-        if (!same[u]) {  // a new cell: each half fetched its x-column, v_permlane32_swap hands both columns to both halves
-          const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0[u]), __float_as_uint(t0[u]), false, false);  // row y0: [0] = x0 column, [1] = x1
-          const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1[u]), __float_as_uint(t1[u]), false, false);  // row y0 + 1
-          c00 = __uint_as_float(s0[0]); c10 = __uint_as_float(s0[1]); c01 = __uint_as_float(s1[0]); c11 = __uint_as_float(s1[1]);
-        }
-        const float vq = bilerp4(c00, c10, c01, c11, w4.x, w4.z, w4.y, w4.w);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t0[u]), __float_as_uint(t0[u]), false, false);  // row y0: [0] = x0 column, [1] = x1
+        const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t1[u]), __float_as_uint(t1[u]), false, false);  // row y0 + 1
+        const float vq = bilerp4(__uint_as_float(s0[0]), __uint_as_float(s0[1]), __uint_as_float(s1[0]), __uint_as_float(s1[1]), w4.x, w4.z, w4.y, w4.w);
         gq = fabsf(vq) >= QUOT_TINY ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;  // zero or subnormal (v_rcp_f32 may flush it): left to the fix-up
       }
       const float v0 = gq * wt.x, v1 = gq * wt.y;
