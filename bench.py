@@ -59,8 +59,6 @@ def parse():
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--no-fused-ray-loss", action="store_true", help="A-B: the nerf level's weights / render / MSE / distortion / weights-backward as five kernels instead of one")
-    ap.add_argument("--prop-on-main", action="store_true", help="A-B: proposal backward on the main stream ahead of the field chain (no concurrency between the two)")
-    ap.add_argument("--bwd-chunks", type=int, default=1, help="ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)")
     return ap.parse_args()
 
 
@@ -163,7 +161,7 @@ def main():
                              fused_ray_loss=not args.no_fused_ray_loss)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
-    trainer.overlap, trainer.bwd_chunks = not args.no_overlap, args.bwd_chunks
+    trainer.overlap = not args.no_overlap
     if args.no_shard:
         trainer.shard_optimizer = False
         if args.cabi_allreduce and world > 1 and backend == "nccl":
@@ -172,7 +170,6 @@ def main():
             trainer.cabi_comm = CAbiComm(pg, dev)
     trainer.step = args.start_step
     trainer.async_field_adam = not args.sync_adam
-    trainer.prop_on_main = args.prop_on_main
     trainer.grad_transport = args.grad_transport
     trainer.param_transport = args.param_transport
 

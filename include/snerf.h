@@ -330,7 +330,13 @@ int snerf_plane_reg(const snerf_kplanes_desc* desc, const float* planes, float* 
  *     1 / sqrt(1 - beta2^t);
  *   the Adam entry points, given `dyn` != NULL, ignore their `step` argument, read {step_size, inv_sqrt_bc2, skip} from it and on a
  *     skipped step leave p, m, v untouched (p_out = p) and only clear the gradient; non-finite gradient ELEMENTS that still reach them
- *     are dropped and counted in `dropped`. */
+ *     are dropped and counted in `dropped`.
+ * Scope of the flag (a documented difference from GradScaler, which inspects every gradient tensor of the optimiser): it is raised where
+ * non-finite gradients originate on this path -- the get_weights backward (an overflowed density makes autograd's 0 * inf there) -- i.e. by
+ * snerf_weights_bwd / snerf_ray_train_fwd_bwd.  A non-finite value that first appears DOWNSTREAM of those kernels (an fp16-operand MLP backward
+ * overflowing its 2^13 loss scale for |g| > 8, the depth term's -k / (w + 1e-7)) does not raise it: such elements take the drop-and-count path of
+ * the Adam kernels instead of skipping the step, and in deterministic mode (fixed-point accumulation) a non-finite contribution adds nothing and
+ * is not counted.  With the default bf16 operands no such case has been observed in 30 k-step runs (`dropped` stays 0). */
 typedef struct {
   int32_t nonfinite;
   int32_t t;           /* optimiser steps taken (Adam's state["step"]) */

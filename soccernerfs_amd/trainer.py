@@ -69,13 +69,10 @@ class KPlanesTrainConfig:
     # ---- execution switches (defaults = the measured best; bench.py / tools expose them for A-B runs) ----
     overlap: bool = True              # independent kernel chains on role streams (False: everything on the caller's stream)
     async_field_adam: bool = True     # field planes' optimiser sweep on its own stream under the NEXT step's proposal levels
-    bwd_chunks: int = 1               # ray chunks of the field backward (MLP bwd of chunk i+1 under the scatter of chunk i)
-    prop_on_main: bool = False        # proposal backward on the main stream ahead of the field chain
     defer_prop: bool = True           # join the proposal chain only in front of the proposal planes' own optimiser kernels
     fused_ray_loss: bool = True       # train_step: the nerf level's weights / render / MSE / distortion / weights-backward as ONE launch
     #                                   (snerf_ray_train_fwd_bwd: bit-identical to the five kernels, ~0.08 ms less on the critical path)
     sorted_scatter: bool = True       # sorted / grouped plane-gradient scatter for the field (csrc/kplanes_sorted.hip)
-    sorted_scatter_proposals: bool = False
     fuse_reg_into_adam: bool = True   # plane regularisers inside the optimiser sweep (ping-pong parameter buffers)
     shard_optimizer: bool = True      # world > 1: reduce-scatter -> Adam on a 1/world shard -> all-gather (False: one all-reduce)
     exchange_chunks: int = 2          # world > 1, sharded: 2 = finest scale exchanged on its own, ahead of the rest (1: one exchange)
@@ -148,8 +145,7 @@ class KPlanesTrainer:
         # proposal levels (which read only the small segments); forward() joins it before the field gather, loss_dict() and
         # synchronize() join it for outside readers -- call synchronize() before reading parameters / Adam state / gradients from
         # outside a train step.  +3-5 % (bench.py --sync-adam for A-B).
-        self.overlap, self.bwd_chunks = cfg.overlap, cfg.bwd_chunks
-        self.prop_on_main, self.defer_prop = cfg.prop_on_main, cfg.defer_prop
+        self.overlap, self.defer_prop = cfg.overlap, cfg.defer_prop
         self.async_field_adam = cfg.async_field_adam
         self._field_adam_done = None
         self._reg_in_adam = False
@@ -266,11 +262,8 @@ class KPlanesTrainer:
         if cfg.emulate_transports not in ("", "grad", "param", "both"):
             raise ValueError(f"emulate_transports must be '', 'grad', 'param' or 'both', got {cfg.emulate_transports!r}")
         self._sort_done = None
-        # sorted scatter for the proposal planes too (opt-in; measured SLOWER at the preset: the planes are small enough that their
-        # atomics are served by L2 -- 0.5 M of 19 M requests reach memory -- while sorting 1.5 M samples x 6 planes costs ~0.6 ms)
-        self.sorted_scatter_proposals = cfg.sorted_scatter_proposals
-        self._ss_prop = None
-        self._sort_done_prop = [None, None]
+        # (the proposal planes keep the sample-major scatter: they are small enough that their atomics are served by L2 -- 0.5 M of 19 M requests
+        # reach memory -- while sorting 1.5 M samples x 6 planes cost ~0.6 ms: measured in round 1, the opt-in path was removed in round 3)
         self.step = 0                 # completed optimiser steps
         self._steps_since_update = 0  # ProposalNetworkSampler bookkeeping (ray_samplers.py:546-557)
         self.last = {}
@@ -445,16 +438,6 @@ class KPlanesTrainer:
             N = R * self.S[lvl]
             if lvl < 2:
                 self._gather(self._desc_prop[lvl], self.prop_planes[lvl].planes, co, N, b["pfeat"][lvl])
-                self._sort_done_prop[lvl] = None
-                if training and self.sorted_scatter_proposals and self.grads_fx is None and R == self.R:
-                    if self._ss_prop is None:
-                        self._ss_prop = [ops.SortedScatter(self.prop_planes[l], R * self.S[l], self.dev, self._gvec_dtype) for l in range(2)]
-                    main = torch.cuda.current_stream()
-                    st = self._stream("sort")
-                    st.wait_stream(main)
-                    with KPlanesTrainer._On(self, st), self._span("kplanes_sort.prop"):
-                        self._ss_prop[lvl].sort(co, self._st)
-                    self._sort_done_prop[lvl] = st.record_event()
                 self._mlp_fwd(self.prop_nets[lvl], b["pfeat"][lvl], cfg.proposal_feature_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
@@ -628,18 +611,7 @@ class KPlanesTrainer:
                                                   self._p(b["gdens"][lvl]), 0, self._p(self._dyn["proposal_networks"]), self._st), "weights_bwd")
             self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
                           b["gpfeat"][lvl], cfg.proposal_feature_dim)
-            if self.sorted_scatter_proposals and self._sort_done_prop[lvl] is not None:
-                torch.cuda.current_stream().wait_event(self._sort_done_prop[lvl])
-                ss = self._ss_prop[lvl]
-                with self._span("kplanes_gradvec.prop"):
-                    _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.prop_planes[lvl].planes), C.byref(self._coords[lvl]),
-                                                              C.c_int64(N), self._p(b["gpfeat"][lvl]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
-                with self._span("kplanes_scatter_sorted.prop"):
-                    _lib.check(self.lib.snerf_kplanes_scatter_sorted(C.byref(ss.desc), C.c_int64(N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
-                                                                     self._p(self.gviews[f"prop{lvl}.planes"]), self._st), "scatter_sorted")
-            else:
-                self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl],
-                              self.gviews[f"prop{lvl}.planes"])
+            self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
 
     def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True,
                  defer_prop_join: bool = False, depth: Optional[torch.Tensor] = None):
@@ -658,7 +630,6 @@ class KPlanesTrainer:
         overlap = self.overlap
         sharded = self._sharded()  # the field-plane gradient leaves for the reduce-scatter as soon as it is complete, and the
         #                            proposal backward runs AFTER it, under the collective
-        n_chunks = max(1, min(self.bwd_chunks, R)) if overlap and not sharded else 1
         joins = []
         reg_done = None
         if include_reg:
@@ -673,9 +644,6 @@ class KPlanesTrainer:
                 self._reg_sweep()
 
         def proposal_chain(after=None):
-            if self.prop_on_main:  # A/B: same kernel order, the proposal chain not concurrent with the field chain
-                self._proposal_backward(proposal_grads)
-                return
             st = self._stream("prop")
             st.wait_stream(main) if after is None else st.wait_event(after)
             if reg_done is not None:
@@ -721,30 +689,18 @@ class KPlanesTrainer:
                                                   self._p(self._dyn["fields"]), self._st), "weights_bwd")
         if reg_done is not None:
             main.wait_event(reg_done)
-        if n_chunks == 1:
-            # the field chain stays on the caller's stream: every extra stream is one more HIP stream competing for the (four)
-            # hardware queues, and two chains that land on one queue serialise (seen in the rocprofv3 timeline, profiles/r01_kernels.md)
-            self._field_backward_chunk(0, R)
-            if sharded:
-                if not self._exchange_started:  # unsorted / deterministic scatter: every chunk is complete only now
-                    for k in range(len(self._exchange)):
-                        self._start_field_grad_exchange(k)
-                self._exchange_started = False
-                if overlap:
-                    proposal_chain(after=main.record_event())
-            if not overlap:
-                self._proposal_backward(proposal_grads)
-        else:
-            ready = main.record_event()
-            bounds = [R * i // n_chunks for i in range(n_chunks + 1)]
-            chunk_streams = [self._stream("chunk0"), self._stream("chunk1")]
-            for i in range(n_chunks):
-                st = chunk_streams[i % 2]
-                if i < 2:
-                    st.wait_event(ready)
-                    joins.append(st)
-                with KPlanesTrainer._On(self, st):
-                    self._field_backward_chunk(bounds[i], bounds[i + 1])
+        # the field chain stays on the caller's stream: every extra stream is one more HIP stream competing for the (four) hardware queues, and
+        # two chains that land on one queue serialise (seen in the rocprofv3 timeline, profiles/r01_kernels.md)
+        self._field_backward_chunk(0, R)
+        if sharded:
+            if not self._exchange_started:  # unsorted / deterministic scatter: every chunk is complete only now
+                for k in range(len(self._exchange)):
+                    self._start_field_grad_exchange(k)
+            self._exchange_started = False
+            if overlap:
+                proposal_chain(after=main.record_event())
+        if not overlap:
+            self._proposal_backward(proposal_grads)
         # defer_prop_join (train_step, single GPU): the proposal chain may still be running when this returns -- nothing before the
         # proposal planes' own optimiser kernels needs its gradients, so its tail runs under the field planes' sweep instead of in
         # front of it; _join_prop() is the barrier
