@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 8
+#define SNERF_ABI_VERSION 9
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -169,8 +169,10 @@ typedef struct {
 int64_t snerf_mlp_param_count(const snerf_mlp_desc* desc);
 /* 1 if the fused kernels are instantiated for this shape (else the caller composes the net from library GEMMs), 0 otherwise. */
 int snerf_mlp_supported(const snerf_mlp_desc* desc);
-/* Single bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) and its backward (act: 0 none, 1 ReLU, 2 Sigmoid; K, M <= 128): the building
- * block for tcnn.Network shapes outside the fused table (full NeRFPlayer: NS/fields/nerfplayer_field.py:231-316).  Backward works from the
+/* Single bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) and its backward (act: 0 none, 1 ReLU, 2 Sigmoid; K, M <= 4096 -- the kernels hold one
+ * 128 x 128 block of W in LDS and the entry points tile wider layers over it): the building
+ * block for tcnn.Network shapes outside the fused table (full NeRFPlayer: NS/fields/nerfplayer_field.py:231-316; the linear decoder's
+ * 3 -> 128 x L -> 3F basis net and F -> 1 density layer, NS/fields/kplanes_field.py:219-246).  Backward works from the
  * stored OUTPUT Y: gX[N,K] is written (may be NULL), gW[K,M] is ACCUMULATED (atomic fp32; may be NULL). */
 int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, float* Y, int32_t ldy,
                     snerf_stream_t stream);
@@ -523,6 +525,19 @@ int snerf_nerfplayer_mix_fwd(const float* logits, const float* v_static, const f
 int snerf_nerfplayer_mix_bwd(const float* probs, const float* v_static, const float* v_deform, const float* v_new, const float* g_v,
                              const float* g_probs, int64_t N, int32_t F, float* g_static, float* g_deform, float* g_new, float* g_logits,
                              snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * KPlanesField's linear decoder, the pointwise pieces (NS/fields/kplanes_field.py:305-311, :349-354; the dense layers are snerf_dense_*):
+ * trunc_exp (NS/field_components/activations.py:25-41): y = exp(x);  gx = g * exp(clamp(x, -15, 15)).
+ * basis_rgb: rgb[N,3] = sigmoid(sum_f feat[n, f] * basis[n, c * F + f]) with basis [N, 3F] = color_basis(direction) and feat [N, F] (row
+ * stride ldf) the interpolated plane features; bwd from the stored rgb: g_feat [N,F] (may be NULL) and g_basis [N,3F], both overwritten.
+ * F and ldf multiples of 4.
+ * ------------------------------------------------------------------------------------------------ */
+int snerf_trunc_exp_fwd(const float* x, int64_t n, float* y, snerf_stream_t stream);
+int snerf_trunc_exp_bwd(const float* x, const float* g, int64_t n, float* gx, snerf_stream_t stream);
+int snerf_basis_rgb_fwd(const float* feat, int32_t ldf, const float* basis, int64_t N, int32_t F, float* rgb, snerf_stream_t stream);
+int snerf_basis_rgb_bwd(const float* feat, int32_t ldf, const float* basis, const float* rgb, const float* g_rgb, int64_t N, int32_t F,
+                        float* g_feat, float* g_basis, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray importance sampling (IST = temporal difference).

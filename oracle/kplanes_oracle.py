@@ -303,8 +303,25 @@ def field_forward(positions, times, aabb, grids, sigma_w, color_w, geo_feat_dim:
     return density, rgb
 
 
-def density_field_forward(positions, times, aabb, grids, sigma_w):
-    """KPlanesDensityField.density_fn/get_density, kplanes_field.py:410-460.
+def field_forward_linear_decoder(positions, directions, times, aabb, grids, sigma_w, basis_w):
+    """KPlanesField with linear_decoder=True (kplanes_field.py:219-246, :305-311, :349-354): the density is ONE linear layer on the
+    interpolated features; the colour is sigmoid(features . basis_c) with a 3 x F basis produced by color_basis from the RAW direction.
+
+    positions / directions [R,S,3], times [R,1]; sigma_w [[1,F]], basis_w the Linear-layout matrices of color_basis.  -> density [R,S], rgb [R,S,3].
+    """
+    R, S = positions.shape[:2]
+    p = normalize_positions(positions, aabb) * 2.0 - 1.0
+    t = (times * 2) - 1
+    pts = torch.cat([p, t[:, None, :].expand(R, S, 1)], dim=-1).reshape(-1, 4)
+    feats = interpolate_kplanes(pts, grids, concat_features=True)
+    density = trunc_exp(mlp(feats, sigma_w, hidden_act="None")).view(R, S)
+    basis = mlp(directions.reshape(-1, 3), basis_w).view(feats.shape[0], 3, -1)
+    rgb = torch.sigmoid(torch.sum(feats[:, None, :] * basis, dim=-1)).view(R, S, 3)
+    return density, rgb
+
+
+def density_field_forward(positions, times, aabb, grids, sigma_w, hidden_act: str = "ReLU"):
+    """KPlanesDensityField.density_fn/get_density, kplanes_field.py:410-460 (hidden_act "None": the proposal field of the linear decoder, :391-393).
 
     NOTE (behaviour, reproduced): positions are normalised to [0,1] and NOT rescaled to [-1,1]
     (:440), so only the upper quadrant of each proposal plane is sampled.
@@ -314,7 +331,7 @@ def density_field_forward(positions, times, aabb, grids, sigma_w):
     t = (times * 2) - 1
     pts = torch.cat([p, t[:, None, :].expand(R, S, 1)], dim=-1).reshape(-1, 4)
     feats = interpolate_kplanes(pts, [grids], concat_features=False)
-    return trunc_exp(mlp(feats, sigma_w)).view(R, S)
+    return trunc_exp(mlp(feats, sigma_w, hidden_act=hidden_act)).view(R, S)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class KPlanesDesc(C.Structure):
@@ -130,6 +130,10 @@ def lib():
     l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]
     l.snerf_render_mse_bwd.argtypes = [P, P, P, I, P, P, F, I, I, P, P, P, P]
     l.snerf_sample_pixels_uniform.argtypes = [P, I, I, I, I, P, P, P, P]
+    l.snerf_trunc_exp_fwd.argtypes = [P, L, P, P]
+    l.snerf_trunc_exp_bwd.argtypes = [P, P, L, P, P]
+    l.snerf_basis_rgb_fwd.argtypes = [P, I, P, L, I, P, P]
+    l.snerf_basis_rgb_bwd.argtypes = [P, I, P, P, P, L, I, P, P, P]
     l.snerf_tgrid_tv_fwd.argtypes = [P, L, I, I, I, P, I, P]
     l.snerf_tgrid_tv_bwd.argtypes = [P, L, I, I, I, P, P, P]
     l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
@@ -214,6 +218,10 @@ EXPORTS = [
     "snerf_kplanes_quotient_fixup",
     "snerf_nerfplayer_mix_fwd",
     "snerf_nerfplayer_mix_bwd",
+    "snerf_trunc_exp_fwd",
+    "snerf_trunc_exp_bwd",
+    "snerf_basis_rgb_fwd",
+    "snerf_basis_rgb_bwd",
     "snerf_comm_unique_id",
     "snerf_comm_create",
     "snerf_comm_destroy",

@@ -38,6 +38,9 @@ struct MlpArgs {
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
   int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
+  // dense layers wider than one 128 x 128 block (snerf_dense_fwd / _bwd tile them): row stride of W in global memory (0 = dout), and
+  // "add to what is there" for the forward's output (later K blocks of a linear layer) / the backward's input gradient (later column blocks)
+  int ldw_g, acc_y, acc_gx;
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
@@ -186,10 +189,12 @@ __device__ __forceinline__ void store_block(float* Ys, int ldy, int mt, int nt, 
 }
 
 // stage one weight matrix [rows_act x cols_act] (global, row-major) into LDS [rows_pad][ldw], zero padded
-__device__ __forceinline__ void stage_weights(const float* __restrict__ Wg, int rows_act, int cols_act, float* Ws, int rows_pad, int cols_pad, int ldw) {
+__device__ __forceinline__ void stage_weights(const float* __restrict__ Wg, int rows_act, int cols_act, float* Ws, int rows_pad, int cols_pad, int ldw,
+                                              int gld = 0) {
+  const int64_t g = gld > 0 ? gld : cols_act;  // row stride in global memory (a column block of a wider matrix: gld = its full width)
   for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += blockDim.x) {
     const int r = idx / cols_pad, c = idx - r * cols_pad;
-    Ws[r * ldw + c] = (r < rows_act && c < cols_act) ? Wg[(int64_t)r * cols_act + c] : 0.f;
+    Ws[r * ldw + c] = (r < rows_act && c < cols_act) ? Wg[(int64_t)r * g + c] : 0.f;
   }
 }
 
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_fwd_kernel(MlpAr
   using P = DensePlan<KP, MP, TS, false>;
   constexpr int MT = TS / 16, NW = dense_waves<MP>(), NTB = MP / 16;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  stage_weights(a.W, a.d0, a.dout, smem + P::W0, KP, MP, P::LW);
+  stage_weights(a.W, a.d0, a.dout, smem + P::W0, KP, MP, P::LW, a.ldw_g);
   XTile<TS, KP, NW * 64> xt;
   xt.fetch(a, (int64_t)blockIdx.x * TS);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -636,6 +641,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_fwd_kernel(MlpAr
           for (int r = 0; r < 4; ++r) {
             if (row0 + r < a.N && col < a.dout) {
               float y = acc[m][r];
+              if (a.acc_y) y += a.Y[(row0 + r) * a.ldy + col];  // a later K block (the launcher sets the activation on the last one only)
               if (a.hidden_act == 1) y = fmaxf(y, 0.f);
               if (a.out_act == 1) y = 1.f / (1.f + expf(-y));
               a.Y[(row0 + r) * a.ldy + col] = y;
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpAr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* Xs = smem + P::XT;
   float* Gs = smem + P::GZ;
-  stage_weights(a.W, a.d0, a.dout, smem + P::W0, KP, MP, P::LW);
+  stage_weights(a.W, a.d0, a.dout, smem + P::W0, KP, MP, P::LW, a.ldw_g);
   f32x4 dW[NB] = {};
   XTile<TS, KP, NT> xt;
   xt.fetch(a, (int64_t)blockIdx.x * TS);
@@ -699,7 +705,10 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpAr
             const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[m][r];
+              if (row0 + r < a.N && col < a.d0) {
+                float* gx = a.gX + (row0 + r) * a.ldgx + col;
+                *gx = a.acc_gx ? *gx + acc[m][r] : acc[m][r];  // a later column block adds its share of dZ W^T
+              }
           }
         }
       }
@@ -715,7 +724,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpAr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = it * 16 + r0 + r, col = nt * 16 + cl;
-          if (row < a.d0 && col < a.dout) gw_add(a, (int64_t)row * a.dout + col, dW[j][r]);
+          if (row < a.d0 && col < a.dout) gw_add(a, (int64_t)row * (a.ldw_g > 0 ? a.ldw_g : a.dout) + col, dW[j][r]);
         }
       }
     }
@@ -931,29 +940,46 @@ extern "C" int snerf_mlp_bwd_x16(const snerf_mlp_desc* d, const float* W, const 
   return mlp_bwd_impl(d, W, reinterpret_cast<const float*>(X16), ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream, 1);
 }
 
-// One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid); K, M <= 128.
+// One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid).  The kernels hold one 128 x 128 block of W in LDS;
+// wider layers are tiled here: column blocks are independent launches, row (K) blocks accumulate into Y and the last one applies the activation.
 extern "C" int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, float* Y, int32_t ldy,
                                snerf_stream_t stream) {
-  SNERF_REQUIRE(K >= 1 && K <= 128 && M >= 1 && M <= 128 && act >= 0 && act <= 2, "dense_fwd: K=%d M=%d act=%d (K, M <= 128)", K, M, act);
+  SNERF_REQUIRE(K >= 1 && K <= 4096 && M >= 1 && M <= 4096 && act >= 0 && act <= 2, "dense_fwd: K=%d M=%d act=%d (K, M <= 4096)", K, M, act);
   SNERF_REQUIRE(N >= 0 && ldx >= K && ldy >= M, "dense_fwd: N=%lld ldx=%d ldy=%d", (long long)N, ldx, ldy);
   if (N == 0) return 0;
   SNERF_REQUIRE(W && X && Y, "dense_fwd: null buffer");
-  MlpArgs a = {};
-  a.X = X; a.N = N; a.ldx = ldx; a.d0 = K; a.W = W; a.dout = M; a.Y = Y; a.ldy = ldy; a.hidden_act = act == 1; a.out_act = act == 2;
-  return dispatch_dense(K, M, a, false, (hipStream_t)stream);
+  for (int k0 = 0; k0 < K; k0 += 128)
+    for (int j0 = 0; j0 < M; j0 += 128) {
+      const int kb = K - k0 < 128 ? K - k0 : 128, mb = M - j0 < 128 ? M - j0 : 128;
+      MlpArgs a = {};
+      a.X = X + k0; a.N = N; a.ldx = ldx; a.d0 = kb; a.W = W + (int64_t)k0 * M + j0; a.ldw_g = M; a.dout = mb; a.Y = Y + j0; a.ldy = ldy;
+      const bool last_k = k0 + 128 >= K;  // the activation belongs to the complete sum
+      a.hidden_act = act == 1 && last_k; a.out_act = act == 2 && last_k; a.acc_y = k0 > 0;
+      int rc = dispatch_dense(kb, mb, a, false, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  return 0;
 }
 
 // Backward of snerf_dense_fwd from the layer's stored output Y: gX[N,K] = dZ W^T (written; may be NULL), gW[K,M] += X^T dZ (atomic; may
-// be NULL), dZ = gY .* act'(Y).
+// be NULL), dZ = gY .* act'(Y).  Tiled like the forward: a K block writes its own columns of gX, later column blocks add to them.
 extern "C" int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
                                const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
-  SNERF_REQUIRE(K >= 1 && K <= 128 && M >= 1 && M <= 128 && act >= 0 && act <= 2, "dense_bwd: K=%d M=%d act=%d (K, M <= 128)", K, M, act);
+  SNERF_REQUIRE(K >= 1 && K <= 4096 && M >= 1 && M <= 4096 && act >= 0 && act <= 2, "dense_bwd: K=%d M=%d act=%d (K, M <= 4096)", K, M, act);
   SNERF_REQUIRE(N >= 0 && ldx >= K && ldy >= M && ldgy >= M && (!gX || ldgx >= K), "dense_bwd: N=%lld ldx=%d ldy=%d ldgy=%d ldgx=%d", (long long)N, ldx,
                 ldy, ldgy, ldgx);
   if (N == 0) return 0;
   SNERF_REQUIRE(W && X && Y && gY && (gX || gW), "dense_bwd: null buffer");
-  MlpArgs a = {};
-  a.X = X; a.N = N; a.ldx = ldx; a.d0 = K; a.W = W; a.dout = M; a.Y = const_cast<float*>(Y); a.ldy = ldy; a.hidden_act = act == 1; a.out_act = act == 2;
-  a.gY = gY; a.ldgy = ldgy; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
-  return dispatch_dense(K, M, a, true, (hipStream_t)stream);
+  for (int k0 = 0; k0 < K; k0 += 128)
+    for (int j0 = 0; j0 < M; j0 += 128) {
+      const int kb = K - k0 < 128 ? K - k0 : 128, mb = M - j0 < 128 ? M - j0 : 128;
+      MlpArgs a = {};
+      a.X = X + k0; a.N = N; a.ldx = ldx; a.d0 = kb; a.W = W + (int64_t)k0 * M + j0; a.ldw_g = M; a.dout = mb;
+      a.Y = const_cast<float*>(Y) + j0; a.ldy = ldy; a.hidden_act = act == 1; a.out_act = act == 2;
+      a.gY = gY + j0; a.ldgy = ldgy; a.gX = gX ? gX + k0 : nullptr; a.ldgx = ldgx; a.acc_gx = j0 > 0;
+      a.gW = gW ? gW + (int64_t)k0 * M + j0 : nullptr;
+      int rc = dispatch_dense(kb, mb, a, true, (hipStream_t)stream);
+      if (rc) return rc;
+    }
+  return 0;
 }

@@ -2,7 +2,7 @@
 same config fields, method names, output / loss / metric dict keys and parameter-group names, running on libsnerf."""
 import functools
 from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -31,6 +31,7 @@ class KPlanesModelConfig:
     multiscale_res: Sequence[int] = (1, 2, 4, 8)
     concat_features_across_scales: bool = True
     linear_decoder: bool = False
+    linear_decoder_layers: Optional[int] = 1
     sigma_net_layers: int = 1
     sigma_net_hidden_dim: int = 64
     rgb_net_layers: int = 2
@@ -91,20 +92,23 @@ class KPlanesModel(nn.Module):
         scene_contraction = None if cfg.bounded else SceneContraction(order=float("inf"))
         self.field = KPlanesField(self.scene_box.aabb, spatial_distortion=scene_contraction, feat_dim=cfg.feature_dim, spacetime_resolution=cfg.spacetime_resolution,
                                   concat_features_across_scales=cfg.concat_features_across_scales, multiscale_res=cfg.multiscale_res,
-                                  linear_decoder=cfg.linear_decoder, disable_viewing_dependent=cfg.disable_viewing_dependent,
+                                  linear_decoder=cfg.linear_decoder, linear_decoder_layers=cfg.linear_decoder_layers,
+                                  disable_viewing_dependent=cfg.disable_viewing_dependent,
                                   sigma_net_layers=cfg.sigma_net_layers, sigma_net_hidden_dim=cfg.sigma_net_hidden_dim,
                                   rgb_net_layers=cfg.rgb_net_layers, rgb_net_hidden_dim=cfg.rgb_net_hidden_dim)
         self.proposal_networks = nn.ModuleList()
         n = cfg.num_proposal_iterations
         if cfg.use_same_proposal_network:
             assert len(cfg.proposal_net_args_list) == 1, "Only one proposal network is allowed."
-            net = KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, **cfg.proposal_net_args_list[0])
+            net = KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, linear_decoder=cfg.linear_decoder,
+                                      **cfg.proposal_net_args_list[0])
             self.proposal_networks.append(net)
             self.density_fns = [net.density_fn for _ in range(n)]
         else:
             for i in range(n):
                 args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
-                self.proposal_networks.append(KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, **args))
+                self.proposal_networks.append(KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction,
+                                                                  linear_decoder=cfg.linear_decoder, **args))
             self.density_fns = [net.density_fn for net in self.proposal_networks]
 
         def update_schedule(step):

@@ -1,5 +1,7 @@
 """K-Planes fields with the interface of NS/fields/kplanes_field.py (KPlanesField :129-370,
-KPlanesDensityField :373-463; non-linear decoder, no appearance embedding -- the `k-planes` preset)."""
+KPlanesDensityField :373-463): the MLP decoder (view-independent -- the `k-planes` preset -- or view-dependent) and the linear decoder
+(a learned colour basis of the direction contracted with the plane features, one linear layer for the density); bounded or contracted scenes;
+no appearance embedding (that branch of the reference cannot run: oracle/gen_golden_field_options.py)."""
 import enum
 from typing import Optional, Sequence
 
@@ -45,14 +47,16 @@ def _pts_from_positions(positions, times, aabb, rescale: bool, spatial_distortio
 class KPlanesField(nn.Module):
     def __init__(self, aabb, spacetime_resolution: Sequence[int] = (256, 256, 256, 150), feat_dim: int = 16,
                  multiscale_res: Optional[Sequence[int]] = None, concat_features_across_scales: bool = False,
-                 linear_decoder: bool = False, disable_viewing_dependent: bool = True, sigma_net_layers: int = 1,
+                 linear_decoder: bool = False, linear_decoder_layers: Optional[int] = None, disable_viewing_dependent: bool = True,
+                 sigma_net_layers: int = 1,
                  sigma_net_hidden_dim: int = 64, rgb_net_layers: int = 2, rgb_net_hidden_dim: int = 64, use_appearance_embedding: bool = False,
                  spatial_distortion=None, **_unused) -> None:
         super().__init__()
-        if linear_decoder or use_appearance_embedding:
+        if use_appearance_embedding:
             # (the reference's appearance-embedding branch, kplanes_field.py:325-346, cannot run with per-sample camera indices: see
             # oracle/gen_golden_field_options.py)
-            raise NotImplementedError("built: the MLP decoder, view-independent (the k-planes preset) or view-dependent, bounded or contracted scenes")
+            raise NotImplementedError("built: the MLP decoder (view-independent or view-dependent) and the linear decoder, bounded or contracted scenes")
+        self.linear_decoder = linear_decoder
         self.spatial_distortion = spatial_distortion
         self.disable_viewing_dependent = disable_viewing_dependent
         self.aabb = nn.Parameter(aabb, requires_grad=False)
@@ -60,8 +64,17 @@ class KPlanesField(nn.Module):
         base = list(spacetime_resolution)
         self.grids = PlaneSet(feat_dim, [[r * m for r in base[:3]] + base[3:] for m in mult], concat=concat_features_across_scales)
         self.feature_dim = self.grids.out_dim
-        self.geo_feat_dim = 15
         cfg = {"otype": "FullyFusedMLP", "activation": "ReLU"}
+        if linear_decoder:
+            # kplanes_field.py:219-246: the net learns a basis (in place of spherical harmonics) from the RAW direction, 3 F weights that combine
+            # the plane features into RGB; the density is one linear layer on the features.  Both run on libsnerf's dense-layer kernels.
+            assert linear_decoder_layers is not None
+            self.color_basis = Network(3, 3 * self.feature_dim, {**cfg, "output_activation": "None", "n_neurons": 128,
+                                                                 "n_hidden_layers": linear_decoder_layers})
+            self.sigma_net = Network(self.feature_dim, 1, {"otype": "CutlassMLP", "activation": "None", "output_activation": "None",
+                                                           "n_neurons": 128, "n_hidden_layers": 0})
+            return
+        self.geo_feat_dim = 15
         self.sigma_net = Network(self.feature_dim, self.geo_feat_dim + 1,
                                  {**cfg, "output_activation": "None", "n_neurons": sigma_net_hidden_dim, "n_hidden_layers": sigma_net_layers})
         self.in_dim_color = self.geo_feat_dim
@@ -83,6 +96,9 @@ class KPlanesField(nn.Module):
     def get_density(self, ray_samples: RaySamples):
         """kplanes_field.py:275-312 -> (density [R,S,1], geo features [N,15])."""
         n_rays, n_samples = ray_samples.frustums.shape[:2]
+        if self.linear_decoder:  # :305-311: the features themselves go on to the colour head
+            features = self._features(ray_samples)
+            return ops.trunc_exp(self.sigma_net(features)).view(n_rays, n_samples, 1), features
         h, dens = self.sigma_net.forward_with_exp_head(self._features(ray_samples), self.geo_feat_dim)
         return dens.view(n_rays, n_samples, 1), h[:, : self.geo_feat_dim]
 
@@ -90,10 +106,13 @@ class KPlanesField(nn.Module):
         """kplanes_field.py:314-358."""
         assert density_embedding is not None
         n_rays, n_samples = ray_samples.frustums.shape[:2]
+        if self.linear_decoder:  # :349-354
+            basis = self.color_basis(ray_samples.frustums.directions.expand(n_rays, n_samples, 3).reshape(-1, 3).contiguous())
+            return ops.basis_rgb(density_embedding, basis).view(n_rays, n_samples, 3)
         if self.disable_viewing_dependent:
             return self.color_net(density_embedding).view(n_rays, n_samples, 3)
         # kplanes_field.py:318-323: get_normalized_directions = (d + 1) / 2 (base_field.py:131-137), SH encoding, [encoded directions | features]
-        directions = ray_samples.frustums.directions.reshape(-1, 3)
+        directions = ray_samples.frustums.directions.expand(n_rays, n_samples, 3).reshape(-1, 3)
         enc = self.direction_encoder((directions + 1.0) / 2.0)
         return self.color_net(torch.cat([enc, density_embedding], dim=-1).contiguous()).view(n_rays, n_samples, 3)
 
@@ -105,13 +124,12 @@ class KPlanesField(nn.Module):
 class KPlanesDensityField(nn.Module):
     def __init__(self, aabb, resolution, feature_dim, spatial_distortion=None, linear_decoder: bool = False, **_unused) -> None:
         super().__init__()
-        if linear_decoder:
-            raise NotImplementedError("the linear decoder of the proposal field is not built")
         self.spatial_distortion = spatial_distortion
         self.aabb = nn.Parameter(aabb, requires_grad=False)
         self.grids = PlaneSet(feature_dim, [list(resolution)], concat=False, a=0.1, b=0.15)
-        self.sigma_net = Network(feature_dim, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
-                                                  "n_neurons": 64, "n_hidden_layers": 1})
+        # kplanes_field.py:391-407: with the linear decoder the hidden layer loses its ReLU
+        self.sigma_net = Network(feature_dim, 1, {"otype": "FullyFusedMLP", "activation": "None" if linear_decoder else "ReLU",
+                                                  "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1})
 
     def density_fn(self, positions, times):
         """kplanes_field.py:410-432: positions [R,S,3] (or [N,3]), times [R,1]."""

@@ -361,6 +361,63 @@ def dense_net_forward(x, params, dims, hidden_act: str, out_act: str):
 
 
 # ----------------------------------------------------------------------------------------------
+# KPlanesField's linear decoder: the pointwise pieces (csrc/linear_decoder.hip)
+# ----------------------------------------------------------------------------------------------
+class _TruncExp(torch.autograd.Function):
+    """trunc_exp (NS/field_components/activations.py:25-41): exp forward, the backward's exponent clamped to [-15, 15]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().snerf_trunc_exp_fwd(_ptr(x), x.numel(), _ptr(y), _stream()), "trunc_exp_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().snerf_trunc_exp_bwd(_ptr(x), _ptr(g), x.numel(), _ptr(gx), _stream()), "trunc_exp_bwd")
+        return gx
+
+
+def trunc_exp(x: torch.Tensor) -> torch.Tensor:
+    return _TruncExp.apply(_f32c(x, "trunc_exp input"))
+
+
+class _BasisRgb(torch.autograd.Function):
+    """rgb = sigmoid(sum_f feat[:, None, f] * basis.view(N, 3, F)) (kplanes_field.py:349-354) without the [N, 3, F] temporary."""
+
+    @staticmethod
+    def forward(ctx, feat, basis):
+        N, F = feat.shape
+        rgb = torch.empty(N, 3, dtype=torch.float32, device=feat.device)
+        _lib.check(_lib.lib().snerf_basis_rgb_fwd(_ptr(feat), feat.stride(0), _ptr(basis), N, F, _ptr(rgb), _stream()), "basis_rgb_fwd")
+        ctx.save_for_backward(feat, basis, rgb)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, basis, rgb = ctx.saved_tensors
+        N, F = feat.shape
+        g = g.contiguous()
+        gf = torch.empty(N, F, dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(basis)
+        _lib.check(_lib.lib().snerf_basis_rgb_bwd(_ptr(feat), feat.stride(0), _ptr(basis), _ptr(rgb), _ptr(g), N, F, _ptr(gf) if gf is not None else None,
+                                                  _ptr(gb), _stream()), "basis_rgb_bwd")
+        return gf, gb
+
+
+def basis_rgb(feat: torch.Tensor, basis: torch.Tensor) -> torch.Tensor:
+    """feat [N,F], basis [N,3F] -> rgb [N,3]."""
+    feat, basis = _f32c(feat, "basis_rgb features"), _f32c(basis, "basis_rgb basis")
+    if feat.dim() != 2 or basis.shape != (feat.shape[0], 3 * feat.shape[1]) or feat.shape[1] % 4:
+        raise ValueError(f"basis_rgb: features {tuple(feat.shape)} and basis {tuple(basis.shape)} (expected [N,F] and [N,3F], F a multiple of 4)")
+    return _BasisRgb.apply(feat, basis)
+
+
+# ----------------------------------------------------------------------------------------------
 # static multiresolution hash grid (tcnn HashGrid)
 # ----------------------------------------------------------------------------------------------
 def hashgrid_desc(n_input_dims: int, n_levels: int, n_features_per_level: int, base_resolution: int, per_level_scale: float,

@@ -110,11 +110,45 @@ def test_mlp_unsupported_shape_raises():
     assert not net.fused and net(torch.zeros(4, 8, device=DEV)).shape == (4, 1)
     with pytest.raises(RuntimeError, match="needs a shape the fused kernels"):
         net.forward_with_exp_head(torch.zeros(4, 8, device=DEV), 0)
-    # ... widths beyond 128 are refused by the library
+    # ... and so do widths beyond one 128 x 128 weight block (tiled by the entry points: test_dense_layers_wider_than_one_block)
     wide = Network(8, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 256,
-                          "n_hidden_layers": 1}).to(DEV)
-    with pytest.raises(RuntimeError, match="K, M <= 128"):
-        wide(torch.zeros(4, 8, device=DEV))
+                          "n_hidden_layers": 2}).to(DEV)
+    assert not wide.fused and wide(torch.zeros(4, 8, device=DEV)).shape == (4, 1)
+
+
+@pytest.mark.parametrize("dims,act,out_act", [
+    ((160, 1), "None", "None"),            # the linear decoder's density layer at the preset's feature width (kplanes_field.py:236-246)
+    ((3, 128, 480), "ReLU", "None"),       # its basis net, 3 F = 480 outputs
+    ((3, 128, 128, 96), "ReLU", "None"),
+    ((300, 200, 5), "None", "Sigmoid"),    # K and M blocks at once, ragged last blocks
+    ((8, 256, 256, 1), "ReLU", "None"),    # a ReLU layer with 256 inputs: the activation is applied by the last K block only
+])
+def test_dense_layers_wider_than_one_block(dims, act, out_act):
+    """snerf_dense_fwd / _bwd tile layers wider than 128 over the 128 x 128 kernels: column blocks are separate launches, K blocks accumulate
+    and the last one applies the activation.  Against the oracle's Linear stack, forward, input gradient and weight gradients."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd import ops
+
+    gen = torch.Generator().manual_seed(sum(dims))
+    N = 777
+    ws = [((torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * (3.0 / dims[i]) ** 0.5).requires_grad_(True) for i in range(len(dims) - 1)]
+    x = (torch.rand(N, dims[0], generator=gen) * 2 - 1).requires_grad_(True)
+    ref = KO.mlp(x, ws, out_act=out_act, hidden_act=act)
+    gy = torch.rand(ref.shape, generator=gen) - 0.5
+    ref.backward(gy)
+    params = torch.cat([w.detach().t().reshape(-1) for w in ws]).to(DEV).requires_grad_(True)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = ops.dense_net_forward(xg, params, list(dims), act, out_act)
+    torch.testing.assert_close(y.cpu(), ref.detach(), rtol=2e-5, atol=2e-6)
+    y.backward(gy.to(DEV))
+    # sums of up to 480 products with cancellation, in another association order: the absolute bound scales with the gradient's size
+    torch.testing.assert_close(xg.grad.cpu(), x.grad, rtol=1e-4, atol=2e-6 * max(1.0, float(x.grad.abs().max())))
+    off = 0
+    for i, w in enumerate(ws):
+        n = dims[i] * dims[i + 1]
+        got = params.grad[off: off + n].view(dims[i], dims[i + 1]).t().cpu()
+        torch.testing.assert_close(got, w.grad, rtol=1e-4, atol=2e-6 * max(1.0, float(w.grad.abs().max())))
+        off += n
 
 
 @pytest.mark.parametrize("operands", ["bf16", "fp16"])

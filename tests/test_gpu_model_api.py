@@ -144,6 +144,77 @@ def test_view_dependent_field_matches_reference_golden():
         torch.testing.assert_close(o[FieldHeadNames.RGB].cpu(), g[f"vd_{mode}_rgb"], rtol=2e-5, atol=2e-6)
 
 
+def test_linear_decoder_fields_match_reference_golden():
+    """KPlanesField / KPlanesDensityField with linear_decoder=True (NS/fields/kplanes_field.py:219-246, :305-311, :349-354, :391-407): G6d, the
+    reference's own classes -- outputs and the gradient of a fixed weighted sum with respect to planes, density layer and basis net.  Shape b has
+    F = 160 features: the density layer is wider than one block of the dense kernels (K tiling) and the basis net has 480 outputs (M tiling)."""
+    from soccernerfs_amd.kplanes_field import FieldHeadNames, KPlanesDensityField, KPlanesField
+    from soccernerfs_amd.rays import Frustums, RaySamples
+
+    g = load_golden("g6d_linear_decoder")
+    pos, dirs, tms = g["positions"].to(DEV), g["directions"].to(DEV), g["times"].to(DEV)
+    w_rgb, w_den = g["w_rgb"].to(DEV), g["w_density"].to(DEV)
+    R, S = pos.shape[:2]
+    rs = RaySamples(frustums=Frustums(origins=pos, directions=dirs, starts=torch.zeros(R, S, 1, device=DEV), ends=torch.zeros(R, S, 1, device=DEV),
+                                      pixel_area=torch.ones(R, S, 1, device=DEV)), times=tms[:, None])
+
+    def wgrads(net):
+        return net.linear_weights(net.params.grad)
+
+    for tag, mult, layers in (("a", [1, 2], 1), ("b", [1, 2, 3, 4, 5], 2)):
+        f = KPlanesField(g["aabb"], spacetime_resolution=[6, 5, 4, 3], feat_dim=32, multiscale_res=mult, concat_features_across_scales=True,
+                         linear_decoder=True, linear_decoder_layers=layers).to(DEV)
+        assert f.sigma_net.dims == [32 * len(mult), 1] and f.color_basis.dims == [3] + [128] * layers + [96 * len(mult)]
+        f.grids.load_reference([[g[f"{tag}_plane_{s}_{q}"] for q in range(6)] for s in range(len(mult))])
+        f.sigma_net.load_linear_weights([g[f"{tag}_sigma_0"].to(DEV)])
+        f.color_basis.load_linear_weights([g[f"{tag}_basis_{i}"].to(DEV) for i in range(layers + 1)])
+        o = f(rs)
+        den, rgb = o[FieldHeadNames.DENSITY][..., 0], o[FieldHeadNames.RGB]
+        torch.testing.assert_close(den.detach().cpu(), g[f"{tag}_density"], rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(rgb.detach().cpu(), g[f"{tag}_rgb"], rtol=2e-5, atol=2e-6)
+        ((w_rgb * rgb).sum() + (w_den * den).sum()).backward()
+        torch.testing.assert_close(wgrads(f.sigma_net)[0].cpu(), g[f"{tag}_g_sigma_0"], rtol=1e-4, atol=2e-6)
+        for i, gw in enumerate(wgrads(f.color_basis)):
+            ref = g[f"{tag}_g_basis_{i}"]
+            torch.testing.assert_close(gw.cpu(), ref, rtol=1e-4, atol=2e-6 * max(1.0, float(ref.abs().max())))
+        for s, pl in enumerate(f.grids.to_reference(f.grids.planes.grad)):
+            for q, gp in enumerate(pl):
+                torch.testing.assert_close(gp.cpu(), g[f"{tag}_g_plane_{s}_{q}"], rtol=1e-4, atol=2e-6)
+    df = KPlanesDensityField(g["aabb"], resolution=[8, 7, 6, 3], feature_dim=8, linear_decoder=True).to(DEV)
+    assert df.sigma_net.hidden_act == "None"
+    df.grids.load_reference([[g[f"prop_plane_{q}"] for q in range(6)]])
+    df.sigma_net.load_linear_weights([g[f"prop_sigma_{i}"].to(DEV) for i in range(2)])
+    den = df.density_fn(pos, tms)[..., 0]
+    torch.testing.assert_close(den.detach().cpu(), g["prop_density"], rtol=2e-5, atol=1e-6)
+    (w_den * den).sum().backward()
+    for i, gw in enumerate(wgrads(df.sigma_net)):
+        torch.testing.assert_close(gw.cpu(), g[f"prop_g_sigma_{i}"], rtol=1e-4, atol=2e-6)
+    for q, gp in enumerate(df.grids.to_reference(df.grids.planes.grad)[0]):
+        torch.testing.assert_close(gp.cpu(), g[f"prop_g_plane_{q}"], rtol=1e-4, atol=2e-6)
+    # KPlanesModelConfig.linear_decoder end to end (NS/models/kplanes.py:92-94,192-246): one training forward + losses + backward
+    from soccernerfs_amd.kplanes import KPlanesModel, KPlanesModelConfig
+    from soccernerfs_amd.rays import RayBundle
+    from soccernerfs_amd.scene_colliders import SceneBox
+
+    cfg = KPlanesModelConfig(linear_decoder=True, linear_decoder_layers=1, multiscale_res=(1, 2), spacetime_resolution=(16, 16, 16, 4), feature_dim=32,
+                             proposal_net_args_list=[{"feature_dim": 8, "resolution": (24, 24, 24, 4)}, {"feature_dim": 8, "resolution": (32, 32, 32, 4)}],
+                             num_proposal_samples_per_ray=(48, 24), num_nerf_samples_per_ray=16)
+    model = KPlanesModel(cfg, SceneBox(aabb=torch.tensor([[-1.0] * 3, [1.0] * 3]))).to(DEV).train()
+    assert model.field.linear_decoder and all(p.sigma_net.hidden_act == "None" for p in model.proposal_networks)
+    gen = torch.Generator().manual_seed(5)
+    R = 64
+    rb = RayBundle(origins=((torch.rand(R, 3, generator=gen) * 2 - 1) * 0.3 - torch.tensor([0.0, 0.0, 2.0])).to(DEV),
+                   directions=torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + (torch.rand(R, 3, generator=gen) - 0.5) * 0.3, dim=-1).to(DEV),
+                   pixel_area=torch.ones(R, 1, device=DEV), camera_indices=torch.zeros(R, 1, dtype=torch.long, device=DEV), times=torch.rand(R, 1, generator=gen).to(DEV))
+    out = model(rb)
+    batch = {"image": torch.rand(R, 3, generator=gen).to(DEV)}
+    ld = model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
+    sum(ld.values()).backward()
+    assert out["rgb"].shape == (R, 3) and bool(torch.isfinite(out["rgb"]).all())
+    for prm in (model.field.grids.planes, model.field.sigma_net.params, model.field.color_basis.params):
+        assert bool(torch.isfinite(prm.grad).all()) and float(prm.grad.abs().sum()) > 0
+
+
 def test_unbounded_scene_contraction_matches_reference_golden():
     """KPlanesModelConfig.bounded = False (NS/models/kplanes.py:194,260-281): L-inf SceneContraction in front of KPlanesField and
     KPlanesDensityField, near / far collider, piecewise initial sampler.  Field values vs the reference's own classes on positions inside and far

@@ -313,3 +313,33 @@ def test_g6c_scene_contraction_fields():
     # KPlanesDensityField: contracted / 2 goes to the planes as is; the oracle's bounded branch would map x -> (x + 1) / 2, so feed 2 (c/2) - ... = c - 1
     pd = KO.density_field_forward(c - 1.0, g["times"], g["aabb"], [g[f"prop_plane_{q}"] for q in range(6)], [g["prop_sigma_0"], g["prop_sigma_1"]])
     close(pd, g["prop_density"], rtol=2e-5, atol=1e-6)
+
+
+def test_g6d_linear_decoder_fields():
+    """G6d (oracle/gen_golden_linear_decoder.py): the reference's KPlanesField / KPlanesDensityField with linear_decoder=True -- outputs and the
+    gradients of a fixed weighted sum with respect to planes, density layer and basis net -- against the oracle's restatement under autograd."""
+    g = load_golden("g6d_linear_decoder")
+    pos, dirs, tms = g["positions"], g["directions"], g["times"]
+    for tag, n_scales, n_basis in (("a", 2, 2), ("b", 5, 3)):
+        grids = [[g[f"{tag}_plane_{s}_{q}"].clone().requires_grad_(True) for q in range(6)] for s in range(n_scales)]
+        sw = [g[f"{tag}_sigma_0"].clone().requires_grad_(True)]
+        bw = [g[f"{tag}_basis_{i}"].clone().requires_grad_(True) for i in range(n_basis)]
+        dens, rgb = KO.field_forward_linear_decoder(pos, dirs, tms, g["aabb"], grids, sw, bw)
+        close(dens, g[f"{tag}_density"], rtol=2e-5, atol=1e-6)
+        close(rgb, g[f"{tag}_rgb"], rtol=2e-5, atol=2e-6)
+        ((g["w_rgb"] * rgb).sum() + (g["w_density"] * dens).sum()).backward()
+        close(sw[0].grad, g[f"{tag}_g_sigma_0"], rtol=1e-4, atol=1e-6)
+        for i in range(n_basis):
+            close(bw[i].grad, g[f"{tag}_g_basis_{i}"], rtol=1e-4, atol=1e-6)
+        for s in range(n_scales):
+            for q in range(6):
+                close(grids[s][q].grad, g[f"{tag}_g_plane_{s}_{q}"], rtol=1e-4, atol=1e-6)
+    pg = [g[f"prop_plane_{q}"].clone().requires_grad_(True) for q in range(6)]
+    pw = [g[f"prop_sigma_{i}"].clone().requires_grad_(True) for i in range(2)]
+    pd = KO.density_field_forward(pos, tms, g["aabb"], pg, pw, hidden_act="None")
+    close(pd, g["prop_density"], rtol=2e-5, atol=1e-6)
+    (g["w_density"] * pd).sum().backward()
+    for i in range(2):
+        close(pw[i].grad, g[f"prop_g_sigma_{i}"], rtol=1e-4, atol=1e-6)
+    for q in range(6):
+        close(pg[q].grad, g[f"prop_g_plane_{q}"], rtol=1e-4, atol=1e-6)
