@@ -224,17 +224,22 @@ def bilinear_plane(plane, coords):
     return corner(iy0, ix0, w_nw) + corner(iy0, ix1, w_ne) + corner(iy1, ix0, w_sw) + corner(iy1, ix1, w_se)
 
 
-def interpolate_kplanes(pts, ms_grids, concat_features: bool):
-    """interpolate_kplanes, NS/fields/kplanes_field.py:77-126 (no frozen planes).
+def interpolate_kplanes(pts, ms_grids, concat_features: bool, freeze_time_planes: bool = False, freeze_space_planes: bool = False):
+    """interpolate_kplanes, NS/fields/kplanes_field.py:77-126.
 
     pts [N,4]; ms_grids: list over scales of 6 planes [1,C,reso[b],reso[a]] for pair (a,b).
-    Product over the 6 planes, then concat (or sum) over scales.
+    Product over the 6 planes, then concat (or sum) over scales.  freeze_time_planes (:95-99): planes holding the time axis are skipped.
+    freeze_space_planes (:101-116): a space plane is interpolated AND multiplied into the running product inside set_grad_enabled(False), which
+    detaches everything accumulated so far -- only the planes after the last space plane (YT, ZT) keep a gradient.
     """
     outs = []
     for grids in ms_grids:
         prod = 1.0
         for ci, comb in enumerate(COO_COMBS):
-            prod = prod * bilinear_plane(grids[ci], pts[:, list(comb)])
+            if freeze_time_planes and 3 in comb:
+                continue
+            v = bilinear_plane(grids[ci], pts[:, list(comb)])
+            prod = (prod * v).detach() if (freeze_space_planes and 3 not in comb) else prod * v
         outs.append(prod)
     if concat_features:
         return torch.cat(outs, dim=-1)
@@ -285,7 +290,7 @@ def normalize_positions(positions, aabb):
     return (positions - aabb[0]) / (aabb[1] - aabb[0])
 
 
-def field_forward(positions, times, aabb, grids, sigma_w, color_w, geo_feat_dim: int = 15):
+def field_forward(positions, times, aabb, grids, sigma_w, color_w, geo_feat_dim: int = 15, **frozen):
     """KPlanesField.get_density + get_outputs, kplanes_field.py:275-358 with
     linear_decoder=False, disable_viewing_dependent=True, no appearance embedding, concat scales.
 
@@ -295,7 +300,7 @@ def field_forward(positions, times, aabb, grids, sigma_w, color_w, geo_feat_dim:
     p = normalize_positions(positions, aabb) * 2.0 - 1.0  # :283-284
     t = (times * 2) - 1  # :290
     pts = torch.cat([p, t[:, None, :].expand(R, S, 1)], dim=-1).reshape(-1, 4)
-    feats = interpolate_kplanes(pts, grids, concat_features=True)
+    feats = interpolate_kplanes(pts, grids, concat_features=True, **frozen)
     h = mlp(feats, sigma_w)
     geo, dpre = h[:, :geo_feat_dim], h[:, geo_feat_dim:]
     density = trunc_exp(dpre).view(R, S)
@@ -320,7 +325,7 @@ def field_forward_linear_decoder(positions, directions, times, aabb, grids, sigm
     return density, rgb
 
 
-def density_field_forward(positions, times, aabb, grids, sigma_w, hidden_act: str = "ReLU"):
+def density_field_forward(positions, times, aabb, grids, sigma_w, hidden_act: str = "ReLU", **frozen):
     """KPlanesDensityField.density_fn/get_density, kplanes_field.py:410-460 (hidden_act "None": the proposal field of the linear decoder, :391-393).
 
     NOTE (behaviour, reproduced): positions are normalised to [0,1] and NOT rescaled to [-1,1]
@@ -330,7 +335,7 @@ def density_field_forward(positions, times, aabb, grids, sigma_w, hidden_act: st
     p = normalize_positions(positions, aabb)
     t = (times * 2) - 1
     pts = torch.cat([p, t[:, None, :].expand(R, S, 1)], dim=-1).reshape(-1, 4)
-    feats = interpolate_kplanes(pts, [grids], concat_features=False)
+    feats = interpolate_kplanes(pts, [grids], concat_features=False, **frozen)
     return trunc_exp(mlp(feats, sigma_w, hidden_act=hidden_act)).view(R, S)
 
 

@@ -32,6 +32,8 @@ class KPlanesModelConfig:
     concat_features_across_scales: bool = True
     linear_decoder: bool = False
     linear_decoder_layers: Optional[int] = 1
+    freeze_time_planes: bool = False
+    freeze_space_planes: bool = False
     sigma_net_layers: int = 1
     sigma_net_hidden_dim: int = 64
     rgb_net_layers: int = 2
@@ -90,17 +92,18 @@ class KPlanesModel(nn.Module):
         cfg = self.config
         # unbounded scenes: L-inf scene contraction in every field, near / far collider, piecewise initial sampler (kplanes.py:194,260-281)
         scene_contraction = None if cfg.bounded else SceneContraction(order=float("inf"))
+        frozen = dict(freeze_time_planes=cfg.freeze_time_planes, freeze_space_planes=cfg.freeze_space_planes)
         self.field = KPlanesField(self.scene_box.aabb, spatial_distortion=scene_contraction, feat_dim=cfg.feature_dim, spacetime_resolution=cfg.spacetime_resolution,
                                   concat_features_across_scales=cfg.concat_features_across_scales, multiscale_res=cfg.multiscale_res,
                                   linear_decoder=cfg.linear_decoder, linear_decoder_layers=cfg.linear_decoder_layers,
                                   disable_viewing_dependent=cfg.disable_viewing_dependent,
                                   sigma_net_layers=cfg.sigma_net_layers, sigma_net_hidden_dim=cfg.sigma_net_hidden_dim,
-                                  rgb_net_layers=cfg.rgb_net_layers, rgb_net_hidden_dim=cfg.rgb_net_hidden_dim)
+                                  rgb_net_layers=cfg.rgb_net_layers, rgb_net_hidden_dim=cfg.rgb_net_hidden_dim, **frozen)
         self.proposal_networks = nn.ModuleList()
         n = cfg.num_proposal_iterations
         if cfg.use_same_proposal_network:
             assert len(cfg.proposal_net_args_list) == 1, "Only one proposal network is allowed."
-            net = KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, linear_decoder=cfg.linear_decoder,
+            net = KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction, linear_decoder=cfg.linear_decoder, **frozen,
                                       **cfg.proposal_net_args_list[0])
             self.proposal_networks.append(net)
             self.density_fns = [net.density_fn for _ in range(n)]
@@ -108,7 +111,7 @@ class KPlanesModel(nn.Module):
             for i in range(n):
                 args = cfg.proposal_net_args_list[min(i, len(cfg.proposal_net_args_list) - 1)]
                 self.proposal_networks.append(KPlanesDensityField(self.scene_box.aabb, spatial_distortion=scene_contraction,
-                                                                  linear_decoder=cfg.linear_decoder, **args))
+                                                                  linear_decoder=cfg.linear_decoder, **frozen, **args))
             self.density_fns = [net.density_fn for net in self.proposal_networks]
 
         def update_schedule(step):

@@ -26,9 +26,7 @@ class FieldHeadNames(enum.Enum):
 def interpolate_kplanes(pts: torch.Tensor, ms_grids: PlaneSet, concat_features: bool = None, freeze_time_planes: bool = False,
                         freeze_space_planes: bool = False) -> torch.Tensor:
     """interpolate_kplanes (kplanes_field.py:77-126) on a PlaneSet (which already knows concat-vs-sum)."""
-    if freeze_time_planes or freeze_space_planes:
-        raise NotImplementedError("frozen planes are not used by the k-planes preset")
-    return ops.interpolate_kplanes(pts, ms_grids)
+    return ops.interpolate_kplanes(pts, ms_grids, freeze_time_planes, freeze_space_planes)
 
 
 def _pts_from_positions(positions, times, aabb, rescale: bool, spatial_distortion=None):
@@ -50,8 +48,9 @@ class KPlanesField(nn.Module):
                  linear_decoder: bool = False, linear_decoder_layers: Optional[int] = None, disable_viewing_dependent: bool = True,
                  sigma_net_layers: int = 1,
                  sigma_net_hidden_dim: int = 64, rgb_net_layers: int = 2, rgb_net_hidden_dim: int = 64, use_appearance_embedding: bool = False,
-                 spatial_distortion=None, **_unused) -> None:
+                 spatial_distortion=None, freeze_time_planes: bool = False, freeze_space_planes: bool = False, **_unused) -> None:
         super().__init__()
+        self.freeze_time_planes, self.freeze_space_planes = freeze_time_planes, freeze_space_planes
         if use_appearance_embedding:
             # (the reference's appearance-embedding branch, kplanes_field.py:325-346, cannot run with per-sample camera indices: see
             # oracle/gen_golden_field_options.py)
@@ -89,9 +88,10 @@ class KPlanesField(nn.Module):
     def _features(self, ray_samples: RaySamples):
         c = ray_samples._compact
         if c is not None and c["times"] is not None and self.spatial_distortion is None:
-            return ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=True)
+            return ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=True,
+                                                freeze_time_planes=self.freeze_time_planes, freeze_space_planes=self.freeze_space_planes)
         pts = _pts_from_positions(ray_samples.frustums.get_positions(), ray_samples.times, self.aabb, True, self.spatial_distortion)
-        return ops.interpolate_kplanes(pts, self.grids)
+        return ops.interpolate_kplanes(pts, self.grids, self.freeze_time_planes, self.freeze_space_planes)
 
     def get_density(self, ray_samples: RaySamples):
         """kplanes_field.py:275-312 -> (density [R,S,1], geo features [N,15])."""
@@ -122,8 +122,10 @@ class KPlanesField(nn.Module):
 
 
 class KPlanesDensityField(nn.Module):
-    def __init__(self, aabb, resolution, feature_dim, spatial_distortion=None, linear_decoder: bool = False, **_unused) -> None:
+    def __init__(self, aabb, resolution, feature_dim, spatial_distortion=None, linear_decoder: bool = False, freeze_time_planes: bool = False,
+                 freeze_space_planes: bool = False, **_unused) -> None:
         super().__init__()
+        self.freeze_time_planes, self.freeze_space_planes = freeze_time_planes, freeze_space_planes
         self.spatial_distortion = spatial_distortion
         self.aabb = nn.Parameter(aabb, requires_grad=False)
         self.grids = PlaneSet(feature_dim, [list(resolution)], concat=False, a=0.1, b=0.15)
@@ -137,14 +139,15 @@ class KPlanesDensityField(nn.Module):
         if positions.dim() == 2:
             positions, times = positions[:, None, :], times
         pts = _pts_from_positions(positions, times, self.aabb, rescale=False, spatial_distortion=self.spatial_distortion)  # bounded: [0,1] coordinates, reference quirk (:440)
-        _, dens = self.sigma_net.forward_with_exp_head(ops.interpolate_kplanes(pts, self.grids), 0)
+        _, dens = self.sigma_net.forward_with_exp_head(ops.interpolate_kplanes(pts, self.grids, self.freeze_time_planes, self.freeze_space_planes), 0)
         return dens.view(*shape, 1)
 
     def density_from_ray_samples(self, ray_samples: RaySamples):
         """Same values as density_fn(ray_samples.frustums.get_positions(), times) with the coordinates derived in-kernel."""
         c = ray_samples._compact
         n_rays, n_samples = ray_samples.frustums.shape[:2]
-        f = ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=False)
+        f = ops.interpolate_kplanes_rays(self.grids, c["origins"], c["directions"], c["times"], c["ebins"], self.aabb, rescale=False,
+                                         freeze_time_planes=self.freeze_time_planes, freeze_space_planes=self.freeze_space_planes)
         _, dens = self.sigma_net.forward_with_exp_head(f, 0)
         return dens.view(n_rays, n_samples, 1)
 

@@ -60,25 +60,34 @@ def coords_from_rays(origins, dirs, times, ebins, aabb, rescale: bool) -> _lib.C
 
 
 class _KPlanesGather(torch.autograd.Function):
+    """freeze: 0 none; bit 0 = freeze_time_planes (the time planes are skipped: the gather runs on the static-scene view of the buffer); bit 1 =
+    freeze_space_planes (kplanes_field.py:101-116: the space planes are interpolated with autograd off AND multiplied into the running product with
+    autograd off, so everything up to the last space plane -- XY, XZ, XT, YZ -- is cut off; only YT and ZT receive a gradient.  Reproduced)."""
+
     @staticmethod
-    def forward(ctx, planes, ps: PlaneSet, coords_keepalive, coords: _lib.Coords, N: int):
+    def forward(ctx, planes, ps: PlaneSet, coords_keepalive, coords: _lib.Coords, N: int, freeze: int = 0):
         out = torch.empty(N, ps.out_dim, dtype=torch.float32, device=planes.device)
-        desc = ps.desc()
+        desc = ps.space_desc() if freeze & 1 else ps.desc()
         _lib.check(_lib.lib().snerf_kplanes_gather_fwd(C.byref(desc), _ptr(planes), C.byref(coords), C.c_int64(N), _ptr(out), _stream()),
                    "kplanes_gather_fwd")
-        ctx.ps, ctx.coords, ctx.keep, ctx.N = ps, coords, coords_keepalive, N
+        ctx.ps, ctx.coords, ctx.keep, ctx.N, ctx.freeze, ctx.desc = ps, coords, coords_keepalive, N, freeze, desc
         ctx.save_for_backward(planes)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         (planes,) = ctx.saved_tensors
+        ps = ctx.ps
+        if ctx.freeze & 2 and (ctx.freeze & 1 or ps.n_coords == 3):  # only space planes take part and they are frozen
+            return None, None, None, None, None, None
         gout = gout.contiguous()
         gplanes = torch.zeros_like(planes)
-        desc = ctx.ps.desc()
-        _lib.check(_lib.lib().snerf_kplanes_gather_bwd(C.byref(desc), _ptr(planes), C.byref(ctx.coords), C.c_int64(ctx.N), _ptr(gout),
+        _lib.check(_lib.lib().snerf_kplanes_gather_bwd(C.byref(ctx.desc), _ptr(planes), C.byref(ctx.coords), C.c_int64(ctx.N), _ptr(gout),
                                                        _ptr(gplanes), _stream()), "kplanes_gather_bwd")
-        return gplanes, None, None, None, None
+        if ctx.freeze & 2:
+            for s in range(len(ps.resolutions)):
+                gplanes[ps.offsets[s][0]: ps.offsets[s][4]].zero_()  # XY XZ XT YZ are contiguous in the buffer
+        return gplanes, None, None, None, None, None
 
 
 class SortedScatter:
@@ -150,20 +159,25 @@ class SortedScatter:
         self.quotient_scatter_scales(planes, coords, gfeat, gplanes, 0, len(self.ps.resolutions), stream)
 
 
-def interpolate_kplanes(pts: torch.Tensor, plane_set: PlaneSet) -> torch.Tensor:
-    """Drop-in for interpolate_kplanes(pts, ms_grids, concat_features, ...) (NS/fields/kplanes_field.py:77-126).
+def interpolate_kplanes(pts: torch.Tensor, plane_set: PlaneSet, freeze_time_planes: bool = False, freeze_space_planes: bool = False) -> torch.Tensor:
+    """Drop-in for interpolate_kplanes(pts, ms_grids, concat_features, freeze_time_planes, freeze_space_planes) (NS/fields/kplanes_field.py:77-126).
     pts [N,4] in [-1,1]; returns [N, C*n_scales] (concat) or [N, C]."""
     pts = _f32c(pts, "pts")
-    return _KPlanesGather.apply(plane_set.planes, plane_set, (pts,), coords_from_points(pts), pts.shape[0])
+    freeze = int(bool(freeze_time_planes)) | (int(bool(freeze_space_planes)) << 1)
+    if freeze & 1 and plane_set.n_coords == 4:
+        pts = pts[:, :3].contiguous()  # the static-scene view reads [N,3] points
+    return _KPlanesGather.apply(plane_set.planes, plane_set, (pts,), coords_from_points(pts), pts.shape[0], freeze)
 
 
-def interpolate_kplanes_rays(plane_set: PlaneSet, origins, dirs, times, ebins, aabb, rescale: bool) -> torch.Tensor:
+def interpolate_kplanes_rays(plane_set: PlaneSet, origins, dirs, times, ebins, aabb, rescale: bool, freeze_time_planes: bool = False,
+                             freeze_space_planes: bool = False) -> torch.Tensor:
     """Same gather with sample coordinates derived in-kernel from rays + euclidean bin edges [R,S+1]."""
     origins, dirs, ebins = _f32c(origins, "origins"), _f32c(dirs, "dirs"), _f32c(ebins, "ebins")
     times = _f32c(times, "times").reshape(-1)
     R, S = ebins.shape[0], ebins.shape[1] - 1
     c = coords_from_rays(origins, dirs, times, ebins, aabb, rescale)
-    return _KPlanesGather.apply(plane_set.planes, plane_set, (origins, dirs, times, ebins), c, R * S)
+    freeze = int(bool(freeze_time_planes)) | (int(bool(freeze_space_planes)) << 1)
+    return _KPlanesGather.apply(plane_set.planes, plane_set, (origins, dirs, times, ebins), c, R * S, freeze)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -68,6 +68,16 @@ class PlaneSet(nn.Module):
                 d.off[s][p] = o
         return d
 
+    def space_desc(self) -> _lib.KPlanesDesc:
+        """The same buffer seen as a static scene: the planes XY, XZ, YZ of every scale (freeze_time_planes, kplanes_field.py:95-99)."""
+        d = self.desc()
+        if self.n_coords == 4:
+            d.n_coords = 3
+            for s in range(len(self.resolutions)):
+                for k, p in enumerate((0, 1, 3)):
+                    d.off[s][k] = self.offsets[s][p]
+        return d
+
     @property
     def out_dim(self) -> int:
         return self.C * len(self.resolutions) if self.concat else self.C

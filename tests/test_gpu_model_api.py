@@ -215,6 +215,68 @@ def test_linear_decoder_fields_match_reference_golden():
         assert bool(torch.isfinite(prm.grad).all()) and float(prm.grad.abs().sum()) > 0
 
 
+def test_frozen_planes_match_reference_golden():
+    """freeze_time_planes / freeze_space_planes (NS/fields/kplanes_field.py:95-116; KPlanesModelConfig :174-177): G6e, the reference's own classes.
+    Time planes frozen = skipped (the gather runs on the static-scene view of the plane buffer); space planes frozen = only YT and ZT receive a
+    gradient (the reference forms the space planes' products with autograd off, which also cuts XT off).  Point path and in-kernel ray path."""
+    from soccernerfs_amd import ops
+    from soccernerfs_amd.kplanes_field import FieldHeadNames, KPlanesDensityField, KPlanesField
+    from soccernerfs_amd.rays import Frustums, RaySamples
+
+    g = load_golden("g6e_frozen_planes")
+    pos, dirs, tms = g["positions"].to(DEV), g["directions"].to(DEV), g["times"].to(DEV)
+    w_rgb, w_den = g["w_rgb"].to(DEV), g["w_density"].to(DEV)
+    R, S = pos.shape[:2]
+    rs = RaySamples(frustums=Frustums(origins=pos, directions=dirs, starts=torch.zeros(R, S, 1, device=DEV), ends=torch.zeros(R, S, 1, device=DEV),
+                                      pixel_area=torch.ones(R, S, 1, device=DEV)), times=tms[:, None])
+    for tag, kw, live in (("time", dict(freeze_time_planes=True), (0, 1, 3)), ("space", dict(freeze_space_planes=True), (4, 5))):
+        f = KPlanesField(g["aabb"], spacetime_resolution=[6, 5, 4, 3], feat_dim=32, multiscale_res=[1, 2], concat_features_across_scales=True,
+                         sigma_net_layers=1, sigma_net_hidden_dim=128, rgb_net_layers=2, rgb_net_hidden_dim=64, **kw).to(DEV)
+        f.grids.load_reference([[g[f"plane_{s}_{q}"] for q in range(6)] for s in range(2)])
+        f.sigma_net.load_linear_weights([g[f"sigma_{i}"].to(DEV) for i in range(2)])
+        f.color_net.load_linear_weights([g[f"color_{i}"].to(DEV) for i in range(3)])
+        o = f(rs)
+        den, rgb = o[FieldHeadNames.DENSITY][..., 0], o[FieldHeadNames.RGB]
+        torch.testing.assert_close(den.detach().cpu(), g[f"{tag}_density"], rtol=2e-5, atol=1e-6)
+        torch.testing.assert_close(rgb.detach().cpu(), g[f"{tag}_rgb"], rtol=2e-5, atol=2e-6)
+        ((w_rgb * rgb).sum() + (w_den * den).sum()).backward()
+        df = KPlanesDensityField(g["aabb"], resolution=[8, 7, 6, 3], feature_dim=8, **kw).to(DEV)
+        df.grids.load_reference([[g[f"prop_plane_{q}"] for q in range(6)]])
+        df.sigma_net.load_linear_weights([g[f"prop_sigma_{i}"].to(DEV) for i in range(2)])
+        pd = df.density_fn(pos, tms)[..., 0]
+        torch.testing.assert_close(pd.detach().cpu(), g[f"{tag}_prop_density"], rtol=2e-5, atol=1e-6)
+        (w_den * pd).sum().backward()
+        got = [(gp, g[f"{tag}_g_plane_{s}_{q}"], q) for s, pl in enumerate(f.grids.to_reference(f.grids.planes.grad)) for q, gp in enumerate(pl)]
+        got += [(gp, g[f"{tag}_prop_g_plane_{q}"], q) for q, gp in enumerate(df.grids.to_reference(df.grids.planes.grad)[0])]
+        for gp, ref, q in got:
+            if q in live:
+                torch.testing.assert_close(gp.cpu(), ref, rtol=1e-4, atol=2e-6)
+            else:
+                assert float(gp.abs().sum()) == 0 and float(ref.abs().sum()) == 0
+        # the in-kernel coordinate path (rays + bin edges) gives the point path's features and gradients
+        gen = torch.Generator().manual_seed(3)
+        o3, d3 = (torch.rand(R, 3, generator=gen) * 0.4 - 0.2).to(DEV), torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) - 0.5, dim=-1).to(DEV)
+        eb = torch.linspace(0.05, 0.9, S + 1, device=DEV).expand(R, S + 1).contiguous()
+        mid = (eb[:, :-1] + eb[:, 1:])[..., None] / 2
+        p = ((o3[:, None] + d3[:, None] * mid) - g["aabb"][0].to(DEV)) / (g["aabb"][1] - g["aabb"][0]).to(DEV) * 2 - 1
+        pts = torch.cat([p, (tms * 2 - 1)[:, None, :].expand(R, S, 1)], -1).reshape(-1, 4)
+        gy = torch.rand(R * S, 64, generator=gen).to(DEV)
+        f.grids.planes.grad = None
+        a = ops.interpolate_kplanes(pts, f.grids, **kw)
+        a.backward(gy)
+        ga, f.grids.planes.grad = f.grids.planes.grad.clone(), None
+        b = ops.interpolate_kplanes_rays(f.grids, o3, d3, tms, eb, g["aabb"].to(DEV), rescale=True, **kw)
+        b.backward(gy)
+        torch.testing.assert_close(b, a, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(f.grids.planes.grad, ga, rtol=1e-4, atol=1e-6)
+    # both at once: nothing left to train in the planes
+    f = KPlanesField(g["aabb"], spacetime_resolution=[6, 5, 4, 3], feat_dim=32, multiscale_res=[1, 2], concat_features_across_scales=True,
+                     sigma_net_hidden_dim=128, freeze_time_planes=True, freeze_space_planes=True).to(DEV)
+    o = f(rs)
+    o[FieldHeadNames.RGB].sum().backward()
+    assert f.grids.planes.grad is None and float(f.sigma_net.params.grad.abs().sum()) > 0
+
+
 def test_unbounded_scene_contraction_matches_reference_golden():
     """KPlanesModelConfig.bounded = False (NS/models/kplanes.py:194,260-281): L-inf SceneContraction in front of KPlanesField and
     KPlanesDensityField, near / far collider, piecewise initial sampler.  Field values vs the reference's own classes on positions inside and far

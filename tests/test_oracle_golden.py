@@ -343,3 +343,28 @@ def test_g6d_linear_decoder_fields():
         close(pw[i].grad, g[f"prop_g_sigma_{i}"], rtol=1e-4, atol=1e-6)
     for q in range(6):
         close(pg[q].grad, g[f"prop_g_plane_{q}"], rtol=1e-4, atol=1e-6)
+
+
+def test_g6e_frozen_planes():
+    """G6e (oracle/gen_golden_frozen_planes.py): the reference's fields with freeze_time_planes (time planes skipped) and freeze_space_planes (only
+    YT and ZT keep a gradient: the space planes' products are formed with autograd off) -- outputs and plane gradients vs the oracle's restatement."""
+    g = load_golden("g6e_frozen_planes")
+    pos, tms = g["positions"], g["times"]
+    for tag, kw in (("time", dict(freeze_time_planes=True)), ("space", dict(freeze_space_planes=True))):
+        grids = [[g[f"plane_{s}_{q}"].clone().requires_grad_(True) for q in range(6)] for s in range(2)]
+        dens, rgb = KO.field_forward(pos, tms, g["aabb"], grids, [g["sigma_0"], g["sigma_1"]], [g["color_0"], g["color_1"], g["color_2"]], **kw)
+        close(dens, g[f"{tag}_density"], rtol=2e-5, atol=1e-6)
+        close(rgb, g[f"{tag}_rgb"], rtol=2e-5, atol=2e-6)
+        ((g["w_rgb"] * rgb).sum() + (g["w_density"] * dens).sum()).backward()
+        pg = [g[f"prop_plane_{q}"].clone().requires_grad_(True) for q in range(6)]
+        pd = KO.density_field_forward(pos, tms, g["aabb"], pg, [g["prop_sigma_0"], g["prop_sigma_1"]], **kw)
+        close(pd, g[f"{tag}_prop_density"], rtol=2e-5, atol=1e-6)
+        (g["w_density"] * pd).sum().backward()
+        live = (0, 1, 3) if tag == "time" else (4, 5)
+        for q in range(6):
+            for got, ref in [(grids[s][q].grad, g[f"{tag}_g_plane_{s}_{q}"]) for s in range(2)] + [(pg[q].grad, g[f"{tag}_prop_g_plane_{q}"])]:
+                if q in live:
+                    assert float(ref.abs().sum()) > 0
+                    close(got, ref, rtol=1e-4, atol=1e-6)
+                else:
+                    assert float(ref.abs().sum()) == 0 and (got is None or float(got.abs().sum()) == 0)
