@@ -207,8 +207,13 @@ struct PlanB {
   static constexpr int A1T = A1 + TS * LKH;        // [H][LKT]; reused for the transposed gradient of Z1 once its weight-gradient product is done
   static constexpr int A2 = A1T + H * LKT;         // [TS][LKH]  (NH == 2)
   static constexpr int A2T = A2 + (NH == 2 ? TS * LKH : 0);  // [H][LKT]; reused for the transposed gradient of Z2
-  static constexpr int GZ = A2T + (NH == 2 ? H * LKT : 0);   // [TS][LKH]  gradient of Z_last
-  static constexpr int GZ1 = GZ + TS * LKH;        // [TS][LKH]  gradient of Z1 (NH == 2)
+  // one hidden layer, input at least as wide as the hidden layer: the row-major X tile is dead once the hidden layer is computed (the weight
+  // gradient reads the transposed image), so the row-major gradient of Z_last takes its place -- that is what lets 64-sample tiles of the
+  // 160 -> 128 net fit (146 KB instead of 163)
+  static constexpr bool GZ_IN_XS = NH == 1 && K0 >= H;
+  static constexpr int GZ_OWN = A2T + (NH == 2 ? H * LKT : 0);
+  static constexpr int GZ = GZ_IN_XS ? XS : GZ_OWN;          // [TS][LKH]  gradient of Z_last
+  static constexpr int GZ1 = GZ_OWN + (GZ_IN_XS ? 0 : TS * LKH);  // [TS][LKH]  gradient of Z1 (NH == 2)
   static constexpr int GZO = GZ1 + (NH == 2 ? TS * LKH : 0);  // [TS][LKO]
   static constexpr int GZOT = GZO + TS * LKO;      // [16][LKT]
   static constexpr int TOTAL = GZOT + 16 * LKT;
@@ -265,6 +270,21 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
     __syncthreads();
     xt.store(Xs, P::LK0, Xt, P::LKT);
     if (tile + gridDim.x < n_tiles) xt.template fetch<T>(a, (tile + gridDim.x) * TS);
+    // this tile's incoming gradients, issued now and consumed by the output phase two barriers later: read there, their latency was a fifth
+    // of the tile's time (per-phase clocks, profiles/r03_kernels.md section 8)
+    constexpr int JO = (MT + NW - 1) / NW;
+    float gyp[JO][4], gap[JO][4];
+#pragma unroll
+    for (int j = 0; j < JO; ++j) {
+      const int mt = wave + NW * j, col = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + mt * 16 + (lane >> 4) * 4 + r;
+        const bool live = mt < MT && n < a.N && col < a.dout;
+        gyp[j][r] = (live && a.gY) ? a.gY[n * a.ldgy + col] : 0.f;
+        gap[j][r] = (live && a.gaux && col == a.aux_col) ? a.gaux[n] : 0.f;
+      }
+    }
     __syncthreads();
     // ---- hidden layer: A1 (row-major) and A1t ----
 #pragma unroll
@@ -323,12 +343,12 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
           float g = 0.f;
           if (n < a.N && col < a.dout) {
             const float y = acc[0][r];
-            if (a.gY) g = a.gY[n * a.ldgy + col];
+            g = gyp[j][r];
             if (a.out_act == 1) {
               const float sg = 1.f / (1.f + expf(-y));
               g = g * sg * (1.f - sg);
             }
-            if (a.gaux && col == a.aux_col) g += a.gaux[n] * expf(fminf(fmaxf(y, -15.f), 15.f));  // trunc_exp backward (activations.py:38-39)
+            if (a.gaux && col == a.aux_col) g += gap[j][r] * expf(fminf(fmaxf(y, -15.f), 15.f));  // trunc_exp backward (activations.py:38-39)
           }
           gv[r] = g * GS;
         }
@@ -414,25 +434,21 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
         dW0[j] = acc[0];
       }
     }
-    // ---- gX = gz W0^T ----
+    // ---- gX = gz W0^T: (column block, row block) units dealt round-robin to the waves (whole column blocks left two of eight waves with
+    //      twice the work of the others: K0 / 16 = 10 of them for the preset's net) ----
     if (a.gX) {
 #pragma unroll
-      for (int j = 0; j < (K0T + NW - 1) / NW; ++j) {
-        const int nt = wave + NW * j;
-        if (nt < K0T) {
-          f32x4 acc[MT] = {};
-          mma_rr<MT, H>(gz1, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
+      for (int j = 0; j < (K0T * MT + NW - 1) / NW; ++j) {
+        const int u = wave + NW * j;
+        if (u < K0T * MT) {
+          const int nt = u / MT, m = u - nt * MT;
+          f32x4 acc[1] = {};
+          mma_rr<1, H>(gz1 + m * 16 * P::LKH, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
           const int col = nt * 16 + (lane & 15);
+          const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
 #pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (row0 + r < a.N && col < a.d0) {
-                const float gx = acc[m][r] * (1.f / GS);
-                a.gX[(row0 + r) * a.ldgx + col] = gx;
-              }
-          }
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[0][r] * (1.f / GS);
         }
       }
     }
@@ -480,7 +496,7 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
     constexpr int TS = (H <= 64 && NH == 1) ? 64 : 32;  // proposal nets: 64-sample tiles halve the barriers per sample (0.217 -> 0.153 ms; 128: 0.221)
     using P = PlanB<K0, H, NH, TS>;
     static_assert(P::BYTES <= LDS_LIMIT_B, "bf16 backward tile does not fit LDS");
-    const int64_t n_tiles = (a.N + TS - 1) / TS;
+    int64_t n_tiles = (a.N + TS - 1) / TS;
     int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int64_t grid = 256 * per_cu;
@@ -490,10 +506,16 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
       if constexpr (H == 128 && NH == 1) {
         SNERF_REQUIRE(a.d0 == K0 && a.ldx % 8 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0,
                       "mlp_bwd_x16: needs d_in a multiple of 32 (%d), ldx a multiple of 8 (%d) and a 16-byte aligned X", a.d0, a.ldx);
-        auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS, true>;
+        // 64-sample tiles where they fit (the 160 -> 128 net of the preset: 146 KB; the 16-bit X prefetch is small enough for the registers,
+        // the fp32 one below is not: 93 spilled VGPRs)
+        constexpr int TS16 = PlanB<K0, H, NH, 64>::BYTES <= LDS_LIMIT_B ? 64 : 32;
+        using P16 = PlanB<K0, H, NH, TS16>;
+        n_tiles = (a.N + TS16 - 1) / TS16;
+        grid = n_tiles < 256 ? n_tiles : 256;
+        auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS16, true>;
         static bool attr_set16 = false;
         if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P16::BYTES, st, a, n_tiles);
       } else {
         set_error("mlp_bwd_x16: 16-bit inputs are built for the d_in -> 128 -> d_out one-hidden-layer shapes (sigma_net), got hidden=%d n_hidden=%d", H, NH);
         return SNERF_ERR_UNSUPPORTED;
