@@ -321,3 +321,43 @@ def test_backward_from_16bit_input_equals_backward_from_its_fp32_image(operands)
         res.append((gx, gw))
     assert torch.equal(res[0][0], res[1][0])
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * float(res[0][1].abs().max()))
+
+
+def test_linear_decoder_pieces_against_torch_and_edge_cases():
+    """csrc/linear_decoder.hip: trunc_exp (forward exp, backward with the exponent clamped to [-15, 15]: NS/field_components/activations.py:25-41)
+    and basis_rgb (sigmoid of the feature / basis contraction, kplanes_field.py:349-354) against the oracle's formulas under autograd; empty
+    inputs, the clamp's two sides, a row-strided feature tensor, F = 4 (one lane of sixteen active) and F = 160."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd import ops
+
+    gen = torch.Generator().manual_seed(2)
+    x = torch.cat([torch.randn(1000, generator=gen) * 3, torch.tensor([-40.0, -15.0, 15.0, 20.0, 0.0])]).requires_grad_(True)
+    g = torch.randn(x.shape, generator=gen)
+    ref = KO.trunc_exp(x)
+    ref.backward(g)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = ops.trunc_exp(xg)
+    y.backward(g.to(DEV))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=2e-6, atol=0)
+    torch.testing.assert_close(xg.grad.cpu(), x.grad, rtol=2e-6, atol=0)
+    assert float(xg.grad[-2].cpu() / g[-2]) == pytest.approx(float(torch.exp(torch.tensor(15.0))), rel=1e-6)  # x = 20: the backward stops at e^15
+    assert ops.trunc_exp(torch.zeros(0, 1, device=DEV)).shape == (0, 1)
+    for F, N in ((4, 33), (64, 1000), (160, 257)):
+        feat = (torch.rand(N, F, generator=gen) * 2 - 1).requires_grad_(True)
+        basis = (torch.rand(N, 3 * F, generator=gen) * 2 - 1).requires_grad_(True)
+        w = torch.rand(N, 3, generator=gen) - 0.5
+        ref = torch.sigmoid(torch.sum(feat[:, None, :] * basis.view(N, 3, F), dim=-1))
+        (ref * w).sum().backward()
+        fg, bg = feat.detach().to(DEV).requires_grad_(True), basis.detach().to(DEV).requires_grad_(True)
+        out = ops.basis_rgb(fg, bg)
+        (out * w.to(DEV)).sum().backward()
+        torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(fg.grad.cpu(), feat.grad, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(bg.grad.cpu(), basis.grad, rtol=1e-4, atol=1e-6)
+    assert ops.basis_rgb(torch.zeros(0, 32, device=DEV), torch.zeros(0, 96, device=DEV)).shape == (0, 3)
+    with pytest.raises(ValueError, match="multiple of 4"):
+        ops.basis_rgb(torch.zeros(5, 6, device=DEV), torch.zeros(5, 18, device=DEV))
+    with pytest.raises(RuntimeError, match="HIP device tensor"):
+        ops.trunc_exp(torch.zeros(4))
+    # wide dense layers: nothing to do for N = 0
+    assert ops.dense_net_forward(torch.zeros(0, 160, device=DEV), torch.zeros(160, device=DEV), [160, 1], "None", "None").shape == (0, 1)
