@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
-    ap.add_argument("--time-sorted-rays", action="store_true", help="EXPERIMENT")
+    ap.add_argument("--no-time-sorted-rays", action="store_true", help="A/B: the batch in the order the pixel sampler drew it (default: in order of frame time)")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="A/B: product form of the field's sorted scatter (gradvec + 1 GB of per-plane gradient vectors) instead of the quotient form")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
@@ -185,12 +185,14 @@ def main():
     images = data["images"]
     M, H, W = images.shape[:3]
 
+    time_sorted = not args.no_time_sorted_rays
+    time_key, n_time_keys = ops.image_time_keys(data["times"])
+
     def one_step():
         # uniform pixel sampler (PixelSampler.sample_method, NS/data/pixel_samplers.py:74-77) + image gather (:111-123)
         idx, target = ops.sample_pixels_uniform(torch.rand(R, 3, device=dev), M, H, W, images)
-        if args.time_sorted_rays:  # EXPERIMENT: the batch in order of frame time
-            order = torch.argsort(data["times"][idx[:, 0]])
-            idx, target = idx[order].contiguous(), target[order].contiguous()
+        if time_sorted:  # the batch in order of frame time (free: a batch is a set; ops.sort_rays_by_time)
+            idx, target = ops.sort_rays_by_time(idx, time_key, n_time_keys, target)
         rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=trainer.aabb,
                                  near_plane=cfg.near_plane, training=True)
         return trainer.train_step(rays, target)
@@ -210,8 +212,8 @@ def main():
 
     def one_step_steady():
         idx = sampler.sample_method(R, M, H, W, batch=batch, device=dev)
-        if args.time_sorted_rays:
-            idx = idx[torch.argsort(data["times"][idx[:, 0]])].contiguous()
+        if time_sorted:
+            idx = ops.sort_rays_by_time(idx, time_key, n_time_keys)
         target = images[idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
         rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=trainer.aabb,
                                  near_plane=cfg.near_plane, training=True)

@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 9
+#define SNERF_ABI_VERSION 10
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -422,6 +422,14 @@ int snerf_raygen(const snerf_raygen_args* args, snerf_stream_t stream);
  * [M,H,W,3] (images may be NULL: indices only). */
 int snerf_sample_pixels_uniform(const float* u, int32_t R, int32_t M, int32_t H, int32_t W, const uint8_t* images, int64_t* indices,
                                 float* target, snerf_stream_t stream);
+
+/* The ray batch in order of a per-image key (image_key[M] in [0, n_keys): the rank of the image's frame time).  A batch is a set (losses are
+ * means over it, the per-ray draws are i.i.d.), so its order is free; with equal-time rays adjacent, the gathers of every plane that holds the
+ * time axis (and the temporal hash grid's rows) become coherent.  Out of place: indices_out [R,3] (and aux_out [R,aux_cols] = the same
+ * permutation of aux_in, e.g. the target colours; aux_cols = 0: none).  The order is a pure function of the batch (ties keep their order).
+ * R <= 16384 (one workgroup sorts in LDS). */
+int snerf_sort_rays_by_key(const int64_t* indices_in, const int32_t* image_key, int32_t n_keys, int32_t R, const float* aux_in, int32_t aux_cols,
+                           int64_t* indices_out, float* aux_out, snerf_stream_t stream);
 
 /* AABBBoxCollider alone: aabb6 = HOST pointer to {min x,y,z, max x,y,z}. */
 int snerf_aabb_collide(const float* origins, const float* dirs, int32_t R, const float* aabb6, float near_plane, int32_t training,

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class KPlanesDesc(C.Structure):
@@ -130,6 +130,7 @@ def lib():
     l.snerf_render_bwd.argtypes = [P, P, P, I, P, P, I, I, P, P, I, P]
     l.snerf_render_mse_bwd.argtypes = [P, P, P, I, P, P, F, I, I, P, P, P, P]
     l.snerf_sample_pixels_uniform.argtypes = [P, I, I, I, I, P, P, P, P]
+    l.snerf_sort_rays_by_key.argtypes = [P, P, I, I, P, I, P, P, P]
     l.snerf_trunc_exp_fwd.argtypes = [P, L, P, P]
     l.snerf_trunc_exp_bwd.argtypes = [P, P, L, P, P]
     l.snerf_basis_rgb_fwd.argtypes = [P, I, P, L, I, P, P]
@@ -187,6 +188,7 @@ EXPORTS = [
     "snerf_isg_maps",
     "snerf_adam_step_tv",
     "snerf_sample_pixels_uniform",
+    "snerf_sort_rays_by_key",
     "snerf_kplanes_scatter_sorted_scales",
     "snerf_raygen",
     "snerf_aabb_collide",

@@ -88,6 +88,38 @@ __global__ void sample_pixels_kernel(const float* __restrict__ u, int R, int M, 
   }
 }
 
+// The ray batch in order of a per-image key (the frame time): a batch is a set -- losses are means over it, the per-ray draws are i.i.d. -- so
+// its order is free, and with equal-time rays next to each other every gather of a time plane (3 of the 6 planes of each scale; the
+// temporal hash grid's rows likewise) finds the same two texel rows of its plane for the whole group instead of rows all over the plane:
+// fused field forward 0.378 -> 0.309 ms at the k-planes preset (profiles/r03_kernels.md section 11).  One workgroup, bitonic sort in LDS of
+// the words key << 14 | ray: unique words, so the order is a pure function of the batch (stable for equal keys).  256 threads on purpose: the
+// kernel starts while the previous step's optimiser sweep fills the GPU, and a 1024-thread workgroup waited for sixteen free wave slots on one CU
+// until the sweep had drained -- the whole head of the step behind it (measured: +0.1 ms per step).
+__global__ __launch_bounds__(256) void sort_rays_kernel(const int64_t* __restrict__ idx_in, const int32_t* __restrict__ image_key, int R, int n_pow2,
+                                                        const float* __restrict__ aux_in, int aux_cols, int64_t* __restrict__ idx_out,
+                                                        float* __restrict__ aux_out) {
+  extern __shared__ uint32_t s_w[];
+  for (int i = threadIdx.x; i < n_pow2; i += blockDim.x)
+    s_w[i] = i < R ? (((uint32_t)image_key[idx_in[(int64_t)i * 3]] << 14) | (uint32_t)i) : 0xffffffffu;
+  __syncthreads();
+  for (int k = 2; k <= n_pow2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < n_pow2 / 2; t += blockDim.x) {
+        const int i = ((t / j) * 2 * j) + (t % j), l = i + j;  // j is a power of two: shifts and masks
+        const bool up = (i & k) == 0;
+        const uint32_t a = s_w[i], b = s_w[l];
+        if ((a > b) == up) { s_w[i] = b; s_w[l] = a; }
+      }
+      __syncthreads();
+    }
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const int64_t src = s_w[r] & 0x3fffu;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) idx_out[(int64_t)r * 3 + c] = idx_in[src * 3 + c];
+    for (int c = 0; c < aux_cols; ++c) aux_out[(int64_t)r * aux_cols + c] = aux_in[src * aux_cols + c];
+  }
+}
+
 __global__ void aabb_kernel(const float* __restrict__ o, const float* __restrict__ d, int R, float near_plane, int training, const float* amin3,
                             float* __restrict__ nears, float* __restrict__ fars, float a0, float a1, float a2, float b0, float b1, float b2) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,6 +167,21 @@ extern "C" int snerf_sample_pixels_uniform(const float* u, int32_t R, int32_t M,
   SNERF_REQUIRE(u && indices && (!images || target), "sample_pixels_uniform: null buffer");
   hipLaunchKernelGGL(sample_pixels_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, u, R, M, H, W, images, indices, target);
   SNERF_LAUNCH_CHECK("sample_pixels_uniform");
+  return 0;
+}
+
+extern "C" int snerf_sort_rays_by_key(const int64_t* indices_in, const int32_t* image_key, int32_t n_keys, int32_t R, const float* aux_in,
+                                      int32_t aux_cols, int64_t* indices_out, float* aux_out, snerf_stream_t stream) {
+  SNERF_REQUIRE(R >= 0 && R <= 16384 && n_keys >= 1 && n_keys <= (1 << 18) && aux_cols >= 0,
+                "sort_rays_by_key: R=%d (<= 16384) n_keys=%d (<= 262144) aux_cols=%d", R, n_keys, aux_cols);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(indices_in && image_key && indices_out && indices_in != indices_out && (aux_cols == 0 || (aux_in && aux_out && aux_in != aux_out)),
+                "sort_rays_by_key: null or aliased buffer (the sort is out of place)");
+  int n = 2;
+  while (n < R) n <<= 1;
+  hipLaunchKernelGGL(sort_rays_kernel, dim3(1), dim3(256), (size_t)n * sizeof(uint32_t), (hipStream_t)stream, indices_in, image_key, R, n, aux_in, aux_cols,
+                     indices_out, aux_out);
+  SNERF_LAUNCH_CHECK("sort_rays_by_key");
   return 0;
 }
 

@@ -750,6 +750,30 @@ def generate_rays(indices, fx, fy, cx, cy, c2w, cam_times=None, aabb=None, near_
     return out
 
 
+def image_time_keys(times: torch.Tensor):
+    """-> (key [M] int32: the rank of each image's time among the distinct times, number of distinct times): the key table of sort_rays_by_time."""
+    uniq, inv = torch.unique(times.reshape(-1), sorted=True, return_inverse=True)
+    return inv.to(torch.int32).contiguous(), int(uniq.numel())
+
+
+def sort_rays_by_time(indices: torch.Tensor, image_key: torch.Tensor, n_keys: int, aux: Optional[torch.Tensor] = None):
+    """The batch's pixel indices [R,3] (image, row, col) -- and, with them, aux [R,k] (e.g. the target colours) -- in order of the images' frame
+    time (snerf_sort_rays_by_key: why, and why that is free).  Batches beyond 16384 rays are returned as they are."""
+    R = indices.shape[0]
+    if R > 16384 or R == 0:
+        return (indices, aux) if aux is not None else indices
+    if not indices.is_cuda or indices.dtype != torch.int64 or image_key.dtype != torch.int32 or not image_key.is_cuda:
+        raise RuntimeError("sort_rays_by_time: indices must be an int64 HIP tensor [R,3] and image_key an int32 HIP tensor")
+    indices = indices.contiguous()
+    out = torch.empty_like(indices)
+    aux_c = _f32c(aux, "sort_rays_by_time aux").reshape(R, -1) if aux is not None else None
+    aux_out = torch.empty_like(aux_c) if aux_c is not None else None
+    _lib.check(_lib.lib().snerf_sort_rays_by_key(_ptr(indices), _ptr(image_key), n_keys, R, _ptr(aux_c) if aux_c is not None else None,
+                                                 aux_c.shape[1] if aux_c is not None else 0, _ptr(out), _ptr(aux_out) if aux_out is not None else None,
+                                                 _stream()), "sort_rays_by_key")
+    return (out, aux_out.view(aux.shape)) if aux is not None else out
+
+
 def sample_pixels_uniform(u: torch.Tensor, num_images: int, height: int, width: int, images: Optional[torch.Tensor] = None):
     """PixelSampler.sample_method's uniform draw (pixel_samplers.py:74-77) from u = rand(R,3), fused with the image gather of
     collate_image_dataset_batch (:111-123) when the uint8 image cache [M,H,W,3] is given.  Returns (indices int64 [R,3], target fp32 [R,3] | None)."""

@@ -142,10 +142,14 @@ class PixelSampler:
         device = batch["image"].device
         M, H, W, _ = batch["image"].shape
         indices = self.sample_method(num_rays_per_batch, M, H, W, batch=batch, device=device)
+        if batch.get("time_key") is not None:
+            # optional, not in the reference: the batch in order of the images' frame time (batch["time_key"], batch["n_time_keys"] =
+            # ops.image_time_keys(times)).  A batch is a set, so this is free, and it makes every time-plane / temporal-grid gather coherent
+            indices = ops.sort_rays_by_time(indices, batch["time_key"], int(batch["n_time_keys"]))
         c, y, x = indices[:, 0], indices[:, 1], indices[:, 2]
         out = {}
         for key, value in batch.items():
-            if key in ("image_idx", "iter_steps", "ist_cdf", "ist_nonempty", "ist_nnz") or value is None or not isinstance(value, torch.Tensor):
+            if key in ("image_idx", "iter_steps", "ist_cdf", "ist_nonempty", "ist_nnz", "time_key", "n_time_keys") or value is None or not isinstance(value, torch.Tensor):
                 continue
             v = value[c, y, x]
             out[key] = v.float() / 255.0 if v.dtype == torch.uint8 else v

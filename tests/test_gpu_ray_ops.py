@@ -261,3 +261,37 @@ def test_adam_drops_non_finite_gradient_elements():
     ops.adam_step(p, g, m, v, 1, 1e-2, zero_grad=True)
     assert bool(torch.isfinite(p).all()) and bool(torch.isfinite(m).all()) and bool(torch.isfinite(v).all())
     assert float(p[3]) == 1.0 and float(p[7]) == 1.0 and float(p[0]) < 1.0 and float(g.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [1, 2, 777, 4096, 5000, 16384])
+def test_sort_rays_by_time_is_a_stable_permutation(R):
+    """snerf_sort_rays_by_key: the batch's pixel indices (and the target colours with them) in order of the images' frame time; rays of the same
+    time keep the order they were drawn in (the result is a pure function of the batch); nothing but a permutation happens."""
+    from soccernerfs_amd import ops
+
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(R)
+    M = 60
+    times = (torch.randint(0, 25, (M,), generator=gen).float() / 24.0).to(dev)  # several images share a frame time
+    key, n_keys = ops.image_time_keys(times)
+    assert n_keys == int(torch.unique(times).numel()) and key.dtype == torch.int32
+    idx = torch.stack([torch.randint(0, M, (R,), generator=gen), torch.randint(0, 540, (R,), generator=gen), torch.randint(0, 960, (R,), generator=gen)], -1).to(dev)
+    tgt = torch.rand(R, 3, generator=gen).to(dev)
+    out, tout = ops.sort_rays_by_time(idx, key, n_keys, tgt)
+    order = torch.argsort(key[idx[:, 0]].long(), stable=True)
+    assert torch.equal(out, idx[order]) and torch.equal(tout, tgt[order])
+    assert bool((torch.diff(times[out[:, 0]]) >= 0).all())
+    only = ops.sort_rays_by_time(idx, key, n_keys)
+    assert torch.equal(only, out)
+
+
+@pytest.mark.gpu
+def test_sort_rays_by_time_leaves_oversized_batches_alone():
+    from soccernerfs_amd import ops
+
+    dev = "cuda:0"
+    key, n_keys = ops.image_time_keys(torch.tensor([0.5, 0.0], device=dev))
+    idx = torch.zeros(20000, 3, dtype=torch.int64, device=dev)
+    idx[::2, 0] = 1
+    assert ops.sort_rays_by_time(idx, key, n_keys) is idx

@@ -11,6 +11,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=60)
 ap.add_argument("--warmup", type=int, default=10)
 ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--frames", type=int, default=0, help="quantise the ray times to this many frame times (0: continuous)")
+ap.add_argument("--sort-times", action="store_true", help="with --frames: the batch in order of frame time")
 ap.add_argument("--optim", default="snerf", choices=["snerf", "fused", "foreach", "single"])
 ap.add_argument("--no-fuse-tv", action="store_true")
 ap.add_argument("--fused", action="store_true", help="soccernerfs_amd.nerfplayer_trainer.NerfplayerTrainer instead of the autograd model")
@@ -29,8 +31,12 @@ if args.fused:
     def fstep():
         o = (torch.rand(R, 3, device=dev) * 2 - 1) * 0.6
         d = torch.nn.functional.normalize(torch.rand(R, 3, device=dev) * 2 - 1, dim=-1)
-        tr.train_step({"origins": o, "directions": d, "times": torch.rand(R, 1, device=dev)}, torch.randint(0, 3600, (R,), device=dev),
-                      torch.rand(R, 3, device=dev))
+        t = torch.rand(R, 1, device=dev)
+        if args.frames:  # frame times as a dataset has them (stadium-players: 100 frames), optionally the batch in order of time
+            t = torch.floor(t * args.frames) / max(args.frames - 1, 1)
+            if args.sort_times:
+                t = torch.sort(t, dim=0).values
+        tr.train_step({"origins": o, "directions": d, "times": t}, torch.randint(0, 3600, (R,), device=dev), torch.rand(R, 3, device=dev))
 
     for _ in range(args.warmup):
         fstep()

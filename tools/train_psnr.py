@@ -76,6 +76,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     batch = {"image": train["images"], "image_idx": torch.arange(M, device=dev), "ist_weights": ist, "iter_steps": 0}
     sampler = DynamicBasedPixelSampler(R, is_pixel_ratio=0.15, iters_to_start_ist=2000)
     DynamicBasedPixelSampler.prepare(batch)
+    time_key, n_time_keys = ops.image_time_keys(train["times"])
     run = {"seed": seed, "evals": []}
     t_train = 0.0
     for step in range(args.steps):
@@ -84,6 +85,8 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
             t1 = time.time()
         batch["iter_steps"] = step
         idx = sampler.sample_method(R, M, H, W, batch=batch, device=dev)
+        if args.time_sorted_rays:  # the batch in order of frame time (ops.sort_rays_by_time: a batch is a set), as bench.py runs it
+            idx = ops.sort_rays_by_time(idx, time_key, n_time_keys)
         target = train["images"][idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
         rays = ops.generate_rays(idx, train["fx"], train["fy"], train["cx"], train["cy"], train["c2w"], train["times"], aabb=trainer.aabb,
                                  near_plane=cfg.near_plane, training=True)
@@ -134,6 +137,7 @@ def main():
     ap.add_argument("--no-quotient-scatter", action="store_true", help="product form of the field's sorted scatter")
     ap.add_argument("--emulate-transports", default="", choices=["", "grad", "param", "both"],
                     help="single-GPU emulation of the bf16 gradient / parameter-update transports of the sharded multi-GPU step (KPlanesTrainConfig.emulate_transports)")
+    ap.add_argument("--time-sorted-rays", action="store_true", help="every batch in order of frame time, as bench.py runs it")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -153,7 +157,7 @@ def main():
     log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps,
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
            "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
-           "emulate_transports": args.emulate_transports, "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
+           "emulate_transports": args.emulate_transports, "time_sorted_rays": args.time_sorted_rays, "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
            "eval_sets": {"camera_20": "20th arc camera (reference 'all' split eval camera; extrapolated view), %d frames" % len(sets["camera_20"][1]),
                          "novel": "3 evaluation-only cameras between training cameras (interpolated views), %d images" % len(sets["novel"][1]),
                          "train": "4 training images"},
