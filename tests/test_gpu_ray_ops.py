@@ -295,3 +295,30 @@ def test_sort_rays_by_time_leaves_oversized_batches_alone():
     idx = torch.zeros(20000, 3, dtype=torch.int64, device=dev)
     idx[::2, 0] = 1
     assert ops.sort_rays_by_time(idx, key, n_keys) is idx
+
+
+@pytest.mark.gpu
+def test_pixel_sampler_batches_in_order_of_frame_time():
+    """PixelSampler.collate_image_dataset_batch with batch["time_key"]: the batch comes out in order of the images' frame time, every per-pixel
+    entry gathered at the permuted indices (so image, depth etc. stay attached to their rays) and image_idx remapped as without the option."""
+    from soccernerfs_amd import ops
+    from soccernerfs_amd.pixel_samplers import PixelSampler
+
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(4)
+    M, H, W = 12, 20, 30
+    images = torch.randint(0, 256, (M, H, W, 3), generator=gen, dtype=torch.uint8).to(dev)
+    depth = torch.rand(M, H, W, 1, generator=gen).to(dev)
+    times = torch.tensor([0.5, 0.0, 1.0, 0.25] * 3, device=dev)
+    key, n = ops.image_time_keys(times)
+    batch = {"image": images, "depth_image": depth, "image_idx": torch.arange(100, 100 + M, device=dev), "time_key": key, "n_time_keys": n}
+    torch.manual_seed(9)
+    out = PixelSampler(512).sample(batch)
+    c = out["indices"][:, 0] - 100
+    assert bool((torch.diff(times[c]) >= 0).all()) and len(torch.unique(c)) > 4
+    y, x = out["indices"][:, 1], out["indices"][:, 2]
+    assert torch.equal(out["image"], images[c, y, x].float() / 255.0) and torch.equal(out["depth_image"], depth[c, y, x])
+    assert "time_key" not in out and "n_time_keys" not in out
+    torch.manual_seed(9)
+    plain = PixelSampler(512).sample({k: v for k, v in batch.items() if k not in ("time_key", "n_time_keys")})
+    assert torch.equal(torch.sort(plain["indices"].view(-1, 3)[:, 0]).values, torch.sort(out["indices"][:, 0]).values)  # the same draw, permuted
