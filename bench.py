@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
-    ap.add_argument("--no-time-sorted-rays", action="store_true", help="A/B: the batch in the order the pixel sampler drew it (default: in order of frame time)")
+    ap.add_argument("--time-sorted-rays", action="store_true", help="A/B: every batch in order of frame time (ops.sort_rays_by_time); faster field forward, but 1.5 %% slower trained steps: profiles/r03_kernels.md section 11")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="A/B: product form of the field's sorted scatter (gradvec + 1 GB of per-plane gradient vectors) instead of the quotient form")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
@@ -185,7 +185,7 @@ def main():
     images = data["images"]
     M, H, W = images.shape[:3]
 
-    time_sorted = not args.no_time_sorted_rays
+    time_sorted = args.time_sorted_rays
     time_key, n_time_keys = ops.image_time_keys(data["times"])
 
     def one_step():
