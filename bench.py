@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
     ap.add_argument("--mlp-operands", default=DEFAULT_OPERANDS, choices=["fp32", "bf16", "fp16"], help="MFMA operand type of sigma_net, color_net and the proposal "
                     "nets: bf16 = bf16 operands with fp32 accumulation (BASELINE config 2 names bf16; tcnn computes these nets in fp16); fp32 = exact (the parity path)")
+    ap.add_argument("--trained-until", type=int, default=5000, help="third leg: really train to this step (untimed, ~12 s), then time K steady-state steps (0 or --no-steady-state: skip)")
     ap.add_argument("--time-sorted-rays", action="store_true", help="A/B: every batch in order of frame time (ops.sort_rays_by_time); faster field forward, but 1.5 %% slower trained steps: profiles/r03_kernels.md section 11")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="A/B: product form of the field's sorted scatter (gradvec + 1 GB of per-plane gradient vectors) instead of the quotient form")
@@ -282,6 +283,22 @@ def main():
         breakdown = trainer.kernel_times_ms()
         trainer.disable_kernel_timing()
 
+    # trained state: the model REALLY trained up to --trained-until (default 5000; the reference's schedule: uniform pixels for 2000 steps,
+    # then 15 % IST rays; cosine lr; proposal updates every 5th step from step 5000), untimed, then K timed steps.  BASELINE.json's metric is
+    # quoted "past step 5000": with the density learnt the samples sit on the surfaces and a step costs less than on the untrained planes above.
+    trained_line = None
+    if steady and args.trained_until > 0:
+        trainer.synchronize()
+        trainer.step, trainer._steps_since_update = 0, 0
+        while trainer.step < args.trained_until:
+            batch["iter_steps"] = trainer.step
+            one_step_steady()
+        batch["iter_steps"] = trainer.step
+        el3 = timed(one_step_steady, args.steps)
+        trained_line = {"value": R * world * args.steps / el3, "unit": "rays/s", "ms_per_step": el3 / args.steps * 1e3, "steps": args.steps,
+                        "what": f"the same steady-state schedule after {args.trained_until} real training steps on the synthetic scene (untimed): density learnt, "
+                                "samples concentrated on the surfaces"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         S2 = cfg.num_nerf_samples_per_ray
@@ -369,6 +386,8 @@ def main():
         }
         if steady_line is not None:
             line["steady_state"] = steady_line
+        if trained_line is not None:
+            line["trained_state"] = trained_line
         # second half of BASELINE.json's metric (PSNR@30k): not re-measured here (a 30 k-step run takes minutes) -- the committed results of
         # tools/train_psnr.py on this workload are read from their files and quoted with their source
         psnr = {}
