@@ -277,13 +277,15 @@ def test_bench_script_two_ranks_on_one_gpu(tmp_path):
 
     env = dict(os.environ, PYTHONPATH=ROOT, SNERF_BENCH_ONE_DEVICE="1", SNERF_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--images", "38"]
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--images", "38",
+           "--trained-until", "6"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 3
     assert "reduce-scatter" in line["config"]["parallelism"]
     assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    assert line["steady_state"]["value"] > 0 and line["trained_state"]["value"] > 0 and line["trained_state"]["steps"] == 3
 
 
 def test_bf16_gradient_transport_two_ranks(tmp_path):
