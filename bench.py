@@ -286,7 +286,7 @@ def main():
     # trained state: the model REALLY trained up to --trained-until (default 5000; the reference's schedule: uniform pixels for 2000 steps,
     # then 15 % IST rays; cosine lr; proposal updates every 5th step from step 5000), untimed, then K timed steps.  BASELINE.json's metric is
     # quoted "past step 5000": with the density learnt the samples sit on the surfaces and a step costs less than on the untrained planes above.
-    trained_line = None
+    trained_line, breakdown_trained = None, None
     if steady and args.trained_until > 0:
         trainer.synchronize()
         trainer.step, trainer._steps_since_update = 0, 0
@@ -295,6 +295,12 @@ def main():
             one_step_steady()
         batch["iter_steps"] = trainer.step
         el3 = timed(one_step_steady, args.steps)
+        if args.breakdown:
+            trainer.enable_kernel_timing(None)
+            for _ in range(20):
+                one_step_steady()
+            breakdown_trained = trainer.kernel_times_ms()
+            trainer.disable_kernel_timing()
         trained_line = {"value": R * world * args.steps / el3, "unit": "rays/s", "ms_per_step": el3 / args.steps * 1e3, "steps": args.steps,
                         "what": f"the same steady-state schedule after {args.trained_until} real training steps on the synthetic scene (untimed): density learnt, "
                                 "samples concentrated on the surfaces"}
@@ -407,10 +413,12 @@ def main():
             line["reference_standin"] = reference_standin(dev, R, line["value"])
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps)
-        if breakdown:
-            tot = sum(v[0] * v[1] for v in breakdown.values()) / 20
-            print(f"per-step kernel time by group (sum {tot:.3f} ms):", file=sys.stderr)
-            for k, (ms, n) in sorted(breakdown.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        for title, bd in (("per-step kernel time by group", breakdown), ("trained state, per-step kernel time by group", breakdown_trained)):
+            if not bd:
+                continue
+            tot = sum(v[0] * v[1] for v in bd.values()) / 20
+            print(f"{title} (sum {tot:.3f} ms):", file=sys.stderr)
+            for k, (ms, n) in sorted(bd.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
                 print(f"  {k:32s} {ms:8.3f} ms x {n / 20:4.1f}/step = {ms * n / 20:8.3f} ms", file=sys.stderr)
         print(json.dumps(line))
     if world > 1:
