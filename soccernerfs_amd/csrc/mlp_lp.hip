@@ -490,10 +490,381 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward, transposed-read form (gfx950 ds_read_b64_tr_b16): ONE LDS image per activation / gradient tile
+// ---------------------------------------------------------------------------------------------
+// The kernel above keeps every tile twice -- [sample][unit] for the products that contract over units, [unit][sample] for those that contract
+// over samples -- and the accumulator layout (a lane holds 4 consecutive SAMPLES of one unit) makes the [sample][unit] copy 16 scattered 2-byte
+// LDS stores per 16 x 16 block: ~150 ds_write_b16 per lane and 64-sample tile against ~80 MFMAs.  Here only the [unit][sample] image is written
+// (one 8-byte store per block: the 4 samples are contiguous there) and the products that need the other orientation read it with
+// ds_read_b64_tr_b16, which hands each lane a COLUMN of a 4 x 16 block: two of them make the 8-element operand fragment of a 16x16x32 MFMA.
+// X stays row-major [sample][feature] (written with 16-byte stores) and is read transposed for the layer-0 weight gradient.
+typedef short tr_v4 __attribute__((ext_vector_type(4)));
+
+// A-operand fragment from a k-major image Tm[k][row] (row stride ld elements): element j of lane (r = lane & 15, g = lane >> 4) =
+// Tm[kbase + 8 g + j][r0 + r].  Lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
+// (cdna_hip_programming.md T10).  EXEC must be all ones: call from wave-uniform control flow only.
+template <typename T>
+__device__ __forceinline__ typename Ops<T>::v8 ld8_tr(const T* Tm, int ld, int kbase, int r0, int lane) {
+  const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
+  const T* a0 = Tm + (kbase + 8 * g + q) * ld + r0 + 4 * p;
+  typedef __attribute__((address_space(3))) tr_v4 lds_v4;
+  const tr_v4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+  const tr_v4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ld));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(typename Ops<T>::v8, w);
+}
+
+// acc[m] (row block row_base / 16 + m, column block nt) += A * Bt^T with A given k-major (At[k][row], read transposed) and Bt row-major along k
+template <int MT, int K, typename T>
+__device__ __forceinline__ void mma_tr(const T* At, int ldat, int row_base, const T* Bt, int ldbt, int nt, f32x4 (&acc)[MT], int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const T* bp = Bt + (nt * 16 + lr) * ldbt + lk * 8;
+#pragma unroll
+  for (int ks = 0; ks < K / 32; ++ks) {
+    const typename Ops<T>::v8 b = ld8(bp + ks * 32);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8_tr<T>(At, ldat, ks * 32, row_base + m * 16, lane), b, acc[m]);
+  }
+}
+
+template <int K0, int H, int NH, int TS>
+struct PlanT {
+  static constexpr int LK0 = ldb(K0), LKH = ldb(H), LKO = ldb(32), LKT = ldb(TS);
+  static constexpr int W0T = 0;                                       // [H][LK0]   forward (absent when register-resident)
+  static constexpr int W0R = W0T + (wreg_b<H, NH>() ? 0 : H * LK0);   // [K0][LKH]  dX
+  static constexpr int W1T = W0R + K0 * LKH;                          // [H][LKH]   forward, layer 1 (NH == 2)
+  static constexpr int W1R = W1T + (NH == 2 ? H * LKH : 0);           // [H][LKH]   dA1 (NH == 2)
+  static constexpr int WOT = W1R + (NH == 2 ? H * LKH : 0);           // [16][LKH]  forward
+  static constexpr int WOR = WOT + 16 * LKH;                          // [H][LKO]   dZ_last
+  static constexpr int XS = WOR + H * LKO;                            // [TS][LK0]  X, row-major
+  static constexpr int A1T = XS + TS * LK0;                           // [H][LKT]   A1 (unit-major); later, in place, the gradient of Z1
+  static constexpr int A2T = A1T + H * LKT;                           // [H][LKT]   A2 (NH == 2); later, in place, the gradient of Z2
+  static constexpr int GZOT = A2T + (NH == 2 ? H * LKT : 0);          // [32][LKT]  gradient of the output pre-activation; rows 16..31 stay zero
+  static constexpr int TOTAL = GZOT + 32 * LKT;
+  static constexpr size_t BYTES = (size_t)TOTAL * 2;
+};
+
+template <typename T, int K0, int H, int NH, int TS, bool X16 = false>
+__global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_tr_kernel(MlpArgs a, int64_t n_tiles) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  constexpr float GS = Ops<T>::GS;
+  using P = PlanT<K0, H, NH, TS>;
+  static_assert(TS % 32 == 0, "the weight-gradient products contract over the tile's samples in steps of 32");
+  constexpr int MT = TS / 16, NW = waves_b<H>(), HT = H / 16, K0T = K0 / 16;
+  constexpr int NB0 = (K0T * HT + NW - 1) / NW, NBO = (HT + NW - 1) / NW, NBH = (HT * HT + NW - 1) / NW;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T *Xs = smem + P::XS, *A1t = smem + P::A1T, *gzot = smem + P::GZOT;
+  T* Alt = NH == 2 ? smem + P::A2T : A1t;  // last hidden activations, unit-major; the gradient of Z_last replaces them in place
+  constexpr bool WREG = wreg_b<H, NH>();
+  stage_w<T>(a.W + a.woff[0], a.d0, H, K0, H, smem + P::W0R, P::LKH, WREG ? (T*)nullptr : smem + P::W0T, P::LK0);
+  typename Ops<T>::v8 breg[WREG ? K0 / 32 : 1];
+  if (WREG) {  // this wave's hidden units 16 wave .. +15, k = 32 ks + 8 (lane >> 4) .. +8
+    const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < K0 / 32; ++ks) {
+      typename Ops<T>::v8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = ks * 32 + lk * 8 + e;
+        b[e] = Ops<T>::cvt(k < a.d0 ? a.W[a.woff[0] + (int64_t)k * H + wave * 16 + lr] : 0.f);
+      }
+      breg[ks] = b;
+    }
+  }
+  if (NH == 2) stage_w<T>(a.W + a.woff[1], H, H, H, H, smem + P::W1R, P::LKH, smem + P::W1T, P::LKH);
+  stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 32, smem + P::WOR, P::LKO, nullptr, 0);
+  stage_w<T>(a.W + a.woff[NH], H, a.dout, H, 16, nullptr, 0, smem + P::WOT, P::LKH);
+  // rows 16..31 of gzot (the padded half of the K = 32 contraction over the outputs) stay zero for the whole kernel
+  for (int idx = threadIdx.x; idx < 16 * P::LKT; idx += blockDim.x) gzot[16 * P::LKT + idx] = (T)0.f;
+  const bool relu = a.hidden_act == 1;
+  f32x4 dW0[NB0] = {};
+  f32x4 dWh[NH == 2 ? NBH : 1] = {};
+  f32x4 dWo[NBO] = {};
+  typedef typename Ops<T>::v4 v4t;
+  // (gradient block .* relu'(activation block)) written over the activation block: same lane, same 8 bytes
+  auto mask_store = [&](T* At, int mt, int nt, f32x4 v) {
+    const int col = nt * 16 + (lane & 15), row0 = mt * 16 + (lane >> 4) * 4;
+    v4t* cell = reinterpret_cast<v4t*>(At + col * P::LKT + row0);
+    if (relu) {
+      const v4t act = *cell;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (!((float)act[r] > 0.f)) v[r] = 0.f;
+    }
+    const v4t t = {Ops<T>::cvtg(v[0]), Ops<T>::cvtg(v[1]), Ops<T>::cvtg(v[2]), Ops<T>::cvtg(v[3])};
+    *cell = t;
+  };
+  std::conditional_t<X16, XTile16<TS, K0, NW * 64, T>, XTileB<TS, K0, NW * 64>> xt;
+  xt.template fetch<T>(a, (int64_t)blockIdx.x * TS);
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t n0 = tile * TS;
+    __syncthreads();
+    xt.store(Xs, P::LK0, (T*)nullptr, 0);
+    if (tile + gridDim.x < n_tiles) xt.template fetch<T>(a, (tile + gridDim.x) * TS);
+    // this tile's incoming gradients, issued now and consumed by the output phase two barriers later
+    constexpr int JO = (MT + NW - 1) / NW;
+    float gyp[JO][4], gap[JO][4];
+#pragma unroll
+    for (int j = 0; j < JO; ++j) {
+      const int mt = wave + NW * j, col = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = n0 + mt * 16 + (lane >> 4) * 4 + r;
+        const bool live = mt < MT && n < a.N && col < a.dout;
+        gyp[j][r] = (live && a.gY) ? a.gY[n * a.ldgy + col] : 0.f;
+        gap[j][r] = (live && a.gaux && col == a.aux_col) ? a.gaux[n] : 0.f;
+      }
+    }
+    __syncthreads();
+    // ---- hidden layer: A1t ----
+#pragma unroll
+    for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+      const int nt = wave + NW * j;
+      if (nt < HT) {
+        f32x4 acc[MT] = {};
+        if (WREG) {
+          const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+          for (int ks = 0; ks < K0 / 32; ++ks)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8(Xs + (m * 16 + lr) * P::LK0 + ks * 32 + lk * 8), breg[WREG ? ks : 0], acc[m]);
+        } else {
+          mma_rr<MT, K0>(Xs, P::LK0, smem + P::W0T, P::LK0, nt, acc, lane);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f32x4 v = acc[m];
+          if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+          store_rt<T>(nullptr, 0, A1t, P::LKT, m, nt, v, lane);
+        }
+      }
+    }
+    __syncthreads();
+    if (NH == 2) {  // ---- second hidden layer: A2t = relu(A1 W1), A1 read transposed ----
+#pragma unroll
+      for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < HT) {
+          f32x4 acc[MT] = {};
+          mma_tr<MT, H, T>(A1t, P::LKT, 0, smem + P::W1T, P::LKH, nt, acc, lane);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            f32x4 v = acc[m];
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            store_rt<T>(nullptr, 0, Alt, P::LKT, m, nt, v, lane);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- output layer forward + gradient w.r.t. its pre-activation: gzot rows 0..15 ----
+#pragma unroll
+    for (int j = 0; j < JO; ++j) {
+      const int mt = wave + NW * j;
+      if (mt < MT) {
+        f32x4 acc[1] = {};
+        mma_tr<1, H, T>(Alt, P::LKT, mt * 16, smem + P::WOT, P::LKH, 0, acc, lane);
+        const int col = lane & 15;
+        const int rl0 = mt * 16 + (lane >> 4) * 4;
+        f32x4 gv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t n = n0 + rl0 + r;
+          float g = 0.f;
+          if (n < a.N && col < a.dout) {
+            const float y = acc[0][r];
+            g = gyp[j][r];
+            if (a.out_act == 1) {
+              const float sg = 1.f / (1.f + expf(-y));
+              g = g * sg * (1.f - sg);
+            }
+            if (a.gaux && col == a.aux_col) g += gap[j][r] * expf(fminf(fmaxf(y, -15.f), 15.f));  // trunc_exp backward (activations.py:38-39)
+          }
+          gv[r] = g * GS;
+        }
+        store_rt<T>(nullptr, 0, gzot, P::LKT, mt, 0, gv, lane);
+      }
+    }
+    __syncthreads();
+    // ---- dWO += A_last^T gzo (contraction over the tile's samples) ----
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) {
+      const int it = wave + NW * j;
+      if (it < HT) {
+        f32x4 acc[1] = {dWo[j]};
+        mma_rr<1, TS>(Alt + it * 16 * P::LKT, P::LKT, gzot, P::LKT, 0, acc, lane);
+        dWo[j] = acc[0];
+      }
+    }
+    __syncthreads();  // Alt is overwritten below
+    // ---- gradient of Z_last = (gzo WO^T) .* relu'(A_last), over A_last; gzo read transposed ----
+#pragma unroll
+    for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+      const int nt = wave + NW * j;
+      if (nt < HT) {
+        f32x4 acc[MT] = {};
+        mma_tr<MT, 32, T>(gzot, P::LKT, 0, smem + P::WOR, P::LKO, nt, acc, lane);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) mask_store(Alt, m, nt, acc[m]);
+      }
+    }
+    __syncthreads();
+    if (NH == 2) {
+      // ---- dW1 += A1^T gz ----
+#pragma unroll
+      for (int j = 0; j < NBH; ++j) {
+        const int t = wave + NW * j;
+        if (t < HT * HT) {
+          f32x4 acc[1] = {dWh[j]};
+          mma_rr<1, TS>(A1t + (t / HT) * 16 * P::LKT, P::LKT, Alt, P::LKT, t % HT, acc, lane);
+          dWh[j] = acc[0];
+        }
+      }
+      __syncthreads();  // A1t is overwritten below
+      // ---- gradient of Z1 = (gz W1^T) .* relu'(A1), over A1; gz read transposed ----
+#pragma unroll
+      for (int j = 0; j < (HT + NW - 1) / NW; ++j) {
+        const int nt = wave + NW * j;
+        if (nt < HT) {
+          f32x4 acc[MT] = {};
+          mma_tr<MT, H, T>(Alt, P::LKT, 0, smem + P::W1R, P::LKH, nt, acc, lane);
+#pragma unroll
+          for (int m = 0; m < MT; ++m) mask_store(A1t, m, nt, acc[m]);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- dW0 += X^T gz1: X read transposed ([sample][feature] is the k-major image of X^T).  t = wave + NW j: with NW a multiple of HT the
+    //      wave's hidden block (t % HT) is the same for every j, so its gz1 fragments are read once ----
+    {
+      static_assert(NW % HT == 0 || HT % NW == 0, "block-to-wave map of the layer-0 weight gradient");
+      const int lr = lane & 15, lk = lane >> 4;
+      if constexpr (NW % HT == 0) {
+        const int nt = wave % HT;
+        typename Ops<T>::v8 bf[TS / 32];
+#pragma unroll
+        for (int ks = 0; ks < TS / 32; ++ks) bf[ks] = ld8(A1t + (nt * 16 + lr) * P::LKT + ks * 32 + lk * 8);
+#pragma unroll
+        for (int j = 0; j < NB0; ++j) {
+          const int t = wave + NW * j;
+          if (t < K0T * HT) {
+#pragma unroll
+            for (int ks = 0; ks < TS / 32; ++ks) dW0[j] = Ops<T>::mfma(ld8_tr<T>(Xs, P::LK0, ks * 32, (t / HT) * 16, lane), bf[ks], dW0[j]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NB0; ++j) {
+          const int t = wave + NW * j;
+          if (t < K0T * HT) {
+            f32x4 acc[1] = {dW0[j]};
+            mma_tr<1, TS, T>(Xs, P::LK0, (t / HT) * 16, A1t, P::LKT, t % HT, acc, lane);
+            dW0[j] = acc[0];
+          }
+        }
+      }
+    }
+    // ---- gX = gz1 W0^T, gz1 read transposed: a wave keeps ONE row block's operand fragments (all of k) in registers and walks the
+    //      column blocks with them -- the transposed reads are paid once per row block, not once per 16 x 16 output block ----
+    if (a.gX) {
+      static_assert(NW % MT == 0, "waves per workgroup must be a multiple of the tile's row blocks");
+      constexpr int NG = NW / MT;
+      const int m = wave % MT, grp = wave / MT, lr = lane & 15, lk = lane >> 4;
+      typename Ops<T>::v8 af[H / 32];
+#pragma unroll
+      for (int ks = 0; ks < H / 32; ++ks) af[ks] = ld8_tr<T>(A1t, P::LKT, ks * 32, m * 16, lane);
+#pragma unroll
+      for (int jn = 0; jn < (K0T + NG - 1) / NG; ++jn) {
+        const int nt = grp + NG * jn;
+        if (nt < K0T) {
+          f32x4 acc = {};
+          const T* bp = smem + P::W0R + (nt * 16 + lr) * P::LKH + lk * 8;
+#pragma unroll
+          for (int ks = 0; ks < H / 32; ++ks) acc = Ops<T>::mfma(af[ks], ld8(bp + ks * 32), acc);
+          const int col = nt * 16 + lr;
+          const int64_t row0 = n0 + m * 16 + lk * 4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[r] * (1.f / GS);
+        }
+      }
+    }
+  }
+  // ---- flush weight gradients ----
+  if (a.gW || a.gWfx) {
+    const int cl = lane & 15, r0 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NB0; ++j) {
+      const int t = wave + NW * j;
+      if (t < K0T * HT) {
+        const int it = t / HT, nt = t % HT;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = it * 16 + r0 + r;
+          if (row < a.d0) gw_add(a, a.woff[0] + (int64_t)row * H + nt * 16 + cl, dW0[j][r] * (1.f / GS));
+        }
+      }
+    }
+    if (NH == 2) {
+#pragma unroll
+      for (int j = 0; j < NBH; ++j) {
+        const int t = wave + NW * j;
+        if (t < HT * HT) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gw_add(a, a.woff[1] + (int64_t)((t / HT) * 16 + r0 + r) * H + (t % HT) * 16 + cl, dWh[j][r] * (1.f / GS));
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NBO; ++j) {
+      const int it = wave + NW * j;
+      if (it < HT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (cl < a.dout) gw_add(a, a.woff[NH] + (int64_t)(it * 16 + r0 + r) * a.dout + cl, dWo[j][r] * (1.f / GS));
+      }
+    }
+  }
+}
+
+template <typename T, int K0, int H, int NH, bool X16>
+static int launch_b_tr(const MlpArgs& a, hipStream_t st) {
+  constexpr int TS = 64;
+  using P = PlanT<K0, H, NH, TS>;
+  static_assert(P::BYTES <= LDS_LIMIT_B, "transposed-read backward tile does not fit LDS");
+  const int64_t n_tiles = (a.N + TS - 1) / TS;
+  int per_cu = (int)(LDS_LIMIT_B / P::BYTES);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);
+  if (waves_b<H>() * per_cu > 8) per_cu = 8 / waves_b<H>();  // the kernels hold 130-250 VGPRs: two waves per SIMD
+  int64_t grid = 256 * per_cu;
+  if (grid > n_tiles) grid = n_tiles;
+  auto k = mlp_lp_bwd_tr_kernel<T, K0, H, NH, TS, X16>;
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
+  SNERF_LAUNCH_CHECK("mlp_bwd (16-bit operands, transposed reads)");
+  return 0;
+}
+
 template <typename T, int K0, int H, int NH>
 static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
-  if (bwd) {
-    constexpr int TS = (H <= 64 && NH == 1) ? 64 : 32;  // proposal nets: 64-sample tiles halve the barriers per sample (0.217 -> 0.153 ms; 128: 0.221)
+  // 64-wide nets (color_net, the proposal nets, NeRFPlayer's heads): the transposed-read kernel (color_net 0.149 -> 0.123 ms, proposal nets
+  // 0.140 -> 0.124).  128-wide nets (sigma_net) stay on the two-image kernel: their time goes into the layer-0 weight gradient and the input
+  // gradient over a 160-wide input, which read more and write less -- 0.142 ms against 0.147 (64-sample tiles) / 0.152 (128) transposed.
+  if constexpr (H <= 64) {
+    if (bwd) {
+      if (a.x16) {
+        set_error("mlp_bwd_x16: 16-bit inputs are built for the d_in -> 128 -> d_out one-hidden-layer shapes (sigma_net), got hidden=%d n_hidden=%d", H, NH);
+        return SNERF_ERR_UNSUPPORTED;
+      }
+      return launch_b_tr<T, K0, H, NH, false>(a, st);
+    }
+  }
+  if constexpr (H > 64) if (bwd) {
+    constexpr int TS = 32;
     using P = PlanB<K0, H, NH, TS>;
     static_assert(P::BYTES <= LDS_LIMIT_B, "bf16 backward tile does not fit LDS");
     int64_t n_tiles = (a.N + TS - 1) / TS;
@@ -526,7 +897,10 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
       hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
     }
-  } else {
+    SNERF_LAUNCH_CHECK("mlp_bwd (16-bit operands)");
+    return 0;
+  }
+  {
     constexpr int TS = (H <= 64 && NH == 1) ? 64 : 32;
     using P = PlanF<K0, H, NH, TS>;
     const int64_t n_tiles = (a.N + TS - 1) / TS;
@@ -539,7 +913,7 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
   }
-  SNERF_LAUNCH_CHECK(bwd ? "mlp_bwd (16-bit operands)" : "mlp_fwd (16-bit operands)");
+  SNERF_LAUNCH_CHECK("mlp_fwd (16-bit operands)");
   return 0;
 }
 
