@@ -9,9 +9,9 @@ mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --no-cpu-baseline --no-standin --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --trained-until 0 > /dev/null 2>&1
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --trained-until 0 > /dev/null 2>&1
 done
 cd $ROOT
 python - <<PY
@@ -23,7 +23,7 @@ f = glob.glob(f"{out}/{tag}_stats/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.reader(open(f[0])))
     with open(f"{out}/{tag}_kernel_stats.csv", "w") as g:
-        g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline\n")
+        g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --trained-until 0\n")
         csv.writer(g).writerows(rows[:45])
 # pmc
 acc = collections.defaultdict(dict)
@@ -38,7 +38,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum"):
     for k, v in tmp.items():
         acc[k][c] = sum(v) / len(v)
 with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
-    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --images 38  (one counter per pass)\n")
+    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --trained-until 0  (one counter per pass)\n")
     g.write("# mean per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE reads 1/2 of a coalesced stream -> traffic = 2*FETCH + WRITE)\n")
     g.write("kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,TCC_EA0_ATOMIC_requests,traffic_bytes\n")
     for k, v in sorted(acc.items(), key=lambda kv: -(2 * kv[1].get("FETCH_SIZE", 0) + kv[1].get("WRITE_SIZE", 0))):
