@@ -183,6 +183,37 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_fwd_kernel(MlpArgs a
   }
 }
 
+// ---- transposed LDS reads (gfx950 ds_read_b64_tr_b16): operand fragments from a [k][row] image ----
+typedef short tr_v4 __attribute__((ext_vector_type(4)));
+
+// A-operand fragment from a k-major image Tm[k][row] (row stride ld elements): element j of lane (r = lane & 15, g = lane >> 4) =
+// Tm[kbase + 8 g + j][r0 + r].  Lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
+// (cdna_hip_programming.md T10).  EXEC must be all ones: call from wave-uniform control flow only.
+template <typename T>
+__device__ __forceinline__ typename Ops<T>::v8 ld8_tr(const T* Tm, int ld, int kbase, int r0, int lane) {
+  const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
+  const T* a0 = Tm + (kbase + 8 * g + q) * ld + r0 + 4 * p;
+  typedef __attribute__((address_space(3))) tr_v4 lds_v4;
+  const tr_v4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
+  const tr_v4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ld));
+  typedef short s8 __attribute__((ext_vector_type(8)));
+  const s8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(typename Ops<T>::v8, w);
+}
+
+// acc[m] (row block row_base / 16 + m, column block nt) += A * Bt^T with A given k-major (At[k][row], read transposed) and Bt row-major along k
+template <int MT, int K, typename T>
+__device__ __forceinline__ void mma_tr(const T* At, int ldat, int row_base, const T* Bt, int ldbt, int nt, f32x4 (&acc)[MT], int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const T* bp = Bt + (nt * 16 + lr) * ldbt + lk * 8;
+#pragma unroll
+  for (int ks = 0; ks < K / 32; ++ks) {
+    const typename Ops<T>::v8 b = ld8(bp + ks * 32);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8_tr<T>(At, ldat, ks * 32, row_base + m * 16, lane), b, acc[m]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward (recomputes the forward per tile, as the fp32 kernel)
 // ---------------------------------------------------------------------------------------------
@@ -204,7 +235,8 @@ struct PlanB {
   static constexpr int XS = WOR + H * LKO;         // [TS][LK0]
   static constexpr int XT = XS + TS * LK0;         // [K0][LKT]
   static constexpr int A1 = XT + K0 * LKT;         // [TS][LKH]
-  static constexpr int A1T = A1 + TS * LKH;        // [H][LKT]; reused for the transposed gradient of Z1 once its weight-gradient product is done
+  static constexpr int A1T = A1 + (NH == 1 ? 0 : TS * LKH);  // [H][LKT]; reused for the transposed gradient of Z1 once its weight-gradient product is done.
+                                                   // (one hidden layer: no [sample][unit] copy of A1 -- it is read from this image, transposed)
   static constexpr int A2 = A1T + H * LKT;         // [TS][LKH]  (NH == 2)
   static constexpr int A2T = A2 + (NH == 2 ? TS * LKH : 0);  // [H][LKT]; reused for the transposed gradient of Z2
   // one hidden layer, input at least as wide as the hidden layer: the row-major X tile is dead once the hidden layer is computed (the weight
@@ -213,7 +245,7 @@ struct PlanB {
   static constexpr bool GZ_IN_XS = NH == 1 && K0 >= H;
   static constexpr int GZ_OWN = A2T + (NH == 2 ? H * LKT : 0);
   static constexpr int GZ = GZ_IN_XS ? XS : GZ_OWN;          // [TS][LKH]  gradient of Z_last
-  static constexpr int GZ1 = GZ_OWN + (GZ_IN_XS ? 0 : TS * LKH);  // [TS][LKH]  gradient of Z1 (NH == 2)
+  static constexpr int GZ1 = GZ_OWN + ((GZ_IN_XS || NH == 1) ? 0 : TS * LKH);  // [TS][LKH]  gradient of Z1 (NH == 2; one hidden layer: no row-major gradient image at all)
   static constexpr int GZO = GZ1 + (NH == 2 ? TS * LKH : 0);  // [TS][LKO]
   static constexpr int GZOT = GZO + TS * LKO;      // [16][LKT]
   static constexpr int TOTAL = GZOT + 16 * LKT;
@@ -305,7 +337,8 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
         for (int m = 0; m < MT; ++m) {
           f32x4 v = acc[m];
           if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-          store_rt(A1, P::LKH, A1t, P::LKT, m, nt, v, lane);
+          // one hidden layer: only the unit-major image; the output layer and the relu mask read it back (transposed / 8 bytes per block)
+          store_rt(NH == 1 ? (T*)nullptr : A1, P::LKH, A1t, P::LKT, m, nt, v, lane);
         }
       }
     }
@@ -333,7 +366,8 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
       const int mt = wave + NW * j;
       if (mt < MT) {
         f32x4 acc[1] = {};
-        mma_rr<1, H>(Al + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
+        if constexpr (NH == 1) mma_tr<1, H, T>(Alt, P::LKT, mt * 16, smem + P::WOT, P::LKH, 0, acc, lane);
+        else mma_rr<1, H>(Al + mt * 16 * P::LKH, P::LKH, smem + P::WOT, P::LKH, 0, acc, lane);
         const int col = lane & 15;
         const int rl0 = mt * 16 + (lane >> 4) * 4;
         f32x4 gv;
@@ -380,11 +414,18 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
           const int row0 = m * 16 + (lane >> 4) * 4;
           f32x4 v = acc[m];
           if (relu) {
+            if constexpr (NH == 1) {  // the activations of this block: the 8 bytes of Alt that gzt overwrites just below (same lane)
+              const typename Ops<T>::v4 act = *reinterpret_cast<const typename Ops<T>::v4*>(Alt + col * P::LKT + row0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (!((float)Al[(row0 + r) * P::LKH + col] > 0.f)) v[r] = 0.f;
+              for (int r = 0; r < 4; ++r)
+                if (!((float)act[r] > 0.f)) v[r] = 0.f;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (!((float)Al[(row0 + r) * P::LKH + col] > 0.f)) v[r] = 0.f;
+            }
           }
-          store_rt(gz, P::LKH, gzt, P::LKT, m, nt, v, lane);
+          store_rt(NH == 1 ? (T*)nullptr : gz, P::LKH, gzt, P::LKT, m, nt, v, lane);  // one hidden layer: the input gradient reads gzt transposed
         }
       }
     }
@@ -434,21 +475,46 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
         dW0[j] = acc[0];
       }
     }
-    // ---- gX = gz W0^T: (column block, row block) units dealt round-robin to the waves (whole column blocks left two of eight waves with
-    //      twice the work of the others: K0 / 16 = 10 of them for the preset's net) ----
+    // ---- gX = gz1 W0^T.  One hidden layer: gz1 lives unit-major only (gz1t) and is read transposed; a wave keeps ONE row block's fragments
+    //      (all of k) in registers and walks the column blocks with them.  Two hidden layers: (column block, row block) units dealt
+    //      round-robin to the waves, operands from the row-major image ----
     if (a.gX) {
+      if constexpr (NH == 1) {
+        static_assert(NW % MT == 0, "waves per workgroup must be a multiple of the tile's row blocks");
+        constexpr int NG = NW / MT;
+        const int m = wave % MT, grp = wave / MT, lr = lane & 15, lk = lane >> 4;
+        typename Ops<T>::v8 af[H / 32];
 #pragma unroll
-      for (int j = 0; j < (K0T * MT + NW - 1) / NW; ++j) {
-        const int u = wave + NW * j;
-        if (u < K0T * MT) {
-          const int nt = u / MT, m = u - nt * MT;
-          f32x4 acc[1] = {};
-          mma_rr<1, H>(gz1 + m * 16 * P::LKH, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
-          const int col = nt * 16 + (lane & 15);
-          const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
+        for (int ks = 0; ks < H / 32; ++ks) af[ks] = ld8_tr<T>(gz1t, P::LKT, ks * 32, m * 16, lane);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[0][r] * (1.f / GS);
+        for (int jn = 0; jn < (K0T + NG - 1) / NG; ++jn) {
+          const int nt = grp + NG * jn;
+          if (nt < K0T) {
+            f32x4 acc = {};
+            const T* bp = smem + P::W0R + (nt * 16 + lr) * P::LKH + lk * 8;
+#pragma unroll
+            for (int ks = 0; ks < H / 32; ++ks) acc = Ops<T>::mfma(af[ks], ld8(bp + ks * 32), acc);
+            const int col = nt * 16 + lr;
+            const int64_t row0 = n0 + m * 16 + lk * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[r] * (1.f / GS);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < (K0T * MT + NW - 1) / NW; ++j) {
+          const int u = wave + NW * j;
+          if (u < K0T * MT) {
+            const int nt = u / MT, m = u - nt * MT;
+            f32x4 acc[1] = {};
+            mma_rr<1, H>(gz1 + m * 16 * P::LKH, P::LKH, smem + P::W0R, P::LKH, nt, acc, lane);
+            const int col = nt * 16 + (lane & 15);
+            const int64_t row0 = n0 + m * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[0][r] * (1.f / GS);
+          }
         }
       }
     }
@@ -499,36 +565,6 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
 // (one 8-byte store per block: the 4 samples are contiguous there) and the products that need the other orientation read it with
 // ds_read_b64_tr_b16, which hands each lane a COLUMN of a 4 x 16 block: two of them make the 8-element operand fragment of a 16x16x32 MFMA.
 // X stays row-major [sample][feature] (written with 16-byte stores) and is read transposed for the layer-0 weight gradient.
-typedef short tr_v4 __attribute__((ext_vector_type(4)));
-
-// A-operand fragment from a k-major image Tm[k][row] (row stride ld elements): element j of lane (r = lane & 15, g = lane >> 4) =
-// Tm[kbase + 8 g + j][r0 + r].  Lane 4 q + p of a 16-lane group supplies the address of row q, columns 4 p .. 4 p + 3 of its 4 x 16 block
-// (cdna_hip_programming.md T10).  EXEC must be all ones: call from wave-uniform control flow only.
-template <typename T>
-__device__ __forceinline__ typename Ops<T>::v8 ld8_tr(const T* Tm, int ld, int kbase, int r0, int lane) {
-  const int q = (lane & 15) >> 2, p = lane & 3, g = lane >> 4;
-  const T* a0 = Tm + (kbase + 8 * g + q) * ld + r0 + 4 * p;
-  typedef __attribute__((address_space(3))) tr_v4 lds_v4;
-  const tr_v4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0));
-  const tr_v4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(a0 + 4 * ld));
-  typedef short s8 __attribute__((ext_vector_type(8)));
-  const s8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(typename Ops<T>::v8, w);
-}
-
-// acc[m] (row block row_base / 16 + m, column block nt) += A * Bt^T with A given k-major (At[k][row], read transposed) and Bt row-major along k
-template <int MT, int K, typename T>
-__device__ __forceinline__ void mma_tr(const T* At, int ldat, int row_base, const T* Bt, int ldbt, int nt, f32x4 (&acc)[MT], int lane) {
-  const int lr = lane & 15, lk = lane >> 4;
-  const T* bp = Bt + (nt * 16 + lr) * ldbt + lk * 8;
-#pragma unroll
-  for (int ks = 0; ks < K / 32; ++ks) {
-    const typename Ops<T>::v8 b = ld8(bp + ks * 32);
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = Ops<T>::mfma(ld8_tr<T>(At, ldat, ks * 32, row_base + m * 16, lane), b, acc[m]);
-  }
-}
-
 template <int K0, int H, int NH, int TS>
 struct PlanT {
   static constexpr int LK0 = ldb(K0), LKH = ldb(H), LKO = ldb(32), LKT = ldb(TS);
