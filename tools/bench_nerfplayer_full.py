@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Step time of the FULL NeRFPlayer preset (458.6 M parameters) through the fused flat-buffer trainer on random rays (frame times as a
+100-frame clip has them).  `--profile-steps N`: run only N steps after warm-up (for rocprofv3 --kernel-trace --stats).
+
+    python tools/bench_nerfplayer_full.py [--steps 30] [--warmup 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soccernerfs_amd.nerfplayer import NerfplayerModelConfig  # noqa: E402
+from soccernerfs_amd.nerfplayer_full_trainer import NerfplayerFullTrainer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--rays", type=int, default=4096)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+R = args.rays
+tr = NerfplayerFullTrainer(NerfplayerModelConfig(), R, aabb_scale=1.0, device=dev, max_steps=30000, seed=0)
+tr.step = 600
+
+
+def step():
+    o = (torch.rand(R, 3, device=dev) * 2 - 1) * 0.6
+    d = torch.nn.functional.normalize(torch.rand(R, 3, device=dev) * 2 - 1, dim=-1)
+    t = torch.floor(torch.rand(R, 1, device=dev) * 100) / 99
+    tr.train_step({"origins": o, "directions": d, "times": t}, torch.rand(R, 3, device=dev))
+
+
+for _ in range(args.warmup):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    step()
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(json.dumps({"config": "nerfplayer preset, full NeRFPlayer (fused flat-buffer trainer)", "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
+                  "rays_per_s": R * args.steps / dt, "launches_per_step": tr.launches}))
