@@ -44,11 +44,13 @@ def parse():
     ap.add_argument("--start-step", type=int, default=0, help="pretend this many optimiser steps are done: >= 5000 gives the steady-state "
                     "schedule (proposal networks updated every 5th step, kplanes.py:254-259) instead of the every-step schedule of early training")
     ap.add_argument("--sync-adam", action="store_true", help="A-B: field-plane optimiser sweep on the main stream instead of its own stream under the next step's proposal levels")
-    ap.add_argument("--grad-transport", default="bf16", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
-                    "gradient on the links.  bf16 (the bench default since round 3: half the reduce-scatter bytes; 10 paired 30 k-step seeds of the single-GPU "
-                    "emulation: PSNR -0.03 +- 0.12 dB, profiles/r03_psnr_30k_bf16_emulated_bf16_transports.json); fp32 = the reference's DDP arithmetic")
-    ap.add_argument("--param-transport", default="bf16", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: bf16 (bench default) = all-gather the "
-                    "parameter UPDATES in bf16 and apply them identically on every rank; fp32 = all-gather the new field planes (reference arithmetic)")
+    ap.add_argument("--grad-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: element type of the field-plane "
+                    "gradient on the links.  fp32 (default: the headline `value` is the reference's DDP arithmetic, NS/pipelines/base_pipeline.py:244-246); "
+                    "bf16 = half the reduce-scatter bytes (single-GPU emulation over 10 paired 30 k-step seeds: PSNR -0.03 +- 0.12 dB, "
+                    "profiles/r03_psnr_30k_bf16_emulated_bf16_transports.json) -- timed in the same process as the labelled leg `bf16_transports`")
+    ap.add_argument("--param-transport", default="fp32", choices=["fp32", "bf16"], help="world > 1, sharded optimiser: fp32 (default) = all-gather the new "
+                    "field planes (reference arithmetic); bf16 = all-gather the parameter UPDATES in bf16 and apply them identically on every rank")
+    ap.add_argument("--no-bf16-transport-leg", action="store_true", help="world > 1: skip the extra timed region with both transports in bf16")
     ap.add_argument("--cabi-allreduce", action="store_true", help="world > 1 with --no-shard: the flat gradient all-reduce goes through libsnerf's own "
                     "RCCL communicator (snerf_allreduce_grads) instead of torch.distributed")
     ap.add_argument("--no-shard", action="store_true", help="world > 1: one all-reduce of the whole gradient + replicated Adam (A-B)")
@@ -174,6 +176,8 @@ def main():
     trainer.async_field_adam = not args.sync_adam
     trainer.grad_transport = args.grad_transport
     trainer.param_transport = args.param_transport
+    trainer.synchronize()
+    init_params = trainer.params.clone()  # the trained-state leg restarts from here (0.6 GB)
 
     # ---- synthetic Broadcast-style data, resident in HBM ----
     cams = synthetic.make_cameras(20, 960, 540)
@@ -247,6 +251,23 @@ def main():
     elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
     trainer.disable_kernel_timing()
+    # world > 1: the same K steps once more with BOTH transports of the sharded step in bf16 -- a labelled second leg, never `value`
+    bf16_leg = None
+    if world > 1 and trainer._sharded() and not args.no_bf16_transport_leg and (args.grad_transport, args.param_transport) == ("fp32", "fp32"):
+        trainer.synchronize()
+        barrier()
+        trainer.grad_transport = trainer.param_transport = "bf16"
+        for _ in range(max(2, args.warmup // 4)):
+            one_step()
+        elb = timed(one_step, args.steps)
+        trainer.synchronize()
+        barrier()
+        trainer.grad_transport, trainer.param_transport = args.grad_transport, args.param_transport
+        bf16_leg = {"value": R * world * args.steps / elb, "unit": "rays/s", "ms_per_step": elb / args.steps * 1e3, "steps": args.steps,
+                    "what": "same schedule and step as `value`, but the field-plane gradient is rounded to bf16 before the reduce-scatter and the parameter UPDATES "
+                            "are all-gathered in bf16 (half the bytes on the xGMI links).  NOT the reference's fp32 DDP arithmetic: reported next to the headline, "
+                            "never as it.  PSNR effect bounded on one GPU by emulation only (profiles/r03_psnr_30k_bf16_emulated_bf16_transports.json: "
+                            "-0.03 +- 0.12 dB over 10 paired seeds; one rounding where a W-rank ring sum makes ~log2 W)"}
     steady_line = None
     if steady:
         trainer.synchronize()
@@ -288,8 +309,7 @@ def main():
     # quoted "past step 5000": with the density learnt the samples sit on the surfaces and a step costs less than on the untrained planes above.
     trained_line, breakdown_trained = None, None
     if steady and args.trained_until > 0:
-        trainer.synchronize()
-        trainer.step, trainer._steps_since_update = 0, 0
+        trainer.restart(init_params)  # fresh parameters, zero Adam moments, step 0: a clean run, not a continuation of the legs above
         while trainer.step < args.trained_until:
             batch["iter_steps"] = trainer.step
             one_step_steady()
@@ -302,8 +322,8 @@ def main():
             breakdown_trained = trainer.kernel_times_ms()
             trainer.disable_kernel_timing()
         trained_line = {"value": R * world * args.steps / el3, "unit": "rays/s", "ms_per_step": el3 / args.steps * 1e3, "steps": args.steps,
-                        "what": f"the same steady-state schedule after {args.trained_until} real training steps on the synthetic scene (untimed): density learnt, "
-                                "samples concentrated on the surfaces"}
+                        "what": f"the same steady-state schedule after {args.trained_until} real training steps FROM THE INITIAL PARAMETERS (trainer.restart: Adam "
+                                "moments and step counters cleared) on the synthetic scene (untimed): density learnt, samples concentrated on the surfaces"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -369,7 +389,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else (
                            f"ray-sharded x{world}; field-plane gradients: RCCL reduce-scatter ({trainer.grad_transport}) -> Adam on a 1/{world} shard -> all-gather of "
                            f"the {'parameter updates (bf16)' if trainer.param_transport == 'bf16' else 'new planes (fp32)'} (= one all-reduce's worth of "
-                           "traffic, halved by the bf16 transports), small segments: fp32 all-reduce" if trainer._sharded() else
+                           "traffic), small segments: fp32 all-reduce" if trainer._sharded() else
                            f"ray-sharded x{world}, one RCCL all-reduce of the flat gradient buffer per step")},
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": alg_bytes,
@@ -390,6 +410,8 @@ def main():
                          "other_kernels_frac": {k: round(alg[k][1] / (v[0] * 1e-3) / 1e9 / (HBM_PEAK_GBS if alg[k][0] == "hbm" else 157300.0), 3)
                                                 for k, v in timed_k.items() if k != DOMINANT}},
         }
+        if bf16_leg is not None:
+            line["bf16_transports"] = bf16_leg
         if steady_line is not None:
             line["steady_state"] = steady_line
         if trained_line is not None:

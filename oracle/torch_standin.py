@@ -69,3 +69,91 @@ def time_train_steps(device, rays_per_step: int = 4096, steps: int = 8, warmup: 
         KO.USE_GRID_SAMPLE = prev
     return {"seconds_per_step": dt, "rays_per_s": R / dt, "steps": steps, "warmup": warmup, "rays_per_step": R, "loss": float(loss),
             "autocast": str(autocast).replace("torch.", "") if autocast is not None else None}
+
+
+class StandinTrainer:
+    """The reference's K-Planes training loop in stock PyTorch, for PSNR@30k runs next to the HIP trainer (tools/train_psnr.py --standin).
+
+    What one `train_step` does follows Trainer.train_iteration (NS/engine/trainer.py:383-412) for the `k-planes` preset
+    (NS/configs/method_configs.py:481-560): callbacks (proposal-weight annealing kplanes.py:326-331, the proposal sampler's update
+    schedule ray_samplers.py:544-557 with its one-step lag, kplanes.py:340-346) -> forward -> loss dict -> ONE backward ->
+    the two optimisers ("proposal_networks", "fields": Adam lr 1e-2 eps 1e-12, cosine schedule with 512 warm-up steps), each skipped
+    when one of its gradients is non-finite as GradScaler.step does per optimiser (trainer.py:394-408; no loss scaling is emulated: fp32).
+    Interface = what tools/train_psnr.py uses of KPlanesTrainer: R, aabb, cfg.near_plane, step, train_step, forward(training=False),
+    loss_dict, skipped_steps, synchronize, params."""
+
+    class _Cfg:
+        near_plane = 0.0
+        proposal_weights_anneal_max_num_iters = 1000
+        proposal_weights_anneal_slope = 10.0
+
+    def __init__(self, device, num_rays: int = 4096, seed: int = 0, max_steps: int = 30000, model: Dict = PRESET, samples=(256, 128, 64),
+                 eval_chunk: int = 32768):
+        self.dev = torch.device(device)
+        self.R, self.S, self.max_steps, self.eval_chunk = num_rays, tuple(samples), max_steps, eval_chunk
+        self.cfg = self._Cfg()
+        self.P = params_to(KO.make_kplanes_params(seed=seed, **model), self.dev)
+        self.aabb = self.P["aabb"]
+        prop = [t for lv in self.P["prop_grids"] for t in lv] + [w for lv in self.P["prop_sigma"] for w in lv]
+        fld = [t for sc in self.P["field_grids"] for t in sc] + list(self.P["field_sigma"]) + list(self.P["field_color"])
+        for x in prop + fld:
+            x.requires_grad_(True)
+        self.groups = {"proposal_networks": prop, "fields": fld}
+        self.opts = {k: torch.optim.Adam(v, lr=1e-2, eps=1e-12) for k, v in self.groups.items()}
+        self.step = 0
+        self._since = 0
+        self._skipped = {k: 0 for k in self.groups}
+        self._ld: Dict[str, torch.Tensor] = {}
+        self.gen = torch.Generator(device=self.dev).manual_seed(seed)
+
+    @property
+    def params(self) -> torch.Tensor:
+        return torch.cat([x.detach().reshape(-1) for g in self.groups.values() for x in g])
+
+    def synchronize(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def skipped_steps(self) -> Dict[str, int]:
+        return dict(self._skipped)
+
+    def loss_dict(self) -> Dict[str, torch.Tensor]:
+        return self._ld
+
+    def train_step(self, rays: Dict[str, torch.Tensor], target: torch.Tensor):
+        R, (S0, S1, S2) = self.R, self.S
+        step = self.step
+        anneal = KO.anneal_value(step)
+        sstep = max(step - 1, 0)  # the sampler's counter is set AFTER the iteration (kplanes.py:340-346)
+        updated = self._since > KO.update_schedule(sstep) or sstep < 10
+        rnd = lambda *s: torch.rand(*s, device=self.dev, generator=self.gen)
+        rng = {"t_rand": rnd(R, S0 + 1), "u": [rnd(R, S1 + 1), rnd(R, S2 + 1)], "bg": rnd(R, 3)}
+        lr = 1e-2 * KO.cosine_lr_factor(step, max_steps=self.max_steps)
+        for opt in self.opts.values():
+            for g in opt.param_groups:
+                g["lr"] = lr
+            opt.zero_grad(set_to_none=True)
+        out = KO.kplanes_forward(self.P, rays, rng, (S0, S1), S2, anneal=anneal, training=True, proposal_requires_grad=updated)
+        ld = KO.kplanes_loss_dict(self.P, out, target)
+        sum(ld.values()).backward()
+        self._ld = {k: v.detach() for k, v in ld.items()}
+        norms = {k: torch.stack(torch._foreach_norm([x.grad for x in v if x.grad is not None])).sum() for k, v in self.groups.items()}
+        finite = torch.stack([torch.isfinite(norms[k]) for k in self.groups]).tolist()  # the one host read of the step (GradScaler's found_inf)
+        for ok, k in zip(finite, self.groups):
+            if ok:
+                self.opts[k].step()
+            else:
+                self._skipped[k] += 1
+        if updated:
+            self._since = 0
+        self._since += 1
+        self.step += 1
+        return out["rgb"].detach()
+
+    @torch.no_grad()
+    def forward(self, rays: Dict[str, torch.Tensor], rng, anneal: float, training: bool = False) -> torch.Tensor:
+        """Eval render (base_model.py:162-186: eval-mode samplers, 'last_sample' background, clamped rgb)."""
+        assert not training
+        S0, S1, S2 = self.S
+        out = KO.kplanes_forward(self.P, rays, None, (S0, S1), S2, anneal=anneal, training=False, proposal_requires_grad=False)
+        return out["rgb"]

@@ -73,8 +73,19 @@ def _sphere_hit(o, d, c, r):
     return torch.where((disc > 0) & (t > 0), t, torch.full_like(t, float("inf")))
 
 
-def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
-    """Analytic colour in [0,1] for rays (o,d [N,3], unit d) at times [N]."""
+def _cell_hash(ix: torch.Tensor, iy: torch.Tensor, salt: int) -> torch.Tensor:
+    """Integer lattice -> pseudo-random value in [0,1) (a fixed integer mix: the same on every device)."""
+    h = (ix.long() * 374761393 + iy.long() * 668265263 + salt * 2246822519) & 0xFFFFFFFF
+    h = ((h ^ (h >> 13)) * 1274126177) & 0xFFFFFFFF
+    return ((h ^ (h >> 16)) & 0xFFFF).float() / 65536.0
+
+
+def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor, variant: str = "default") -> torch.Tensor:
+    """Analytic colour in [0,1] for rays (o,d [N,3], unit d) at times [N].  variant "textured" (round 4; PSNR studies on content that does
+    not saturate): the same pitch with fine grass / wear texture on it, an advertising board and a crowd stand behind the far touchline,
+    and ten players instead of three."""
+    textured = variant == "textured"
+    assert variant in ("default", "textured")
     N = o.shape[0]
     sky = torch.stack([0.55 + 0.2 * d[:, 2], 0.7 + 0.15 * d[:, 2], 0.95 * torch.ones_like(d[:, 2])], -1).clamp(0, 1)
     # ground plane z = -0.1: mown-stripe pitch + lines
@@ -84,10 +95,31 @@ def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
     stripe = ((pg[:, 0] * 6).floor() % 2)
     green = torch.stack([0.12 + 0.05 * stripe, 0.45 + 0.12 * stripe, 0.15 + 0.03 * stripe], -1)
     line = ((pg[:, 0].abs() - 1.0).abs() < 0.01) | ((pg[:, 1].abs() - 0.65).abs() < 0.01) | (pg[:, 0].abs() < 0.008)
+    if textured:  # grass grain (three octaves of a lattice hash, bilinear in the coarsest), worn patches in front of the goals
+        gx, gy = pg[:, 0].clamp(-2, 2), pg[:, 1].clamp(-2, 2)
+        grain = sum(a * (_cell_hash((gx * f).floor(), (gy * f).floor(), k) - 0.5) for k, (f, a) in enumerate(((40.0, 0.10), (110.0, 0.08), (300.0, 0.05))))
+        wear = torch.exp(-(((gx.abs() - 0.85) / 0.12) ** 2 + (gy / 0.2) ** 2))
+        green = (green * (1.0 + grain[:, None]) * (1 - 0.45 * wear[:, None]) + wear[:, None] * torch.tensor([0.20, 0.15, 0.08], device=o.device)).clamp(0, 1)
     green = torch.where(line[:, None], torch.ones_like(green) * 0.92, green)
     inside = (pg[:, 0].abs() < 1.45) & (pg[:, 1].abs() < 1.45)
     col = torch.where((torch.isfinite(tg) & inside)[:, None], green, sky)
     depth = torch.where(torch.isfinite(tg) & inside, tg, torch.full_like(tg, float("inf")))
+    if textured:  # far side (the cameras sit at y < 0): advertising board y = 0.8, z in [-0.1, -0.04]; crowd stand y = 1.2, z in [-0.1, 0.5]
+        for y_w, z_hi, kind in ((1.2, 0.5, "crowd"), (0.8, -0.04, "board")):
+            tw = (y_w - o[:, 1]) / torch.where(d[:, 1].abs() < 1e-6, torch.full_like(d[:, 1], 1e-6), d[:, 1])
+            pw = o + d * tw.clamp(min=0, max=1e4)[:, None]
+            hit = (tw > 0) & (tw < depth) & (pw[:, 0].abs() < 1.45) & (pw[:, 2] > -0.1) & (pw[:, 2] < z_hi)
+            if kind == "crowd":  # seats: 1.5 cm cells of three hashed colour channels, darker towards the top
+                ix, iz = (pw[:, 0].clamp(-2, 2) * 66).floor(), (pw[:, 2].clamp(-1, 1) * 66).floor()
+                c = torch.stack([_cell_hash(ix, iz, 11 + k) for k in range(3)], -1) * 0.7 + 0.15
+                c = c * (1.0 - 0.5 * ((pw[:, 2] + 0.1) / 0.6).clamp(0, 1))[:, None]
+            else:  # board: 0.29-wide panels of a hashed base colour with vertical bars (lettering) in the complementary one
+                panel = (pw[:, 0].clamp(-2, 2) * 3.5).floor()
+                base = torch.stack([_cell_hash(panel, torch.zeros_like(panel), 31 + k) for k in range(3)], -1)
+                bars = (_cell_hash((pw[:, 0].clamp(-2, 2) * 90).floor(), ((pw[:, 2] + 0.1) * 50).floor(), 7) > 0.55).float()
+                c = base * (1 - bars[:, None]) + (1 - base) * bars[:, None]
+            col = torch.where(hit[:, None], c, col)
+            depth = torch.where(hit, tw, depth)
     # dynamic content: three players (torso + head) that move a few body widths during the clip, and a ball on a parabolic arc
     tt = time
     z0 = torch.full_like(tt, -0.08)
@@ -97,6 +129,11 @@ def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
         (torch.stack([-0.35 + 0.05 * torch.cos(3.14 * tt), 0.15 + 0.06 * tt, z0], -1), (0.1, 0.15, 0.8)),
         (torch.stack([-0.05 - 0.06 * tt, 0.35 - 0.05 * tt * tt, z0], -1), (0.95, 0.85, 0.1)),
     )
+    if textured:  # seven more players on deterministic tracks (straight runs and arcs of a few body widths)
+        kits = ((0.85, 0.1, 0.1), (0.1, 0.15, 0.8), (0.95, 0.85, 0.1), (0.9, 0.9, 0.9), (0.1, 0.1, 0.1), (0.9, 0.4, 0.05), (0.5, 0.1, 0.6))
+        for k in range(7):
+            x0, y0 = -0.9 + 0.27 * k, 0.45 * math.sin(1.7 * k + 0.4)
+            players = players + ((torch.stack([x0 + 0.08 * math.cos(k) * tt + 0.02 * torch.sin(6.28 * tt + k), y0 + 0.08 * math.sin(k) * tt, z0], -1), kits[k]),)
     ball_c = torch.stack([-0.25 + 0.4 * tt, 0.08 * torch.sin(6.28 * tt), -0.09 + 0.5 * tt * (1 - tt)], -1)
     spheres = [(ball_c, 0.008, (0.95, 0.95, 0.9))]
     for body_c, shirt in players:
@@ -113,7 +150,7 @@ def shade(o: torch.Tensor, d: torch.Tensor, time: torch.Tensor) -> torch.Tensor:
     return col.clamp(0, 1)
 
 
-def render_dataset(cams: Dict[str, torch.Tensor], times: torch.Tensor, cam_ids, device, chunk_rows: int = 135) -> Dict[str, torch.Tensor]:
+def render_dataset(cams: Dict[str, torch.Tensor], times: torch.Tensor, cam_ids, device, chunk_rows: int = 135, variant: str = "default") -> Dict[str, torch.Tensor]:
     """uint8 images [M,H,W,3] on `device` for every (camera in cam_ids) x (time), plus per-image camera tables
     (one 'camera' per image, as nerfstudio's Cameras object holds them: c2w/intrinsics repeated per frame + times)."""
     from . import ops
@@ -140,6 +177,6 @@ def render_dataset(cams: Dict[str, torch.Tensor], times: torch.Tensor, cam_ids, 
             yy, xx = torch.meshgrid(rows, xs, indexing="ij")
             idx = torch.stack([torch.full_like(yy, m), yy, xx], -1).reshape(-1, 3)
             rays = ops.generate_rays(idx, table["fx"], table["fy"], table["cx"], table["cy"], table["c2w"], table["times"])
-            col = shade(rays["origins"], rays["directions"], rays["times"][:, 0])
+            col = shade(rays["origins"], rays["directions"], rays["times"][:, 0], variant)
             imgs[m, r0:r0 + rows.numel()] = (col.view(rows.numel(), W, 3) * 255.0 + 0.5).to(torch.uint8)
     return {"images": imgs, **table, "width": W, "height": H}

@@ -768,6 +768,21 @@ class KPlanesTrainer:
         self._wait_params()
         torch.cuda.synchronize(self.dev)
 
+    @torch.no_grad()
+    def restart(self, params: Optional[torch.Tensor] = None):
+        """Back to optimiser step 0: Adam moments, gradients and the device-side step / skip counters cleared; `params` (a flat copy of
+        self.params taken earlier, e.g. right after construction) restores the parameters too.  bench.py's trained-state leg starts from here."""
+        self.synchronize()
+        if params is not None:
+            self.params.copy_(params)
+        for t in (self.exp_avg, self.exp_avg_sq, self.grads) + ((self.grads_fx,) if self.grads_fx is not None else ()):
+            t.zero_()
+        for d in self._dyn.values():
+            d.zero_()
+        self.step = self._dyn_step = 0
+        self._steps_since_update = 0
+        torch.cuda.synchronize(self.dev)
+
     def _start_field_grad_exchange(self, k: int):
         """Called on the stream that produced the gradient of exchange chunk k, right after its scatter: reduce-scatter(SUM) of the chunk
         into this rank's shard buffer, asynchronous on RCCL's stream."""

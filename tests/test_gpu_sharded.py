@@ -283,7 +283,9 @@ def test_bench_script_two_ranks_on_one_gpu(tmp_path):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 3
-    assert "reduce-scatter" in line["config"]["parallelism"]
+    # the headline is the reference's DDP arithmetic (fp32 on the links); the bf16 transports are a labelled second leg of the same process
+    assert "reduce-scatter (fp32)" in line["config"]["parallelism"] and "new planes (fp32)" in line["config"]["parallelism"]
+    assert line["bf16_transports"]["value"] > 0 and line["bf16_transports"]["steps"] == 3 and "NOT the reference" in line["bf16_transports"]["what"]
     assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
     assert line["steady_state"]["value"] > 0 and line["trained_state"]["value"] > 0 and line["trained_state"]["steps"] == 3
 

@@ -36,7 +36,7 @@ def eval_set(trainer, data, image_ids, anneal, with_ssim=True):
     """PSNR (and SSIM) of full-image renders of data["images"][image_ids]."""
     imgs = data["images"]
     H, W = imgs.shape[1:3]
-    R = trainer.R
+    R = getattr(trainer, "eval_chunk", trainer.R)
     ys, xs = torch.meshgrid(torch.arange(H, device=imgs.device), torch.arange(W, device=imgs.device), indexing="ij")
     psnrs, ssims = [], []
     for m in image_ids:
@@ -69,16 +69,26 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
                              emulate_transports=args.emulate_transports,
                              sigma_operands=args.sigma_operands, color_operands=args.color_operands, proposal_operands=args.proposal_operands)
     R = 4096
-    trainer = KPlanesTrainer(cfg, R, dev)
-    if args.no_overlap:
-        trainer.overlap, trainer.async_field_adam = False, False
+    if args.standin:
+        # the reference's algorithm in stock PyTorch (oracle/torch_standin.py: checker / baseline code, imported ONLY for this mode) on the same
+        # pixel draws (same sampler, same seed), the same rays and the same evaluation; F.grid_sample per plane as the reference calls it
+        from oracle import kplanes_oracle as KO, torch_standin as TS
+        KO.USE_GRID_SAMPLE = True
+        trainer = TS.StandinTrainer(dev, R, seed=seed, max_steps=args.schedule_steps)
+    else:
+        trainer = KPlanesTrainer(cfg, R, dev)
+        if args.oracle_init:  # the stand-in's initial parameters (same generator, same seed) instead of the trainer's own draw
+            from oracle import kplanes_oracle as KO, torch_standin as TS
+            trainer.load_oracle_params(KO.make_kplanes_params(seed=seed, **TS.PRESET))
+        if args.no_overlap:
+            trainer.overlap, trainer.async_field_adam = False, False
     M, H, W = train["images"].shape[:3]
     batch = {"image": train["images"], "image_idx": torch.arange(M, device=dev), "ist_weights": ist, "iter_steps": 0}
     sampler = DynamicBasedPixelSampler(R, is_pixel_ratio=0.15, iters_to_start_ist=2000)
     DynamicBasedPixelSampler.prepare(batch)
     time_key, n_time_keys = ops.image_time_keys(train["times"])
     run = {"seed": seed, "evals": []}
-    t_train = 0.0
+    t_train, t_eval = 0.0, 0.0
     for step in range(args.steps):
         if step % 1000 == 0:
             torch.cuda.synchronize()
@@ -91,6 +101,8 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
         rays = ops.generate_rays(idx, train["fx"], train["fy"], train["cx"], train["cy"], train["c2w"], train["times"], aabb=trainer.aabb,
                                  near_plane=cfg.near_plane, training=True)
         trainer.train_step(rays, target)
+        if args.standin and step % 100 == 99:
+            print(f"[standin seed {seed}] step {step + 1} {time.time() - t1:.1f}s into this thousand", flush=True)
         if step % 1000 == 999:
             torch.cuda.synchronize()
             dt = time.time() - t1
@@ -103,18 +115,22 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
         if (step + 1) % args.eval_every == 0 or step + 1 == args.steps:
             an = anneal_value(step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope)
             ev = {"step": step + 1}
+            t2 = time.time()
             for name, (data, ids) in sets.items():
                 ps, ss = eval_set(trainer, data, ids, an, with_ssim=name != "train")
                 ev[name] = {"psnr_mean": sum(ps) / len(ps), "psnr_min": min(ps), "images": len(ps)}
                 if ss:
                     ev[name]["ssim_mean"] = sum(ss) / len(ss)
             run["evals"].append(ev)
+            torch.cuda.synchronize()
+            t_eval += time.time() - t2
             print(f"== [seed {seed}] step {step + 1}: " + "  ".join(f"{k} {v['psnr_mean']:.2f} dB" for k, v in ev.items() if k != "step"), flush=True)
     run["train_seconds"] = t_train
     run["train_rays_per_s_mean"] = R * (args.steps // 1000 * 1000) / max(t_train, 1e-9)
     run["skipped_steps"] = trainer.skipped_steps()
     trainer.synchronize()
     run["param_checksum"] = float(trainer.params.double().sum())
+    run["eval_seconds"] = t_eval
     return run
 
 
@@ -138,14 +154,19 @@ def main():
     ap.add_argument("--emulate-transports", default="", choices=["", "grad", "param", "both"],
                     help="single-GPU emulation of the bf16 gradient / parameter-update transports of the sharded multi-GPU step (KPlanesTrainConfig.emulate_transports)")
     ap.add_argument("--time-sorted-rays", action="store_true", help="every batch in order of frame time, as bench.py runs it")
+    ap.add_argument("--standin", action="store_true",
+                    help="train the REFERENCE'S ALGORITHM in stock PyTorch (oracle/torch_standin.StandinTrainer: F.grid_sample per plane, Linear stacks, autograd, "
+                         "two torch.optim.Adam, fp32) instead of the HIP trainer -- same pixel draws, rays, schedule and evaluation; ~95 ms / step")
+    ap.add_argument("--oracle-init", action="store_true", help="HIP trainer from the stand-in's initial parameters of the same seed")
+    ap.add_argument("--scene", default="default", choices=["default", "textured"], help="synthetic.shade variant (textured: grass grain, board, crowd, ten players)")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cams = synthetic.make_cameras(20, 960, 540)
     times = synthetic.frame_times(100, 3)
-    train = synthetic.render_dataset(cams, times, list(range(19)), dev, chunk_rows=540)
-    held = synthetic.render_dataset(cams, times, [19], dev, chunk_rows=540)
-    novel = synthetic.render_dataset(synthetic.make_novel_cameras(3, 960, 540), times, [0, 1, 2], dev, chunk_rows=540)
+    train = synthetic.render_dataset(cams, times, list(range(19)), dev, chunk_rows=540, variant=args.scene)
+    held = synthetic.render_dataset(cams, times, [19], dev, chunk_rows=540, variant=args.scene)
+    novel = synthetic.render_dataset(synthetic.make_novel_cameras(3, 960, 540), times, [0, 1, 2], dev, chunk_rows=540, variant=args.scene)
     t0 = time.time()
     ist = compute_ist(train["images"], train["cam_id"], train["times"], ist_range=1.0)  # method_configs.py:503
     torch.cuda.synchronize()
@@ -154,7 +175,9 @@ def main():
                           for f in torch.linspace(0, len(times) - 1, args.eval_frames).long().tolist()])
     sets = {"camera_20": (held, pick(held)), "novel": (novel, pick(novel)),
             "train": (train, torch.linspace(0, train["images"].shape[0] - 1, 4).long().tolist())}
-    log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps,
+    log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps, "scene": args.scene,
+           "trainer": "oracle/torch_standin.StandinTrainer: the reference's algorithm in stock PyTorch-ROCm, fp32" if args.standin else "soccernerfs_amd KPlanesTrainer (HIP)",
+           "oracle_init": bool(args.oracle_init or args.standin),
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
            "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
            "emulate_transports": args.emulate_transports, "time_sorted_rays": args.time_sorted_rays, "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
