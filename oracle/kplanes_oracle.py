@@ -573,10 +573,10 @@ def kplanes_forward(
     bins = None
     for li, S in enumerate(levels):
         if li == 0:
-            bins = spaced_bins(R, S, rng["t_rand"] if training else None)
+            bins = spaced_bins(R, S, rng["t_rand"] if training else None).to(o.device)
         else:
             annealed = torch.pow(weights, anneal)  # ray_samplers.py:584
-            u = pdf_u(R, S, rng["u"][li - 1] if training else None)
+            u = pdf_u(R, S, rng["u"][li - 1] if training else None).to(o.device)
             bins, _, _ = pdf_sample(annealed, bins, u)
         eucl = spacing_to_euclidean(bins, nears, fars)
         starts, ends = eucl[:, :-1], eucl[:, 1:]

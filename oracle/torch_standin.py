@@ -99,7 +99,9 @@ class StandinTrainer:
         for x in prop + fld:
             x.requires_grad_(True)
         self.groups = {"proposal_networks": prop, "fields": fld}
-        self.opts = {k: torch.optim.Adam(v, lr=1e-2, eps=1e-12) for k, v in self.groups.items()}
+        # fused = one multi-tensor kernel per optimiser (same update rule as the default foreach path)
+        self.opts = {k: torch.optim.Adam(v, lr=1e-2, eps=1e-12, **({"fused": True} if self.dev.type == "cuda" else {})) for k, v in self.groups.items()}
+        self._one = torch.ones(1, device=self.dev)
         self.step = 0
         self._since = 0
         self._skipped = {k: 0 for k in self.groups}
@@ -137,10 +139,15 @@ class StandinTrainer:
         ld = KO.kplanes_loss_dict(self.P, out, target)
         sum(ld.values()).backward()
         self._ld = {k: v.detach() for k, v in ld.items()}
-        norms = {k: torch.stack(torch._foreach_norm([x.grad for x in v if x.grad is not None])).sum() for k, v in self.groups.items()}
-        finite = torch.stack([torch.isfinite(norms[k]) for k in self.groups]).tolist()  # the one host read of the step (GradScaler's found_inf)
-        for ok, k in zip(finite, self.groups):
-            if ok:
+        # found_inf per optimiser with GradScaler's own kernel (unscale by 1), then the one host read of the step, as GradScaler.step does
+        found = []
+        for k, v in self.groups.items():
+            f = torch.zeros(1, device=self.dev)
+            torch._amp_foreach_non_finite_check_and_unscale_([x.grad for x in v if x.grad is not None], f, self._one)
+            found.append(f)
+        found = torch.cat(found).tolist()
+        for bad, k in zip(found, self.groups):
+            if not bad:
                 self.opts[k].step()
             else:
                 self._skipped[k] += 1

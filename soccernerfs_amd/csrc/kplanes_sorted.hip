@@ -511,6 +511,139 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
   }
 }
 
+// ---- pass B, round 4: lane = channel, each HALF of the wave walks its own 128 of the wave's 256 re-sorted entries ----
+// scatter_grouped_kernel above spends a wave instruction per entry on 64 lanes = (x-corner, channel): both halves interpolate the same v_q, the
+// per-entry scalars go through v_readfirstlane, the x-carry through ds_bpermute, and every run end costs ~100 issued instructions (64-bit
+// texel addresses, four exec-masked atomics) -- ~125 per entry, issue-bound at 0.35 of the HBM roofline (profiles/r03_kernels.md section 1).
+// Here a lane owns ONE channel of ALL FOUR texels of the cell: it loads the four texels itself (no lane swaps; v_q is computed once per
+// channel), keeps four accumulators, and an x-adjacent next cell moves the x0 + 1 column's accumulators to the x0 column IN THE LANE.  Two
+// entries advance per wave instruction (lanes 0-31: entries [0, 128) of the walk order, lanes 32-63: [128, 256)), so everything per-entry is
+// either lane-parallel (records, prepared as before) or costs half an instruction; the run-end logic is branch-free selects plus atomics
+// under the lanes' own predicates, addressed with 32-bit byte offsets from wave-uniform bases (saddr form).  Same arithmetic per
+// contribution as before except that the weighted add is one fma (gq * w + acc).
+template <int NP, bool QUOT>
+__global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
+                                                              const float4* __restrict__ sorted_rec, float* __restrict__ gplanes,
+                                                              int64_t groups_per_seg, int seg_begin, int per_scale,
+                                                              const float* __restrict__ planes, int row_stride) {
+  constexpr int C = 32, CH = 256, HALF = CH / 2, UNROLL = 8;
+  // per wave, per entry (in WALK order) 8 dwords: {gvec row BYTE offset, x0 | y0 << 16, texel (x0, y0) BYTE offset in the plane,
+  // x1-exists ? 128 : 0 | y1-exists << 31, w(x0y0), w(x0y1), w(x1y0), w(x1y1)}
+  __shared__ __align__(16) uint32_t s_rec[4][CH * 8];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int half = lane >> 5, ch = lane & 31;
+  const int64_t group = (int64_t)blockIdx.x * 4 + wave;
+  const int seg = seg_begin + (int)(group / groups_per_seg);
+  if (seg >= d.n_scales * NP) return;
+  const int64_t i0 = (group - (int64_t)(seg - seg_begin) * groups_per_seg) * CH;
+  if (i0 >= N) return;
+  const int cnt = (int)((N - i0) < CH ? (N - i0) : CH);
+  const int s = seg / NP, q = seg % NP;
+  int a, b;
+  seg_axes<NP>(q, a, b);
+  const int W = d.res[s][a], H = d.res[s][b] > 0 ? d.res[s][b] : 1;
+  const float4* rec = sorted_rec + (int64_t)(per_scale ? seg : q) * N + i0;
+  const char* gseg = reinterpret_cast<const char*>(QUOT ? gvec + (int64_t)s * C : gvec + (int64_t)seg * N * C);
+  const uint32_t rstrideB = (QUOT ? (uint32_t)row_stride : (uint32_t)C) * 4u;
+  char* gbase = reinterpret_cast<char*>(gplanes + d.off[s][q]);
+  const char* pbase = QUOT ? reinterpret_cast<const char*>(planes + d.off[s][q]) : nullptr;
+  uint32_t* R = s_rec[wave];
+  const bool sortable = (int64_t)W * H <= (1 << 23);
+  const uint32_t rowB = (uint32_t)W * (uint32_t)(C * 4);
+
+  uint32_t word[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    word[r] = 0xffffffffu;
+    if (e < cnt) {
+      const float4 rc = rec[e];
+      const int x0 = (int)floorf(axis_pix(rc.y, W)), y0 = (int)floorf(axis_pix(rc.z, H));
+      word[r] = sortable ? (((uint32_t)(y0 * W + x0) << 8) | (uint32_t)e) : (uint32_t)e;
+    }
+  }
+  if (sortable) BitonicK<CH>::run(word, lane);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int e = r * 64 + lane;
+    uint4 hd = make_uint4(0u, 0xffffffffu, 0u, 0u);  // null record: zero weights, a key no cell has
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e < cnt) {
+      const float4 rc = rec[word[r] & 255u];
+      const AxisTap tx = axis_tap(rc.y, W);
+      const AxisTap ty = axis_tap(rc.z, H);
+      hd.x = (uint32_t)__float_as_int(rc.x) * rstrideB;
+      hd.y = (uint32_t)tx.i0 | ((uint32_t)ty.i0 << 16);
+      hd.z = (uint32_t)(ty.i0 * W + tx.i0) * (uint32_t)(C * 4);
+      hd.w = (tx.i1 != tx.i0 ? (uint32_t)(C * 4) : 0u) | (ty.i1 != ty.i0 ? 0x80000000u : 0u);
+      const float4 tw = tap_weights(tx, ty);     // (x0y0, x1y0, x0y1, x1y1): the forward's products, bit for bit
+      wt = make_float4(tw.x, tw.z, tw.y, tw.w);  // stored (x0y0, x0y1, x1y0, x1y1)
+    }
+    *reinterpret_cast<uint4*>(R + e * 8) = hd;
+    *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
+  }
+  // the walk: this half's entries are R[half * HALF + i]; pending cell = (pk, pa: byte offset of its (x0, y0) texel + this lane's channel,
+  // pdx / pdy: byte steps to its x0 + 1 column / y0 + 1 row, 0 where clamped) with accumulators p00 (x0,y0), p01 (x0,y1), p10 (x1,y0), p11 (x1,y1)
+  const uint32_t* Rh = R + half * (HALF * 8);
+  const uint32_t chB = (uint32_t)ch * 4u;
+  uint32_t pk = 0xfffffff0u, pa = chB, pdx = 0u, pdy = 0u;
+  float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
+  auto flush = [&](uint32_t off, float v) {
+    if (v != 0.f) atomicAdd(reinterpret_cast<float*>(gbase + off), v);
+  };
+  const int iters = cnt > HALF ? HALF : cnt;  // half 1 walks null records where the chunk is short
+  for (int e0 = 0; e0 < iters; e0 += UNROLL) {
+    float g[UNROLL];
+    float t00[QUOT ? UNROLL : 1], t10[QUOT ? UNROLL : 1], t01[QUOT ? UNROLL : 1], t11[QUOT ? UNROLL : 1];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint4 hd = *reinterpret_cast<const uint4*>(Rh + (e0 + u) * 8);
+      g[u] = *reinterpret_cast<const float*>(gseg + (hd.x + chB));
+      if constexpr (QUOT) {
+        const uint32_t o00 = hd.z + chB, dx = hd.w & 0xffu, dy = (hd.w >> 31) ? rowB : 0u;
+        t00[u] = *reinterpret_cast<const float*>(pbase + o00);
+        t10[u] = *reinterpret_cast<const float*>(pbase + (o00 + dx));
+        t01[u] = *reinterpret_cast<const float*>(pbase + (o00 + dy));
+        t11[u] = *reinterpret_cast<const float*>(pbase + (o00 + dx + dy));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint4 hd = *reinterpret_cast<const uint4*>(Rh + (e0 + u) * 8);
+      const float4 w = *reinterpret_cast<const float4*>(Rh + (e0 + u) * 8 + 4);
+      float gq = g[u];
+      if constexpr (QUOT) {
+        const float vq = bilerp4(t00[u], t10[u], t01[u], t11[u], w.x, w.z, w.y, w.w);  // the forward's own number
+        gq = fabsf(vq) >= QUOT_TINY ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;           // vanished value: left to the fix-up
+      }
+      const uint32_t key = hd.y;
+      const bool same = key == pk, adj = key == pk + 1u;
+      if (!same) {
+        flush(pa, p00);
+        flush(pa + pdy, p01);
+        if (!adj) {
+          flush(pa + pdx, p10);
+          flush(pa + pdx + pdy, p11);
+        }
+      }
+      const float n00 = same ? p00 : (adj ? p10 : 0.f), n01 = same ? p01 : (adj ? p11 : 0.f);
+      const float n10 = same ? p10 : 0.f, n11 = same ? p11 : 0.f;
+      p00 = __fmaf_rn(gq, w.x, n00);
+      p01 = __fmaf_rn(gq, w.y, n01);
+      p10 = __fmaf_rn(gq, w.z, n10);
+      p11 = __fmaf_rn(gq, w.w, n11);
+      pk = key;
+      pa = hd.z + chB;
+      pdx = hd.w & 0xffu;
+      pdy = (hd.w >> 31) ? rowB : 0u;
+    }
+  }
+  flush(pa, p00);
+  flush(pa + pdy, p01);
+  flush(pa + pdx, p10);
+  flush(pa + pdx + pdy, p11);
+}
+
 // ---- quotient form, the two small kernels around pass B ----
 // G = gfeat .* feat (C / 4 lanes per (sample, scale) row, float4 each); rows in which a feature is exactly 0 while its gradient is not
 // are listed for quotient_fixup_kernel (G / v_q cannot give plane q's gradient there: v_q == 0 took the other planes' product with it).
@@ -678,6 +811,18 @@ static int launch_gradvec(const snerf_kplanes_desc* d, const float* planes, cons
   SNERF_LAUNCH_CHECK("kplanes_gradvec");
   return 0;
 }
+// scatter_halfwave_kernel addresses texels and gradient rows with 32-bit BYTE offsets.  SNERF_PASSB_GROUPED=1 (dev A-B) keeps the round-2 kernel.
+static bool halfwave_ok(const snerf_kplanes_desc* d, int scale_begin, int scale_end) {
+  static const bool forced_off = getenv("SNERF_PASSB_GROUPED") && atoi(getenv("SNERF_PASSB_GROUPED")) != 0;
+  if (forced_off || d->C != 32) return false;
+  for (int s = scale_begin; s < scale_end; ++s) {
+    int64_t mx = 1;
+    for (int k = 0; k < d->n_coords; ++k) mx = mx > d->res[s][k] ? mx : d->res[s][k];
+    if (mx * mx * d->C * 4 >= (1LL << 32) || mx >= 65536) return false;
+  }
+  return true;
+}
+
 template <int C, int NP>
 static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const void* gvec, int gvec_bf16, const float4* sorted_n, float* gp, int scale_begin,
                                  int scale_end, hipStream_t st) {
@@ -692,6 +837,12 @@ static int launch_scatter_sorted(const snerf_kplanes_desc* d, int64_t N, const v
   if (C == 32 && N * C < (1LL << 31)) {  // 32-bit gvec row offsets inside the kernel
     const int64_t gps = (N + 255) / 256;
     const dim3 grid((unsigned)ceil_div(gps * (scale_end - scale_begin) * NP, 4));
+    if (!gvec_bf16 && N * C * 4 < (1LL << 32) && halfwave_ok(d, scale_begin, scale_end)) {
+      hipLaunchKernelGGL((scatter_halfwave_kernel<NP, false>), grid, dim3(256), 0, st, dd, N, (const float*)gvec, sorted_n, gp, gps, scale_begin * NP,
+                         stb.per_scale, nullptr, 0);
+      SNERF_LAUNCH_CHECK("kplanes_scatter_halfwave");
+      return 0;
+    }
     if (gvec_bf16) hipLaunchKernelGGL((scatter_grouped_kernel<NP, __bf16>), grid, dim3(256), 0, st, dd, N, (const __bf16*)gvec, sorted_n, gp, gps,
                                       scale_begin * NP, stb.per_scale);
     else hipLaunchKernelGGL((scatter_grouped_kernel<NP, float>), grid, dim3(256), 0, st, dd, N, (const float*)gvec, sorted_n, gp, gps, scale_begin * NP,
@@ -809,6 +960,12 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
   const float4* rec = reinterpret_cast<const float4*>(sorted_rec);
   const int stride = desc->C * desc->n_scales;
   hipStream_t st = (hipStream_t)stream;
+  if ((int64_t)N * stride * 4 < (1LL << 32) && halfwave_ok(desc, scale_begin, scale_end)) {
+    if (NP == 6) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
+    else hipLaunchKernelGGL((scatter_halfwave_kernel<3, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
+    SNERF_LAUNCH_CHECK("kplanes_scatter_quotient");
+    return 0;
+  }
   if (NP == 6) hipLaunchKernelGGL((scatter_grouped_kernel<6, float, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale,
                                   planes, stride);
   else hipLaunchKernelGGL((scatter_grouped_kernel<3, float, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale,

@@ -1,5 +1,8 @@
-"""Config 3 (K-Planes multiscale-res 1-32, IST range 0.75, fps-downsample 4; 546 M parameters) through the fused trainer: rays/s of the
-full train step incl. the IST importance sampler.  Dev tool / profile note, not the bench line."""
+"""Config 3 (K-Planes multiscale-res 1-32, IST range 0.75, fps-downsample 4) through the fused trainer: rays/s of the full train step incl.
+the IST importance sampler, with a `roofline` object for its dominant kernel.  The MODEL is the k-planes preset with six scales -- the reference's
+README (README.md:39-44) changes multiscale-res, ist-range and fps-downsample only, so spacetime_resolution stays (64,64,64,100)
+(NS/configs/method_configs.py:515): 578 367 744 parameters; the DATA has 25 frames per camera (fps-downsample 4).
+Dev tool / profile note, not the bench line."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,9 +12,10 @@ from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
 
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 steps, warmup, R = 100, 20, 4096
-cfg = KPlanesTrainConfig(mlp_operands=(sys.argv[1] if len(sys.argv) > 1 else "bf16"), multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 25),
-                         proposal_resolutions=((128, 128, 128, 25), (256, 256, 256, 25)))
+cfg = KPlanesTrainConfig(mlp_operands=(sys.argv[1] if len(sys.argv) > 1 else "bf16"), multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 100),
+                         proposal_resolutions=((128, 128, 128, 100), (256, 256, 256, 100)))
 tr = KPlanesTrainer(cfg, R, dev)
+assert tr.n_params == 578_367_744, tr.n_params
 tr.step = 6000  # steady-state schedule, IST active (iters_to_start_ist = 2000)
 cams = synthetic.make_cameras(20, 960, 540); times = synthetic.frame_times(100, 4)
 data = synthetic.render_dataset(cams, times, list(range(19)), dev, chunk_rows=540)
@@ -29,9 +33,25 @@ def step():
 
 for _ in range(warmup):
     step()
+CAND = ["adam_planes.field", "kplanes_scatter_sorted.field", "kplanes_field_fwd", "kplanes_quotient_prepare", "mlp_bwd.192x128x1"]
+tr.enable_kernel_timing(CAND)
 tr.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     step()
 tr.synchronize(); dt = time.perf_counter() - t0
-print(json.dumps({"config": "K-Planes multiscale 1-32 (6 scales), C=32, 25 frames, IST range 0.75, 15 % importance rays", "mlp_operands": cfg.mlp_operands, "params": int(tr.n_params),
-                  "images": int(M), "ms_per_step": dt / steps * 1e3, "rays_per_s": R * steps / dt}))
+kt = tr.kernel_times_ms()
+tr.disable_kernel_timing()
+S2, ns, C = 64, 6, 32
+gather = R * S2 * ns * 6 * 4 * C * 4
+alg = {"adam_planes.field": 32 * tr.field_planes.numel, "kplanes_scatter_sorted.field": 2 * gather, "kplanes_field_fwd": gather + R * S2 * (16 + 2 * C * ns + 64),
+       "kplanes_quotient_prepare": 3 * R * S2 * C * ns * 4}
+kt = {k: v for k, v in kt.items() if k in alg}
+dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])
+ach = alg[dom] / (kt[dom][0] * 1e-3) / 1e9
+print(json.dumps({"config": "K-Planes multiscale 1-32 (6 scales, spacetime_resolution (64,64,64,100)), C=32, 19 cameras x 25 frames (fps-downsample 4), IST range 0.75, "
+                            "15 % importance rays, steady-state schedule (step 6000+)", "mlp_operands": cfg.mlp_operands, "params": int(tr.n_params),
+                  "images": int(M), "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "rays_per_s": R * steps / dt,
+                  "roofline": {"bound": "hbm", "kernel": dom + " (plane_reg_kernel<32,true>: Adam + regularisers, 32 B / parameter)" if dom == "adam_planes.field" else dom,
+                               "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": None, "algorithmic_per_launch": alg[dom],
+                               "avg_launch_ms": kt[dom][0], "launches_timed": kt[dom][1],
+                               "other_kernels_ms": {k: round(v[0], 4) for k, v in kt.items() if k != dom}}}))

@@ -89,7 +89,30 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     time_key, n_time_keys = ops.image_time_keys(train["times"])
     run = {"seed": seed, "evals": []}
     t_train, t_eval = 0.0, 0.0
+    t_start, last_step = time.time(), args.steps - 1
+
+    def evaluate(step):
+        nonlocal t_eval
+        an = anneal_value(step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope)
+        ev = {"step": step + 1}
+        t2 = time.time()
+        for name, (data, ids) in sets.items():
+            ps, ss = eval_set(trainer, data, ids, an, with_ssim=name != "train")
+            ev[name] = {"psnr_mean": sum(ps) / len(ps), "psnr_min": min(ps), "images": len(ps), "psnr_per_image": [round(p, 3) for p in ps]}
+            if ss:
+                ev[name]["ssim_mean"] = sum(ss) / len(ss)
+        run["evals"].append(ev)
+        torch.cuda.synchronize()
+        t_eval += time.time() - t2
+        print(f"== [seed {seed}] step {step + 1}: " + "  ".join(f"{k} {v['psnr_mean']:.2f} dB" for k, v in ev.items() if k != "step") + f"  (eval {time.time() - t2:.0f} s)", flush=True)
+
     for step in range(args.steps):
+        if args.train_budget_s and step % 100 == 0 and time.time() - t_start > args.train_budget_s:
+            # out of wall-clock (a gpurun call is capped at one hour): stop here, evaluate, and SAY how far the run got
+            last_step = step - 1
+            run["stopped_early_at_step"] = step
+            print(f"[seed {seed}] training budget of {args.train_budget_s} s spent at step {step}: evaluating there", flush=True)
+            break
         if step % 1000 == 0:
             torch.cuda.synchronize()
             t1 = time.time()
@@ -112,21 +135,11 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
                 print(f"[seed {seed}] step {step + 1}: {R * 1000 / dt:,.0f} rays/s  rgb_loss {ld['rgb_loss']:.5f} "
                       f"(psnr~{-10 * torch.log10(torch.tensor(ld['rgb_loss'])).item():.2f}) interlevel {ld['interlevel_loss']:.2e} "
                       f"skipped steps {trainer.skipped_steps()}", flush=True)
-        if (step + 1) % args.eval_every == 0 or step + 1 == args.steps:
-            an = anneal_value(step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope)
-            ev = {"step": step + 1}
-            t2 = time.time()
-            for name, (data, ids) in sets.items():
-                ps, ss = eval_set(trainer, data, ids, an, with_ssim=name != "train")
-                ev[name] = {"psnr_mean": sum(ps) / len(ps), "psnr_min": min(ps), "images": len(ps)}
-                if ss:
-                    ev[name]["ssim_mean"] = sum(ss) / len(ss)
-            run["evals"].append(ev)
-            torch.cuda.synchronize()
-            t_eval += time.time() - t2
-            print(f"== [seed {seed}] step {step + 1}: " + "  ".join(f"{k} {v['psnr_mean']:.2f} dB" for k, v in ev.items() if k != "step"), flush=True)
+        if (step + 1) % args.eval_every == 0 and step + 1 < args.steps:
+            evaluate(step)
+    evaluate(last_step)
     run["train_seconds"] = t_train
-    run["train_rays_per_s_mean"] = R * (args.steps // 1000 * 1000) / max(t_train, 1e-9)
+    run["train_rays_per_s_mean"] = R * ((last_step + 1) // 1000 * 1000) / max(t_train, 1e-9)
     run["skipped_steps"] = trainer.skipped_steps()
     trainer.synchronize()
     run["param_checksum"] = float(trainer.params.double().sum())
@@ -157,6 +170,8 @@ def main():
     ap.add_argument("--standin", action="store_true",
                     help="train the REFERENCE'S ALGORITHM in stock PyTorch (oracle/torch_standin.StandinTrainer: F.grid_sample per plane, Linear stacks, autograd, "
                          "two torch.optim.Adam, fp32) instead of the HIP trainer -- same pixel draws, rays, schedule and evaluation; ~95 ms / step")
+    ap.add_argument("--train-budget-s", type=float, default=0.0, help="stop training when this much wall-clock is spent (a gpurun call is capped at one hour), "
+                    "evaluate there and record `stopped_early_at_step`")
     ap.add_argument("--oracle-init", action="store_true", help="HIP trainer from the stand-in's initial parameters of the same seed")
     ap.add_argument("--scene", default="default", choices=["default", "textured"], help="synthetic.shade variant (textured: grass grain, board, crowd, ten players)")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream step (A/B against stream-ordering effects)")
