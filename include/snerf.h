@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 10
+#define SNERF_ABI_VERSION 11
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -195,6 +195,16 @@ int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * snerf_kplanes_field_fwd wrote.  The kernels round X to that type anyway, so results equal snerf_mlp_bwd on the fp32 image of X. */
 int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                       int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* snerf_mlp_bwd_x16 with the QUOTIENT EPILOGUE (ABI 11; sigma_net shapes 32 k -> 128 -> d_out, 16-bit operands): instead of gX the kernel
+ * writes G[N, ldg] = gX .* X, X being the 16-bit feature tile it holds in LDS for the layer-0 weight gradient anyway -- the tensor pass B of
+ * the quotient scatter divides by v_q (snerf_kplanes_scatter_quotient_scales) -- and appends to the fix list the elements whose X vanished
+ * (|X| below the smallest normal float) while gX did not: {element index n * ldg + col, gX} (two int32 per entry), G = 0 there.  Replaces
+ * snerf_kplanes_quotient_prepare and the gX / fp32-feature round trips between the two kernels.  fix_count / fix_count_next as in
+ * snerf_kplanes_quotient_prepare.  G carries the operand rounding of X (2^-9 relative for bf16: the size of the MFMA operand roundings gX
+ * went through already); ldg must be the scatter's row stride (32 n_scales). */
+int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                               int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
+                               int32_t* fix_count, int32_t* fix_count_next, float* gW, snerf_stream_t stream);
 /* Same with the weight gradients accumulated into fixed-point cells (see snerf_kplanes_gather_bwd_fx). */
 int snerf_mlp_bwd_fx(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                      int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
@@ -609,22 +619,25 @@ int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, cons
  * bit, so that the division cancels the forward's v_q exactly even where v_q is a small difference of large texels.  Differs from the
  * product form by a few ulp.
  * Where a feature vanished (exactly 0, or below the smallest normal float -- also as the underflowing product of six normal plane values) the
- * quotient has lost the other planes' product: _prepare writes G = 0 for such a channel and lists the row (device-side list, capacity
- * N * n_scales covers the worst case); pass B then adds exactly 0 there and _fixup -- which recognises the channel by G == 0 with a non-zero
- * feature gradient -- adds the exact product-form terms (one vanished plane: that plane's; none, i.e. an underflowed product: every plane's).
- *   _prepare : G = grad_feat .* feat; fix_count / fix_list = rows (sample * n_scales + scale) with a zero feature.  fix_count must be 0 on
- *              entry: with fix_count_next == NULL it is reset here (one memset); a caller that alternates between two counters passes the
- *              other one as fix_count_next and the kernel resets THAT one for the next step (no extra launch).
+ * quotient has lost the other planes' product: the producer of G writes G = 0 for such an element and, if its gradient is not zero, appends
+ * {element index n * 32 n_scales + s * 32 + ch, feature gradient} to the fix list (ABI 11: two int32 per entry; rows before.  Device-side,
+ * capacity in ENTRIES; entries beyond it are dropped); pass B then adds exactly 0 there and _fixup adds the exact product-form terms (one
+ * vanished plane: that plane's; none, i.e. an underflowed product: every plane's).  A plane value that is subnormal but not zero beside a
+ * usable G is divided by in IEEE arithmetic inside pass B (v_rcp_f32 may flush it).
+ *   _prepare : G = grad_feat .* feat + the fix list (fix_list: int32[2 * fix_capacity]).  fix_count must be 0 on entry: with
+ *              fix_count_next == NULL it is reset here (one memset); a caller that alternates between two counters passes the other one as
+ *              fix_count_next and the kernel resets THAT one for the next step (no extra launch).  snerf_mlp_bwd_x16_quotient produces
+ *              the same pair from inside the sigma_net backward.
  *   _scatter_quotient_scales : pass B over scales [scale_begin, scale_end), sorted_rec from snerf_kplanes_sort_samples; ACCUMULATES.
- *   _fixup   : exact terms of the listed rows for scales [scale_begin, scale_end); ACCUMULATES.  Launch cost only when the list is empty.
+ *   _fixup   : exact terms of the listed elements for scales [scale_begin, scale_end); ACCUMULATES.  Launch cost only when the list is empty.
  * ------------------------------------------------------------------------------------------------ */
 int snerf_kplanes_quotient_supported(const snerf_kplanes_desc* desc, int64_t N);
 int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, const float* grad_feat, const float* feat, float* G,
                                    int32_t* fix_list, int32_t fix_capacity, int32_t* fix_count, int32_t* fix_count_next, snerf_stream_t stream);
 int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const float* planes, int64_t N, const float* G, const float* sorted_rec,
                                           float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
-int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
-                                 const float* G, const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
+int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                                 const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
                                  int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class KPlanesDesc(C.Structure):
@@ -209,6 +209,7 @@ EXPORTS = [
     "snerf_fx_to_float",
     "snerf_mlp_bwd_fx",
     "snerf_mlp_bwd_x16",
+    "snerf_mlp_bwd_x16_quotient",
     "snerf_adam_prepare",
     "snerf_depth_loss",
     "snerf_urf_depth_loss",

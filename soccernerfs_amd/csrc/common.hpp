@@ -113,6 +113,19 @@ __device__ __forceinline__ double wave_scan_f64(const float* in, float* out, int
   return total;
 }
 
+// ---- quotient form of the K-Planes plane scatter (kplanes_sorted.hip; produced also by the sigma_net backward's epilogue, mlp_lp.hip) ----
+// a value below the smallest normal float counts as "vanished": pass B adds nothing for it and the fix-up supplies the exact term
+// (v_rcp_f32 may flush a subnormal operand, which would turn 0 * inf into a NaN gradient)
+constexpr float QUOT_TINY = 1.17549435e-38f;
+// fix list entry = {element index into the [N, C n_scales] feature tensor, the feature gradient there}
+__device__ __forceinline__ void fix_append(int32_t* __restrict__ list, int capacity, int32_t* __restrict__ count, int32_t elem, float g) {
+  const int slot = atomicAdd(count, 1);
+  if (slot < capacity) {
+    list[2 * slot] = elem;
+    list[2 * slot + 1] = __float_as_int(g);
+  }
+}
+
 // nan_to_num with torch defaults (nan->0, +inf->FLT_MAX, -inf->-FLT_MAX)
 __device__ __forceinline__ float nan_to_num(float v) {
   if (v != v) return 0.f;

@@ -30,9 +30,7 @@ __device__ __forceinline__ uint32_t part1by1(uint32_t v) {
 }
 __device__ __forceinline__ uint32_t morton2(uint32_t x, uint32_t y) { return part1by1(x) | (part1by1(y) << 1); }
 
-// a plane value below the smallest normal float counts as zero in the quotient form: pass B adds nothing for it and the fix-up supplies the exact
-// term (v_rcp_f32 may flush a subnormal operand, which would turn 0 * inf into a NaN gradient)
-constexpr float QUOT_TINY = 1.17549435e-38f;
+// (QUOT_TINY, the "vanished" threshold of the quotient form, lives in common.hpp: the sigma_net backward's epilogue uses it too)
 
 
 inline int build_segs(const snerf_kplanes_desc* d, SegTable& st) {

@@ -614,7 +614,10 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
       float gq = g[u];
       if constexpr (QUOT) {
         const float vq = bilerp4(t00[u], t10[u], t01[u], t11[u], w.x, w.z, w.y, w.w);  // the forward's own number
-        gq = fabsf(vq) >= QUOT_TINY ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;           // vanished value: left to the fix-up
+        const bool normal = fabsf(vq) >= QUOT_TINY;
+        gq = normal ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;  // v_q == 0: G is 0 too, the fix-up supplies the exact term
+        // a SUBNORMAL v_q beside a usable G (the other planes' product is large): v_rcp_f32 may flush it, the IEEE division does not
+        if (__builtin_expect(!normal && vq != 0.f && g[u] != 0.f, 0)) gq = __fdiv_rn(g[u], vq);
       }
       const uint32_t key = hd.y;
       const bool same = key == pk, adj = key == pk + 1u;
@@ -645,8 +648,12 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
 }
 
 // ---- quotient form, the two small kernels around pass B ----
-// G = gfeat .* feat (C / 4 lanes per (sample, scale) row, float4 each); rows in which a feature is exactly 0 while its gradient is not
-// are listed for quotient_fixup_kernel (G / v_q cannot give plane q's gradient there: v_q == 0 took the other planes' product with it).
+// The fix list holds ELEMENTS (round 4; rows before): {index into the [N, C n_scales] feature tensor, the feature gradient there} for every
+// element whose feature vanished (zero, or below the smallest normal float) while its gradient did not: G / v_q cannot give plane q's gradient
+// there (v_q == 0 took the other planes' product with it, or the product of six normal values underflowed).  Producers: quotient_prepare_kernel
+// below, or the sigma_net backward's epilogue (mlp_lp.hip: snerf_mlp_bwd_x16_quotient), which forms G from the feature tile it holds in LDS.
+// G = gfeat .* feat (C / 4 lanes per (sample, scale) row, float4 each); vanished features get G = 0 (pass B then adds exactly nothing for the
+// channel) and, where the gradient is not zero, an entry in the fix list.
 template <int C>
 __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, const float* __restrict__ gfeat, const float* __restrict__ feat,
                                                               float* __restrict__ G, int32_t* __restrict__ list, int capacity, int32_t* __restrict__ count,
@@ -657,48 +664,40 @@ __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, con
   constexpr int LPR = C / 4;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = gid / LPR;
-  bool bad = false;
-  if (row < rows) {
-    const float4 g = *reinterpret_cast<const float4*>(gfeat + gid * 4);
-    const float4 f = *reinterpret_cast<const float4*>(feat + gid * 4);
-    // a vanished feature (zero, or a subnormal product -- of six normal plane values as well) carries no usable quotient: G = 0 there, so that
-    // pass B adds exactly nothing for the channel and the fix-up, which recognises the channel by G == 0 with a non-zero gradient, adds the exact term
-    const bool zx = fabsf(f.x) < QUOT_TINY, zy = fabsf(f.y) < QUOT_TINY, zz = fabsf(f.z) < QUOT_TINY, zw = fabsf(f.w) < QUOT_TINY;
-    float4 Gv = f4_mul(g, f);
-    Gv.x = zx ? 0.f : Gv.x; Gv.y = zy ? 0.f : Gv.y; Gv.z = zz ? 0.f : Gv.z; Gv.w = zw ? 0.f : Gv.w;
-    *reinterpret_cast<float4*>(G + gid * 4) = Gv;
-    bad = (zx && g.x != 0.f) || (zy && g.y != 0.f) || (zz && g.z != 0.f) || (zw && g.w != 0.f);
-  }
-  const unsigned long long m = __ballot(bad);
-  const int lane = threadIdx.x & 63, g0 = lane & ~(LPR - 1);
-  if ((lane & (LPR - 1)) == 0 && ((m >> g0) & ((1ull << LPR) - 1ull))) {
-    const int slot = atomicAdd(count, 1);
-    if (slot < capacity) list[slot] = (int32_t)row;
-  }
+  if (row >= rows) return;
+  const float4 g = *reinterpret_cast<const float4*>(gfeat + gid * 4);
+  const float4 f = *reinterpret_cast<const float4*>(feat + gid * 4);
+  const bool zx = fabsf(f.x) < QUOT_TINY, zy = fabsf(f.y) < QUOT_TINY, zz = fabsf(f.z) < QUOT_TINY, zw = fabsf(f.w) < QUOT_TINY;
+  float4 Gv = f4_mul(g, f);
+  Gv.x = zx ? 0.f : Gv.x; Gv.y = zy ? 0.f : Gv.y; Gv.z = zz ? 0.f : Gv.z; Gv.w = zw ? 0.f : Gv.w;
+  *reinterpret_cast<float4*>(G + gid * 4) = Gv;
+  if (zx && g.x != 0.f) fix_append(list, capacity, count, (int32_t)(gid * 4), g.x);
+  if (zy && g.y != 0.f) fix_append(list, capacity, count, (int32_t)(gid * 4 + 1), g.y);
+  if (zz && g.z != 0.f) fix_append(list, capacity, count, (int32_t)(gid * 4 + 2), g.z);
+  if (zw && g.w != 0.f) fix_append(list, capacity, count, (int32_t)(gid * 4 + 3), g.w);
 }
 
-// Exact gradient of the listed rows (row = sample * n_scales + scale), channel by channel (lane = (x-corner, channel)), for the channels pass B
-// could not serve: G == 0 there (quotient_prepare_kernel) while the feature's gradient is not.  With v_p the six planes' values at the sample:
-//   exactly ONE |v_z| below QUOT_TINY -> plane z receives gfeat * prod_{p != z} v_p (the others' terms contain v_z: zero);
-//   none (the product of six normal values underflowed)  -> EVERY plane q receives gfeat * prod_{p != q} v_p;
+// Exact gradient of the listed elements, one lane per element (sample n, scale s, channel ch; g = the feature gradient).  With v_p the six
+// planes' values at the sample (the forward's own numbers: bilerp4):
+//   exactly ONE |v_z| below QUOT_TINY -> plane z receives g * prod_{p != z} v_p (the others' terms contain v_z: zero);
+//   none (the product of six normal values underflowed)  -> EVERY plane q receives g * prod_{p != q} v_p;
 //   two or more -> every term contains a vanished factor: nothing to add.
 // Rare by construction (a trained texel that is exactly 0.0f, or an underflowing product), so no run-length combining.
 template <int NP>
-__global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c, const float* __restrict__ gfeat,
-                                                            const float* __restrict__ G, const int32_t* __restrict__ list, const int32_t* __restrict__ count,
+__global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c,
+                                                            const int32_t* __restrict__ list, const int32_t* __restrict__ count,
                                                             int capacity, float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end) {
   constexpr int C = 32;
-  const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
   int n_list = *count;
   n_list = n_list < capacity ? n_list : capacity;
-  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n_list; i += gridDim.x * 4) {
-    const int row = list[i];
-    const int64_t n = row / n_scales_total;
-    const int s = row - (int)n * n_scales_total;
+  const int F = n_scales_total * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
+    const int elem = list[2 * i];
+    const float g = __int_as_float(list[2 * i + 1]);
+    const int64_t n = elem / F;
+    const int col = elem - (int)n * F;
+    const int s = col / C, ch = col - s * C;
     if (s < scale_begin || s >= scale_end) continue;
-    const int64_t fo = n * ((int64_t)n_scales_total * C) + s * C + ch;
-    const float g = gfeat[fo];
-    if (g == 0.f || G[fo] != 0.f) continue;  // per lane (channel): nothing to add, or pass B was exact
     float p[4];
     load_coords<NP>(c, n, p);
     AxisTap tap[4];
@@ -713,7 +712,6 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc 
       const int W = d.res[s][pair_a<NP>(q)];
       const float* base = planes + d.off[s][q] + ch;
       const float4 w = tap_weights(tx, ty);
-      // the forward's own number (bilerp4): "vanished" must mean the same here, in the forward and in pass B
       v[q] = bilerp4(base[((int64_t)ty.i0 * W + tx.i0) * C], base[((int64_t)ty.i0 * W + tx.i1) * C], base[((int64_t)ty.i1 * W + tx.i0) * C],
                      base[((int64_t)ty.i1 * W + tx.i1) * C], w.x, w.y, w.z, w.w);
       zeros += fabsf(v[q]) < QUOT_TINY;
@@ -726,18 +724,18 @@ __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc 
     float pre = g;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const float term = pre * suf[q + 1];  // gfeat * prod_{p != q} v_p
+      const float term = pre * suf[q + 1];  // g * prod_{p != q} v_p
       pre *= v[q];
       if (zeros == 1 && fabsf(v[q]) >= QUOT_TINY) continue;  // one vanished plane: only IT has a non-zero gradient
       const AxisTap& tx = tap[pair_a<NP>(q)];
       const AxisTap& ty = tap[pair_b<NP>(q)];
       const int W = d.res[s][pair_a<NP>(q)];
-      const float wx = half ? tx.w1 : tx.w0;
-      const int xi = half ? tx.i1 : tx.i0;
       float* gb = gplanes + d.off[s][q] + ch;
-      const float a0 = term * wx * ty.w0, a1 = term * wx * ty.w1;
-      if (a0 != 0.f) atomicAdd(gb + ((int64_t)ty.i0 * W + xi) * C, a0);
-      if (a1 != 0.f) atomicAdd(gb + ((int64_t)ty.i1 * W + xi) * C, a1);
+      const float a00 = term * tx.w0 * ty.w0, a01 = term * tx.w0 * ty.w1, a10 = term * tx.w1 * ty.w0, a11 = term * tx.w1 * ty.w1;
+      if (a00 != 0.f) atomicAdd(gb + ((int64_t)ty.i0 * W + tx.i0) * C, a00);
+      if (a01 != 0.f) atomicAdd(gb + ((int64_t)ty.i1 * W + tx.i0) * C, a01);
+      if (a10 != 0.f) atomicAdd(gb + ((int64_t)ty.i0 * W + tx.i1) * C, a10);
+      if (a11 != 0.f) atomicAdd(gb + ((int64_t)ty.i1 * W + tx.i1) * C, a11);
     }
   }
 }
@@ -813,7 +811,8 @@ static int launch_gradvec(const snerf_kplanes_desc* d, const float* planes, cons
 }
 // scatter_halfwave_kernel addresses texels and gradient rows with 32-bit BYTE offsets.  SNERF_PASSB_GROUPED=1 (dev A-B) keeps the round-2 kernel.
 static bool halfwave_ok(const snerf_kplanes_desc* d, int scale_begin, int scale_end) {
-  static const bool forced_off = getenv("SNERF_PASSB_GROUPED") && atoi(getenv("SNERF_PASSB_GROUPED")) != 0;
+  const char* env = getenv("SNERF_PASSB_GROUPED");  // read per call: tools/bench_passb.py flips it inside one process
+  const bool forced_off = env && atoi(env) != 0;
   if (forced_off || d->C != 32) return false;
   for (int s = scale_begin; s < scale_end; ++s) {
     int64_t mx = 1;
@@ -974,8 +973,8 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
   return 0;
 }
 
-extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const float* grad_feat,
-                                            const float* G, const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
+extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
+                                            const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
                                             int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
   int rc = check_desc(desc, coords, N);
   if (rc) return rc;
@@ -984,12 +983,12 @@ extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, cons
   SNERF_REQUIRE(scale_begin >= 0 && scale_begin <= scale_end && scale_end <= desc->n_scales, "kplanes_quotient_fixup: scales [%d, %d) of %d", scale_begin,
                 scale_end, desc->n_scales);
   if (N == 0 || fix_capacity == 0 || scale_begin == scale_end) return 0;
-  SNERF_REQUIRE(planes && grad_feat && G && fix_list && fix_count && grad_planes, "kplanes_quotient_fixup: null buffer");
+  SNERF_REQUIRE(planes && fix_list && fix_count && grad_planes, "kplanes_quotient_fixup: null buffer");
   // a fixed small grid that strides over the (device-side) count: an empty list costs one launch
   hipStream_t st = (hipStream_t)stream;
-  if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, G, fix_list, fix_count,
+  if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(64), dim3(256), 0, st, *desc, planes, *coords, fix_list, fix_count,
                                               fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end);
-  else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(256), dim3(256), 0, st, *desc, planes, *coords, grad_feat, G, fix_list, fix_count, fix_capacity,
+  else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(64), dim3(256), 0, st, *desc, planes, *coords, fix_list, fix_count, fix_capacity,
                           grad_planes, desc->n_scales, scale_begin, scale_end);
   SNERF_LAUNCH_CHECK("kplanes_quotient_fixup");
   return 0;

@@ -38,6 +38,11 @@ struct MlpArgs {
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
   int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
+  // quotient epilogue of the backward (snerf_mlp_bwd_x16_quotient; 16-bit kernels, one hidden layer of 128): instead of gX the kernel writes
+  // G = gX .* X (X = the 16-bit tile it holds in LDS) and lists the elements whose X vanished while gX did not (common.hpp: fix_append)
+  float* G; int ldg;
+  int32_t* fix_list; int fix_capacity;
+  int32_t* fix_count; int32_t* fix_count_next;
   // dense layers wider than one 128 x 128 block (snerf_dense_fwd / _bwd tile them): row stride of W in global memory (0 = dout), and
   // "add to what is there" for the forward's output (later K blocks of a linear layer) / the backward's input gradient (later column blocks)
   int ldw_g, acc_y, acc_gx;
@@ -938,6 +943,39 @@ extern "C" int snerf_mlp_bwd_fx(const snerf_mlp_desc* d, const float* W, const f
 extern "C" int snerf_mlp_bwd_x16(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                                  int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
   return mlp_bwd_impl(d, W, reinterpret_cast<const float*>(X16), ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream, 1);
+}
+
+// snerf.h: the sigma_net backward with the quotient epilogue (G = gX .* X16 + the fix list) instead of gX
+extern "C" int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                          int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
+                                          int32_t* fix_count, int32_t* fix_count_next, float* gW, snerf_stream_t stream) {
+  MlpArgs a = {};
+  int rc = fill(d, a);
+  if (rc) return rc;
+  SNERF_REQUIRE(d->operands == 1 || d->operands == 2, "mlp_bwd_x16_quotient: needs 16-bit operands (desc.operands = 1 / 2), got %d", d->operands);
+  SNERF_REQUIRE(d->hidden == 128 && d->n_hidden == 1 && d->d_in % 32 == 0, "mlp_bwd_x16_quotient: built for the sigma_net shapes 32 k -> 128 -> d_out (d_in=%d hidden=%d x %d)",
+                d->d_in, d->hidden, d->n_hidden);
+  SNERF_REQUIRE(N >= 0 && ldx >= d->d_in && ldg >= d->d_in && fix_capacity >= 0, "mlp_bwd_x16_quotient: N=%lld ldx=%d ldg=%d capacity=%d", (long long)N, ldx, ldg,
+                fix_capacity);
+  SNERF_REQUIRE((int64_t)N * ldg < (1LL << 31), "mlp_bwd_x16_quotient: N * ldg = %lld does not fit the 32-bit element index of the fix list", (long long)N * ldg);
+  SNERF_REQUIRE(fix_count, "mlp_bwd_x16_quotient: null counter");
+  hipStream_t st = (hipStream_t)stream;
+  if (!fix_count_next) {
+    rc = check_hip(hipMemsetAsync(fix_count, 0, sizeof(int32_t), st), "mlp_bwd_x16_quotient memset");
+    if (rc) return rc;
+  }
+  if (N == 0) {
+    if (fix_count_next) return check_hip(hipMemsetAsync(fix_count_next, 0, sizeof(int32_t), st), "mlp_bwd_x16_quotient memset");
+    return 0;
+  }
+  SNERF_REQUIRE(W && X16 && G && (fix_list || fix_capacity == 0), "mlp_bwd_x16_quotient: null buffer");
+  SNERF_REQUIRE(gY || gaux, "mlp_bwd_x16_quotient: no incoming gradient");
+  SNERF_REQUIRE(!gY || ldgy >= d->d_out, "mlp_bwd_x16_quotient: ldgy=%d", ldgy);
+  SNERF_REQUIRE(!gaux || (aux_col >= 0 && aux_col < d->d_out), "mlp_bwd_x16_quotient: aux_col=%d", aux_col);
+  a.X = reinterpret_cast<const float*>(X16); a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gW = gW;
+  a.x16 = 1;
+  a.G = G; a.ldg = ldg; a.fix_list = fix_list; a.fix_capacity = fix_capacity; a.fix_count = fix_count; a.fix_count_next = fix_count_next;
+  return dispatch(d, a, true, st);
 }
 
 // One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid).  The kernels hold one 128 x 128 block of W in LDS;

@@ -255,7 +255,11 @@ struct PlanB {
 // (Round 2 also formed the quotient scatter's G = gX .* feat in this kernel's gX epilogue: that instantiation needed 256 VGPRs + spills and the
 // step got slower -- profiles/r02_kernels.md section 10 -- so the separate quotient_prepare pass stayed and the variant was removed.  A lesson
 // kept: an optional epilogue must be a template parameter; as a run-time `if` EVERY instantiation paid its registers.)
-template <typename T, int K0, int H, int NH, int TS, bool X16 = false>
+// QG (round 4): the quotient epilogue again, this time from the LDS-resident 16-bit X tile (Xt stays alive to the end of the tile for the
+// layer-0 weight gradient): G = gX .* X costs one 8-byte LDS read per accumulator block instead of round 2's 160 dependent global loads per
+// sample.  X here is the operand-typed feature (bf16 / fp16 of the forward's fp32 product): G carries that rounding, which is of the size of
+// the MFMA operand roundings gX went through already.  A template parameter: the other instantiations do not pay for it.
+template <typename T, int K0, int H, int NH, int TS, bool X16 = false, bool QG = false>
 __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a, int64_t n_tiles) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -292,6 +296,9 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
   // columns 16..31 of gzo (the padded half of the K = 32 contraction) stay zero for the whole kernel
   for (int idx = threadIdx.x; idx < TS * 16; idx += blockDim.x) gzo[(idx / 16) * P::LKO + 16 + (idx % 16)] = (T)0.f;
   const bool relu = a.hidden_act == 1;
+  if constexpr (QG) {  // the caller alternates between two list counters: reset the one the NEXT step will use (see quotient_prepare_kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.fix_count_next) *a.fix_count_next = 0;
+  }
   f32x4 dW0[NB0] = {};
   f32x4 dWh[NH == 2 ? NBH : 1] = {};
   f32x4 dWo[NBO] = {};
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
     // ---- gX = gz1 W0^T.  One hidden layer: gz1 lives unit-major only (gz1t) and is read transposed; a wave keeps ONE row block's fragments
     //      (all of k) in registers and walks the column blocks with them.  Two hidden layers: (column block, row block) units dealt
     //      round-robin to the waves, operands from the row-major image ----
-    if (a.gX) {
+    if (a.gX || QG) {
       if constexpr (NH == 1) {
         static_assert(NW % MT == 0, "waves per workgroup must be a multiple of the tile's row blocks");
         constexpr int NG = NW / MT;
@@ -496,9 +503,23 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
             for (int ks = 0; ks < H / 32; ++ks) acc = Ops<T>::mfma(af[ks], ld8(bp + ks * 32), acc);
             const int col = nt * 16 + lr;
             const int64_t row0 = n0 + m * 16 + lk * 4;
+            if constexpr (QG) {
+              // X[row0 .. row0 + 3][col] = 8 contiguous bytes of the unit-major image
+              const typename Ops<T>::v4 xv = *reinterpret_cast<const typename Ops<T>::v4*>(Xt + col * P::LKT + m * 16 + lk * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[r] * (1.f / GS);
+              for (int r = 0; r < 4; ++r)
+                if (row0 + r < a.N && col < a.d0) {
+                  const float x = (float)xv[r], gx = acc[r] * (1.f / GS);
+                  const bool vanished = fabsf(x) < QUOT_TINY;
+                  const int64_t e = (row0 + r) * a.ldg + col;
+                  a.G[e] = vanished ? 0.f : gx * x;
+                  if (vanished && gx != 0.f) fix_append(a.fix_list, a.fix_capacity, a.fix_count, (int32_t)e, gx);
+                }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (row0 + r < a.N && col < a.d0) a.gX[(row0 + r) * a.ldgx + col] = acc[r] * (1.f / GS);
+            }
           }
         }
       } else {
@@ -919,10 +940,17 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
         using P16 = PlanB<K0, H, NH, TS16>;
         n_tiles = (a.N + TS16 - 1) / TS16;
         grid = n_tiles < 256 ? n_tiles : 256;
-        auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS16, true>;
-        static bool attr_set16 = false;
-        if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P16::BYTES, st, a, n_tiles);
+        if (a.G) {
+          auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS16, true, true>;
+          static bool attr_setq = false;
+          if (!attr_setq) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_setq = true; }
+          hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P16::BYTES, st, a, n_tiles);
+        } else {
+          auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS16, true>;
+          static bool attr_set16 = false;
+          if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
+          hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P16::BYTES, st, a, n_tiles);
+        }
       } else {
         set_error("mlp_bwd_x16: 16-bit inputs are built for the d_in -> 128 -> d_out one-hidden-layer shapes (sigma_net), got hidden=%d n_hidden=%d", H, NH);
         return SNERF_ERR_UNSUPPORTED;

@@ -43,6 +43,11 @@ struct MlpArgs {  // same fields as mlp.hip's (filled there)
   float* gW;
   long long* gWfx;  // deterministic mode: weight gradients accumulate here as fixed point instead (common.hpp)
   int x16;          // X holds the 16-bit operand type (what snerf_kplanes_field_fwd wrote), not fp32: 16-bit kernels only
+  // quotient epilogue of the backward (snerf_mlp_bwd_x16_quotient; 16-bit kernels, one hidden layer of 128): instead of gX the kernel writes
+  // G = gX .* X (X = the 16-bit tile it holds in LDS) and lists the elements whose X vanished while gX did not (common.hpp: fix_append)
+  float* G; int ldg;
+  int32_t* fix_list; int fix_capacity;
+  int32_t* fix_count; int32_t* fix_count_next;
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {

@@ -113,7 +113,10 @@ class SortedScatter:
                 raise ValueError("the quotient scatter is built for C = 32, concatenated scales and N * 32 * n_scales < 2^31")
             rows = N * len(ps.resolutions)
             self.G = torch.empty(N, ps.out_dim, dtype=torch.float32, device=device)       # gfeat .* feat
-            self.fix_list = torch.empty(max(rows, 1), dtype=torch.int32, device=device)   # rows (sample * n_scales + scale) with an exactly-zero feature
+            # fix list: {element index, feature gradient} per vanished feature with a non-zero gradient (2 int32 per entry; entries beyond the
+            # capacity are dropped -- N * n_scales entries = one per (sample, scale) row is far beyond what training produces)
+            self.fix_capacity = max(rows, 1)
+            self.fix_list = torch.empty(2 * self.fix_capacity, dtype=torch.int32, device=device)
             self.fix_counts = torch.zeros(2, dtype=torch.int32, device=device)  # used alternately: a prepare resets the other one for the next step
             self._fix_parity = 0
             self.fix_count = self.fix_counts[0:1]
@@ -134,23 +137,31 @@ class SortedScatter:
 
 
     # ---- quotient form: g_q = (gfeat .* feat) ./ v_q (include/snerf.h) ----
-    def quotient_prepare(self, gfeat, feat, stream=None):
-        st = stream if stream is not None else _stream()
+    def next_fix_counter(self) -> int:
+        """The two list counters are used alternately (the producer of G resets the OTHER one for the next step): makes counter k the current
+        one (self.fix_count) and returns k."""
         k = self._fix_parity
         self._fix_parity = 1 - k
         self.fix_count = self.fix_counts[k:k + 1]
+        return k
+
+    def quotient_prepare(self, gfeat, feat, stream=None):
+        st = stream if stream is not None else _stream()
+        k = self.next_fix_counter()
         _lib.check(_lib.lib().snerf_kplanes_quotient_prepare(C.byref(self.desc), C.c_int64(self.N), _ptr(gfeat), _ptr(feat), _ptr(self.G), _ptr(self.fix_list),
-                                                             self.fix_list.numel(), _ptr(self.fix_count), _ptr(self.fix_counts[1 - k:2 - k]), st),
+                                                             self.fix_capacity, _ptr(self.fix_count), _ptr(self.fix_counts[1 - k:2 - k]), st),
                    "quotient_prepare")
 
     def quotient_scatter_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
-        """Pass B + the exact terms of zero-feature rows for scales [scale_begin, scale_end); quotient_prepare must have run."""
+        """Pass B + the exact terms of the listed (vanished-feature) elements for scales [scale_begin, scale_end); G and the fix list must have been
+        produced (quotient_prepare, or the sigma_net backward's epilogue: snerf_mlp_bwd_x16_quotient).  gfeat is unused since ABI 11 (the list carries
+        the gradients it needs)."""
         st = stream if stream is not None else _stream()
         L = _lib.lib()
         _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
                                                            scale_begin, scale_end, st), "scatter_quotient")
-        _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(gfeat), _ptr(self.G), _ptr(self.fix_list),
-                                                  _ptr(self.fix_count), self.fix_list.numel(), _ptr(gplanes), scale_begin, scale_end, st),
+        _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(self.fix_list),
+                                                  _ptr(self.fix_count), self.fix_capacity, _ptr(gplanes), scale_begin, scale_end, st),
                    "quotient_fixup")
 
     def scatter_quotient(self, planes, coords: _lib.Coords, gfeat, feat, gplanes, stream=None):

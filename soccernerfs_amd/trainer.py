@@ -101,6 +101,12 @@ class KPlanesTrainConfig:
     # ~1.6 GB less HBM traffic per step.  Equal to the product form to a few ulp (pass B recomputes the forward's v_q bit for bit; rows with an
     # exactly-zero feature take an exact fix-up).  Needs the sorted scatter, C = 32 and no deterministic mode; False = product form (A-B).
     quotient_scatter: bool = True
+    # Round 4: G = gfeat .* feat is formed in the sigma_net backward's EPILOGUE from the 16-bit feature tile that kernel holds in LDS
+    # (snerf_mlp_bwd_x16_quotient) instead of by a separate pass over fp32 copies of both tensors: no quotient_prepare launch on the critical
+    # chain, and neither the forward's fp32 features nor gfeat cross HBM (~0.67 GB per step at the preset).  Needs the fused forward, the
+    # quotient scatter and bf16 operands for sigma_net (fp16's narrow range would coarsen small features); G then carries the 2^-9 operand
+    # rounding of the features.  False = round 3's flow (quotient_prepare on fp32 features; A-B).
+    quotient_epilogue: bool = True
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -275,6 +281,9 @@ class KPlanesTrainer:
         if self.fused_field:  # the forward's operand-typed feature tile, kept for the unfused backward (snerf_mlp_bwd_x16)
             dt16 = torch.bfloat16 if self.sigma_net.desc.operands == 1 else torch.float16
             self.buf["feat16"] = torch.empty(R * self.S[2], self.field_planes.out_dim, dtype=dt16, device=self.dev)
+        self.quotient_epilogue = bool(cfg.quotient_epilogue and self.quotient_scatter and self.fused_field and self.sigma_net.desc.operands == 1
+                                      and self.sigma_net.desc.hidden == 128 and self.sigma_net.desc.n_hidden == 1)
+        self._qg_step = False
         if self.world > 1:
             self._plan_exchange()
 
@@ -446,17 +455,20 @@ class KPlanesTrainer:
                 # behind for the unfused backward kernels
                 self._fwd_fused = self.fused_field
                 keep = training
+                will_sort = bool(training and self.sorted_scatter and self.grads_fx is None and R == self.R)
+                # G comes out of the sigma_net backward's epilogue (quotient_epilogue): the fp32 features are then not needed at all
+                self._qg_step = bool(self._fwd_fused and self.quotient_epilogue and will_sort)
                 if self._fwd_fused:
                     with self._span("kplanes_field_fwd"):
                         _lib.check(self.lib.snerf_kplanes_field_fwd(C.byref(self._desc_field), self._p(self.field_planes.planes), C.byref(co), C.c_int64(N),
                                                                     C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), C.byref(self.color_net.desc),
                                                                     self._p(self.color_net.params), self._p(b["dens"][2]), self._p(b["rgb"]),
                                                                     self._p(b["feat16"]) if keep else None, self._p(b["h"]) if keep else None,
-                                                                    self._p(b["feat"]) if keep and self.quotient_scatter else None, self._st),
+                                                                    self._p(b["feat"]) if keep and self.quotient_scatter and not self._qg_step else None, self._st),
                                    "kplanes_field_fwd")
                 else:
                     self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
-                if training and self.sorted_scatter and self.grads_fx is None and R == self.R:
+                if will_sort:
                     # sort the nerf-level samples per (scale, plane) on a side stream.  Started AFTER the (memory-bound) gather so
                     # that it runs under the MFMA-bound MLP forward / backward that follow on the main stream.
                     main = torch.cuda.current_stream()
@@ -546,16 +558,27 @@ class KPlanesTrainer:
         sl = lambda t: t[n0:n0 + N]
         # colour net: X = h[:, :15] (stride 16); its gX lands in gh[:, :15]; gh[:, 15] stays 0 (density enters through gaux)
         self._mlp_bwd(self.color_net, "field.color", sl(b["h"]), 16, N, sl(b["grgb"]), 3, -1, None, sl(b["gh"]), 16)
-        self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
-                      sl(b["gfeat"]), F, x16=self._fwd_fused)
+        qg = bool(self._qg_step and self._sort_done is not None and r0 == 0 and r1 == self.R)
+        if qg:
+            ss = self._ss
+            k = ss.next_fix_counter()
+            with self._span(f"mlp_bwd.{self.sigma_net.desc.d_in}x{self.sigma_net.desc.hidden}x{self.sigma_net.desc.n_hidden}"):
+                _lib.check(self.lib.snerf_mlp_bwd_x16_quotient(C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), self._p(b["feat16"]), F, C.c_int64(N),
+                                                               self._p(b["gh"]), 16, 15, self._p(b["gdens"][2]), self._p(ss.G), F, self._p(ss.fix_list),
+                                                               ss.fix_capacity, self._p(ss.fix_count), self._p(ss.fix_counts[1 - k:2 - k]),
+                                                               self._p(self.gviews["field.sigma"]), self._st), "mlp_bwd_x16_quotient")
+        else:
+            self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
+                          sl(b["gfeat"]), F, x16=self._fwd_fused)
         rays = self.rays
         co = ops.coords_from_rays(rays["origins"][r0:r1], rays["directions"][r0:r1], rays["times"].reshape(-1)[r0:r1], b["eb"][2][r0:r1], self.aabb, True)
         if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:
             torch.cuda.current_stream().wait_event(self._sort_done)
             ss = self._ss
             if self.quotient_scatter:
-                with self._span("kplanes_quotient_prepare"):
-                    ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
+                if not qg:
+                    with self._span("kplanes_quotient_prepare"):
+                        ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
                 if self.world == 1 and self._reg_in_adam:
                     # the optimiser sweep's two tiny forerunners (skip decision of the group, zeroed regulariser slots) depend on nothing pass B
                     # produces: issued here they are off the scatter -> sweep hand-over

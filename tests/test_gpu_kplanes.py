@@ -289,3 +289,45 @@ def test_quotient_scatter_when_the_product_of_six_normal_values_underflows():
         a, b = ps.plane_view(0, q, got)[0:2, 0:2, :], ps.plane_view(0, q, direct)[0:2, 0:2, :]
         assert float(b.abs().min()) > 1e-36
         torch.testing.assert_close(a, b, rtol=2e-4, atol=0)
+
+
+@pytest.mark.gpu
+def test_quotient_scatter_with_one_subnormal_plane_value_beside_a_normal_feature():
+    """ONE plane value is subnormal (not zero) while the other five multiply to more than 1, so the feature is a normal number and
+    G = gfeat * feat is usable -- but v_rcp_f32 may flush the subnormal divisor.  Pass B divides by it in IEEE arithmetic there; that plane's
+    gradient (gfeat * the others' product) used to be dropped silently."""
+    import ctypes as Ct
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.plane_set import PlaneSet
+
+    dev = _dev()
+    gen = torch.Generator().manual_seed(9)
+    ps = PlaneSet(32, [[11, 9, 7, 5], [22, 18, 14, 5]], concat=True, generator=gen)
+    with torch.no_grad():
+        ps.planes.copy_(torch.rand(ps.numel, generator=gen) * 2.0 + 2.0)  # every value in [2, 4): five of them multiply to >= 32
+        ps.plane_view(1, 4)[0:2, 0:2, :] = 3e-39                           # the first cell of plane YT of scale 1: subnormal
+    ps = ps.to(dev)
+    N = 500
+    pts = torch.rand(N, 4, generator=gen) * 2 - 1
+    pts[:80, 1] = -1.0 + 0.05 * torch.rand(80, generator=gen)  # y and t inside the first cell of scale 1 (cell widths 2 / 17 and 0.5)
+    pts[:80, 3] = -1.0 + 0.3 * torch.rand(80, generator=gen)
+    gout = torch.rand(N, ps.out_dim, generator=gen) + 0.5
+    ptsd, goutd = pts.to(dev), gout.to(dev)
+    co = ops.coords_from_points(ptsd)
+    desc = ps.desc()
+    L = _lib.lib()
+    direct = torch.zeros_like(ps.planes)
+    _lib.check(L.snerf_kplanes_gather_bwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(goutd), ops._ptr(direct), ops._stream()))
+    feat = torch.empty(N, ps.out_dim, device=dev)
+    _lib.check(L.snerf_kplanes_gather_fwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(feat), ops._stream()))
+    f1 = feat[:80, 32:64].abs()
+    assert float(f1.min()) >= 1.17549435e-38 and float(f1.max()) < 1e-35  # normal numbers, carried by a subnormal factor
+    ss = ops.SortedScatter(ps, N, dev, quotient=True)
+    ss.sort(co)
+    got = torch.zeros_like(ps.planes)
+    ss.scatter_quotient(ps.planes, co, goutd, feat, got)
+    assert int(ss.fix_count.item()) == 0  # nothing vanished: no fix-up involved
+    a, b = ps.plane_view(1, 4, got)[0:2, 0:2, :], ps.plane_view(1, 4, direct)[0:2, 0:2, :]
+    assert float(b.abs().min()) > 1.0  # gfeat * (>= 32) summed over the cell's samples
+    torch.testing.assert_close(a, b, rtol=2e-4, atol=0)
+    torch.testing.assert_close(got, direct, rtol=1e-4, atol=2e-6 * float(direct.abs().max()))

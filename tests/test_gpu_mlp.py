@@ -323,6 +323,63 @@ def test_backward_from_16bit_input_equals_backward_from_its_fp32_image(operands)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * float(res[0][1].abs().max()))
 
 
+@pytest.mark.parametrize("d_in,N", [(160, 1000), (192, 333), (32, 64)])
+def test_quotient_epilogue_of_the_sigma_net_backward(d_in, N):
+    """snerf_mlp_bwd_x16_quotient: G = gX .* X16 formed from the LDS-resident feature tile -- bit for bit the product of snerf_mlp_bwd_x16's gX
+    with the fp32 image of X16 -- zero where X16 vanished (zero / subnormal), those elements listed with their gX; the weight gradients are the
+    plain kernel's; the OTHER list counter is reset for the next step; ragged N."""
+    import ctypes as C
+
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.tcnn_compat import Network
+
+    net = Network(d_in, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 1},
+                  operands="bf16").to(DEV)
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(N, d_in, generator=gen) - 0.3
+    x[torch.rand(N, d_in, generator=gen) < 0.01] = 0.0   # vanished features
+    x[3, 5], x[N - 1, d_in - 1] = 3e-39, -2e-39          # subnormal: vanished too
+    x16 = x.to(DEV).to(torch.bfloat16)
+    gy = (torch.rand(N, 16, generator=gen) - 0.5).to(DEV)
+    gaux = (torch.rand(N, generator=gen) - 0.5).to(DEV)
+    L = _lib.lib()
+    gx, gw = torch.empty(N, d_in, device=DEV), torch.zeros_like(net.params)
+    _lib.check(L.snerf_mlp_bwd_x16(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x16), d_in, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux), ops._ptr(gx),
+                                   d_in, ops._ptr(gw), ops._stream()))
+    G, gw2 = torch.full((N, d_in), 7.0, device=DEV), torch.zeros_like(net.params)
+    cap = N * d_in
+    fix_list = torch.full((2 * cap,), -1, dtype=torch.int32, device=DEV)
+    counts = torch.tensor([0, 12345], dtype=torch.int32, device=DEV)
+    _lib.check(L.snerf_mlp_bwd_x16_quotient(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x16), d_in, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux),
+                                            ops._ptr(G), d_in, ops._ptr(fix_list), cap, ops._ptr(counts[0:1]), ops._ptr(counts[1:2]), ops._ptr(gw2), ops._stream()))
+    torch.cuda.synchronize()
+    xf = x16.float()
+    vanished = xf.abs() < 1.17549435e-38
+    assert int(vanished.sum()) > 2
+    want = torch.where(vanished, torch.zeros_like(gx), gx * xf)
+    assert torch.equal(G, want)
+    torch.testing.assert_close(gw2, gw, rtol=1e-4, atol=1e-5 * float(gw.abs().max()))
+    n = int(counts[0])
+    assert int(counts[1]) == 0  # the next step's counter was reset by this launch
+    listed = vanished & (gx != 0)
+    assert n == int(listed.sum())
+    ent = fix_list[:2 * n].view(n, 2).cpu()
+    order = torch.argsort(ent[:, 0])
+    idx = ent[order, 0].long()
+    assert torch.equal(idx, torch.nonzero(listed.reshape(-1).cpu()).reshape(-1))
+    assert torch.equal(ent[order, 1].contiguous().view(torch.float32), gx.reshape(-1).cpu()[idx])
+    # a single counter (fix_count_next = NULL) is reset by the call itself; shapes outside the sigma_net family are refused
+    counts[0] = 999
+    _lib.check(L.snerf_mlp_bwd_x16_quotient(C.byref(net.desc), ops._ptr(net.params), ops._ptr(x16), d_in, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux),
+                                            ops._ptr(G), d_in, ops._ptr(fix_list), cap, ops._ptr(counts[0:1]), None, ops._ptr(gw2), ops._stream()))
+    assert int(counts[0]) == n
+    net64 = Network(32, 1, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 1},
+                    operands="bf16").to(DEV)
+    rc = L.snerf_mlp_bwd_x16_quotient(C.byref(net64.desc), ops._ptr(net64.params), ops._ptr(x16), d_in, C.c_int64(N), None, 1, 0, ops._ptr(gaux),
+                                      ops._ptr(G), d_in, ops._ptr(fix_list), cap, ops._ptr(counts[0:1]), None, ops._ptr(torch.zeros_like(net64.params)), ops._stream())
+    assert rc != 0 and b"sigma_net shapes" in L.snerf_last_error()
+
+
 def test_linear_decoder_pieces_against_torch_and_edge_cases():
     """csrc/linear_decoder.hip: trunc_exp (forward exp, backward with the exponent clamped to [-15, 15]: NS/field_components/activations.py:25-41)
     and basis_rgb (sigmoid of the feature / basis contraction, kplanes_field.py:349-354) against the oracle's formulas under autograd; empty
