@@ -27,7 +27,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
 DEFAULT_OPERANDS = "bf16"  # BASELINE.json configs[1]: "1xMI355X bf16"
-PROFILE_TAG = "r03"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
+PROFILE_TAG = "r04"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
 
 
 def parse():
@@ -335,7 +335,7 @@ def main():
             "adam_step": ("hbm", 32 * trainer.n_params, "adam_kernel: p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
             "adam_planes.field": ("hbm", 32 * (trainer._field_seg[2] // world if trainer._sharded() else trainer.field_planes.numel),
                                   "plane_reg_kernel<32,true> (Adam + K-Planes regularisers fused, field planes): p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
-            "kplanes_scatter_sorted.field": ("hbm", 2 * gather, "scatter_sorted_kernel<32,6>: read-modify-write of every touched texel"),
+            "kplanes_scatter_sorted.field": ("hbm", 2 * gather, "pass B of the sorted scatter (scatter_halfwave_kernel<6,QUOT>): read-modify-write of every touched texel"),
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),
             "kplanes_gather_fwd.field": ("hbm", gather, "kplanes_gather_fwd_kernel<32,6>: texel reads"),
@@ -419,15 +419,19 @@ def main():
         # second half of BASELINE.json's metric (PSNR@30k): not re-measured here (a 30 k-step run takes minutes) -- the committed results of
         # tools/train_psnr.py on this workload are read from their files and quoted with their source
         psnr = {}
-        for op in ("bf16", "fp32"):
-            f = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_psnr_30k_{op}.json")
-            if os.path.exists(f):
-                try:
-                    d = json.load(open(f))
-                    psnr[op] = {"source": f"profiles/{PROFILE_TAG}_psnr_30k_{op}.json (tools/train_psnr.py: same preset, same synthetic scene, {len(d['runs'])} seeds)",
-                                **{k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in d["summary"].items()}}
-                except Exception as e:  # a malformed file must not take the bench line down
-                    psnr[op] = {"source": os.path.basename(f), "error": str(e)}
+        for op in ("bf16", "fp32", "standin"):
+            # this round's file if it exists, else the last round's that does (the source is named in the line either way)
+            f = next((c for c in (os.path.join(ROOT, "profiles", f"{tag}_psnr_30k_{op}.json") for tag in (PROFILE_TAG, "r03")) if os.path.exists(c)), None)
+            if f is None:
+                continue
+            try:
+                d = json.load(open(f))
+                what = ("oracle/torch_standin.StandinTrainer = the reference's algorithm in stock PyTorch, fp32, same scene / sampler / schedule / evaluation"
+                        if op == "standin" else "tools/train_psnr.py: same preset, same synthetic scene")
+                psnr[op] = {"source": f"profiles/{os.path.basename(f)} ({what}, {len(d['runs'])} seed(s), eval frames per camera: {d.get('eval_frames', 'all')})",
+                            **{k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in d["summary"].items()}}
+            except Exception as e:  # a malformed file must not take the bench line down
+                psnr[op] = {"source": os.path.basename(f), "error": str(e)}
         if psnr:
             line["psnr_30k"] = psnr
         if world == 1 and not args.no_standin:

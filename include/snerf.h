@@ -231,6 +231,17 @@ int snerf_kplanes_field_fwd(const snerf_kplanes_desc* desc, const float* planes,
                             float* density, float* rgb, void* feat16, float* h, float* feat32, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fused proposal density = KPlanesDensityField.get_density (NS/fields/kplanes_field.py:410-460) as ProposalNetworkSampler calls it per level
+ * (NS/model_components/ray_samplers.py:559-600) in one kernel (ABI 11): plane gather (one scale of six C = 8 planes) -> sigma_net 8 -> 64 -> 1
+ * (16-bit MFMA operands) -> density = trunc_exp(.).  Bit-identical to snerf_kplanes_gather_fwd + snerf_mlp_fwd (aux = trunc_exp) with the same
+ * operands.  feat (optional, NULL = not written): the [N,8] fp32 features, which the unfused backward kernels of a step that updates the
+ * proposal networks read (snerf_mlp_bwd, snerf_kplanes_gather_bwd).
+ * ------------------------------------------------------------------------------------------------ */
+int snerf_kplanes_density_fwd_supported(const snerf_kplanes_desc* desc, const snerf_mlp_desc* net);
+int snerf_kplanes_density_fwd(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N, const snerf_mlp_desc* net,
+                              const float* W, float* density, float* feat, snerf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Compositing and ray-level losses (one wavefront per ray, S <= 320).
  * ------------------------------------------------------------------------------------------------ */
 

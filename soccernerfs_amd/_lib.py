@@ -215,6 +215,8 @@ EXPORTS = [
     "snerf_urf_depth_loss",
     "snerf_kplanes_field_fwd",
     "snerf_kplanes_field_fwd_supported",
+    "snerf_kplanes_density_fwd",
+    "snerf_kplanes_density_fwd_supported",
     "snerf_kplanes_quotient_supported",
     "snerf_kplanes_quotient_prepare",
     "snerf_kplanes_scatter_quotient_scales",

@@ -583,14 +583,19 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
     *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
   }
   // the walk: this half's entries are R[half * HALF + i]; pending cell = (pk, pa: byte offset of its (x0, y0) texel + this lane's channel,
-  // pdx / pdy: byte steps to its x0 + 1 column / y0 + 1 row, 0 where clamped) with accumulators p00 (x0,y0), p01 (x0,y1), p10 (x1,y0), p11 (x1,y1)
+  // pdx / pdy: byte steps to its x0 + 1 column / y0 + 1 row, 0 where clamped) with accumulators p00 (x0,y0), p01 (x0,y1), p10 (x1,y0), p11 (x1,y1).
+  // The pending cell starts as the half's FIRST entry with empty accumulators, so no flush ever sees an invalid cell and the adds need no
+  // "is there anything" tests: a clamped column / row or a null record (chunk tail) adds 0.0f to a texel that exists, which changes nothing
+  // (+0 + -0 = +0: untouched texels stay exactly zero for the optimiser sweep's skip test).
   const uint32_t* Rh = R + half * (HALF * 8);
   const uint32_t chB = (uint32_t)ch * 4u;
-  uint32_t pk = 0xfffffff0u, pa = chB, pdx = 0u, pdy = 0u;
+  uint32_t pk, pa, pdx, pdy;
+  {
+    const uint4 hd = *reinterpret_cast<const uint4*>(Rh);
+    pk = hd.y; pa = hd.z + chB; pdx = hd.w & 0xffu; pdy = (hd.w >> 31) ? rowB : 0u;
+  }
   float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
-  auto flush = [&](uint32_t off, float v) {
-    if (v != 0.f) atomicAdd(reinterpret_cast<float*>(gbase + off), v);
-  };
+  auto add = [&](uint32_t off, float v) { atomicAdd(reinterpret_cast<float*>(gbase + off), v); };
   const int iters = cnt > HALF ? HALF : cnt;  // half 1 walks null records where the chunk is short
   for (int e0 = 0; e0 < iters; e0 += UNROLL) {
     float g[UNROLL];
@@ -617,16 +622,17 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
         const bool normal = fabsf(vq) >= QUOT_TINY;
         gq = normal ? gq * __builtin_amdgcn_rcpf(vq) : 0.f;  // v_q == 0: G is 0 too, the fix-up supplies the exact term
         // a SUBNORMAL v_q beside a usable G (the other planes' product is large): v_rcp_f32 may flush it, the IEEE division does not
-        if (__builtin_expect(!normal && vq != 0.f && g[u] != 0.f, 0)) gq = __fdiv_rn(g[u], vq);
+        // (G != 0 implies v_q != 0 for a G formed from this forward's features; the inner test only guards callers' inconsistent inputs)
+        if (__builtin_expect(!normal && g[u] != 0.f, 0)) gq = vq != 0.f ? __fdiv_rn(g[u], vq) : 0.f;
       }
       const uint32_t key = hd.y;
       const bool same = key == pk, adj = key == pk + 1u;
       if (!same) {
-        flush(pa, p00);
-        flush(pa + pdy, p01);
+        add(pa, p00);
+        add(pa + pdy, p01);
         if (!adj) {
-          flush(pa + pdx, p10);
-          flush(pa + pdx + pdy, p11);
+          add(pa + pdx, p10);
+          add(pa + pdx + pdy, p11);
         }
       }
       const float n00 = same ? p00 : (adj ? p10 : 0.f), n01 = same ? p01 : (adj ? p11 : 0.f);
@@ -641,10 +647,10 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
       pdy = (hd.w >> 31) ? rowB : 0u;
     }
   }
-  flush(pa, p00);
-  flush(pa + pdy, p01);
-  flush(pa + pdx, p10);
-  flush(pa + pdx + pdy, p11);
+  add(pa, p00);
+  add(pa + pdy, p01);
+  add(pa + pdx, p10);
+  add(pa + pdx + pdy, p11);
 }
 
 // ---- quotient form, the two small kernels around pass B ----

@@ -107,6 +107,9 @@ class KPlanesTrainConfig:
     # quotient scatter and bf16 operands for sigma_net (fp16's narrow range would coarsen small features); G then carries the 2^-9 operand
     # rounding of the features.  False = round 3's flow (quotient_prepare on fp32 features; A-B).
     quotient_epilogue: bool = True
+    # Round 4: each proposal level's density as ONE kernel (csrc/proposal_fused.hip: gather -> 8 -> 64 -> 1 net -> trunc_exp; bit-identical to
+    # the two unfused kernels).  The [N,8] features go to HBM only on steps that update the proposal networks.  16-bit operands only.
+    fused_proposal: bool = True
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -284,6 +287,9 @@ class KPlanesTrainer:
         self.quotient_epilogue = bool(cfg.quotient_epilogue and self.quotient_scatter and self.fused_field and self.sigma_net.desc.operands == 1
                                       and self.sigma_net.desc.hidden == 128 and self.sigma_net.desc.n_hidden == 1)
         self._qg_step = False
+        self.fused_proposal = bool(cfg.fused_proposal and all(self.lib.snerf_kplanes_density_fwd_supported(C.byref(dp), C.byref(net.desc))
+                                                             for dp, net in zip(self._desc_prop, self.prop_nets)))
+        self._keep_pfeat = True  # train_step clears it for steps that do not update the proposal networks
         if self.world > 1:
             self._plan_exchange()
 
@@ -445,7 +451,15 @@ class KPlanesTrainer:
             co = ops.coords_from_rays(o, d, t, b["eb"][lvl], self.aabb, rescale)
             self._coords.append(co)
             N = R * self.S[lvl]
-            if lvl < 2:
+            if lvl < 2 and self.fused_proposal:
+                net = self.prop_nets[lvl]
+                with self._span("kplanes_density_fwd"):
+                    _lib.check(self.lib.snerf_kplanes_density_fwd(C.byref(self._desc_prop[lvl]), self._p(self.prop_planes[lvl].planes), C.byref(co), C.c_int64(N),
+                                                                  C.byref(net.desc), self._p(net.params), self._p(b["dens"][lvl]),
+                                                                  self._p(b["pfeat"][lvl]) if training and self._keep_pfeat else None, self._st),
+                               "kplanes_density_fwd")
+                self._resample(lvl, rng["u"][lvl] if training else None, anneal)
+            elif lvl < 2:
                 self._gather(self._desc_prop[lvl], self.prop_planes[lvl].planes, co, N, b["pfeat"][lvl])
                 self._mlp_fwd(self.prop_nets[lvl], b["pfeat"][lvl], cfg.proposal_feature_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
@@ -1065,7 +1079,11 @@ class KPlanesTrainer:
         rng = rng if rng is not None else self.random_draws()
         co = cfg.loss_coefficients
         defer = bool(cfg.fused_ray_loss and (depth is None or co.get("depth_loss", 0) <= 0))
-        out = self.forward(rays, rng, anneal, training=True, defer_render=defer)
+        self._keep_pfeat = bool(updated)  # the proposal levels' features cross HBM only when their backward will read them
+        try:
+            out = self.forward(rays, rng, anneal, training=True, defer_render=defer)
+        finally:
+            self._keep_pfeat = True
         fuse = self.fuse_reg_into_adam
         self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
                       defer_prop_join=fuse and self.world == 1 and self.defer_prop, depth=depth)

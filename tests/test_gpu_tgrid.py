@@ -37,6 +37,24 @@ def test_reference_known_answer():
     model.get_temporal_tv_loss()
 
 
+@pytest.mark.parametrize("gridtype", ["hash", "tiled"])
+def test_dense_3d_levels_hand_computed_kat(gridtype):
+    """tgrid_kernel on DENSE 3-D levels against numbers computed by hand from the reference kernel's text (tests/tgrid_dense_kat.py): the
+    levels config 4 takes with (res + 1)^3 <= 2^19 were pinned only by oracle == kernel before."""
+    from soccernerfs_amd.temporal_grid import TemporalGridEncoder
+    from tests import tgrid_dense_kat as K
+
+    model = TemporalGridEncoder(gridtype=gridtype, **K.KW).to(DEV)
+    assert model.offsets.tolist() == K.OFFSETS
+    x, t, want = K.inputs(torch)
+    for explicit in (False, True):
+        model.embeddings = torch.nn.Parameter(K.embedding(torch).to(DEV), requires_grad=True)
+        out = model(x.to(DEV), t.to(DEV), explicit_rows=explicit)
+        assert torch.equal(out.cpu(), want), out
+        model(x[1:2].to(DEV), t[1:2].to(DEV), explicit_rows=explicit).sum().backward()
+        assert torch.equal(model.embeddings.grad.cpu(), K.expected_grad(torch))
+
+
 @pytest.mark.parametrize("kw", [
     dict(temporal_dim=8, level_dim=2, num_levels=4, log2_hashmap_size=10, base_resolution=4, per_level_scale=1.7),            # hashed levels
     dict(temporal_dim=6, level_dim=4, num_levels=3, log2_hashmap_size=12, base_resolution=3, per_level_scale=2.0),

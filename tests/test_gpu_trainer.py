@@ -46,23 +46,35 @@ def test_fused_step_matches_reference_golden():
     t = lambda k: g[k].to(DEV).contiguous()
     rays = {"origins": t("origins"), "directions": t("directions"), "times": t("times")}
     rng = {"t_rand": t("t_rand"), "u": [t("u0"), t("u1")], "bg": t("bg")}
+    from tests._measure import record
+
     rgb = tr.forward(rays, rng, float(g["anneal"]), training=True)
     for i in range(3):
+        record(f"g11_fp32.sbins_{i}", tr.buf["sb"][i], g[f"sbins_{i}"])
+        record(f"g11_fp32.ebins_{i}", tr.buf["eb"][i], g[f"ebins_{i}"])
+        record(f"g11_fp32.weights_{i}", tr.buf["w"][i], g[f"weights_{i}"], floor=1e-3)
         torch.testing.assert_close(tr.buf["sb"][i].cpu(), g[f"sbins_{i}"], rtol=0, atol=1e-5)
         torch.testing.assert_close(tr.buf["eb"][i].cpu(), g[f"ebins_{i}"], rtol=0, atol=3e-5)
         torch.testing.assert_close(tr.buf["w"][i].cpu(), g[f"weights_{i}"], rtol=2e-3, atol=2e-5)
+    record("g11_fp32.rgb", rgb, g["rgb"], floor=1e-2)
+    record("g11_fp32.accumulation", tr.buf["acc"], g["accumulation"][:, 0], floor=1e-2)
+    record("g11_fp32.depth", tr.buf["depth"], g["depth"][:, 0])
     torch.testing.assert_close(rgb.cpu(), g["rgb"], rtol=1e-3, atol=2e-5)
     torch.testing.assert_close(tr.buf["acc"].cpu(), g["accumulation"][:, 0], rtol=1e-3, atol=2e-5)
     torch.testing.assert_close(tr.buf["depth"].cpu(), g["depth"][:, 0], rtol=0, atol=1e-4)
     tr.backward(t("target"), rng, proposal_grads=True)
     ld = tr.loss_dict()
     for k, v in ld.items():
+        record("g11_fp32.loss_" + k, v, g["loss_" + k])
         torch.testing.assert_close(v.cpu(), torch.as_tensor(g["loss_" + k]), rtol=2e-3, atol=1e-9)
     total = sum(v for v in ld.values())
     torch.testing.assert_close(total.cpu(), torch.as_tensor(g["loss_total"]), rtol=1e-3, atol=1e-8)
     for name in [str(n) for n in g["grad_names"]]:
         got = _name_to_view(tr, name).cpu()
         gabs = float(g["gabs_" + name])
+        record("g11_fp32.gsum_over_gabs." + name, float(got.double().sum()) / gabs, float(g["gsum_" + name]) / gabs)
+        record("g11_fp32.gabs_rel." + name, float(got.double().abs().sum()) / gabs, 1.0)
+        record("g11_fp32.gprobe." + name, got.flatten()[:: max(1, got.numel() // 64)][:64], g["gprobe_" + name])
         assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= 3e-3 * gabs + 1e-9, name
         assert abs(float(got.double().abs().sum()) - gabs) <= 3e-3 * gabs + 1e-9, name
         probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
@@ -109,6 +121,10 @@ def test_three_training_steps_match_oracle():
         dv = lambda z: z.to(DEV).contiguous()
         rgb = tr.train_step({"origins": dv(o), "directions": dv(d), "times": dv(times)}, dv(target),
                             {"t_rand": dv(rng["t_rand"]), "u": [dv(rng["u"][0]), dv(rng["u"][1])], "bg": dv(rng["bg"])})
+        from tests._measure import record
+
+        record(f"three_steps_fp32.rgb_step{step}", rgb, out["rgb"].detach(), floor=1e-2)
+        record(f"three_steps_fp32.loss_step{step}", sum(tr.loss_dict().values()), loss.detach())
         torch.testing.assert_close(rgb.cpu(), out["rgb"].detach(), rtol=2e-3, atol=5e-5)
         torch.testing.assert_close(sum(tr.loss_dict().values()).cpu(), loss.detach(), rtol=2e-3, atol=1e-7)
     # after step k Adam moves every touched parameter by ~lr: compare parameters (reference layout)
@@ -116,12 +132,17 @@ def test_three_training_steps_match_oracle():
     got = tr.field_planes.to_reference()
     for s in range(2):
         for p in range(6):
+            record("three_steps_fp32.field_planes", got[s][p], P["field_grids"][s][p].detach())
             torch.testing.assert_close(got[s][p].cpu(), P["field_grids"][s][p].detach(), rtol=0, atol=2e-3)
     for a, b in zip(tr.sigma_net.linear_weights(), P["field_sigma"]):
+        record("three_steps_fp32.sigma_net", a, b.detach())
         torch.testing.assert_close(a.cpu(), b.detach(), rtol=0, atol=2e-3)
+    for a, b in zip(tr.color_net.linear_weights(), P["field_color"]):
+        record("three_steps_fp32.color_net", a, b.detach())
     for i in range(2):
         gp = tr.prop_planes[i].to_reference()[0]
         for p in range(6):
+            record("three_steps_fp32.prop_planes", gp[p], P["prop_grids"][i][p].detach())
             torch.testing.assert_close(gp[p].cpu(), P["prop_grids"][i][p].detach(), rtol=0, atol=2e-3)
     assert tr.step == 3 and float(tr.grads.abs().max()) == 0.0  # Adam cleared the gradient buffer
 

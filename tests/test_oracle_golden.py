@@ -368,3 +368,23 @@ def test_g6e_frozen_planes():
                     close(got, ref, rtol=1e-4, atol=1e-6)
                 else:
                     assert float(ref.abs().sum()) == 0 and (got is None or float(got.abs().sum()) == 0)
+
+
+def test_tgrid_oracle_dense_3d_levels_hand_computed_kat():
+    """Dense (non-hashed) 3-D levels of the temporal grid against numbers computed by hand from the reference kernel's text
+    (tests/tgrid_dense_kat.py: strides 1 / 3 / 9 and 1 / 5 / 25, two levels, channel blending, out-of-range inputs, the gradient's support)."""
+    from oracle import tgrid_oracle as TO
+    from tests import tgrid_dense_kat as K
+
+    kw = K.KW
+    offs = TO.level_offsets(kw["num_levels"], kw["base_resolution"], kw["per_level_scale"], kw["log2_hashmap_size"])
+    assert offs == K.OFFSETS
+    tab = TO.channel_table(kw["temporal_dim"], kw["level_dim"])
+    x, t, want = K.inputs(torch)
+    trow = TO.temporal_index(t[:, 0], tab)
+    for gridtype in (0, 1):  # the stride after the loop (27, 125) never exceeds the level's rows: "hash" levels are dense too
+        emb = K.embedding(torch).requires_grad_(True)
+        out = TO.encode(x, trow, emb, offs, float(np.log2(kw["per_level_scale"])), kw["base_resolution"], gridtype, kw["level_dim"])
+        assert torch.equal(out.detach(), want)
+        TO.encode(x[1:2], trow[1:2], emb, offs, 1.0, kw["base_resolution"], gridtype, kw["level_dim"]).sum().backward()
+        assert torch.equal(emb.grad, K.expected_grad(torch))

@@ -2,16 +2,22 @@
 # Run on the GPU box from the repo root: bench line, rocprofv3 kernel stats and the three PMC passes for the judged profiles.
 # usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>_*)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-python bench.py --no-cpu-baseline --no-standin --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null
+fail() { echo "collect_profiles.sh: $1" >&2; exit 1; }
+python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || fail "bench.py failed (see $OUT/${TAG}_bench.err)"
+python bench.py --no-cpu-baseline --no-standin --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null || fail "bench.py --breakdown failed"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --trained-until 0 > /dev/null 2>&1
+# every pass: exit code AND the CSV it must leave behind are checked -- a failed pass must not pass stale or empty numbers on
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --trained-until 0 > $OUT/${TAG}_stats.log 2>&1 \
+  || fail "rocprofv3 --stats pass failed (see $OUT/${TAG}_stats.log)"
+ls $OUT/${TAG}_stats/*/*kernel_stats.csv > /dev/null 2>&1 || ls $OUT/${TAG}_stats/*kernel_stats.csv > /dev/null 2>&1 || fail "no kernel_stats.csv from the --stats pass"
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --trained-until 0 > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --trained-until 0 > $OUT/${TAG}_pmc_$C.log 2>&1 \
+    || fail "rocprofv3 --pmc $C pass failed (see $OUT/${TAG}_pmc_$C.log)"
+  find $OUT/${TAG}_pmc_$C -name '*counter_collection.csv' | grep -q . || fail "no counter_collection.csv from the --pmc $C pass"
 done
 cd $ROOT
 python - <<PY
@@ -46,12 +52,16 @@ with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
             continue
         tr = (2 * v.get("FETCH_SIZE", 0) + v.get("WRITE_SIZE", 0)) * 1024
         g.write(f'"{k}",{v.get("FETCH_SIZE", 0):.1f},{v.get("WRITE_SIZE", 0):.1f},{v.get("TCC_EA0_ATOMIC_sum", 0):.1f},{tr:.0f}\n')
-names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_grouped_kernel<6",
+names = {"adam_planes.field": "snerf::plane_reg_kernel<32, true>", "kplanes_scatter_sorted.field": "snerf::scatter_halfwave_kernel<6",
          "kplanes_gradvec.field": "snerf::gradvec_kernel<32, 6", "kplanes_gather_fwd.field": "snerf::kplanes_gather_fwd_kernel<32, 6>",
          "mlp_bwd.160x128x1": "bwd_kernel<__bf16, 160, 128, 1", "kplanes_gather_bwd.prop": "snerf::kplanes_gather_bwd_kernel<8, 6",
          "kplanes_field_fwd": "field_fwd_kernel", "kplanes_quotient_prepare": "quotient_prepare_kernel"}
 tj = {"_note": "traffic_bytes_per_launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->B) from separate rocprofv3 --pmc passes, k-planes preset, 4096 rays "
-               f"(profiles/{tag}_pmc_counters.csv)"}
+               f"(profiles/{tag}_pmc_counters.csv)",
+      "_fetch_factor": "the factor 2 is MI355X_MICROARCH.md's gfx950 correction ('FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read', "
+                       "16 B per lane; WRITE_SIZE exact for 16-B streaming stores and float atomics).  It is CALIBRATED for the optimiser sweep (float4 per lane: the "
+                       "dominant kernel, whose corrected traffic lands at 0.93x its algorithmic bytes) and uncalibrated for the gather / scatter kernels' narrower "
+                       "accesses: read their figures as ratios between variants, not absolutes"}
 for span, pat in names.items():
     hit = [k for k in acc if pat in k]
     if hit:

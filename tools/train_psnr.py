@@ -190,7 +190,7 @@ def main():
                           for f in torch.linspace(0, len(times) - 1, args.eval_frames).long().tolist()])
     sets = {"camera_20": (held, pick(held)), "novel": (novel, pick(novel)),
             "train": (train, torch.linspace(0, train["images"].shape[0] - 1, 4).long().tolist())}
-    log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps, "scene": args.scene,
+    log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps, "scene": args.scene, "eval_frames": args.eval_frames or "all",
            "trainer": "oracle/torch_standin.StandinTrainer: the reference's algorithm in stock PyTorch-ROCm, fp32" if args.standin else "soccernerfs_amd KPlanesTrainer (HIP)",
            "oracle_init": bool(args.oracle_init or args.standin),
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
