@@ -521,12 +521,13 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
 // either lane-parallel (records, prepared as before) or costs half an instruction; the run-end logic is branch-free selects plus atomics
 // under the lanes' own predicates, addressed with 32-bit byte offsets from wave-uniform bases (saddr form).  Same arithmetic per
 // contribution as before except that the weighted add is one fma (gq * w + acc).
-template <int NP, bool QUOT>
+template <int NP, bool QUOT, int UNROLL = 8>
 __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_desc d, int64_t N, const float* __restrict__ gvec,
                                                               const float4* __restrict__ sorted_rec, float* __restrict__ gplanes,
                                                               int64_t groups_per_seg, int seg_begin, int per_scale,
                                                               const float* __restrict__ planes, int row_stride) {
-  constexpr int C = 32, CH = 256, HALF = CH / 2, UNROLL = 8;
+  constexpr int C = 32, CH = 256, HALF = CH / 2;
+  static_assert(HALF % UNROLL == 0, "a half's records must not run into the other half's");
   // per wave, per entry (in WALK order) 8 dwords: {gvec row BYTE offset, x0 | y0 << 16, texel (x0, y0) BYTE offset in the plane,
   // x1-exists ? 128 : 0 | y1-exists << 31, w(x0y0), w(x0y1), w(x1y0), w(x1y1)}
   __shared__ __align__(16) uint32_t s_rec[4][CH * 8];
@@ -966,7 +967,11 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
   const int stride = desc->C * desc->n_scales;
   hipStream_t st = (hipStream_t)stream;
   if ((int64_t)N * stride * 4 < (1LL << 32) && halfwave_ok(desc, scale_begin, scale_end)) {
-    if (NP == 6) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
+    const char* eu = getenv("SNERF_PASSB_UNROLL");  // dev switch (tools/bench_passb.py)
+    const int un = eu ? atoi(eu) : 8;
+    if (NP == 6 && un == 16) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true, 16>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
+    else if (NP == 6 && un == 4) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true, 4>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
+    else if (NP == 6) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
     else hipLaunchKernelGGL((scatter_halfwave_kernel<3, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
     SNERF_LAUNCH_CHECK("kplanes_scatter_quotient");
     return 0;

@@ -113,9 +113,11 @@ class SortedScatter:
                 raise ValueError("the quotient scatter is built for C = 32, concatenated scales and N * 32 * n_scales < 2^31")
             rows = N * len(ps.resolutions)
             self.G = torch.empty(N, ps.out_dim, dtype=torch.float32, device=device)       # gfeat .* feat
-            # fix list: {element index, feature gradient} per vanished feature with a non-zero gradient (2 int32 per entry; entries beyond the
-            # capacity are dropped -- N * n_scales entries = one per (sample, scale) row is far beyond what training produces)
-            self.fix_capacity = max(rows, 1)
+            # fix list: {element index, feature gradient} per vanished feature with a non-zero gradient (2 int32 per entry).  Sized for the
+            # WORST case -- every element of the feature tensor (planes that are all zero, e.g. an imported checkpoint): entries beyond the
+            # capacity would be dropped silently, and with them the only gradient such planes can receive.  8 B x N x C n_scales (335 MB at the
+            # preset, never touched in normal training) of 288 GB.
+            self.fix_capacity = max(N * ps.out_dim, 1)
             self.fix_list = torch.empty(2 * self.fix_capacity, dtype=torch.int32, device=device)
             self.fix_counts = torch.zeros(2, dtype=torch.int32, device=device)  # used alternately: a prepare resets the other one for the next step
             self._fix_parity = 0

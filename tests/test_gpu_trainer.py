@@ -53,32 +53,39 @@ def test_fused_step_matches_reference_golden():
         record(f"g11_fp32.sbins_{i}", tr.buf["sb"][i], g[f"sbins_{i}"])
         record(f"g11_fp32.ebins_{i}", tr.buf["eb"][i], g[f"ebins_{i}"])
         record(f"g11_fp32.weights_{i}", tr.buf["w"][i], g[f"weights_{i}"], floor=1e-3)
-        torch.testing.assert_close(tr.buf["sb"][i].cpu(), g[f"sbins_{i}"], rtol=0, atol=1e-5)
-        torch.testing.assert_close(tr.buf["eb"][i].cpu(), g[f"ebins_{i}"], rtol=0, atol=3e-5)
-        torch.testing.assert_close(tr.buf["w"][i].cpu(), g[f"weights_{i}"], rtol=2e-3, atol=2e-5)
+        # bounds = ~5x the deviations measured on MI355X (profiles/r04_parity_deviations.json): bins 4.2e-7 / 1.2e-6 abs,
+        # weights 2.1e-7 abs, rgb / accumulation / depth 2.4e-7 abs
+        torch.testing.assert_close(tr.buf["sb"][i].cpu(), g[f"sbins_{i}"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(tr.buf["eb"][i].cpu(), g[f"ebins_{i}"], rtol=0, atol=6e-6)
+        torch.testing.assert_close(tr.buf["w"][i].cpu(), g[f"weights_{i}"], rtol=1e-5, atol=1e-6)
     record("g11_fp32.rgb", rgb, g["rgb"], floor=1e-2)
     record("g11_fp32.accumulation", tr.buf["acc"], g["accumulation"][:, 0], floor=1e-2)
     record("g11_fp32.depth", tr.buf["depth"], g["depth"][:, 0])
-    torch.testing.assert_close(rgb.cpu(), g["rgb"], rtol=1e-3, atol=2e-5)
-    torch.testing.assert_close(tr.buf["acc"].cpu(), g["accumulation"][:, 0], rtol=1e-3, atol=2e-5)
-    torch.testing.assert_close(tr.buf["depth"].cpu(), g["depth"][:, 0], rtol=0, atol=1e-4)
+    torch.testing.assert_close(rgb.cpu(), g["rgb"], rtol=1e-5, atol=1e-6)  # SURVEY 8d's fp32 tolerance, at the model level too
+    torch.testing.assert_close(tr.buf["acc"].cpu(), g["accumulation"][:, 0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(tr.buf["depth"].cpu(), g["depth"][:, 0], rtol=0, atol=2e-6)
     tr.backward(t("target"), rng, proposal_grads=True)
     ld = tr.loss_dict()
     for k, v in ld.items():
         record("g11_fp32.loss_" + k, v, g["loss_" + k])
-        torch.testing.assert_close(v.cpu(), torch.as_tensor(g["loss_" + k]), rtol=2e-3, atol=1e-9)
+        # measured: every term <= 1.3e-7 relative, except the interlevel loss (a sum of near-cancelling (w - w_outer)^2 / w terms, 2.3e-8 in value):
+        # 1.6e-4 relative = 3.6e-12 absolute
+        torch.testing.assert_close(v.cpu(), torch.as_tensor(g["loss_" + k]), rtol=1e-3 if k == "interlevel_loss" else 1e-6, atol=1e-12)
     total = sum(v for v in ld.values())
-    torch.testing.assert_close(total.cpu(), torch.as_tensor(g["loss_total"]), rtol=1e-3, atol=1e-8)
+    torch.testing.assert_close(total.cpu(), torch.as_tensor(g["loss_total"]), rtol=1e-6, atol=1e-10)
     for name in [str(n) for n in g["grad_names"]]:
         got = _name_to_view(tr, name).cpu()
         gabs = float(g["gabs_" + name])
         record("g11_fp32.gsum_over_gabs." + name, float(got.double().sum()) / gabs, float(g["gsum_" + name]) / gabs)
         record("g11_fp32.gabs_rel." + name, float(got.double().abs().sum()) / gabs, 1.0)
         record("g11_fp32.gprobe." + name, got.flatten()[:: max(1, got.numel() // 64)][:64], g["gprobe_" + name])
-        assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= 3e-3 * gabs + 1e-9, name
-        assert abs(float(got.double().abs().sum()) - gabs) <= 3e-3 * gabs + 1e-9, name
+        # measured (relative to sum |g|): field planes and nets <= 7.6e-6; the proposal levels' tensors 1.1e-4 (level 0) and 8.2e-4 (level 1), one
+        # common factor per level -- they all hang off the interlevel loss' gradient, whose cancellation the line above describes
+        lim = 4e-3 if name.startswith("prop.") else 4e-5
+        assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= lim * gabs + 1e-12, name
+        assert abs(float(got.double().abs().sum()) - gabs) <= lim * gabs + 1e-12, name
         probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
-        torch.testing.assert_close(probe, g["gprobe_" + name], rtol=5e-3, atol=1e-7 + 2e-3 * float(g["gprobe_" + name].abs().max()))
+        torch.testing.assert_close(probe, g["gprobe_" + name], rtol=0, atol=1e-12 + (4e-3 if name.startswith("prop.") else 6e-5) * float(g["gprobe_" + name].abs().max()))
 
 
 def test_three_training_steps_match_oracle():
@@ -125,25 +132,26 @@ def test_three_training_steps_match_oracle():
 
         record(f"three_steps_fp32.rgb_step{step}", rgb, out["rgb"].detach(), floor=1e-2)
         record(f"three_steps_fp32.loss_step{step}", sum(tr.loss_dict().values()), loss.detach())
-        torch.testing.assert_close(rgb.cpu(), out["rgb"].detach(), rtol=2e-3, atol=5e-5)
-        torch.testing.assert_close(sum(tr.loss_dict().values()).cpu(), loss.detach(), rtol=2e-3, atol=1e-7)
+        torch.testing.assert_close(rgb.cpu(), out["rgb"].detach(), rtol=1e-5, atol=1e-6)  # measured 1.2e-7 abs
+        torch.testing.assert_close(sum(tr.loss_dict().values()).cpu(), loss.detach(), rtol=1e-6, atol=1e-9)  # measured 7.6e-8 rel
     # after step k Adam moves every touched parameter by ~lr: compare parameters (reference layout)
     tr.synchronize()  # the field planes' optimiser sweep runs on its own stream
     got = tr.field_planes.to_reference()
     for s in range(2):
         for p in range(6):
             record("three_steps_fp32.field_planes", got[s][p], P["field_grids"][s][p].detach())
-            torch.testing.assert_close(got[s][p].cpu(), P["field_grids"][s][p].detach(), rtol=0, atol=2e-3)
+            torch.testing.assert_close(got[s][p].cpu(), P["field_grids"][s][p].detach(), rtol=0, atol=1.5e-5)  # measured 2.9e-6 after three Adam steps
     for a, b in zip(tr.sigma_net.linear_weights(), P["field_sigma"]):
         record("three_steps_fp32.sigma_net", a, b.detach())
-        torch.testing.assert_close(a.cpu(), b.detach(), rtol=0, atol=2e-3)
+        torch.testing.assert_close(a.cpu(), b.detach(), rtol=0, atol=1.5e-6)  # measured 2.4e-7
     for a, b in zip(tr.color_net.linear_weights(), P["field_color"]):
         record("three_steps_fp32.color_net", a, b.detach())
+        torch.testing.assert_close(a.cpu(), b.detach(), rtol=0, atol=1.5e-6)  # measured 2.2e-7
     for i in range(2):
         gp = tr.prop_planes[i].to_reference()[0]
         for p in range(6):
             record("three_steps_fp32.prop_planes", gp[p], P["prop_grids"][i][p].detach())
-            torch.testing.assert_close(gp[p].cpu(), P["prop_grids"][i][p].detach(), rtol=0, atol=2e-3)
+            torch.testing.assert_close(gp[p].cpu(), P["prop_grids"][i][p].detach(), rtol=0, atol=1e-5)  # measured 2.0e-6
     assert tr.step == 3 and float(tr.grads.abs().max()) == 0.0  # Adam cleared the gradient buffer
 
 

@@ -42,7 +42,9 @@ def main():
     b, ss = tr.buf, tr._ss
     co = ops.coords_from_rays(tr.rays["origins"], tr.rays["directions"], tr.rays["times"].reshape(-1), b["eb"][2], tr.aabb, True)
     ss.sort(co)
-    ss.quotient_prepare(b["gfeat"], b["feat"])
+    if not tr._qg_step:  # round 3's flow: G from the separate pass; with the quotient epilogue the last step's G is still in ss.G
+        ss.quotient_prepare(b["gfeat"], b["feat"])
+    assert float(ss.G.abs().max()) > 0
     planes = tr.field_planes.planes
     g = torch.zeros_like(planes)
     ns = len(cfg.multiscale_res)
@@ -60,15 +62,17 @@ def main():
         return e0.elapsed_time(e1) / args.iters
 
     res, grads = {}, {}
-    for name, env in (("scatter_grouped (round 2)", "1"), ("scatter_halfwave (round 4)", "0")):
+    for name, env, un in (("scatter_grouped (round 2)", "1", "8"), ("scatter_halfwave (round 4)", "0", "8"), ("scatter_halfwave unroll 16", "0", "16"),
+                          ("scatter_halfwave unroll 4", "0", "4")):
         os.environ["SNERF_PASSB_GROUPED"] = env
+        os.environ["SNERF_PASSB_UNROLL"] = un
         res[name] = {"ms_all_scales": timed(0, ns), "ms_finest": timed(ns - 1, ns), "ms_coarser": timed(0, ns - 1)}
         g.zero_()
         ss.quotient_scatter_scales(planes, co, b["gfeat"], g, 0, ns)
         torch.cuda.synchronize()
         grads[name] = g.clone()
         res[name]["grad_norm"] = float(g.double().norm())
-    a, c = grads.values()
+    a, c = list(grads.values())[:2]
     out = {"entries": int(ss.N) * ns * 6, "kernels": res, "rel_l2_between_kernels": float((a - c).double().norm() / a.double().norm()),
            "max_abs_diff": float((a - c).abs().max()), "grad_abs_max": float(a.abs().max()), "fix_rows": int(ss.fix_count.item())}
     print(json.dumps(out))

@@ -1,36 +1,41 @@
 #!/bin/bash
-# Run on the GPU box from the repo root: MFMA-pipe utilisation of the MLP kernels (separate --pmc passes, kernel-trace only).
+# Run on the GPU box from the repo root: MFMA-pipe utilisation, LDS waits and occupancy of the MFMA kernels of the DEFAULT path (mlp_lp_fwd / bwd /
+# bwd_tr, field_fwd_kernel, density_fwd_kernel) -- separate --pmc passes, kernel-trace only.
 # usage: bash tools/collect_mfma_pmc.sh <tag> [bench flags]     -> gpurun_out/<tag>_mfma_pmc.csv
 set -u
-TAG=${1:-r01}; shift
+TAG=${1:-r04}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for C in SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmcm_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --images 38 "$@" > /dev/null 2>&1
+n_ok=0
+for SET in "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU"; do
+  t=$(echo $SET | tr ' ' '_' | cut -c1-40)
+  if rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/${TAG}_pmcm_$t -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --no-steady-state "$@" > $OUT/${TAG}_pmcm_$t.log 2>&1 \
+     && find $OUT/${TAG}_pmcm_$t -name '*counter_collection.csv' | grep -q .; then n_ok=$((n_ok + 1)); else echo "collect_mfma_pmc.sh: pass '$SET' failed (see $OUT/${TAG}_pmcm_$t.log)" >&2; fi
 done
 cd $ROOT
-python - <<PY
-import csv, glob, collections
-out, tag = "gpurun_out", "$TAG"
-acc = collections.defaultdict(dict)
-for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE"):
-    f = glob.glob(f"{out}/{tag}_pmcm_{c}/**/*counter_collection.csv", recursive=True)
-    if not f:
-        continue
-    tmp = collections.defaultdict(list)
-    for r in csv.DictReader(open(f[0])):
-        if r["Counter_Name"] == c and "mlp" in r["Kernel_Name"]:
-            tmp[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
-    for k, v in tmp.items():
-        acc[k][c] = sum(v) / len(v)
+if [ $n_ok -lt 3 ]; then echo "collect_mfma_pmc.sh: fewer than three counter passes succeeded" >&2; exit 1; fi
+TAG=$TAG ARGS="$*" python - <<'PY'
+import csv, glob, collections, os
+out, tag = "gpurun_out", os.environ["TAG"]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{out}/{tag}_pmcm_*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if any(p in k for p in ("mlp_lp_", "field_fwd_kernel", "density_fwd_kernel")):
+            acc[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+cols = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+        "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU"]
 with open(f"{out}/{tag}_mfma_pmc.csv", "w") as g:
-    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --images 38 $*   (one counter per pass; mean per launch)\n")
-    g.write("# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): share of the chip's matrix pipes busy while the kernel\n# runs (GRBM_GUI_ACTIVE is summed over the 8 XCDs; cross-check: sigma_net backward issues 16.4 M v_mfma_f32_16x16x4_f32 x 32 cycles = 524 M)\n")
-    g.write("kernel,SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CU_CYCLES,GRBM_GUI_ACTIVE,mfma_busy_frac\n")
-    for k, v in sorted(acc.items()):
-        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
-        frac = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4 * 256 * gui / 8) if gui else float("nan")
-        g.write(f'"{k}",{v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0):.0f},{v.get("SQ_BUSY_CU_CYCLES", 0):.0f},{gui:.0f},{frac:.3f}\n')
+    g.write(f"# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --no-steady-state {os.environ['ARGS']}   (one counter set per pass; mean per launch)\n")
+    g.write("# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): share of the chip's matrix pipes busy while the kernel runs\n")
+    g.write("# (GRBM_GUI_ACTIVE is summed over the 8 XCDs).  wait_frac / lds_wait_frac / issue_frac = SQ_WAIT_ANY / SQ_WAIT_INST_LDS / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES\n")
+    g.write("# (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES); waves_per_simd = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES x (SQ_BUSY_CYCLES counts per SE: a relative figure)\n")
+    g.write("kernel," + ",".join(cols) + ",mfma_busy_frac,wait_frac,lds_wait_frac,issue_frac\n")
+    for k, d in sorted(acc.items()):
+        m = {c: (sum(d[c]) / len(d[c]) if d.get(c) else float("nan")) for c in cols}
+        gui, wc = m["GRBM_GUI_ACTIVE"], m["SQ_WAVE_CYCLES"]
+        frac = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * gui / 8) if gui == gui and gui else float("nan")
+        g.write(f'"{k}",' + ",".join(f"{m[c]:.0f}" for c in cols) + f",{frac:.3f},{m['SQ_WAIT_ANY'] / wc:.3f},{m['SQ_WAIT_INST_LDS'] / wc:.3f},{m['SQ_ACTIVE_INST_ANY'] / wc:.3f}\n")
 print(open(f"{out}/{tag}_mfma_pmc.csv").read())
 PY
 rm -rf $OUT/${TAG}_pmcm_*

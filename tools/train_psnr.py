@@ -90,6 +90,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     run = {"seed": seed, "evals": []}
     t_train, t_eval = 0.0, 0.0
     t_start, last_step = time.time(), args.steps - 1
+    eval_at = {int(x) for x in args.eval_at.split(",") if x}
 
     def evaluate(step):
         nonlocal t_eval
@@ -135,7 +136,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
                 print(f"[seed {seed}] step {step + 1}: {R * 1000 / dt:,.0f} rays/s  rgb_loss {ld['rgb_loss']:.5f} "
                       f"(psnr~{-10 * torch.log10(torch.tensor(ld['rgb_loss'])).item():.2f}) interlevel {ld['interlevel_loss']:.2e} "
                       f"skipped steps {trainer.skipped_steps()}", flush=True)
-        if (step + 1) % args.eval_every == 0 and step + 1 < args.steps:
+        if ((step + 1) % args.eval_every == 0 or (step + 1) in eval_at) and step + 1 < args.steps:
             evaluate(step)
     evaluate(last_step)
     run["train_seconds"] = t_train
@@ -170,6 +171,7 @@ def main():
     ap.add_argument("--standin", action="store_true",
                     help="train the REFERENCE'S ALGORITHM in stock PyTorch (oracle/torch_standin.StandinTrainer: F.grid_sample per plane, Linear stacks, autograd, "
                          "two torch.optim.Adam, fp32) instead of the HIP trainer -- same pixel draws, rays, schedule and evaluation; ~95 ms / step")
+    ap.add_argument("--eval-at", default="", help="extra evaluation steps, comma separated (e.g. the step a stand-in run got to)")
     ap.add_argument("--train-budget-s", type=float, default=0.0, help="stop training when this much wall-clock is spent (a gpurun call is capped at one hour), "
                     "evaluate there and record `stopped_early_at_step`")
     ap.add_argument("--oracle-init", action="store_true", help="HIP trainer from the stand-in's initial parameters of the same seed")
