@@ -76,6 +76,40 @@ def _cpu_model():
     return "unknown"
 
 
+def _physical_cores():
+    """Distinct (physical id, core id) pairs of /proc/cpuinfo; falls back to the logical count."""
+    try:
+        seen, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((phys, ln.split(":", 1)[1].strip()))
+        return len(seen) or (os.cpu_count() or 1)
+    except OSError:
+        return os.cpu_count() or 1
+
+
+def cpu_all_cores_leg(timeout_s=75):
+    """BASELINE.md section 3 asks for torch.set_num_threads(all physical cores).  The step is ~1500 small ops, so that many threads only
+    synchronise; to put a NUMBER on it without risking the bench's run time, config 1 is timed with every physical core in a child process
+    under a time limit (no GPU is touched there)."""
+    import subprocess
+
+    n = _physical_cores()
+    code = ("import sys, json, torch; sys.path.insert(0, %r); torch.set_num_threads(%d); torch.manual_seed(0);"
+            "from oracle import torch_standin as TS; r = TS.time_train_steps('cpu', 256, steps=3, warmup=1, model=TS.CONFIG1);"
+            "print(json.dumps({'rays_per_s': r['rays_per_s'], 'ms_per_step': r['seconds_per_step'] * 1e3}))") % (ROOT, n)
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+        return {"threads": n, "value": r["rays_per_s"], "unit": "rays/s", "ms_per_step": r["ms_per_step"], "sample": "config 1, 3 full train steps after 1 warm-up"}
+    except subprocess.TimeoutExpired:
+        return {"threads": n, "value": None, "note": f"did not finish 4 train steps of config 1 within {timeout_s} s (the 16-thread run takes ~0.1 s per step)"}
+    except Exception as e:
+        return {"threads": n, "value": None, "note": f"{type(e).__name__}: {e}"[:200]}
+
+
 def cpu_baseline(rays_per_step=256, steps=4):
     """The stock-PyTorch restatement of the reference's K-Planes train step (oracle/torch_standin.py: F.grid_sample per plane, Linear
     stacks, autograd, torch.optim.Adam) on the host cores: a 256-ray slice of config 2 (the preset's planes) and config 1 itself
@@ -91,7 +125,8 @@ def cpu_baseline(rays_per_step=256, steps=4):
     return {"value": c2["rays_per_s"], "unit": "rays/s", "cores": n_threads, "kind": "port",
             "sample": f"{steps} full train steps (fwd + autograd bwd + torch.optim.Adam, k-planes preset planes = config 2, fp32) of {rays_per_step} rays each, "
                       "stock PyTorch on the host cores (oracle/torch_standin.py)",
-            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "torch_threads": n_threads, "torch": torch.__version__,
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": _physical_cores(), "torch_threads": n_threads,
+            "torch": torch.__version__, "config1_all_physical_cores": cpu_all_cores_leg(),
             "config1": {"value": c1["rays_per_s"], "unit": "rays/s", "ms_per_step": c1["seconds_per_step"] * 1e3,
                         "sample": "BASELINE.json configs[0]: single scale (64,64,64,8), C=32, proposals (128^3,8)/(256^3,8), samples 256/128/64, 256 rays/step, "
                                   "fp32, 20 full train steps after 2 warm-up"}}

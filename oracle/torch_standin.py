@@ -122,14 +122,16 @@ class StandinTrainer:
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         return self._ld
 
-    def train_step(self, rays: Dict[str, torch.Tensor], target: torch.Tensor):
+    def train_step(self, rays: Dict[str, torch.Tensor], target: torch.Tensor, rng: Optional[Dict] = None):
+        """rng: the step's uniform draws {"t_rand", "u": [.,.], "bg"} (tools/compare_standin_steps.py feeds both trainers the same ones); None = own draws."""
         R, (S0, S1, S2) = self.R, self.S
         step = self.step
         anneal = KO.anneal_value(step)
         sstep = max(step - 1, 0)  # the sampler's counter is set AFTER the iteration (kplanes.py:340-346)
         updated = self._since > KO.update_schedule(sstep) or sstep < 10
         rnd = lambda *s: torch.rand(*s, device=self.dev, generator=self.gen)
-        rng = {"t_rand": rnd(R, S0 + 1), "u": [rnd(R, S1 + 1), rnd(R, S2 + 1)], "bg": rnd(R, 3)}
+        if rng is None:
+            rng = {"t_rand": rnd(R, S0 + 1), "u": [rnd(R, S1 + 1), rnd(R, S2 + 1)], "bg": rnd(R, 3)}
         lr = 1e-2 * KO.cosine_lr_factor(step, max_steps=self.max_steps)
         for opt in self.opts.values():
             for g in opt.param_groups:

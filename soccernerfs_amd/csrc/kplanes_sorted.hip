@@ -585,9 +585,8 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
   }
   // the walk: this half's entries are R[half * HALF + i]; pending cell = (pk, pa: byte offset of its (x0, y0) texel + this lane's channel,
   // pdx / pdy: byte steps to its x0 + 1 column / y0 + 1 row, 0 where clamped) with accumulators p00 (x0,y0), p01 (x0,y1), p10 (x1,y0), p11 (x1,y1).
-  // The pending cell starts as the half's FIRST entry with empty accumulators, so no flush ever sees an invalid cell and the adds need no
-  // "is there anything" tests: a clamped column / row or a null record (chunk tail) adds 0.0f to a texel that exists, which changes nothing
-  // (+0 + -0 = +0: untouched texels stay exactly zero for the optimiser sweep's skip test).
+  // The pending cell starts as the half's FIRST entry with empty accumulators, so no flush ever sees an invalid cell.  Zero sums (a clamped
+  // column / row, a null record of the chunk's tail) are not sent: measured 0.445 -> 0.431 ms, 13 % fewer atomic requests.
   const uint32_t* Rh = R + half * (HALF * 8);
   const uint32_t chB = (uint32_t)ch * 4u;
   uint32_t pk, pa, pdx, pdy;
@@ -596,7 +595,9 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
     pk = hd.y; pa = hd.z + chB; pdx = hd.w & 0xffu; pdy = (hd.w >> 31) ? rowB : 0u;
   }
   float p00 = 0.f, p01 = 0.f, p10 = 0.f, p11 = 0.f;
-  auto add = [&](uint32_t off, float v) { atomicAdd(reinterpret_cast<float*>(gbase + off), v); };
+  auto add = [&](uint32_t off, float v) {
+    if (v != 0.f) atomicAdd(reinterpret_cast<float*>(gbase + off), v);
+  };
   const int iters = cnt > HALF ? HALF : cnt;  // half 1 walks null records where the chunk is short
   for (int e0 = 0; e0 < iters; e0 += UNROLL) {
     float g[UNROLL];
@@ -967,11 +968,7 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
   const int stride = desc->C * desc->n_scales;
   hipStream_t st = (hipStream_t)stream;
   if ((int64_t)N * stride * 4 < (1LL << 32) && halfwave_ok(desc, scale_begin, scale_end)) {
-    const char* eu = getenv("SNERF_PASSB_UNROLL");  // dev switch (tools/bench_passb.py)
-    const int un = eu ? atoi(eu) : 8;
-    if (NP == 6 && un == 16) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true, 16>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
-    else if (NP == 6 && un == 4) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true, 4>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
-    else if (NP == 6) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
+    if (NP == 6) hipLaunchKernelGGL((scatter_halfwave_kernel<6, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
     else hipLaunchKernelGGL((scatter_halfwave_kernel<3, true>), grid, dim3(256), 0, st, dd, N, G, rec, grad_planes, gps, scale_begin * NP, stb.per_scale, planes, stride);
     SNERF_LAUNCH_CHECK("kplanes_scatter_quotient");
     return 0;

@@ -62,10 +62,8 @@ def main():
         return e0.elapsed_time(e1) / args.iters
 
     res, grads = {}, {}
-    for name, env, un in (("scatter_grouped (round 2)", "1", "8"), ("scatter_halfwave (round 4)", "0", "8"), ("scatter_halfwave unroll 16", "0", "16"),
-                          ("scatter_halfwave unroll 4", "0", "4")):
+    for name, env in (("scatter_grouped (round 2)", "1"), ("scatter_halfwave (round 4)", "0")):
         os.environ["SNERF_PASSB_GROUPED"] = env
-        os.environ["SNERF_PASSB_UNROLL"] = un
         res[name] = {"ms_all_scales": timed(0, ns), "ms_finest": timed(ns - 1, ns), "ms_coarser": timed(0, ns - 1)}
         g.zero_()
         ss.quotient_scatter_scales(planes, co, b["gfeat"], g, 0, ns)

@@ -60,3 +60,27 @@ for K in (64, 256, 1024):
     if K == 64:
         print(f"  today: {tot_now / 1e6:.2f} M texel-row flushes")
     print(f"  chunk {K:5d}: {tot_distinct / 1e6:.2f} M distinct (chunk, texel) rows")
+
+# ---- round 4: what a larger re-sort window of pass B would save.  A wave re-sorts ITS window of consecutive sorted entries by this scale's key, so
+# the cell flushes it issues = the distinct keys inside the window, summed over the windows (x-carry aside).
+print("distinct (cell) keys per window, summed over the windows, per entry -- windows of 256 (pass B today), 1024, 4096 entries; 'all' = distinct keys of the segment")
+tot = {256: 0, 1024: 0, 4096: 0, "all": 0}
+for si, m in enumerate((1, 2, 4, 8, 16)):
+    res = [64 * m, 64 * m, 64 * m, 100]
+    line = f"scale {m:2d}:"
+    for q, (a, b) in enumerate(pairs):
+        xa, xb = rec[q, :, 1], rec[q, :, 2]
+        pa = (((xa + 1) / 2) * (res[a] - 1)).clamp(0, res[a] - 1).floor().long()
+        pb = (((xb + 1) / 2) * (res[b] - 1)).clamp(0, res[b] - 1).floor().long()
+        key = pb * res[a] + pa
+        cell = []
+        for wnd in (256, 1024, 4096):
+            k2 = key.view(-1, wnd) + (torch.arange(N // wnd, device=dev)[:, None] << 40)  # keys made unique per window
+            n = torch.unique(k2).numel()
+            tot[wnd] += n
+            cell.append(n / N)
+        u = torch.unique(key).numel()
+        tot["all"] += u
+        line += " " + "/".join(f"{c:.3f}" for c in cell) + f"/{u / N:.3f}"
+    print(line)
+print({k: round(v / 1e6, 3) for k, v in tot.items()}, "M cell flushes per step")
