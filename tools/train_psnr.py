@@ -66,7 +66,7 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
     random.seed(seed)
     cfg = KPlanesTrainConfig(max_steps=args.schedule_steps, mlp_operands=args.mlp_operands, seed=seed, deterministic=args.deterministic,
                              nonfinite_policy=args.nonfinite_policy, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter, gvec_dtype=args.gvec_dtype,
-                             emulate_transports=args.emulate_transports,
+                             emulate_transports=args.emulate_transports, quotient_epilogue=not args.no_quotient_epilogue, fused_proposal=not args.no_fused_proposal,
                              sigma_operands=args.sigma_operands, color_operands=args.color_operands, proposal_operands=args.proposal_operands)
     R = 4096
     if args.standin:
@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--deterministic", action="store_true", help="fixed-point gradient accumulation: bit-identical reruns")
     ap.add_argument("--nonfinite-policy", default="skip_step", choices=["skip_step", "drop_elements"])
     ap.add_argument("--no-fused-field", action="store_true", help="unfused forward kernels")
+    ap.add_argument("--no-quotient-epilogue", action="store_true", help="round 3's flow: G = gfeat .* feat from the separate pass over fp32 features (A-B)")
+    ap.add_argument("--no-fused-proposal", action="store_true", help="proposal levels as gather + net kernels (A-B; bit-identical densities)")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="product form of the field's sorted scatter")
     ap.add_argument("--emulate-transports", default="", choices=["", "grad", "param", "both"],
                     help="single-GPU emulation of the bf16 gradient / parameter-update transports of the sharded multi-GPU step (KPlanesTrainConfig.emulate_transports)")
@@ -198,6 +200,7 @@ def main():
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
            "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
            "emulate_transports": args.emulate_transports, "time_sorted_rays": args.time_sorted_rays, "fused_field": not args.no_fused_field, "quotient_scatter": not args.no_quotient_scatter,
+           "quotient_epilogue": not args.no_quotient_epilogue, "fused_proposal": not args.no_fused_proposal,
            "eval_sets": {"camera_20": "20th arc camera (reference 'all' split eval camera; extrapolated view), %d frames" % len(sets["camera_20"][1]),
                          "novel": "3 evaluation-only cameras between training cameras (interpolated views), %d images" % len(sets["novel"][1]),
                          "train": "4 training images"},
