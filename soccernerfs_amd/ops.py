@@ -160,11 +160,13 @@ class SortedScatter:
         the gradients it needs)."""
         st = stream if stream is not None else _stream()
         L = _lib.lib()
-        _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
-                                                           scale_begin, scale_end, st), "scatter_quotient")
+        # the fix-up first: both kernels only ADD to the gradient planes, and this way pass B -- not a 5 us launch behind it -- is what the optimiser
+        # sweep's stream waits for
         _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(self.fix_list),
                                                   _ptr(self.fix_count), self.fix_capacity, _ptr(gplanes), scale_begin, scale_end, st),
                    "quotient_fixup")
+        _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
+                                                           scale_begin, scale_end, st), "scatter_quotient")
 
     def scatter_quotient(self, planes, coords: _lib.Coords, gfeat, feat, gplanes, stream=None):
         """gplanes += d(sum gfeat . features)/d planes, with feat = the forward's features [N, C n_scales] (fp32)."""
