@@ -12,6 +12,8 @@
 //    atomically added by ADJACENT lanes, so a corner costs one 64-B request instead of up to three;
 //  * outputs are written [B, L*C] directly (the reference writes [L,B,C] and permutes in Python);
 //  * sample coordinates can be derived in-kernel from rays (snerf_coords mode 1), as for the K-Planes gather.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace snerf {
@@ -171,6 +173,114 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
   }
 }
 
+// ---- backward, run-length form (round 4): samples of ONE ray, per-ray times (what the fused trainers hand over) ----
+// tgrid_kernel<true> issues one float atomic per (sample, level, corner, live column): 20.7 M 64-B requests per step of config 4, and the pass runs AT the
+// chip-wide float-atomic rate (1.2 TB/s of written bytes, profiles/r04_kernels.md section 7).  Consecutive samples of a ray fall into the same cell on
+// every level whose cells are wider than the sample spacing -- all of them for the proposal grids (max_res 64 / 256 against 256 / 96 samples per ray),
+// the coarser half for the main grid -- and a ray has ONE time, hence one set of live columns.  Here a lane group (2 C lanes = (channel, a | b column),
+// as before) walks a SEGMENT of consecutive samples of one ray at one level and sums the eight corner contributions in registers while the cell stays
+// the same; it sends them when the cell changes.  Same additions as before in another association (float atomics are order-dependent anyway).
+constexpr int TG_RUN = 32;  // samples per segment (a ray of S samples = ceil(S / 32) segments of equal length, the last one shorter)
+
+__global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int segs, int run) {
+  const int C = a.d.C, LPG = 2 * C;
+  const int S = a.c.S;
+  const int64_t R = a.B / S;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t grp = gid / LPG;
+  const int k = (int)(gid - grp * LPG);
+  const int ch = k >> 1, ab = k & 1;
+  const int level = blockIdx.y;
+  const int64_t r = grp / segs;
+  const int seg = (int)(grp - r * segs);
+  if (r >= R) return;
+  int col;
+  float wt;
+  tg_slot_from_time(a.times[r], C, a.d.grid_C - C - 1, ch, ab, col, wt);
+  if (wt == 0.f) return;  // this (channel, column) slot is dead for the whole ray
+  const int s0 = seg * run, s1 = (s0 + run) < S ? (s0 + run) : S;
+
+  const uint32_t off0 = (uint32_t)a.d.offsets[level];
+  const uint32_t hashmap_size = (uint32_t)(a.d.offsets[level + 1] - a.d.offsets[level]);
+  const float scale = exp2f((float)level * a.d.S) * (float)a.d.H - 1.0f;
+  const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+  const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+  uint32_t mult[3];
+  bool hashed;
+  {
+    uint32_t stride = 1;
+    for (int d = 0; d < 3 && stride <= hashmap_size; ++d) stride *= a.d.align_corners ? resolution : (resolution + 1);
+    hashed = a.d.gridtype == 0 && stride > hashmap_size;
+    uint32_t st = 1;
+    for (int d = 0; d < 3; ++d) {
+      mult[d] = hashed ? primes[d] : (st <= hashmap_size ? st : 0u);
+      if (st <= hashmap_size) st *= a.d.align_corners ? resolution : (resolution + 1);
+    }
+  }
+  const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
+  float o[3], dir[3], inv[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    o[d] = a.c.origins[r * 3 + d];
+    dir[d] = a.c.dirs[r * 3 + d];
+    inv[d] = a.c.aabb_max[d] - a.c.aabb_min[d];
+  }
+  const float* eb = a.c.ebins + r * (S + 1);
+  const float* gp = a.gout + (r * S) * (int64_t)(a.d.L * C) + level * C + ch;
+  const int gstride = a.d.L * C;
+
+  uint32_t ppg[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};  // no cell: floor() of a coordinate in [0, scale + 0.5] never gives this
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  auto flush = [&]() {
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      if (acc[idx] != 0.f) {
+        uint32_t index = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const uint32_t t = (ppg[d] + ((idx >> d) & 1)) * mult[d];
+          index = hashed ? (index ^ t) : (index + t);
+        }
+        const uint32_t row = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
+        atomicAdd(a.gemb + ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)col, acc[idx]);
+        acc[idx] = 0.f;
+      }
+    }
+  };
+  for (int s = s0; s < s1; ++s) {
+    const float g = gp[(int64_t)s * gstride] * wt;
+    const float mid = eb[s] + eb[s + 1];
+    float pos[3];
+    uint32_t pg[3];
+    bool oob = false;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float p = o[d] + (dir[d] * mid) / 2.f;
+      const float x = (p - a.c.aabb_min[d]) / inv[d];
+      oob |= (x < 0.f) || (x > 1.f);
+      pos[d] = x * scale + (a.d.align_corners ? 0.0f : 0.5f);
+      const float f = floorf(pos[d]);
+      pg[d] = (uint32_t)f;
+      pos[d] -= f;
+    }
+    if (oob || g == 0.f) continue;  // out-of-range samples get no gradient (.cu:119-124); nothing to add
+    if (pg[0] != ppg[0] || pg[1] != ppg[1] || pg[2] != ppg[2]) {
+      flush();
+      ppg[0] = pg[0]; ppg[1] = pg[1]; ppg[2] = pg[2];
+    }
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+      float w = 1.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) w *= ((idx >> d) & 1) ? pos[d] : 1.f - pos[d];
+      acc[idx] += w * g;
+    }
+  }
+  flush();
+}
+
 static int validate(const snerf_tgrid_desc* d, const snerf_coords* c, const float* trow, const float* times, int spr, int64_t B) {
   SNERF_REQUIRE(d && c, "tgrid: null descriptor");
   SNERF_REQUIRE(d->D >= 1 && d->D <= 3, "tgrid: D=%d unsupported (1..3)", d->D);
@@ -184,6 +294,12 @@ static int validate(const snerf_tgrid_desc* d, const snerf_coords* c, const floa
   if (c->mode == 0) SNERF_REQUIRE(c->pts || B == 0, "tgrid: pts is null");
   if (c->mode == 1) SNERF_REQUIRE(c->S >= 1 && B % c->S == 0 && c->origins && c->dirs && c->ebins, "tgrid: bad ray coords");
   return 0;
+}
+
+// SNERF_TGRID_RUNS=0: dev A-B switch back to the per-sample backward (read per call)
+static bool tgrid_runs_off() {
+  const char* e = getenv("SNERF_TGRID_RUNS");
+  return e && atoi(e) == 0;
 }
 
 // coordinate gradient (kernel_input_backward, .cu:373-398): grad_inputs[b, d] = sum_{l, ch} grad[b, l, ch] * dy_dx[b, l, d, ch]; one lane per (b, d)
@@ -201,6 +317,15 @@ __global__ __launch_bounds__(256) void tgrid_input_bwd_kernel(const float* __res
 
 template <bool BWD>
 static int launch(const TgridArgs& a, hipStream_t st) {
+  if (BWD && a.c.mode == 1 && a.d.D == 3 && a.times && !a.trow && a.spr == a.c.S && a.B % a.c.S == 0 && !tgrid_runs_off()) {
+    // per-ray times + in-kernel ray samples (the fused trainers' calls): the run-length form
+    const int S = a.c.S;
+    const int segs = (S + TG_RUN - 1) / TG_RUN, run = (S + segs - 1) / segs;  // (segments of 8 ... 256 samples: 4.03 - 4.07 ms per step of config 4, no trend)
+    const int64_t threads = (a.B / S) * segs * 2 * a.d.C;
+    hipLaunchKernelGGL(tgrid_bwd_runs_kernel, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, segs, run);
+    SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs)");
+    return 0;
+  }
   const int64_t threads = a.B * 2 * a.d.C;
   dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)a.d.L);
   if (!BWD && a.dy_dx) hipLaunchKernelGGL((tgrid_kernel<false, true>), grid, dim3(256), 0, st, a);

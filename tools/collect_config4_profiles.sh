@@ -52,7 +52,7 @@ R, P = line["rays"], line["params"]
 ms = lambda pat: sum(float(r["TotalDurationNs"]) for r in rows if pat in r["Name"]) / steps / 1e6
 tr = lambda pat: sum(v for k, v in per_step.items() if pat in k)
 adam_ms = ms("adam_tv_kernel") + ms("adam_kernel")
-fwd_ms, bwd_ms = ms("tgrid_kernel<false"), ms("tgrid_kernel<true")
+fwd_ms, bwd_ms = ms("tgrid_kernel<false"), ms("tgrid_kernel<true") + ms("tgrid_bwd_runs_kernel")
 alg_ray, sec_ray = 242688, 256 * 40 * 64 + 96 * 40 * 64 + 48 * 128 * 64  # algorithmic bytes / 64-B sectors touched per ray, forward
 line["roofline"] = {
     "bound": "hbm", "kernel": "optimiser sweep: adam_tv_kernel (temporal grids, TV term fused) + adam_kernel (MLPs): p, g, m, v read + p, m, v written + g cleared = 32 B / parameter",
@@ -64,7 +64,7 @@ line["roofline"] = {
         "algorithmic_bytes_per_step_forward": alg_ray * R, "sector_granular_bytes_per_step_forward": sec_ray * R,
         "forward_algorithmic_GBps": alg_ray * R / (fwd_ms * 1e-3) / 1e9, "forward_sector_granular_GBps": sec_ray * R / (fwd_ms * 1e-3) / 1e9,
         "backward_algorithmic_GBps_rmw": 2 * alg_ray * R / (bwd_ms * 1e-3) / 1e9, "backward_sector_granular_GBps_rmw": 2 * sec_ray * R / (bwd_ms * 1e-3) / 1e9,
-        "pmc_traffic_bytes_per_step": {"forward": tr("tgrid_kernel<false"), "backward": tr("tgrid_kernel<true")},
+        "pmc_traffic_bytes_per_step": {"forward": tr("tgrid_kernel<false"), "backward": tr("tgrid_kernel<true") + tr("tgrid_bwd_runs_kernel")},
         "conventions": "SURVEY 8d: per sample 16 levels x 8 corners x 3 floats x 4 B = 1536 B algorithmic (main) / 480 B (proposal levels); each corner row is its own 64-B sector: "
                        "128 / 40 sectors per sample.  Per ray 256 x 480 + 96 x 480 + 48 x 1536 = 242 688 B algorithmic, 1.29 MB sector-granular; the backward reads and writes them (x 2)"},
     "source": f"rocprofv3 --kernel-trace --stats over {steps} steps (profiles/{tag}_nerfplayer_fused_kernel_stats.csv) and separate --pmc passes (profiles/{tag}_nerfplayer_fused_pmc.csv)"}
