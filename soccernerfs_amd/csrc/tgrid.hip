@@ -182,23 +182,37 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
 // the same; it sends them when the cell changes.  Same additions as before in another association (float atomics are order-dependent anyway).
 constexpr int TG_RUN = 32;  // samples per segment (a ray of S samples = ceil(S / 32) segments of equal length, the last one shorter)
 
+// RAYS: snerf_coords mode 1 (a segment lies inside one ray: origin, direction and the time slot are loaded once); otherwise explicit points [B,3] in
+// sample order with times[b / spr] -- the full NeRFPlayer's deformed positions: consecutive points are still consecutive samples of a ray with one time,
+// and where they are not, the (cell, column) key changes and the sum is sent, so any input order is handled correctly.
+template <bool RAYS>
 __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int segs, int run) {
   const int C = a.d.C, LPG = 2 * C;
-  const int S = a.c.S;
-  const int64_t R = a.B / S;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t grp = gid / LPG;
   const int k = (int)(gid - grp * LPG);
   const int ch = k >> 1, ab = k & 1;
   const int level = blockIdx.y;
-  const int64_t r = grp / segs;
-  const int seg = (int)(grp - r * segs);
-  if (r >= R) return;
-  int col;
-  float wt;
-  tg_slot_from_time(a.times[r], C, a.d.grid_C - C - 1, ch, ab, col, wt);
-  if (wt == 0.f) return;  // this (channel, column) slot is dead for the whole ray
-  const int s0 = seg * run, s1 = (s0 + run) < S ? (s0 + run) : S;
+  int64_t b0, b1, r = 0;
+  if (RAYS) {
+    const int S = a.c.S;
+    r = grp / segs;
+    const int seg = (int)(grp - r * segs);
+    if (r >= a.B / S) return;
+    const int s0 = seg * run, s1 = (s0 + run) < S ? (s0 + run) : S;
+    b0 = r * S + s0; b1 = r * S + s1;
+  } else {
+    b0 = grp * run;
+    if (b0 >= a.B) return;
+    b1 = (b0 + run) < a.B ? (b0 + run) : a.B;
+  }
+  const int n_rows = a.d.grid_C - C - 1;
+  int col = 0;
+  float wt = 0.f;
+  if (RAYS) {
+    tg_slot_from_time(a.times[r], C, n_rows, ch, ab, col, wt);
+    if (wt == 0.f) return;  // this (channel, column) slot is dead for the whole ray
+  }
 
   const uint32_t off0 = (uint32_t)a.d.offsets[level];
   const uint32_t hashmap_size = (uint32_t)(a.d.offsets[level + 1] - a.d.offsets[level]);
@@ -218,18 +232,22 @@ __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int se
     }
   }
   const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
-  float o[3], dir[3], inv[3];
+  float o[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f}, inv[3] = {1.f, 1.f, 1.f};
+  const float* eb = nullptr;
+  if (RAYS) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    o[d] = a.c.origins[r * 3 + d];
-    dir[d] = a.c.dirs[r * 3 + d];
-    inv[d] = a.c.aabb_max[d] - a.c.aabb_min[d];
+    for (int d = 0; d < 3; ++d) {
+      o[d] = a.c.origins[r * 3 + d];
+      dir[d] = a.c.dirs[r * 3 + d];
+      inv[d] = a.c.aabb_max[d] - a.c.aabb_min[d];
+    }
+    eb = a.c.ebins + r * (a.c.S + 1) - r * a.c.S;  // eb[b] = edge s of ray r for b = r S + s
   }
-  const float* eb = a.c.ebins + r * (S + 1);
-  const float* gp = a.gout + (r * S) * (int64_t)(a.d.L * C) + level * C + ch;
   const int gstride = a.d.L * C;
+  const float* gp = a.gout + level * C + ch;
 
   uint32_t ppg[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};  // no cell: floor() of a coordinate in [0, scale + 0.5] never gives this
+  int pcol = col;
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -244,21 +262,28 @@ __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int se
           index = hashed ? (index ^ t) : (index + t);
         }
         const uint32_t row = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
-        atomicAdd(a.gemb + ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)col, acc[idx]);
+        atomicAdd(a.gemb + ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)pcol, acc[idx]);
         acc[idx] = 0.f;
       }
     }
   };
-  for (int s = s0; s < s1; ++s) {
-    const float g = gp[(int64_t)s * gstride] * wt;
-    const float mid = eb[s] + eb[s + 1];
+  for (int64_t b = b0; b < b1; ++b) {
+    if (!RAYS) tg_slot_from_time(a.times[b / a.spr], C, n_rows, ch, ab, col, wt);
+    const float g = gp[b * gstride] * wt;
     float pos[3];
     uint32_t pg[3];
     bool oob = false;
+    float mid = 0.f;
+    if (RAYS) mid = eb[b] + eb[b + 1];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const float p = o[d] + (dir[d] * mid) / 2.f;
-      const float x = (p - a.c.aabb_min[d]) / inv[d];
+      float x;
+      if (RAYS) {
+        const float p = o[d] + (dir[d] * mid) / 2.f;
+        x = (p - a.c.aabb_min[d]) / inv[d];
+      } else {
+        x = a.c.pts[b * 3 + d];
+      }
       oob |= (x < 0.f) || (x > 1.f);
       pos[d] = x * scale + (a.d.align_corners ? 0.0f : 0.5f);
       const float f = floorf(pos[d]);
@@ -266,9 +291,10 @@ __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int se
       pos[d] -= f;
     }
     if (oob || g == 0.f) continue;  // out-of-range samples get no gradient (.cu:119-124); nothing to add
-    if (pg[0] != ppg[0] || pg[1] != ppg[1] || pg[2] != ppg[2]) {
+    if (pg[0] != ppg[0] || pg[1] != ppg[1] || pg[2] != ppg[2] || col != pcol) {
       flush();
       ppg[0] = pg[0]; ppg[1] = pg[1]; ppg[2] = pg[2];
+      pcol = col;
     }
 #pragma unroll
     for (int idx = 0; idx < 8; ++idx) {
@@ -317,14 +343,22 @@ __global__ __launch_bounds__(256) void tgrid_input_bwd_kernel(const float* __res
 
 template <bool BWD>
 static int launch(const TgridArgs& a, hipStream_t st) {
-  if (BWD && a.c.mode == 1 && a.d.D == 3 && a.times && !a.trow && a.spr == a.c.S && a.B % a.c.S == 0 && !tgrid_runs_off()) {
-    // per-ray times + in-kernel ray samples (the fused trainers' calls): the run-length form
-    const int S = a.c.S;
-    const int segs = (S + TG_RUN - 1) / TG_RUN, run = (S + segs - 1) / segs;  // (segments of 8 ... 256 samples: 4.03 - 4.07 ms per step of config 4, no trend)
-    const int64_t threads = (a.B / S) * segs * 2 * a.d.C;
-    hipLaunchKernelGGL(tgrid_bwd_runs_kernel, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, segs, run);
-    SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs)");
-    return 0;
+  if (BWD && a.d.D == 3 && a.times && !a.trow && !tgrid_runs_off()) {
+    // times instead of explicit temporal rows (every caller but the reference-shaped API test): the run-length form
+    if (a.c.mode == 1 && a.spr == a.c.S && a.B % a.c.S == 0) {  // rays: segments inside a ray
+      const int S = a.c.S;
+      const int segs = (S + TG_RUN - 1) / TG_RUN, run = (S + segs - 1) / segs;  // (segments of 8 ... 256 samples: 4.03 - 4.07 ms per step of config 4, no trend)
+      const int64_t threads = (a.B / S) * segs * 2 * a.d.C;
+      hipLaunchKernelGGL(tgrid_bwd_runs_kernel<true>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, segs, run);
+      SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs)");
+      return 0;
+    }
+    if (a.c.mode == 0) {  // explicit points in sample order
+      const int64_t threads = ((a.B + TG_RUN - 1) / TG_RUN) * 2 * a.d.C;
+      hipLaunchKernelGGL(tgrid_bwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, 1, TG_RUN);
+      SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs, points)");
+      return 0;
+    }
   }
   const int64_t threads = a.B * 2 * a.d.C;
   dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)a.d.L);

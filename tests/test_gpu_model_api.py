@@ -327,5 +327,6 @@ def test_unbounded_scene_contraction_matches_reference_golden():
     sum(ld.values()).backward()
     assert out["rgb"].shape == (R, 3) and bool(torch.isfinite(out["rgb"]).all())
     far = float(out["ray_samples_list"][-1].frustums.ends.max())
-    assert far > 10.0  # the piecewise sampler reaches far beyond the unit cube; those samples are contracted onto [-2, 2]^3
+    assert far > 5.0  # the piecewise sampler reaches far beyond the unit cube (whose diagonal is 3.5); those samples are contracted onto [-2, 2]^3
+    #                   (the largest end of 64 rays x 16 resampled intervals depends on the draws: 9.5 ... 40 over repeated runs)
     assert float(model.field.grids.planes.grad.abs().sum()) > 0 and all(float(p.grids.planes.grad.abs().sum()) > 0 for p in model.proposal_networks)
