@@ -154,19 +154,26 @@ class SortedScatter:
                                                              self.fix_capacity, _ptr(self.fix_count), _ptr(self.fix_counts[1 - k:2 - k]), st),
                    "quotient_prepare")
 
-    def quotient_scatter_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
-        """Pass B + the exact terms of the listed (vanished-feature) elements for scales [scale_begin, scale_end); G and the fix list must have been
-        produced (quotient_prepare, or the sigma_net backward's epilogue: snerf_mlp_bwd_x16_quotient).  gfeat is unused since ABI 11 (the list carries
-        the gradients it needs)."""
+    def quotient_fixup_scales(self, planes, coords: _lib.Coords, gplanes, scale_begin: int, scale_end: int, stream=None):
+        """The exact terms of the listed (vanished-feature) elements for scales [scale_begin, scale_end): reads the sample coordinates, so it belongs on
+        the stream that owns the ray buffers."""
         st = stream if stream is not None else _stream()
-        L = _lib.lib()
-        # the fix-up first: both kernels only ADD to the gradient planes, and this way pass B -- not a 5 us launch behind it -- is what the optimiser
-        # sweep's stream waits for
-        _lib.check(L.snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(self.fix_list),
-                                                  _ptr(self.fix_count), self.fix_capacity, _ptr(gplanes), scale_begin, scale_end, st),
+        _lib.check(_lib.lib().snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(self.fix_list),
+                                                           _ptr(self.fix_count), self.fix_capacity, _ptr(gplanes), scale_begin, scale_end, st),
                    "quotient_fixup")
-        _lib.check(L.snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec), _ptr(gplanes),
-                                                           scale_begin, scale_end, st), "scatter_quotient")
+
+    def quotient_pass_b_scales(self, planes, gplanes, scale_begin: int, scale_end: int, stream=None):
+        """Pass B for scales [scale_begin, scale_end): reads only the sorted records, G and the planes -- never the ray buffers."""
+        st = stream if stream is not None else _stream()
+        _lib.check(_lib.lib().snerf_kplanes_scatter_quotient_scales(C.byref(self.desc), _ptr(planes), C.c_int64(self.N), _ptr(self.G), _ptr(self.sorted_rec),
+                                                                    _ptr(gplanes), scale_begin, scale_end, st), "scatter_quotient")
+
+    def quotient_scatter_scales(self, planes, coords: _lib.Coords, gfeat, gplanes, scale_begin: int, scale_end: int, stream=None):
+        """Fix-up + pass B for scales [scale_begin, scale_end); G and the fix list must have been produced (quotient_prepare, or the sigma_net backward's
+        epilogue: snerf_mlp_bwd_x16_quotient).  gfeat is unused since ABI 11 (the list carries the gradients it needs).  The fix-up goes first: both
+        kernels only ADD to the gradient planes, and this way pass B -- not a 5 us launch behind it -- is what the optimiser sweep's stream waits for."""
+        self.quotient_fixup_scales(planes, coords, gplanes, scale_begin, scale_end, stream)
+        self.quotient_pass_b_scales(planes, gplanes, scale_begin, scale_end, stream)
 
     def scatter_quotient(self, planes, coords: _lib.Coords, gfeat, feat, gplanes, stream=None):
         """gplanes += d(sum gfeat . features)/d planes, with feat = the forward's features [N, C n_scales] (fp32)."""

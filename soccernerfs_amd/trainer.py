@@ -110,6 +110,11 @@ class KPlanesTrainConfig:
     # Round 4: each proposal level's density as ONE kernel (csrc/proposal_fused.hip: gather -> 8 -> 64 -> 1 net -> trunc_exp; bit-identical to
     # the two unfused kernels).  The [N,8] features go to HBM only on steps that update the proposal networks.  16-bit operands only.
     fused_proposal: bool = True
+    # Round 4: inside train_step (single GPU) pass B of the field scatter is issued on the optimiser sweep's stream, in front of the sweep, instead of
+    # on the caller's stream: the caller's stream is then free as soon as the sigma_net backward is queued, so the NEXT step's head (pixel draw, ray
+    # generation, proposal levels) runs beside pass B (bound by float atomics) and has mostly finished when the sweep (bound by HBM) starts; and the
+    # pass B -> sweep hand-over stays inside one stream.  False: pass B on the caller's stream (round 3; A-B).
+    pass_b_beside_head: bool = True
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -287,6 +292,8 @@ class KPlanesTrainer:
         self.quotient_epilogue = bool(cfg.quotient_epilogue and self.quotient_scatter and self.fused_field and self.sigma_net.desc.operands == 1
                                       and self.sigma_net.desc.hidden == 128 and self.sigma_net.desc.n_hidden == 1)
         self._qg_step = False
+        self.pass_b_beside_head = cfg.pass_b_beside_head
+        self._in_train_step = False
         self.fused_proposal = bool(cfg.fused_proposal and all(self.lib.snerf_kplanes_density_fwd_supported(C.byref(dp), C.byref(net.desc))
                                                              for dp, net in zip(self._desc_prop, self.prop_nets)))
         self._keep_pfeat = True  # train_step clears it for steps that do not update the proposal networks
@@ -554,13 +561,15 @@ class KPlanesTrainer:
         d = self.field_planes.desc()
         return bool(_lib.lib().snerf_kplanes_quotient_supported(C.byref(d), C.c_int64(N)))
 
-    def _scatter_field_scales(self, co, lo: int, hi: int):
+    def _scatter_field_scales(self, co, lo: int, hi: int, fixup: bool = True):
         """Pass B of the field's sorted scatter for scales [lo, hi): product form (gradient vectors from gradvec / the fused backward) or
-        quotient form (G from quotient_prepare + the exact terms of zero-feature rows)."""
+        quotient form (G + the exact terms of the listed vanished-feature elements; fixup = False: the caller has issued the fix-up itself)."""
         ss, b = self._ss, self.buf
         with self._span("kplanes_scatter_sorted.field"):
             if self.quotient_scatter:
-                ss.quotient_scatter_scales(self.field_planes.planes, co, b["gfeat"], self.gviews["field.planes"], lo, hi, self._st)
+                if fixup:
+                    ss.quotient_fixup_scales(self.field_planes.planes, co, self.gviews["field.planes"], lo, hi, self._st)
+                ss.quotient_pass_b_scales(self.field_planes.planes, self.gviews["field.planes"], lo, hi, self._st)
             else:
                 _lib.check(self.lib.snerf_kplanes_scatter_sorted_scales(C.byref(ss.desc), C.c_int64(ss.N), self._p(ss.gvec), ss.gvec_bf16, self._p(ss.sorted_rec),
                                                                         self._p(self.gviews["field.planes"]), lo, hi, self._st), "scatter_sorted")
@@ -614,7 +623,21 @@ class KPlanesTrainer:
                 self._start_field_grad_exchange(1)
                 self._exchange_started = True
                 return
-            self._scatter_field_scales(co, 0, ns)
+            if (self.pass_b_beside_head and self._in_train_step and self.world == 1 and self.overlap and self.async_field_adam and self._reg_in_adam
+                    and not self.cfg.emulate_transports):
+                # only inside train_step: the one consumer of these gradients is then the sweep, queued behind pass B on the same stream (a
+                # caller of backward() may read the gradient buffer from ITS stream)
+                # The fix-up reads the sample coordinates (the caller's ray tensors, the nerf level's bin edges, which the next step's head overwrites):
+                # it stays on the caller's stream.  Pass B reads only the sorted records, G and the planes.
+                if self.quotient_scatter:
+                    self._ss.quotient_fixup_scales(self.field_planes.planes, co, self.gviews["field.planes"], 0, ns, self._st)
+                main = torch.cuda.current_stream()
+                st = self._stream("adam")
+                st.wait_stream(main)  # G (sigma_net backward), the sort (joined above), the zeroed regulariser slots, the group's skip decision
+                with KPlanesTrainer._On(self, st):
+                    self._scatter_field_scales(co, 0, ns, fixup=False)
+            else:
+                self._scatter_field_scales(co, 0, ns)
         else:
             self._scatter(self._desc_field, self.field_planes.planes, co, N, sl(b["gfeat"]), self.gviews["field.planes"])
 
@@ -1085,8 +1108,12 @@ class KPlanesTrainer:
         finally:
             self._keep_pfeat = True
         fuse = self.fuse_reg_into_adam
-        self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
-                      defer_prop_join=fuse and self.world == 1 and self.defer_prop, depth=depth)
+        self._in_train_step = True
+        try:
+            self.backward(target, rng, proposal_grads=updated, include_reg=not fuse,
+                          defer_prop_join=fuse and self.world == 1 and self.defer_prop, depth=depth)
+        finally:
+            self._in_train_step = False
         if self._sharded():
             self._sharded_optimizer_step()
         else:
