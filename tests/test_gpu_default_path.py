@@ -52,17 +52,29 @@ def test_default_step_matches_reference_golden():
     rgb = tr.forward(rays, rng, float(g["anneal"]), training=True, defer_render=True)
     tr.backward(t("target"), rng, proposal_grads=True, include_reg=True)
     torch.cuda.synchronize()
+    from tests._measure import record
+
+    for i in range(3):  # the measured side of the 16-bit tolerances below (profiles/r04_parity_deviations.json, keys g11_bf16.*)
+        record(f"g11_bf16.sbins_{i}", tr.buf["sb"][i], g[f"sbins_{i}"])
+        record(f"g11_bf16.weights_{i}_rel_to_ray_max", (tr.buf["w"][i].cpu() - g[f"weights_{i}"]) / (g[f"weights_{i}"].abs().amax(-1, keepdim=True) + 1e-6),
+               torch.zeros_like(g[f"weights_{i}"]))
+    record("g11_bf16.rgb", rgb, g["rgb"])
+    record("g11_bf16.accumulation", tr.buf["acc"], g["accumulation"][:, 0])
+    for k, v in tr.loss_dict().items():
+        record("g11_bf16.loss_" + k, v, g["loss_" + k])
     # level 0 sees no network: exact.  Levels 1, 2 are PDF samples of 16-bit proposal densities: the CDF moves by the density's rounding
     torch.testing.assert_close(tr.buf["sb"][0].cpu(), g["sbins_0"], rtol=0, atol=1e-5)
     torch.testing.assert_close(tr.buf["eb"][0].cpu(), g["ebins_0"], rtol=0, atol=3e-5)
+    # (r04) bounds ~20x the measured deviations of this path (profiles/r04_parity_deviations.json: bins 9.5e-7, weights 1.5e-4 of the ray's largest, rgb 1.0e-5,
+    # accumulation 1.3e-5) -- all far inside SURVEY 8d's 16-bit tolerance (density rtol 2e-2, rgb atol 4e-3), which stays the contract
     for i in (1, 2):
-        torch.testing.assert_close(tr.buf["sb"][i].cpu(), g[f"sbins_{i}"], rtol=0, atol=2e-3)
+        torch.testing.assert_close(tr.buf["sb"][i].cpu(), g[f"sbins_{i}"], rtol=0, atol=2e-5)
     for i in range(3):
         w, ref = tr.buf["w"][i].cpu(), g[f"weights_{i}"]
         # weights: rtol 2e-2 of the density carried through alpha compositing, relative to the ray's largest weight
-        assert float(((w - ref).abs() / (ref.abs().amax(-1, keepdim=True) + 1e-6)).max()) < 3e-2, i
-    torch.testing.assert_close(rgb.cpu(), g["rgb"], rtol=0, atol=4e-3)  # bf16 MLP path
-    torch.testing.assert_close(tr.buf["acc"].cpu(), g["accumulation"][:, 0], rtol=0, atol=4e-3)
+        assert float(((w - ref).abs() / (ref.abs().amax(-1, keepdim=True) + 1e-6)).max()) < 3e-3, i
+    torch.testing.assert_close(rgb.cpu(), g["rgb"], rtol=0, atol=2e-4)
+    torch.testing.assert_close(tr.buf["acc"].cpu(), g["accumulation"][:, 0], rtol=0, atol=2e-4)
     ld = tr.loss_dict()
     for k, v in ld.items():
         torch.testing.assert_close(v.cpu(), torch.as_tensor(g["loss_" + k]), rtol=3e-2, atol=1e-8, msg=lambda m: f"{k}: {m}")
@@ -76,6 +88,7 @@ def test_default_step_matches_reference_golden():
         e1 = abs(float(got.double().sum()) - float(g["gsum_" + name])) / (gabs + 1e-12)
         e2 = abs(float(got.double().abs().sum()) - gabs) / (gabs + 1e-12)
         worst = max(worst, e1, e2)
+        record("g11_bf16.gsum_and_gabs_over_gabs." + name, torch.tensor([e1, e2]), torch.zeros(2))
         assert e1 <= 3e-2 and e2 <= 3e-2, (name, e1, e2)
         probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
         torch.testing.assert_close(probe, g["gprobe_" + name], rtol=5e-2, atol=1e-7 + 3e-2 * float(g["gprobe_" + name].abs().max()))
