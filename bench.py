@@ -157,18 +157,71 @@ def reference_standin(dev, rays, hip_rays_per_s):
             "note": "vs_baseline stays null: BASELINE.md holds no published number for this metric; this ratio is the measured stand-in for north_star's >= 10x"}
 
 
+def _die(code, msg):
+    print(f"bench.py: FATAL: {msg}", file=sys.stderr, flush=True)
+    sys.exit(code)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as the reference's train.py does
+    (NSR/scripts/train.py:187-200 mp.spawn, :124-137 NCCL init) -- one CHILD process per GPU through torch.distributed.run, rendezvous on
+    127.0.0.1.  Runs BEFORE this process touches the GPU (torch.cuda.device_count() does not initialise it on this image) and never
+    exec()s: the children's stdout / stderr are ours, their exit code is ours."""
+    import socket
+    import subprocess
+
+    one_device = os.environ.get("SNERF_BENCH_ONE_DEVICE") == "1"
+    if not one_device and os.environ.get("SNERF_BENCH_BACKEND", "nccl") == "nccl":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            _die(4, f"--gpus {args.gpus} but only {have} HIP device(s) visible: refusing to run a smaller job under the name of a larger one")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (the HIP path has no fallback)"
-    # test hooks (tests/test_gpu_sharded.py): exercise the multi-rank code path of this script on a ONE-GPU box -- every rank on
-    # device 0, collectives through gloo (staged via host memory by dist.py).  Never set by the driver.
+    if world != args.gpus:
+        # a SCALE record must never carry a rank count other than the one it was asked for
+        _die(2, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
+    # test hooks (tests/test_gpu_sharded.py, tests/test_bench_launch_cpu.py): exercise the multi-rank code path of this script on a
+    # ONE-GPU box -- every rank on device 0, collectives through gloo (staged via host memory by dist.py).  Never set by the driver.
     one_device = os.environ.get("SNERF_BENCH_ONE_DEVICE") == "1"
     backend = os.environ.get("SNERF_BENCH_BACKEND", "nccl")
+    rank_check_only = os.environ.get("SNERF_BENCH_RANK_CHECK_ONLY") == "1"  # CPU test of the launcher: rendezvous + rank count, then stop
+    if rank_check_only:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        counted = 1
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            probe = torch.ones(1)
+            if os.environ.get("SNERF_BENCH_TEST_DROP_RANK") == str(rank):  # test hook: this rank is not counted
+                probe.zero_()
+            dist.all_reduce(probe)
+            counted = int(probe.item())
+            dist.destroy_process_group()
+        if counted != args.gpus:
+            _die(3, f"{counted} rank(s) counted by the all-reduce, --gpus {args.gpus} asked for")
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "rank_check_only": True, "ranks_counted_by_all_reduce": counted}))
+        return
+    if world > 1 and backend == "nccl" and not one_device and torch.cuda.device_count() < world:
+        _die(4, f"{world} ranks but only {torch.cuda.device_count()} HIP device(s) visible")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (the HIP path has no fallback)"
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -196,6 +249,8 @@ def main():
         dist.all_reduce(probe)  # SUM of ones over the communicator = the number of ranks that really take part
         comm_info = {"backend": dist.get_backend(pg) + (" (RCCL over xGMI)" if backend == "nccl" else ""), "world_size": dist.get_world_size(pg),
                      "ranks_counted_by_all_reduce": int(probe.item()), "devices_visible": torch.cuda.device_count()}
+        if comm_info["ranks_counted_by_all_reduce"] != args.gpus:
+            _die(3, f"{comm_info['ranks_counted_by_all_reduce']} rank(s) counted by the all-reduce, --gpus {args.gpus} asked for")
 
     # each rank draws its own rays: seed + rank (NSR/scripts/train.py:84)
     torch.manual_seed(20231029 + rank)
@@ -286,10 +341,27 @@ def main():
     # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
     CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
             "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_quotient_prepare"]
-    trainer.enable_kernel_timing(CAND)
+    COMM = list(trainer.COMM_WAIT_SPANS) if world > 1 else []
+    trainer.enable_kernel_timing(CAND + COMM)
     elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
     trainer.disable_kernel_timing()
+
+    def comm_report(kt_, n_steps):
+        """world > 1: what one step puts on the links and how long the compute chain stood waiting for them (HIP events on the chain's
+        own stream around every wait: see KPlanesTrainer._comm_wait)."""
+        lb = trainer.link_bytes_per_step()
+        waits = {k: {"ms_per_step": round(kt_[k][0] * kt_[k][1] / n_steps, 4), "waits_per_step": round(kt_[k][1] / n_steps, 2)} for k in COMM if k in kt_}
+        exposed = sum(v["ms_per_step"] for v in waits.values())
+        return {"link_bytes_per_step_per_gpu": {k: int(v) for k, v in lb.items()},
+                "link_bytes_note": "bytes each rank sends (= receives) per step: (W-1)/W x elements x element size per reduce-scatter / all-gather, twice that per all-reduce",
+                "exposed_ms_per_step": round(exposed, 4), "exposed_by_wait": waits,
+                "exposed_note": "time the compute chain's stream stood at a collective's wait (events on that stream before and after the wait); the rest of "
+                                "the collectives' duration ran under kernels.  With gloo (test hook) collectives block the host instead, so this reads ~0",
+                "xgmi_floor_ms": round(lb["total"] / (7 * 153e9) * 1e3, 4),
+                "xgmi_floor_note": "link_bytes total / (7 links x 153 GB/s): the time the step's bytes need with every xGMI link of this GPU busy in one direction"}
+
+    comm_timed = comm_report(kt, args.steps) if world > 1 else None
     # world > 1: the same K steps once more with BOTH transports of the sharded step in bf16 -- a labelled second leg, never `value`
     bf16_leg = None
     if world > 1 and trainer._sharded() and not args.no_bf16_transport_leg and (args.grad_transport, args.param_transport) == ("fp32", "fp32"):
@@ -298,11 +370,14 @@ def main():
         trainer.grad_transport = trainer.param_transport = "bf16"
         for _ in range(max(2, args.warmup // 4)):
             one_step()
+        trainer.enable_kernel_timing(COMM)
         elb = timed(one_step, args.steps)
+        comm16 = comm_report(trainer.kernel_times_ms(), args.steps)
+        trainer.disable_kernel_timing()
         trainer.synchronize()
         barrier()
         trainer.grad_transport, trainer.param_transport = args.grad_transport, args.param_transport
-        bf16_leg = {"value": R * world * args.steps / elb, "unit": "rays/s", "ms_per_step": elb / args.steps * 1e3, "steps": args.steps,
+        bf16_leg = {"comm": comm16, "value": R * world * args.steps / elb, "unit": "rays/s", "ms_per_step": elb / args.steps * 1e3, "steps": args.steps,
                     "what": "same schedule and step as `value`, but the field-plane gradient is rounded to bf16 before the reduce-scatter and the parameter UPDATES "
                             "are all-gathered in bf16 (half the bytes on the xGMI links).  NOT the reference's fp32 DDP arithmetic: reported next to the headline, "
                             "never as it.  PSNR effect bounded on one GPU by emulation only (profiles/r03_psnr_30k_bf16_emulated_bf16_transports.json: "
@@ -449,6 +524,8 @@ def main():
                          "other_kernels_frac": {k: round(alg[k][1] / (v[0] * 1e-3) / 1e9 / (HBM_PEAK_GBS if alg[k][0] == "hbm" else 157300.0), 3)
                                                 for k, v in timed_k.items() if k != DOMINANT}},
         }
+        if comm_timed is not None:
+            line["comm"].update(comm_timed)
         if bf16_leg is not None:
             line["bf16_transports"] = bf16_leg
         if steady_line is not None:

@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 11
+#define SNERF_ABI_VERSION 12
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -641,6 +641,9 @@ int snerf_kplanes_scatter_sorted(const snerf_kplanes_desc* desc, int64_t N, cons
  *              the same pair from inside the sigma_net backward.
  *   _scatter_quotient_scales : pass B over scales [scale_begin, scale_end), sorted_rec from snerf_kplanes_sort_samples; ACCUMULATES.
  *   _fixup   : exact terms of the listed elements for scales [scale_begin, scale_end); ACCUMULATES.  Launch cost only when the list is empty.
+ *              ABI 12: overflow_peak (device int32, may be NULL) -- when more entries were appended than fix_capacity holds, the demanded
+ *              count is max-ed into it (sticky; the caller clears it), so that lost entries are an error the host can raise, not a silent
+ *              drop.  The producers keep counting beyond the capacity (fix_count then exceeds it).
  * ------------------------------------------------------------------------------------------------ */
 int snerf_kplanes_quotient_supported(const snerf_kplanes_desc* desc, int64_t N);
 int snerf_kplanes_quotient_prepare(const snerf_kplanes_desc* desc, int64_t N, const float* grad_feat, const float* feat, float* G,
@@ -649,7 +652,7 @@ int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* desc, const 
                                           float* grad_planes, int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
 int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                                  const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
-                                 int32_t scale_begin, int32_t scale_end, snerf_stream_t stream);
+                                 int32_t scale_begin, int32_t scale_end, int32_t* overflow_peak, snerf_stream_t stream);
 /* Step 3 for the scales [scale_begin, scale_end) only: lets the caller start the optimiser sweep of the planes whose gradient is
  * complete (snerf_adam_planes_step_range) while the remaining scales are still being scattered. */
 int snerf_kplanes_scatter_sorted_scales(const snerf_kplanes_desc* desc, int64_t N, const void* gvec, int32_t gvec_bf16, const float* sorted_rec,

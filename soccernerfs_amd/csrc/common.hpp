@@ -27,9 +27,26 @@ int check_hip(hipError_t e, const char* what);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Dynamic LDS above 64 KB has to be allowed per kernel function AND per device (hipFuncSetAttribute acts on the current device).  Which
+// (kernel, device) pairs have been told already is a write-once cache of a device property, not library state: one atomic bit per device
+// ordinal, set after the call, so any thread on any device gets the same launch behaviour whichever arrives first (core.hip).
+void allow_dynamic_lds(const void* kernel, int bytes, unsigned long long* done_bits);
+#define SNERF_ALLOW_LDS(kernel, bytes)                                             \
+  do {                                                                             \
+    static unsigned long long _snerf_lds_done = 0;                                 \
+    ::snerf::allow_dynamic_lds((const void*)(kernel), (bytes), &_snerf_lds_done);  \
+  } while (0)
+
 constexpr int WAVE = 64;  // CDNA wavefront
 
 // ---- wave-level primitives (64 lanes) ----
+// LDS written by some lanes of a wave and read by other lanes of the SAME wave: release the stores, hold the wave's instruction stream at a
+// scheduling barrier (no instruction emitted), acquire for the loads.  Costs one s_waitcnt lgkmcnt(0).
+__device__ __forceinline__ void wave_lds_publish() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

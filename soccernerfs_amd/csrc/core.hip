@@ -20,6 +20,15 @@ int check_hip(hipError_t e, const char* what) {
   return (int)e;
 }
 
+void allow_dynamic_lds(const void* kernel, int bytes, unsigned long long* done_bits) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done_bits, __ATOMIC_ACQUIRE) & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);  // a failure surfaces at the launch check
+  __atomic_fetch_or(done_bits, bit, __ATOMIC_RELEASE);
+}
+
 // fixed-point gradient cells -> float gradients (deterministic mode, common.hpp): out (+)= fx * 2^-50; the cells are cleared
 __global__ __launch_bounds__(256) void fx_to_float_kernel(long long* __restrict__ fx, float* __restrict__ out, int64_t n, int accumulate) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -235,8 +235,7 @@ static int launch_field_fwd_k(const FieldArgs& a, hipStream_t st) {
   int64_t grid = 256 * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   auto k = field_fwd_kernel<T, NS, KEEP>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+  SNERF_ALLOW_LDS(k, LDS_LIMIT_B);
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(FF_NW * 64), P::BYTES, st, a, n_tiles);
   SNERF_LAUNCH_CHECK("kplanes_field_fwd");
   return 0;

@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void scatter_grouped_kernel(snerf_kplanes_desc
     *reinterpret_cast<uint4*>(R + e * 8) = hd;
     *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
   }
+  // the records were stored one lane per entry and are read back by every lane of the wave: order the LDS stores before the loads
+  // explicitly (same wave, so no s_barrier -- but neither the compiler nor the LDS queue may move a load above these stores)
+  wave_lds_publish();
   // 4. the walk.  One pending cell (x0 | y0 << 16 = ppk) with two accumulators per lane: rows y0 and y0 + 1; lane = (x-corner, channel).
   //    A row or column beyond the border only ever accumulates zeros and is never flushed (guards on != 0).
   uint32_t ppk = 0xfffffff0u;  // matches no record, nor record - 1
@@ -583,6 +586,9 @@ __global__ __launch_bounds__(256) void scatter_halfwave_kernel(snerf_kplanes_des
     *reinterpret_cast<uint4*>(R + e * 8) = hd;
     *reinterpret_cast<float4*>(R + e * 8 + 4) = wt;
   }
+  // the records were stored one lane per entry and are read back by every lane of the wave: order the LDS stores before the loads
+  // explicitly (same wave, so no s_barrier -- but neither the compiler nor the LDS queue may move a load above these stores)
+  wave_lds_publish();
   // the walk: this half's entries are R[half * HALF + i]; pending cell = (pk, pa: byte offset of its (x0, y0) texel + this lane's channel,
   // pdx / pdy: byte steps to its x0 + 1 column / y0 + 1 row, 0 where clamped) with accumulators p00 (x0,y0), p01 (x0,y1), p10 (x1,y0), p11 (x1,y1).
   // The pending cell starts as the half's FIRST entry with empty accumulators, so no flush ever sees an invalid cell.  Zero sums (a clamped
@@ -694,9 +700,13 @@ __global__ __launch_bounds__(256) void quotient_prepare_kernel(int64_t rows, con
 template <int NP>
 __global__ __launch_bounds__(256) void quotient_fixup_kernel(snerf_kplanes_desc d, const float* __restrict__ planes, snerf_coords c,
                                                             const int32_t* __restrict__ list, const int32_t* __restrict__ count,
-                                                            int capacity, float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end) {
+                                                            int capacity, float* __restrict__ gplanes, int n_scales_total, int scale_begin, int scale_end,
+                                                            int32_t* __restrict__ overflow_peak) {
   constexpr int C = 32;
   int n_list = *count;
+  // more entries were appended than the list holds: the ones beyond the capacity are lost.  Record it where the host can see it (sticky
+  // maximum of the demanded entry count) instead of dropping gradients silently.
+  if (overflow_peak && n_list > capacity && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(overflow_peak, n_list);
   n_list = n_list < capacity ? n_list : capacity;
   const int F = n_scales_total * C;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_list; i += gridDim.x * blockDim.x) {
@@ -983,7 +993,7 @@ extern "C" int snerf_kplanes_scatter_quotient_scales(const snerf_kplanes_desc* d
 
 extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, const float* planes, const snerf_coords* coords, int64_t N,
                                             const int32_t* fix_list, const int32_t* fix_count, int32_t fix_capacity, float* grad_planes,
-                                            int32_t scale_begin, int32_t scale_end, snerf_stream_t stream) {
+                                            int32_t scale_begin, int32_t scale_end, int32_t* overflow_peak, snerf_stream_t stream) {
   int rc = check_desc(desc, coords, N);
   if (rc) return rc;
   rc = quotient_ok(desc, N);
@@ -995,9 +1005,9 @@ extern "C" int snerf_kplanes_quotient_fixup(const snerf_kplanes_desc* desc, cons
   // a fixed small grid that strides over the (device-side) count: an empty list costs one launch
   hipStream_t st = (hipStream_t)stream;
   if (desc->n_coords == 4) hipLaunchKernelGGL((quotient_fixup_kernel<6>), dim3(64), dim3(256), 0, st, *desc, planes, *coords, fix_list, fix_count,
-                                              fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end);
+                                              fix_capacity, grad_planes, desc->n_scales, scale_begin, scale_end, overflow_peak);
   else hipLaunchKernelGGL((quotient_fixup_kernel<3>), dim3(64), dim3(256), 0, st, *desc, planes, *coords, fix_list, fix_count, fix_capacity,
-                          grad_planes, desc->n_scales, scale_begin, scale_end);
+                          grad_planes, desc->n_scales, scale_begin, scale_end, overflow_peak);
   SNERF_LAUNCH_CHECK("kplanes_quotient_fixup");
   return 0;
 }

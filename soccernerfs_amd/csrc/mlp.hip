@@ -748,8 +748,7 @@ static int launch_dense(const MlpArgs& a, bool bwd, hipStream_t st) {
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     auto k = dense_bwd_kernel<KP, MP, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    SNERF_ALLOW_LDS(k, LDS_LIMIT);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(dense_waves<MP>() * 64), P::BYTES, st, a, n_tiles);
   } else {
     using P = DensePlan<KP, MP, TS, false>;
@@ -758,8 +757,7 @@ static int launch_dense(const MlpArgs& a, bool bwd, hipStream_t st) {
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     auto k = dense_fwd_kernel<KP, MP, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    SNERF_ALLOW_LDS(k, LDS_LIMIT);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(dense_waves<MP>() * 64), P::BYTES, st, a, n_tiles);
   }
   SNERF_LAUNCH_CHECK(bwd ? "dense_bwd" : "dense_fwd");
@@ -791,8 +789,7 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     auto k = mlp_bwd_kernel<D0P, H, NH, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    SNERF_ALLOW_LDS(k, LDS_LIMIT);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_of<H>() * 64), P::BYTES, st, a, n_tiles);
   } else if (NH == 1 && H / 16 == waves_of<H>()) {
     constexpr int TS = H >= 128 ? 16 : 64;
@@ -804,8 +801,7 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     auto k = mlp_fwd_wreg_kernel<D0P, H, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    SNERF_ALLOW_LDS(k, LDS_LIMIT);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(H / 16 * 64), P::BYTES, st, a, n_tiles);
   } else {
     constexpr int TS = pick_ts<D0P, H, NH, false>();
@@ -817,8 +813,7 @@ static int launch(const MlpArgs& a, bool bwd, hipStream_t st) {
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     auto k = mlp_fwd_kernel<D0P, H, NH, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT); attr_set = true; }
+    SNERF_ALLOW_LDS(k, LDS_LIMIT);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_of<H>() * 64), P::BYTES, st, a, n_tiles);
   }
   SNERF_LAUNCH_CHECK(bwd ? "mlp_bwd" : "mlp_fwd");

@@ -899,8 +899,7 @@ static int launch_b_tr(const MlpArgs& a, hipStream_t st) {
   int64_t grid = 256 * per_cu;
   if (grid > n_tiles) grid = n_tiles;
   auto k = mlp_lp_bwd_tr_kernel<T, K0, H, NH, TS, X16>;
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+  SNERF_ALLOW_LDS(k, LDS_LIMIT_B);
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
   SNERF_LAUNCH_CHECK("mlp_bwd (16-bit operands, transposed reads)");
   return 0;
@@ -942,13 +941,11 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
         grid = n_tiles < 256 ? n_tiles : 256;
         if (a.G) {
           auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS16, true, true>;
-          static bool attr_setq = false;
-          if (!attr_setq) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_setq = true; }
+          SNERF_ALLOW_LDS(k, LDS_LIMIT_B);
           hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P16::BYTES, st, a, n_tiles);
         } else {
           auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS16, true>;
-          static bool attr_set16 = false;
-          if (!attr_set16) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set16 = true; }
+          SNERF_ALLOW_LDS(k, LDS_LIMIT_B);
           hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P16::BYTES, st, a, n_tiles);
         }
       } else {
@@ -957,8 +954,7 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
       }
     } else {
       auto k = mlp_lp_bwd_kernel<T, K0, H, NH, TS>;
-      static bool attr_set = false;
-      if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+      SNERF_ALLOW_LDS(k, LDS_LIMIT_B);
       hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
     }
     SNERF_LAUNCH_CHECK("mlp_bwd (16-bit operands)");
@@ -973,8 +969,7 @@ static int launch_b(const MlpArgs& a, bool bwd, hipStream_t st) {
     int64_t grid = 256 * per_cu;
     if (grid > n_tiles) grid = n_tiles;
     auto k = mlp_lp_fwd_kernel<T, K0, H, NH, TS>;
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_B); attr_set = true; }
+    SNERF_ALLOW_LDS(k, LDS_LIMIT_B);
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(waves_b<H>() * 64), P::BYTES, st, a, n_tiles);
   }
   SNERF_LAUNCH_CHECK("mlp_fwd (16-bit operands)");

@@ -93,7 +93,8 @@ class _KPlanesGather(torch.autograd.Function):
 class SortedScatter:
     """Workspace + driver of the sorted plane-gradient scatter (csrc/kplanes_sorted.hip) for a fixed sample count N."""
 
-    def __init__(self, ps: PlaneSet, N: int, device, gvec_dtype: torch.dtype = torch.float32, quotient: bool = False):
+    def __init__(self, ps: PlaneSet, N: int, device, gvec_dtype: torch.dtype = torch.float32, quotient: bool = False,
+                 fix_capacity: Optional[int] = None):
         """gvec_dtype: element type of the per-plane gradient vectors between pass A and pass B -- float32 (exact) or bfloat16 (half the
         bytes of the step's largest intermediate; the scatter accumulates in fp32 either way).  quotient: the quotient form
         (scatter_quotient: one [N, C n_scales] tensor instead of the vectors; C = 32, concatenated scales) -- the vector buffer is then
@@ -113,12 +114,16 @@ class SortedScatter:
                 raise ValueError("the quotient scatter is built for C = 32, concatenated scales and N * 32 * n_scales < 2^31")
             rows = N * len(ps.resolutions)
             self.G = torch.empty(N, ps.out_dim, dtype=torch.float32, device=device)       # gfeat .* feat
-            # fix list: {element index, feature gradient} per vanished feature with a non-zero gradient (2 int32 per entry).  Sized for the
-            # WORST case -- every element of the feature tensor (planes that are all zero, e.g. an imported checkpoint): entries beyond the
-            # capacity would be dropped silently, and with them the only gradient such planes can receive.  8 B x N x C n_scales (335 MB at the
-            # preset, never touched in normal training) of 288 GB.
-            self.fix_capacity = max(N * ps.out_dim, 1)
+            # fix list: {element index, feature gradient} per vanished feature with a non-zero gradient (2 int32 per entry).  In training it
+            # stays empty (planes initialised in [0.1, 0.5] / [1, 1]: no feature is exactly 0), so the default holds one entry per (sample,
+            # scale) -- 10 MB at the preset instead of the worst case's 335 MB (N x C n_scales: EVERY feature vanished, e.g. imported all-zero
+            # planes; pass fix_capacity=N * ps.out_dim for that).  Entries beyond the capacity are NOT lost silently: the fix-up kernel records
+            # the demanded count in fix_peak and check_fix_overflow() / the trainer raise on it.
+            self.fix_capacity = max(int(fix_capacity) if fix_capacity is not None else N * len(ps.resolutions), 1)
+            if self.fix_capacity > N * ps.out_dim:
+                self.fix_capacity = max(N * ps.out_dim, 1)
             self.fix_list = torch.empty(2 * self.fix_capacity, dtype=torch.int32, device=device)
+            self.fix_peak = torch.zeros(1, dtype=torch.int32, device=device)  # sticky: the largest entry count that did not fit
             self.fix_counts = torch.zeros(2, dtype=torch.int32, device=device)  # used alternately: a prepare resets the other one for the next step
             self._fix_parity = 0
             self.fix_count = self.fix_counts[0:1]
@@ -159,8 +164,20 @@ class SortedScatter:
         the stream that owns the ray buffers."""
         st = stream if stream is not None else _stream()
         _lib.check(_lib.lib().snerf_kplanes_quotient_fixup(C.byref(self.desc), _ptr(planes), C.byref(coords), C.c_int64(self.N), _ptr(self.fix_list),
-                                                           _ptr(self.fix_count), self.fix_capacity, _ptr(gplanes), scale_begin, scale_end, st),
+                                                           _ptr(self.fix_count), self.fix_capacity, _ptr(gplanes), scale_begin, scale_end,
+                                                           _ptr(self.fix_peak), st),
                    "quotient_fixup")
+
+    def check_fix_overflow(self, peak: Optional[int] = None):
+        """Raises if a fix-up ever found more listed entries than the list holds (their gradient terms were lost).  Reads the device
+        counter (synchronises) unless the caller hands over a value it copied itself."""
+        if not self.quotient:
+            return
+        peak = int(self.fix_peak.item()) if peak is None else int(peak)
+        if peak > self.fix_capacity:
+            raise RuntimeError(f"quotient scatter: {peak} vanished-feature entries in one step but the fix list holds {self.fix_capacity}: the gradient terms "
+                               f"of the rest were dropped.  Construct SortedScatter / the trainer with fix_capacity >= {peak} (worst case N * C * n_scales = "
+                               f"{self.N * self.ps.out_dim}), or use the product-form scatter (quotient_scatter=False) for planes with this many exact zeros")
 
     def quotient_pass_b_scales(self, planes, gplanes, scale_begin: int, scale_end: int, stream=None):
         """Pass B for scales [scale_begin, scale_end): reads only the sorted records, G and the planes -- never the ray buffers."""

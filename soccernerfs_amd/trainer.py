@@ -75,6 +75,7 @@ class KPlanesTrainConfig:
     sorted_scatter: bool = True       # sorted / grouped plane-gradient scatter for the field (csrc/kplanes_sorted.hip)
     fuse_reg_into_adam: bool = True   # plane regularisers inside the optimiser sweep (ping-pong parameter buffers)
     shard_optimizer: bool = True      # world > 1: reduce-scatter -> Adam on a 1/world shard -> all-gather (False: one all-reduce)
+    fix_capacity: Optional[int] = None  # quotient scatter: entries of the vanished-feature fix list (None: one per (sample, scale); ops.SortedScatter)
     exchange_chunks: int = 2          # world > 1, sharded: 2 = finest scale exchanged on its own, ahead of the rest (1: one exchange)
     grad_transport: str = "fp32"      # world > 1, sharded: "bf16" halves the reduce-scatter bytes (not the reference's fp32 DDP)
     param_transport: str = "fp32"     # world > 1, sharded: "bf16" gathers the parameter UPDATES in bf16
@@ -271,7 +272,9 @@ class KPlanesTrainer:
         self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[cfg.gvec_dtype]
         self.quotient_scatter = bool(cfg.quotient_scatter and self.sorted_scatter and not cfg.deterministic
                                      and cfg.gvec_dtype == "fp32" and self.lib_quotient_ok(R * S2))
-        self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype, quotient=self.quotient_scatter)
+        self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype, quotient=self.quotient_scatter,
+                                     fix_capacity=cfg.fix_capacity)
+        self._fix_peak_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.quotient_scatter else None
         self._ss.desc = self.field_planes.desc()
         if cfg.emulate_transports not in ("", "grad", "param", "both"):
             raise ValueError(f"emulate_transports must be '', 'grad', 'param' or 'both', got {cfg.emulate_transports!r}")
@@ -366,6 +369,35 @@ class KPlanesTrainer:
 
     def _span(self, name):
         return KPlanesTrainer._Span(self, name)
+
+    COMM_WAIT_SPANS = ("comm_wait.reduce_scatter", "comm_wait.all_gather", "comm_wait.all_reduce", "comm_wait.flags", "allreduce_grads")
+
+    def _comm_wait(self, work, name: str):
+        """The current stream waits for an asynchronous collective.  Under kernel timing the wait sits between two events on that
+        stream: the first fires when the chain has nothing left to run, the second when the collective is complete, so their distance
+        is the EXPOSED communication time of this wait (0 when the collective finished under the kernels before it)."""
+        with self._span(name):
+            work.wait()
+
+    def link_bytes_per_step(self) -> Dict[str, float]:
+        """Bytes this rank SENDS over the links per optimiser step (= bytes it receives), by collective, from the segment sizes:
+        reduce-scatter and all-gather of n elements move (W-1)/W * n * elt each, an all-reduce twice that (ring or direct: the same
+        per-rank volume).  World 1: all zero."""
+        W = self.world
+        if W <= 1:
+            return {"total": 0.0}
+        f = (W - 1) / W
+        o, n, npad = self._field_seg
+        if self._sharded():
+            eg = 2 if self.grad_transport == "bf16" else 4
+            ep = 2 if self.param_transport == "bf16" else 4
+            small = self.n_params - npad
+            d = {"reduce_scatter.field": f * npad * eg, "all_gather.field": f * npad * ep, "all_reduce.small_segments": 2 * f * small * 4,
+                 "all_reduce.flags_and_reg_values": 2 * f * (2 * 4 + self.buf["reg"][0].numel() * 4)}
+        else:
+            d = {"all_reduce.flat_gradient": 2 * f * self.n_params * 4, "all_reduce.flags": 2 * f * 2 * 4}
+        d["total"] = float(sum(d.values()))
+        return d
 
     def _p(self, t):
         return C.c_void_p(t.data_ptr())
@@ -808,7 +840,7 @@ class KPlanesTrainer:
         multi-GPU) or the sweep on the "adam" stream (async_field_adam).  No host block."""
         for ch in self._exchange:
             if ch["ag"] is not None:
-                ch["ag"].wait()
+                self._comm_wait(ch["ag"], "comm_wait.all_gather")
                 ch["ag"] = None
                 if self._delta_pending:
                     # bf16 parameter transport: what was gathered are the ranks' parameter UPDATES; every rank (the owner of a shard
@@ -827,6 +859,8 @@ class KPlanesTrainer:
         self._join_prop()
         self._wait_params()
         torch.cuda.synchronize(self.dev)
+        if getattr(self, "_fix_peak_host", None) is not None:
+            self._ss.check_fix_overflow()
 
     @torch.no_grad()
     def restart(self, params: Optional[torch.Tensor] = None):
@@ -876,7 +910,8 @@ class KPlanesTrainer:
         if self.world > 1:  # DDP all-reduces the gradients, so a non-finite value on one rank is one on every rank: share the flag
             from . import dist as sdist
 
-            sdist.all_reduce_max_(self._dyn[name][:1], self.pg)
+            with self._span("comm_wait.flags"):  # synchronous and tiny: its whole duration is link latency the chain waits for
+                sdist.all_reduce_max_(self._dyn[name][:1], self.pg)
         ops.adam_prepare(self._dyn[name], lr, policy=self.cfg.nonfinite_policy)
         self._prepared.add(name)
 
@@ -928,7 +963,7 @@ class KPlanesTrainer:
         for ch in self._exchange:  # in exchange order: the finest scale's shard is swept and gathered while the rest is still on the links
             lo = ch["lo"] + self.rank * ch["shard"]
             hi = min(lo + ch["shard"], n4)
-            ch["rs"].wait()
+            self._comm_wait(ch["rs"], "comm_wait.reduce_scatter")
             ch["rs"] = None
             self.grads[o + lo:o + lo + ch["shard"]].copy_(ch["g16_shard"] if self.grad_transport == "bf16" else ch["g_shard"])
             with self._span("adam_planes.field"):
@@ -953,7 +988,7 @@ class KPlanesTrainer:
                 with self._span("all_gather.field"):
                     ch["ag"] = sdist.all_gather_shards(new[o + ch["lo"]:o + ch["hi"]], ch["p_shard"], self.pg, async_op=True)
         for w in self._ar_work:
-            w.wait()
+            self._comm_wait(w, "comm_wait.all_reduce")
         for i in range(2):
             name, ps = f"prop{i}.planes", self.prop_planes[i]
             with self._span(f"adam_planes.prop{i}"):
@@ -1122,6 +1157,11 @@ class KPlanesTrainer:
         if updated:
             self._steps_since_update = 0
         self._steps_since_update += 1  # step_cb (ray_samplers.py:554-557)
+        if self._fix_peak_host is not None and (self.step & 63) == 0:
+            # fix-list overflow (ops.SortedScatter.check_fix_overflow) without ever blocking: look at the value copied 64 steps ago,
+            # then start the next copy into the pinned word
+            self._ss.check_fix_overflow(int(self._fix_peak_host[0]))
+            self._fix_peak_host.copy_(self._ss.fix_peak, non_blocking=True)
         return out
 
     # ---- nerfstudio checkpoint files (trainer.py:331-380 of the reference; formats in soccernerfs_amd/checkpoint.py) ----

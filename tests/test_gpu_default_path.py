@@ -4,7 +4,7 @@ one-launch per-ray kernel, quotient-form sorted scatter, regularisers inside the
 * the reference model's own output (G11, captured from NS/models/kplanes.py by oracle/gen_golden.py) at SURVEY 8d's 16-bit
   tolerance: rgb atol 4e-3, density / weights rtol 2e-2, losses and gradient checksums with the bounds stated below;
 * the CPU oracle over three Adam steps through `train_step` itself;
-* the unfused 16-bit kernels at BASELINE config 2 and config 3 plane sizes (153 M / 546 M plane floats, N = 262 144): bit for bit.
+* the unfused 16-bit kernels at BASELINE config 2 and config 3 plane sizes (153.1 M / 575.4 M plane floats, N = 262 144): bit for bit.
 
 (tests/test_gpu_trainer.py runs the same comparisons with fp32 operands at fp32 tolerance: that is the exact-arithmetic parity path;
 this file pins what `bench.py` and `tools/train_psnr.py` actually execute.)"""
@@ -162,9 +162,51 @@ def test_default_train_steps_match_oracle():
     assert tr.step == 3 and float(tr.grads.abs().max()) == 0.0
 
 
+def test_quotient_epilogue_field_plane_gradient_within_one_bf16_rounding():
+    """with the epilogue on (default), G = gX .* bf16(feat) -- the 16-bit feature tile the sigma_net backward already holds --
+    instead of quotient_prepare's gX .* fp32 feat.  Same inputs, same kernels otherwise: the field-plane gradient may differ by ONE operand
+    rounding per element (bf16: 2^-9 relative) and by nothing else.  Bounds: relative L2 <= 2^-9 (roundings are independent across the
+    samples a texel sums, so the norm sits well below the per-term bound), max error <= 2^-8 of the largest gradient.  A precision /
+    throughput trade stated in DESIGN.md 7; quotient_epilogue=False keeps fp32 features (the parity path uses fp32 operands anyway)."""
+    from oracle import kplanes_oracle as KO
+    from oracle.gen_golden import E2E_CFG
+    from soccernerfs_amd.trainer import KPlanesTrainer
+
+    g = load_golden("g11_model")
+    R = g["origins"].shape[0]
+    t = lambda k: g[k].to(DEV).contiguous()
+    rays = {"origins": t("origins"), "directions": t("directions"), "times": t("times")}
+    rng = {"t_rand": t("t_rand"), "u": [t("u0"), t("u1")], "bg": t("bg")}
+    grads = {}
+    for epi in (True, False):
+        tr = KPlanesTrainer(_default_cfg(E2E_CFG, quotient_epilogue=epi), R, DEV)
+        _assert_default(tr)
+        tr.load_oracle_params(KO.make_kplanes_params(**E2E_CFG))
+        tr.forward(rays, rng, float(g["anneal"]), training=True, defer_render=True)
+        tr.backward(t("target"), rng, proposal_grads=True, include_reg=False)
+        torch.cuda.synchronize()
+        grads[epi] = tr.gviews["field.planes"].clone()
+        others = {n: v.clone() for n, v in tr.gviews.items() if n != "field.planes"}
+        if epi:
+            first_others = others
+        else:  # nothing but the field-plane gradient depends on the switch (float atomics reorder sums: tolerance, not equality)
+            for n, v in others.items():
+                torch.testing.assert_close(v, first_others[n], rtol=1e-3, atol=1e-6 * float(v.abs().max()) + 1e-12)
+    a, b = grads[True].double(), grads[False].double()
+    assert float(b.abs().max()) > 0
+    rel_l2 = float((a - b).norm() / b.norm())
+    max_err = float((a - b).abs().max() / b.abs().max())
+    from tests._measure import record
+
+    record("epilogue_vs_prepare.field_plane_grad_rel_l2_and_max", torch.tensor([rel_l2, max_err]), torch.zeros(2))
+    print(f"quotient epilogue vs quotient_prepare: field-plane gradient rel L2 {rel_l2:.2e}, max error / max gradient {max_err:.2e}")
+    assert rel_l2 <= 2.0 ** -9, rel_l2
+    assert max_err <= 2.0 ** -8, max_err
+
+
 @pytest.mark.parametrize("name,ms,n_times", [("config 2", (1, 2, 4, 8, 16), 100), ("config 3", (1, 2, 4, 8, 16, 32), 100)])
 def test_fused_forward_bit_exact_at_full_plane_sizes(name, ms, n_times):
-    """snerf_kplanes_field_fwd at BASELINE config 2 / config 3 plane sizes (153 M / 546 M floats) and the preset's N = 4096 x 64 samples:
+    """snerf_kplanes_field_fwd at BASELINE config 2 / config 3 plane sizes (153.1 M / 575.4 M floats) and the preset's N = 4096 x 64 samples:
     density, rgb, the 16-bit feature tile, the sigma_net outputs and the fp32 features equal the unfused 16-bit kernels bit for bit."""
     from soccernerfs_amd import _lib, ops
     from soccernerfs_amd.plane_set import PlaneSet

@@ -230,13 +230,25 @@ def test_quotient_scatter_equals_direct_scatter(ms, N, zeros):
     _lib.check(L.snerf_kplanes_gather_bwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(goutd), ops._ptr(direct), ops._stream()))
     feat = torch.empty(N, ps.out_dim, device=dev)
     _lib.check(L.snerf_kplanes_gather_fwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(feat), ops._stream()))
-    ss = ops.SortedScatter(ps, N, dev, quotient=True)
-    assert ss.gvec is None
+    # planted zeros make thousands of features vanish at once: the list is sized for the worst case there (the default holds one entry
+    # per (sample, scale), which training never comes near)
+    ss = ops.SortedScatter(ps, N, dev, quotient=True, fix_capacity=N * ps.out_dim if zeros else None)
+    assert ss.gvec is None and ss.fix_capacity == (N * ps.out_dim if zeros else N * len(ms))
     ss.sort(co)
     got = torch.zeros_like(ps.planes)
     ss.scatter_quotient(ps.planes, co, goutd, feat, got)
     n_fix = int(ss.fix_count.item())
     assert (n_fix > 0) == zeros
+    ss.check_fix_overflow()  # nothing was dropped
+    if zeros:
+        # the same scatter with a list that is too short must not lose gradient terms SILENTLY: the fix-up records the demanded count
+        # and check_fix_overflow raises
+        small = ops.SortedScatter(ps, N, dev, quotient=True, fix_capacity=max(n_fix // 2, 1))
+        small.sort(co)
+        small.scatter_quotient(ps.planes, co, goutd, feat, torch.zeros_like(ps.planes))
+        assert int(small.fix_peak.item()) == n_fix
+        with pytest.raises(RuntimeError, match="fix list holds"):
+            small.check_fix_overflow()
     scale = float(direct.abs().max())
     torch.testing.assert_close(got, direct, rtol=1e-4, atol=2e-6 * scale)
     assert float((got - direct).norm() / direct.norm()) < 2e-6
@@ -279,7 +291,7 @@ def test_quotient_scatter_when_the_product_of_six_normal_values_underflows():
     feat = torch.empty(N, ps.out_dim, device=dev)
     _lib.check(L.snerf_kplanes_gather_fwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(feat), ops._stream()))
     assert float(feat[:64, :32].abs().max()) < 1.2e-38  # the features of scale 0 underflowed ...
-    ss = ops.SortedScatter(ps, N, dev, quotient=True)
+    ss = ops.SortedScatter(ps, N, dev, quotient=True, fix_capacity=N * ps.out_dim)  # 64 samples x 32 channels vanish at once
     ss.sort(co)
     got = torch.zeros_like(ps.planes)
     ss.scatter_quotient(ps.planes, co, goutd, feat, got)

@@ -270,19 +270,32 @@ if __name__ == "__main__":
     _worker_main()
 
 
-def test_bench_script_two_ranks_on_one_gpu(tmp_path):
-    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), but with both ranks on
-    device 0 and gloo collectives: the N > 1 branches of the script (sharded optimiser, MAX over ranks, JSON line) run end to end."""
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_script_two_ranks_on_one_gpu(tmp_path, launcher):
+    """bench.py for N = 2 -- as the driver launches it (torch.distributed.run, one process per rank) and as a bare `python bench.py --gpus 2`
+    (the script starts its own ranks as child processes) -- with both ranks on device 0 and gloo collectives: the N > 1 branches of the
+    script (sharded optimiser, MAX over ranks, JSON line with the link-byte / exposed-communication report) run end to end."""
     import json
 
-    env = dict(os.environ, PYTHONPATH=ROOT, SNERF_BENCH_ONE_DEVICE="1", SNERF_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--images", "38",
-           "--trained-until", "6"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, SNERF_BENCH_ONE_DEVICE="1", SNERF_BENCH_BACKEND="gloo")
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--images", "38", "--trained-until", "6"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["steps"] == 3
+    assert line["comm"]["ranks_counted_by_all_reduce"] == 2
+    lb = line["comm"]["link_bytes_per_step_per_gpu"]
+    npad = line["config"]["params"]  # the field planes are ~98 % of it: reduce-scatter + all-gather of fp32 = (W-1)/W x 4 B each way
+    assert 0.9 * 0.5 * 4 * npad < lb["reduce_scatter.field"] <= 0.5 * 4 * npad and lb["all_gather.field"] == lb["reduce_scatter.field"]
+    assert lb["total"] == sum(v for k, v in lb.items() if k != "total")
+    assert line["comm"]["exposed_ms_per_step"] >= 0 and "comm_wait.reduce_scatter" in line["comm"]["exposed_by_wait"]
+    assert line["bf16_transports"]["comm"]["link_bytes_per_step_per_gpu"]["reduce_scatter.field"] * 2 == lb["reduce_scatter.field"]
     # the headline is the reference's DDP arithmetic (fp32 on the links); the bf16 transports are a labelled second leg of the same process
     assert "reduce-scatter (fp32)" in line["config"]["parallelism"] and "new planes (fp32)" in line["config"]["parallelism"]
     assert line["bf16_transports"]["value"] > 0 and line["bf16_transports"]["steps"] == 3 and "NOT the reference" in line["bf16_transports"]["what"]

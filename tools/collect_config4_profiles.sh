@@ -3,6 +3,7 @@
 # counters of its kernels, and a `roofline` object in BOTH byte conventions of SURVEY 8d.
 # usage: bash tools/collect_config4_profiles.sh <tag>    -> gpurun_out/<tag>_nerfplayer_fused_{bench.json,kernel_stats.csv,pmc.csv}
 set -u
+set -o pipefail
 TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out

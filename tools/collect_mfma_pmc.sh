@@ -3,6 +3,7 @@
 # bwd_tr, field_fwd_kernel, density_fwd_kernel) -- separate --pmc passes, kernel-trace only.
 # usage: bash tools/collect_mfma_pmc.sh <tag> [bench flags]     -> gpurun_out/<tag>_mfma_pmc.csv
 set -u
+set -o pipefail
 TAG=${1:-r04}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -35,7 +36,8 @@ with open(f"{out}/{tag}_mfma_pmc.csv", "w") as g:
         m = {c: (sum(d[c]) / len(d[c]) if d.get(c) else float("nan")) for c in cols}
         gui, wc = m["GRBM_GUI_ACTIVE"], m["SQ_WAVE_CYCLES"]
         frac = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * gui / 8) if gui == gui and gui else float("nan")
-        g.write(f'"{k}",' + ",".join(f"{m[c]:.0f}" for c in cols) + f",{frac:.3f},{m['SQ_WAIT_ANY'] / wc:.3f},{m['SQ_WAIT_INST_LDS'] / wc:.3f},{m['SQ_ACTIVE_INST_ANY'] / wc:.3f}\n")
+        per_wc = lambda c: m[c] / wc if wc == wc and wc else float("nan")  # a pass that reported no wave cycles gives nan, not a traceback
+        g.write(f'"{k}",' + ",".join(f"{m[c]:.0f}" for c in cols) + f",{frac:.3f},{per_wc('SQ_WAIT_ANY'):.3f},{per_wc('SQ_WAIT_INST_LDS'):.3f},{per_wc('SQ_ACTIVE_INST_ANY'):.3f}\n")
 print(open(f"{out}/{tag}_mfma_pmc.csv").read())
 PY
 rm -rf $OUT/${TAG}_pmcm_*

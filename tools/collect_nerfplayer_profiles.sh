@@ -2,6 +2,7 @@
 # Run on the GPU box from the repo root: rocprofv3 kernel stats of the NeRFPlayer configurations (config 4 fused trainer, config 4 through
 # the nerfstudio-shaped model, full NeRFPlayer).  usage: bash tools/collect_nerfplayer_profiles.sh <tag>   (writes gpurun_out/<tag>_*)
 set -u
+set -o pipefail
 TAG=${1:-r01}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out

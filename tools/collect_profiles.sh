@@ -2,6 +2,7 @@
 # Run on the GPU box from the repo root: bench line, rocprofv3 kernel stats and the three PMC passes for the judged profiles.
 # usage: bash tools/collect_profiles.sh <tag>     (writes gpurun_out/<tag>_*)
 set -u
+set -o pipefail
 TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out

@@ -2,6 +2,7 @@
 # SQ / TCC counters of named kernels (what do the waves wait on?), one rocprofv3 --pmc pass per counter set.  Run on the GPU box from the repo root.
 # usage: bash tools/pmc_kernels.sh <tag> "<kernel substring> [<kernel substring> ...]" [extra bench.py flags]   (writes gpurun_out/<tag>_pmc_kernels.txt)
 set -u
+set -o pipefail
 TAG=${1:?usage: pmc_kernels.sh <tag> "<kernel substrings>" [bench flags]}
 PATS=${2:?kernel name substrings}
 shift 2

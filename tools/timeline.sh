@@ -2,6 +2,7 @@
 # One training step as the GPU saw it: rocprofv3 --kernel-trace of a short bench run -> tools/timeline.py.  Run on the GPU box from the repo root.
 # usage: bash tools/timeline.sh <tag> [extra bench.py flags]     (writes gpurun_out/<tag>_timeline.txt)
 set -u
+set -o pipefail
 TAG=${1:?usage: timeline.sh <tag> [bench flags]}
 shift
 ROOT=$(pwd)
