@@ -191,6 +191,11 @@ int snerf_mlp_fwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * NULL = not needed).  The forward is recomputed tile by tile; nothing is saved between fwd and bwd. */
 int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                   int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* ABI 12: snerf_mlp_bwd through the workgroup-tile kernels (a 64-sample tile shared by 4 / 8 waves that split the COLUMNS of every layer)
+ * whatever the default for the shape is.  Since round 5 the 64-wide nets with 16-bit operands default to the wave-owns-rows kernel
+ * (csrc/mlp_rows.hip: no barrier inside the loop); this entry keeps the older kernel callable for A-B runs and as a cross-check. */
+int snerf_mlp_bwd_tile(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                       int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
 /* Same with X given in the net's 16-bit operand type (desc.operands = 1: bf16, 2: fp16; row stride ldx in elements) -- the feature tile
  * snerf_kplanes_field_fwd wrote.  The kernels round X to that type anyway, so results equal snerf_mlp_bwd on the fp32 image of X. */
 int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,

@@ -208,6 +208,7 @@ EXPORTS = [
     "snerf_kplanes_gather_bwd_fx",
     "snerf_fx_to_float",
     "snerf_mlp_bwd_fx",
+    "snerf_mlp_bwd_tile",
     "snerf_mlp_bwd_x16",
     "snerf_mlp_bwd_x16_quotient",
     "snerf_adam_prepare",

@@ -43,6 +43,7 @@ struct MlpArgs {
   float* G; int ldg;
   int32_t* fix_list; int fix_capacity;
   int32_t* fix_count; int32_t* fix_count_next;
+  int variant;      // backward only: 0 = the default kernel for the shape, 1 = the workgroup-tile kernels of mlp_lp.hip (snerf_mlp_bwd_tile)
   // dense layers wider than one 128 x 128 block (snerf_dense_fwd / _bwd tile them): row stride of W in global memory (0 = dout), and
   // "add to what is there" for the forward's output (later K blocks of a linear layer) / the backward's input gradient (later column blocks)
   int ldw_g, acc_y, acc_gx;
@@ -907,7 +908,7 @@ extern "C" int snerf_mlp_fwd(const snerf_mlp_desc* d, const float* W, const floa
 
 static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                         int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream,
-                        int x16 = 0) {
+                        int x16 = 0, int variant = 0) {
   MlpArgs a = {};
   int rc = fill(d, a);
   if (rc) return rc;
@@ -921,6 +922,7 @@ static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X,
   a.X = X; a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gX = gX; a.ldgx = ldgx; a.gW = gW;
   a.gWfx = gWfx;
   a.x16 = x16;
+  a.variant = variant;
   SNERF_REQUIRE(!x16 || d->operands == 1 || d->operands == 2, "mlp_bwd_x16: a 16-bit input needs 16-bit operands (desc.operands = 1 / 2), got %d", d->operands);
   return dispatch(d, a, true, (hipStream_t)stream);
 }
@@ -928,6 +930,12 @@ static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X,
 extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                              int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
   return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream);
+}
+
+// the workgroup-tile backward of mlp_lp.hip whatever the default kernel for the shape is (A-B runs; cross-check of the wave-owns-rows kernel)
+extern "C" int snerf_mlp_bwd_tile(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                  int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+  return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream, 0, 1);
 }
 
 extern "C" int snerf_mlp_bwd_fx(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,

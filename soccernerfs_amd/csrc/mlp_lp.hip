@@ -285,7 +285,8 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = ks * 32 + lk * 8 + e;
-        b[e] = Ops<T>::cvt(k < a.d0 ? a.W[a.woff[0] + (int64_t)k * H + wave * 16 + lr] : 0.f);
+        const float wv = a.W[a.woff[0] + (int64_t)(k < a.d0 ? k : a.d0 - 1) * H + wave * 16 + lr];  // unconditional (clamped) load: see stage_w
+        b[e] = Ops<T>::cvt(k < a.d0 ? wv : 0.f);
       }
       breg[ks] = b;
     }
@@ -626,7 +627,8 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_tr_kernel(MlpArg
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = ks * 32 + lk * 8 + e;
-        b[e] = Ops<T>::cvt(k < a.d0 ? a.W[a.woff[0] + (int64_t)k * H + wave * 16 + lr] : 0.f);
+        const float wv = a.W[a.woff[0] + (int64_t)(k < a.d0 ? k : a.d0 - 1) * H + wave * 16 + lr];  // unconditional (clamped) load: see stage_w
+        b[e] = Ops<T>::cvt(k < a.d0 ? wv : 0.f);
       }
       breg[ks] = b;
     }
@@ -990,8 +992,13 @@ bool mlp_bf16_supported(const snerf_mlp_desc* d) {
   return false;
 }
 
+// wave-owns-rows backward of the 64-wide nets (mlp_rows.hip)
+bool mlp_rows_supported(const snerf_mlp_desc* d, const void* args);
+int mlp_rows_dispatch(const snerf_mlp_desc* d, const void* args, hipStream_t st);
+
 int mlp_bf16_dispatch(const snerf_mlp_desc* d, const void* args, bool bwd, hipStream_t st) {
   const MlpArgs& a = *static_cast<const MlpArgs*>(args);
+  if (bwd && a.variant == 0 && mlp_rows_supported(d, args)) return mlp_rows_dispatch(d, args, st);
   const int k0 = (d->d_in + 31) / 32 * 32;
 #define CASE(K0, H, NH)                                                                   \
   if (k0 == K0 && d->hidden == H && d->n_hidden == NH)                                    \

@@ -48,6 +48,7 @@ struct MlpArgs {  // same fields as mlp.hip's (filled there)
   float* G; int ldg;
   int32_t* fix_list; int fix_capacity;
   int32_t* fix_count; int32_t* fix_count_next;
+  int variant;      // backward only: 0 = the default kernel for the shape, 1 = the workgroup-tile kernels of mlp_lp.hip (snerf_mlp_bwd_tile: A-B, cross-check)
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
@@ -87,14 +88,32 @@ __device__ __forceinline__ void store_rt(T* R, int ldr, T* Tr, int ldt, int mt, 
   if (Tr) *reinterpret_cast<typename Ops<T>::v4*>(Tr + col * ldt + row0) = t;
 }
 
-// W [rows_act][cols_act] fp32 row-major (global) -> LDS as stored (R [rows_pad][ldr], zero padded) and/or transposed (T [cols_pad][ldt])
+// W [rows_act][cols_act] fp32 row-major (global) -> LDS as stored (R [rows_pad][ldr], zero padded) and/or transposed (T [cols_pad][ldt]).
+// Eight UNCONDITIONAL loads (clamped, always valid addresses) are in flight per thread before the first LDS store waits for one: written as
+// `cond ? Wg[i] : 0` the load sits in a branch with its own `s_waitcnt vmcnt(0)`, one L2 round trip per element and thread -- 40 in a row for
+// sigma_net's 160 x 128 layer, ~25 us in front of every launch (round 5, seen in the ISA).
 template <typename T>
 __device__ __forceinline__ void stage_w(const float* __restrict__ Wg, int rows_act, int cols_act, int rows_pad, int cols_pad, T* R, int ldr, T* Tr, int ldt) {
-  for (int idx = threadIdx.x; idx < rows_pad * cols_pad; idx += blockDim.x) {
-    const int r = idx / cols_pad, c = idx - r * cols_pad;
-    const T v = Ops<T>::cvt((r < rows_act && c < cols_act) ? Wg[(int64_t)r * cols_act + c] : 0.f);
-    if (R) R[r * ldr + c] = v;
-    if (Tr) Tr[c * ldt + r] = v;
+  constexpr int U = 8;
+  const int total = rows_pad * cols_pad, nt = blockDim.x;
+  for (int base = threadIdx.x; base < total; base += nt * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nt < total ? base + u * nt : total - 1;
+      const int r = idx / cols_pad, c = idx - r * cols_pad;
+      v[u] = Wg[(int64_t)(r < rows_act ? r : rows_act - 1) * cols_act + (c < cols_act ? c : cols_act - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * nt;
+      if (idx < total) {
+        const int r = idx / cols_pad, c = idx - r * cols_pad;
+        const T b = Ops<T>::cvt((r < rows_act && c < cols_act) ? v[u] : 0.f);
+        if (R) R[r * ldr + c] = b;
+        if (Tr) Tr[c * ldt + r] = b;
+      }
+    }
   }
 }
 

@@ -108,6 +108,7 @@ class NerfplayerTrainer:
         self.lib = _lib.lib()
         self.step = 0
         self._steps_since_update = 0
+        self._timing, self._timing_all = None, False
         self.tv_rows: Optional[List[int]] = None  # parity hook: fixed table rows [field, prop0, prop1] instead of the random draw
         self._tv_cols = [(0, 1)] * 3
 
@@ -115,11 +116,31 @@ class NerfplayerTrainer:
     def _p(self, t):
         return C.c_void_p(t.data_ptr())
 
+    # ---- HIP events around kernel groups (bench.py's config-4 leg; same contract as KPlanesTrainer.enable_kernel_timing) ----
+    def enable_kernel_timing(self, names=None):
+        self._timing = {} if names is None else {n: [] for n in names}
+        self._timing_all = names is None
+
+    def disable_kernel_timing(self):
+        self._timing = None
+
+    def kernel_times_ms(self):
+        """name -> (mean milliseconds per launch, launches).  Synchronises."""
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in evs) / len(evs), len(evs)) for k, evs in (self._timing or {}).items() if evs}
+
+    def _span(self, name):
+        from .trainer import KPlanesTrainer
+
+        return KPlanesTrainer._Span(self, name)
+
     def _tgrid_fwd(self, enc, table, co, times, S, N, out):
+      with self._span("tgrid_fwd.field" if enc is self.enc else "tgrid_fwd.prop"):
         _lib.check(self.lib.snerf_tgrid_encode_fwd(C.byref(enc.desc), self._p(table), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(out),
                                                    self._st), "tgrid_fwd")
 
     def _tgrid_bwd(self, enc, co, times, S, N, gout, gtable):
+      with self._span("tgrid_bwd.field" if enc is self.enc else "tgrid_bwd.prop"):
         _lib.check(self.lib.snerf_tgrid_encode_bwd(C.byref(enc.desc), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(gout), self._p(gtable),
                                                    self._st), "tgrid_bwd")
 
@@ -279,7 +300,8 @@ class NerfplayerTrainer:
                 ca, cb = self._tv_cols[kk]
                 rows_, gc = enc.embeddings.shape
                 sl = slice(o, o + n)
-                _lib.check(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
+                with self._span("adam_tv." + name):
+                  _lib.check(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
                                                        C.c_int64(rows_), gc, ca, cb, self._p(self._srow[kk]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
                                                        None, st), "adam_step_tv")
                 done = o + n
