@@ -196,6 +196,17 @@ int snerf_mlp_bwd(const snerf_mlp_desc* desc, const float* W, const float* X, in
  * (csrc/mlp_rows.hip: no barrier inside the loop); this entry keeps the older kernel callable for A-B runs and as a cross-check. */
 int snerf_mlp_bwd_tile(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                        int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* ABI 12: weight gradients through a WORKSPACE instead of straight into gW.  Every workgroup of a backward launch ends by adding its share
+ * of the weight gradient to the same few thousand addresses; 256 same-address float atomics queue up at the memory side (~25 us at the
+ * end of every launch, measured, whatever the element count).  With a workspace of 16 replicas of the flat gradient, workgroup b adds into
+ * replica b % 16 -- 16 atomics per address -- and snerf_mlp_gw_reduce folds the replicas into gW (ACCUMULATED) and clears them, on whatever
+ * stream and at whatever later point the caller chooses (the optimiser is the only reader of gW).
+ *   workspace: snerf_mlp_gw_workspace_floats(desc) floats, caller-owned, ZERO before the first use; _reduce leaves it zero again.
+ *   16-bit operands only route by replica; the exact-fp32 kernels add everything into replica 0 (same results through _reduce). */
+int64_t snerf_mlp_gw_workspace_floats(const snerf_mlp_desc* desc);
+int snerf_mlp_bwd_ws(const snerf_mlp_desc* desc, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                     int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* workspace, snerf_stream_t stream);
+int snerf_mlp_gw_reduce(const snerf_mlp_desc* desc, float* workspace, float* gW, snerf_stream_t stream);
 /* Same with X given in the net's 16-bit operand type (desc.operands = 1: bf16, 2: fp16; row stride ldx in elements) -- the feature tile
  * snerf_kplanes_field_fwd wrote.  The kernels round X to that type anyway, so results equal snerf_mlp_bwd on the fp32 image of X. */
 int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
@@ -207,6 +218,9 @@ int snerf_mlp_bwd_x16(const snerf_mlp_desc* desc, const float* W, const void* X1
  * snerf_kplanes_quotient_prepare and the gX / fp32-feature round trips between the two kernels.  fix_count / fix_count_next as in
  * snerf_kplanes_quotient_prepare.  G carries the operand rounding of X (2^-9 relative for bf16: the size of the MFMA operand roundings gX
  * went through already); ldg must be the scatter's row stride (32 n_scales). */
+int snerf_mlp_bwd_x16_quotient_ws(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                  int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
+                                  int32_t* fix_count, int32_t* fix_count_next, float* workspace, snerf_stream_t stream);
 int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* desc, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                                int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
                                int32_t* fix_count, int32_t* fix_count_next, float* gW, snerf_stream_t stream);

@@ -111,6 +111,7 @@ def lib():
     l.snerf_last_error.restype = C.c_char_p
     l.snerf_target_arch.restype = C.c_char_p
     l.snerf_mlp_param_count.restype = C.c_int64
+    l.snerf_mlp_gw_workspace_floats.restype = C.c_int64
     l.snerf_hashgrid_layout.restype = C.c_int64
     l.snerf_hashgrid_layout.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32]
     # float arguments must be declared or ctypes passes them as ints/doubles
@@ -209,6 +210,10 @@ EXPORTS = [
     "snerf_fx_to_float",
     "snerf_mlp_bwd_fx",
     "snerf_mlp_bwd_tile",
+    "snerf_mlp_bwd_ws",
+    "snerf_mlp_bwd_x16_quotient_ws",
+    "snerf_mlp_gw_reduce",
+    "snerf_mlp_gw_workspace_floats",
     "snerf_mlp_bwd_x16",
     "snerf_mlp_bwd_x16_quotient",
     "snerf_adam_prepare",

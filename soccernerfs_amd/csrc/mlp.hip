@@ -44,6 +44,7 @@ struct MlpArgs {
   int32_t* fix_list; int fix_capacity;
   int32_t* fix_count; int32_t* fix_count_next;
   int variant;      // backward only: 0 = the default kernel for the shape, 1 = the workgroup-tile kernels of mlp_lp.hip (snerf_mlp_bwd_tile)
+  float* ws; int ws_rep; int64_t ws_stride;  // weight-gradient workspace (mlp_lp_common.hpp; honoured by the 16-bit kernels only)
   // dense layers wider than one 128 x 128 block (snerf_dense_fwd / _bwd tile them): row stride of W in global memory (0 = dout), and
   // "add to what is there" for the forward's output (later K blocks of a linear layer) / the backward's input gradient (later column blocks)
   int ldw_g, acc_y, acc_gx;
@@ -886,6 +887,26 @@ extern "C" int snerf_mlp_supported(const snerf_mlp_desc* d) {
   return 0;
 }
 
+// weight-gradient workspace of snerf_mlp_bwd_ws: GW_REPLICAS_H replicas of the flat gradient, each padded to 64 floats
+constexpr int GW_REPLICAS_H = 16;  // = mlp_lp_common.hpp's GW_REPLICAS
+static int64_t gw_ws_stride(const snerf_mlp_desc* d) {
+  int64_t n = 0, prev = d->d_in;
+  for (int l = 0; l < d->n_hidden; ++l) { n += prev * d->hidden; prev = d->hidden; }
+  n += prev * d->d_out;
+  return (n + 63) / 64 * 64;
+}
+
+__global__ __launch_bounds__(256) void gw_reduce_kernel(float* __restrict__ ws, int64_t stride, int reps, float* __restrict__ gW, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < reps; ++k) {  // fixed order; the replicas themselves were filled by float atomics
+    s += ws[k * stride + i];
+    ws[k * stride + i] = 0.f;
+  }
+  if (s != 0.f) atomicAdd(gW + i, s);
+}
+
 extern "C" int64_t snerf_mlp_param_count(const snerf_mlp_desc* d) {
   if (!d) return -1;
   int64_t n = 0, prev = d->d_in;
@@ -908,7 +929,7 @@ extern "C" int snerf_mlp_fwd(const snerf_mlp_desc* d, const float* W, const floa
 
 static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                         int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream,
-                        int x16 = 0, int variant = 0) {
+                        int x16 = 0, int variant = 0, float* ws = nullptr) {
   MlpArgs a = {};
   int rc = fill(d, a);
   if (rc) return rc;
@@ -923,6 +944,8 @@ static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X,
   a.gWfx = gWfx;
   a.x16 = x16;
   a.variant = variant;
+  if (ws && d->operands != 0) { a.ws = ws; a.ws_rep = GW_REPLICAS_H; a.ws_stride = gw_ws_stride(d); }
+  else if (ws) { a.gW = ws; }  // exact-fp32 kernels: no replica routing -- everything lands in replica 0, which the reduce folds in like the others
   SNERF_REQUIRE(!x16 || d->operands == 1 || d->operands == 2, "mlp_bwd_x16: a 16-bit input needs 16-bit operands (desc.operands = 1 / 2), got %d", d->operands);
   return dispatch(d, a, true, (hipStream_t)stream);
 }
@@ -930,6 +953,26 @@ static int mlp_bwd_impl(const snerf_mlp_desc* d, const float* W, const float* X,
 extern "C" int snerf_mlp_bwd(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
                              int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
   return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, gW, nullptr, stream);
+}
+
+extern "C" int64_t snerf_mlp_gw_workspace_floats(const snerf_mlp_desc* d) {
+  if (!d || d->d_in < 1 || d->n_hidden < 1 || d->n_hidden > 2) return -1;
+  return GW_REPLICAS_H * gw_ws_stride(d);
+}
+
+extern "C" int snerf_mlp_bwd_ws(const snerf_mlp_desc* d, const float* W, const float* X, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                int32_t aux_col, const float* gaux, float* gX, int32_t ldgx, float* workspace, snerf_stream_t stream) {
+  SNERF_REQUIRE(workspace, "mlp_bwd_ws: null workspace");
+  return mlp_bwd_impl(d, W, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, nullptr, nullptr, stream, 0, 0, workspace);
+}
+
+extern "C" int snerf_mlp_gw_reduce(const snerf_mlp_desc* d, float* workspace, float* gW, snerf_stream_t stream) {
+  SNERF_REQUIRE(d && workspace && gW, "mlp_gw_reduce: null argument");
+  const int64_t n = snerf_mlp_param_count(d);
+  SNERF_REQUIRE(n > 0, "mlp_gw_reduce: bad descriptor");
+  hipLaunchKernelGGL(gw_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, gw_ws_stride(d), GW_REPLICAS_H, gW, n);
+  SNERF_LAUNCH_CHECK("mlp_gw_reduce");
+  return 0;
 }
 
 // the workgroup-tile backward of mlp_lp.hip whatever the default kernel for the shape is (A-B runs; cross-check of the wave-owns-rows kernel)
@@ -949,9 +992,9 @@ extern "C" int snerf_mlp_bwd_x16(const snerf_mlp_desc* d, const float* W, const 
 }
 
 // snerf.h: the sigma_net backward with the quotient epilogue (G = gX .* X16 + the fix list) instead of gX
-extern "C" int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
-                                          int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
-                                          int32_t* fix_count, int32_t* fix_count_next, float* gW, snerf_stream_t stream) {
+static int mlp_bwd_x16_quotient_impl(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                      int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
+                                      int32_t* fix_count, int32_t* fix_count_next, float* gW, float* ws, snerf_stream_t stream) {
   MlpArgs a = {};
   int rc = fill(d, a);
   if (rc) return rc;
@@ -978,7 +1021,21 @@ extern "C" int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* d, const float* 
   a.X = reinterpret_cast<const float*>(X16); a.N = N; a.ldx = ldx; a.W = W; a.gY = gY; a.ldgy = ldgy; a.aux_col = aux_col; a.gaux = gaux; a.gW = gW;
   a.x16 = 1;
   a.G = G; a.ldg = ldg; a.fix_list = fix_list; a.fix_capacity = fix_capacity; a.fix_count = fix_count; a.fix_count_next = fix_count_next;
+  if (ws) { a.ws = ws; a.ws_rep = GW_REPLICAS_H; a.ws_stride = gw_ws_stride(d); }
   return dispatch(d, a, true, st);
+}
+
+extern "C" int snerf_mlp_bwd_x16_quotient(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                          int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
+                                          int32_t* fix_count, int32_t* fix_count_next, float* gW, snerf_stream_t stream) {
+  return mlp_bwd_x16_quotient_impl(d, W, X16, ldx, N, gY, ldgy, aux_col, gaux, G, ldg, fix_list, fix_capacity, fix_count, fix_count_next, gW, nullptr, stream);
+}
+
+extern "C" int snerf_mlp_bwd_x16_quotient_ws(const snerf_mlp_desc* d, const float* W, const void* X16, int32_t ldx, int64_t N, const float* gY, int32_t ldgy,
+                                             int32_t aux_col, const float* gaux, float* G, int32_t ldg, int32_t* fix_list, int32_t fix_capacity,
+                                             int32_t* fix_count, int32_t* fix_count_next, float* workspace, snerf_stream_t stream) {
+  SNERF_REQUIRE(workspace, "mlp_bwd_x16_quotient_ws: null workspace");
+  return mlp_bwd_x16_quotient_impl(d, W, X16, ldx, N, gY, ldgy, aux_col, gaux, G, ldg, fix_list, fix_capacity, fix_count, fix_count_next, nullptr, workspace, stream);
 }
 
 // One bias-free dense layer Y[N,M] = act(X[N,K] W[K,M]) (act: 0 none, 1 ReLU, 2 Sigmoid).  The kernels hold one 128 x 128 block of W in LDS;

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_kernel(MlpArgs a
     }
   }
   // ---- flush weight gradients ----
-  if (a.gW || a.gWfx) {
+  if (a.gW || a.gWfx || a.ws) {
     const int cl = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(waves_b<H>() * 64) void mlp_lp_bwd_tr_kernel(MlpArg
     }
   }
   // ---- flush weight gradients ----
-  if (a.gW || a.gWfx) {
+  if (a.gW || a.gWfx || a.ws) {
     const int cl = lane & 15, r0 = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NB0; ++j) {

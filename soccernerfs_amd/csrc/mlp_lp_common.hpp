@@ -49,11 +49,18 @@ struct MlpArgs {  // same fields as mlp.hip's (filled there)
   int32_t* fix_list; int fix_capacity;
   int32_t* fix_count; int32_t* fix_count_next;
   int variant;      // backward only: 0 = the default kernel for the shape, 1 = the workgroup-tile kernels of mlp_lp.hip (snerf_mlp_bwd_tile: A-B, cross-check)
+  // weight-gradient workspace (snerf_mlp_bwd_ws; 16-bit kernels): ws_rep replicas of the flat gradient, ws_stride floats apart.  Workgroup b adds
+  // into replica b % ws_rep instead of gW, so an address collects grid / ws_rep same-address atomics instead of one per workgroup (256 of
+  // them took ~25 us at the end of every launch, whatever the element count); snerf_mlp_gw_reduce folds the replicas into gW later.
+  float* ws; int ws_rep; int64_t ws_stride;
 };
 
 __device__ __forceinline__ void gw_add(const MlpArgs& a, int64_t idx, float v) {
-  if (a.gWfx) fx_atomic_add(a.gWfx + idx, v); else atomicAdd(a.gW + idx, v);
+  if (a.gWfx) fx_atomic_add(a.gWfx + idx, v);
+  else if (a.ws) atomicAdd(a.ws + (int64_t)(blockIdx.x % (unsigned)a.ws_rep) * a.ws_stride + idx, v);
+  else atomicAdd(a.gW + idx, v);
 }
+constexpr int GW_REPLICAS = 16;  // replicas of a snerf_mlp_bwd_ws workspace
 
 constexpr int LDS_LIMIT_B = 160 * 1024;
 __host__ __device__ constexpr int ldb(int k) { return k + 8; }

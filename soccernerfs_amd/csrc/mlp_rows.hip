@@ -507,7 +507,7 @@ __global__ __launch_bounds__(ROWS_NW * 64) void mlp_rows_bwd_kernel(MlpArgs a, i
 
   // ---- weight gradients: sum the workgroup's waves through LDS, then one atomic per element and workgroup ----
   // LDS image: [block][r][lane] (a wave's accumulator register r of block `blk` is 64 consecutive floats: conflict-free).
-  if (a.gW || a.gWfx) {
+  if (a.gW || a.gWfx || a.ws) {
     float* red = reinterpret_cast<float*>(smem + P::WEND);
     constexpr int NB0 = KB0 * HB, NB1 = NH == 2 ? HB * HB : 0, NBLK = NB0 + NB1 + HB;
     __syncthreads();  // every wave is done with its scratch

@@ -75,6 +75,9 @@ class KPlanesTrainConfig:
     sorted_scatter: bool = True       # sorted / grouped plane-gradient scatter for the field (csrc/kplanes_sorted.hip)
     fuse_reg_into_adam: bool = True   # plane regularisers inside the optimiser sweep (ping-pong parameter buffers)
     shard_optimizer: bool = True      # world > 1: reduce-scatter -> Adam on a 1/world shard -> all-gather (False: one all-reduce)
+    # weight gradients of the 16-bit MLP backward kernels through 16-replica workspaces (snerf_mlp_bwd_ws / snerf_mlp_gw_reduce): the flush of a
+    # launch queues 16 same-address atomics instead of 256 (~25 us per launch), folded into the gradient buffer before the optimiser reads it
+    mlp_grad_workspace: bool = True
     fix_capacity: Optional[int] = None  # quotient scatter: entries of the vanished-feature fix list (None: one per (sample, scale); ops.SortedScatter)
     exchange_chunks: int = 2          # world > 1, sharded: 2 = finest scale exchanged on its own, ahead of the rest (1: one exchange)
     grad_transport: str = "fp32"      # world > 1, sharded: "bf16" halves the reduce-scatter bytes (not the reference's fp32 DDP)
@@ -272,6 +275,14 @@ class KPlanesTrainer:
         self._gvec_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[cfg.gvec_dtype]
         self.quotient_scatter = bool(cfg.quotient_scatter and self.sorted_scatter and not cfg.deterministic
                                      and cfg.gvec_dtype == "fp32" and self.lib_quotient_ok(R * S2))
+        # weight-gradient workspaces of the 16-bit MLP backward kernels (cfg.mlp_grad_workspace; not in deterministic mode: fixed-point cells
+        # are order-independent already)
+        self._mlp_nets = {"field.sigma": self.sigma_net, "field.color": self.color_net, **{f"prop{i}.mlp": n for i, n in enumerate(self.prop_nets)}}
+        self._mlp_ws, self._ws_dirty = {}, set()
+        if cfg.mlp_grad_workspace and not cfg.deterministic:
+            for gname, net in self._mlp_nets.items():
+                if net.desc.operands != 0:
+                    self._mlp_ws[gname] = torch.zeros(int(_lib.lib().snerf_mlp_gw_workspace_floats(C.byref(net.desc))), dtype=torch.float32, device=self.dev)
         self._ss = ops.SortedScatter(self.field_planes, R * S2, self.dev, self._gvec_dtype, quotient=self.quotient_scatter,
                                      fix_capacity=cfg.fix_capacity)
         self._fix_peak_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.quotient_scatter else None
@@ -427,6 +438,13 @@ class KPlanesTrainer:
 
     def _mlp_bwd(self, net, gname, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx, x16=False):
       with self._span(f"mlp_bwd.{net.desc.d_in}x{net.desc.hidden}x{net.desc.n_hidden}"):
+        ws = self._mlp_ws.get(gname) if not x16 else None
+        if ws is not None:
+            self._ws_dirty.add(gname)
+            _lib.check(self.lib.snerf_mlp_bwd_ws(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
+                                                 self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
+                                                 self._p(gX) if gX is not None else None, ldgx, self._p(ws), self._st), "mlp_bwd_ws")
+            return
         fn = self.lib.snerf_mlp_bwd_fx if self.grads_fx is not None else (self.lib.snerf_mlp_bwd_x16 if x16 else self.lib.snerf_mlp_bwd)
         if x16 and self.grads_fx is not None:  # deterministic mode: the fixed-point kernel takes fp32 inputs (exact image of the 16-bit tile)
             X = X.float()
@@ -434,6 +452,16 @@ class KPlanesTrainer:
         _lib.check(fn(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N),
                       self._p(gY) if gY is not None else None, ldgy, aux_col, self._p(gaux) if gaux is not None else None,
                       self._p(gX) if gX is not None else None, ldgx, self._p(gw), self._st), "mlp_bwd")
+
+    def _reduce_mlp_grads(self, names):
+        """Folds the weight-gradient workspaces of `names` into self.grads (current stream) and clears them; only those a backward kernel of this
+        step has written."""
+        for gname in names:
+            if gname in self._ws_dirty:
+                net = self._mlp_nets[gname]
+                with self._span("mlp_gw_reduce"):
+                    _lib.check(self.lib.snerf_mlp_gw_reduce(C.byref(net.desc), self._p(self._mlp_ws[gname]), self._p(self.gviews[gname]), self._st), "mlp_gw_reduce")
+                self._ws_dirty.discard(gname)
 
     def _resample(self, lvl, rand, anneal):
         """density[lvl] -> weights[lvl] (stored) -> PDF sample level lvl+1 bins."""
@@ -618,10 +646,14 @@ class KPlanesTrainer:
             ss = self._ss
             k = ss.next_fix_counter()
             with self._span(f"mlp_bwd.{self.sigma_net.desc.d_in}x{self.sigma_net.desc.hidden}x{self.sigma_net.desc.n_hidden}"):
-                _lib.check(self.lib.snerf_mlp_bwd_x16_quotient(C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), self._p(b["feat16"]), F, C.c_int64(N),
-                                                               self._p(b["gh"]), 16, 15, self._p(b["gdens"][2]), self._p(ss.G), F, self._p(ss.fix_list),
-                                                               ss.fix_capacity, self._p(ss.fix_count), self._p(ss.fix_counts[1 - k:2 - k]),
-                                                               self._p(self.gviews["field.sigma"]), self._st), "mlp_bwd_x16_quotient")
+                ws = self._mlp_ws.get("field.sigma")
+                if ws is not None:
+                    self._ws_dirty.add("field.sigma")
+                fnq = self.lib.snerf_mlp_bwd_x16_quotient_ws if ws is not None else self.lib.snerf_mlp_bwd_x16_quotient
+                _lib.check(fnq(C.byref(self.sigma_net.desc), self._p(self.sigma_net.params), self._p(b["feat16"]), F, C.c_int64(N),
+                               self._p(b["gh"]), 16, 15, self._p(b["gdens"][2]), self._p(ss.G), F, self._p(ss.fix_list),
+                               ss.fix_capacity, self._p(ss.fix_count), self._p(ss.fix_counts[1 - k:2 - k]),
+                               self._p(ws if ws is not None else self.gviews["field.sigma"]), self._st), "mlp_bwd_x16_quotient")
         else:
             self._mlp_bwd(self.sigma_net, "field.sigma", sl(b["feat16"] if self._fwd_fused else b["feat"]), F, N, sl(b["gh"]), 16, 15, b["gdens"][2][r0:r1],
                           sl(b["gfeat"]), F, x16=self._fwd_fused)
@@ -802,11 +834,16 @@ class KPlanesTrainer:
                 self._prop_pending = st
             else:
                 main.wait_stream(st)
+        # weight-gradient workspaces -> self.grads: the field's nets now, the proposal nets once their chain has been joined
+        self._reduce_mlp_grads(("field.sigma", "field.color"))
+        if self._prop_pending is None:
+            self._reduce_mlp_grads(("prop0.mlp", "prop1.mlp"))
 
     def _join_prop(self):
         if self._prop_pending is not None:
             torch.cuda.current_stream().wait_stream(self._prop_pending)
             self._prop_pending = None
+            self._reduce_mlp_grads(("prop0.mlp", "prop1.mlp"))
 
     def loss_dict(self) -> Dict[str, torch.Tensor]:
         """Scaled loss terms of the last step, keys as KPlanesModel.get_loss_dict (kplanes.py:414-452).  Lazy: a few tiny

@@ -133,3 +133,34 @@ def test_rows_backward_fixed_point_weight_gradient_is_reproducible():
         outs.append((gX, fx))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert int(outs[0][1].abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape", [(15, 3, 2, 16), (8, 1, 1, 8)])
+def test_weight_gradient_through_the_replica_workspace(shape):
+    """snerf_mlp_bwd_ws + snerf_mlp_gw_reduce = snerf_mlp_bwd: same gX bit for bit, same weight gradient up to the order of the fp32 sums;
+    the workspace is zero again after the reduce, and the reduce ACCUMULATES into gW."""
+    from soccernerfs_amd import _lib, ops
+
+    d_in, d_out, nh, ldx = shape
+    L = _lib.lib()
+    d = _desc(d_in, d_out, nh, 1, "bf16")
+    gen = torch.Generator().manual_seed(9)
+    N = 70001
+    W = ((torch.rand(L.snerf_mlp_param_count(C.byref(d)), generator=gen) - 0.5) * 0.5).to(DEV)
+    X = (torch.rand(N, ldx, generator=gen) - 0.3).to(DEV)
+    gY = (torch.rand(N, d_out, generator=gen) - 0.5).to(DEV)
+    gX_a, gW_a = _bwd(L.snerf_mlp_bwd, d, W, X, ldx, N, gY, d_out, -1, None, ldx)
+    ws = torch.zeros(int(L.snerf_mlp_gw_workspace_floats(C.byref(d))), device=DEV)
+    gX_b = torch.full((N, ldx), 7.0, device=DEV)
+    _lib.check(L.snerf_mlp_bwd_ws(C.byref(d), ops._ptr(W), ops._ptr(X), ldx, C.c_int64(N), ops._ptr(gY), d_out, -1, None, ops._ptr(gX_b), ldx, ops._ptr(ws),
+                                  ops._stream()), "mlp_bwd_ws")
+    torch.cuda.synchronize()
+    assert torch.equal(gX_a, gX_b)
+    n = W.numel()
+    stride = ws.numel() // 16
+    assert int((ws.view(16, stride)[:, :n].abs().sum(1) > 0).sum()) == 16  # every replica received a share
+    gW_b = torch.ones_like(W)  # ACCUMULATED: starts at 1
+    _lib.check(L.snerf_mlp_gw_reduce(C.byref(d), ops._ptr(ws), ops._ptr(gW_b), ops._stream()), "mlp_gw_reduce")
+    torch.cuda.synchronize()
+    assert float(ws.abs().max()) == 0.0
+    torch.testing.assert_close(gW_b - 1.0, gW_a, rtol=1e-3, atol=2e-5 * float(gW_a.abs().max()) + 1e-6)

@@ -55,6 +55,12 @@ def main():
             call = lambda: _lib.check(fn(C.byref(d), ops._ptr(W), ops._ptr(X), ldx, C.c_int64(N), ops._ptr(gY) if gY is not None else None, ldgy,
                                          0 if aux else -1, ops._ptr(gaux) if gaux is not None else None, ops._ptr(gX), ldgx, ops._ptr(gW), ops._stream()), label)
             row[label + "_ms"] = round(timed(call), 4)
+        # weight gradients through the 16-replica workspace (snerf_mlp_bwd_ws) + the reduce that folds it into gW
+        L.snerf_mlp_gw_workspace_floats.restype = C.c_int64
+        ws = torch.zeros(int(L.snerf_mlp_gw_workspace_floats(C.byref(d))), device=DEV)
+        row["rows_ws_ms"] = round(timed(lambda: _lib.check(L.snerf_mlp_bwd_ws(C.byref(d), ops._ptr(W), ops._ptr(X), ldx, C.c_int64(N), ops._ptr(gY) if gY is not None else None, ldgy,
+                                                           0 if aux else -1, ops._ptr(gaux) if gaux is not None else None, ops._ptr(gX), ldgx, ops._ptr(ws), ops._stream()), "ws")), 4)
+        row["gw_reduce_ms"] = round(timed(lambda: _lib.check(L.snerf_mlp_gw_reduce(C.byref(d), ops._ptr(ws), ops._ptr(gW), ops._stream()), "reduce")), 4)
         # where the fixed cost sits: the same launch without weight gradients (no flush) and on 2048 samples (launch + staging + flush only)
         row["rows_no_gW_ms"] = round(timed(lambda: _lib.check(L.snerf_mlp_bwd(C.byref(d), ops._ptr(W), ops._ptr(X), ldx, C.c_int64(N), ops._ptr(gY) if gY is not None else None, ldgy,
                                                               0 if aux else -1, ops._ptr(gaux) if gaux is not None else None, ops._ptr(gX), ldgx, None, ops._stream()), "nogw")), 4)
