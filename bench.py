@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--no-fused-ray-loss", action="store_true", help="A-B: the nerf level's weights / render / MSE / distortion / weights-backward as five kernels instead of one")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (K-Planes multiscale 1-32, IST range 0.75, fps-downsample 4; N = 1 only, ~15 s)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (nerfplayer-nerfacto preset on the synthetic stadium-players scene; N = 1 only, ~20 s)")
+    ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of the config-3 / config-4 legs")
     return ap.parse_args()
 
 
@@ -184,6 +187,137 @@ def launch_ranks(args):
     print(f"bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
+
+
+def _hbm_roofline(kernel, alg_bytes, ms, launches, **extra):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_per_launch": int(alg_bytes), "avg_launch_ms": ms, "launches_timed": launches, **extra}
+
+
+def config3_leg(dev, args):
+    """BASELINE.json configs[2]: K-Planes multiscale-res 1-32 + IST range 0.75, fps-downsample 4 (REF/README.md:39-44 changes those three
+    settings of the k-planes preset only, so spacetime_resolution stays (64,64,64,100), method_configs.py:515): 578 367 744 parameters, 19
+    cameras x 25 frames, 15 % IST importance rays, steady-state schedule.  Whole train steps, timed like the headline."""
+    from soccernerfs_amd import ops, synthetic
+    from soccernerfs_amd.pixel_samplers import DynamicBasedPixelSampler, compute_ist
+    from soccernerfs_amd.trainer import KPlanesTrainConfig, KPlanesTrainer
+
+    R, steps = args.rays, args.leg_steps
+    torch.manual_seed(20231029)
+    cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 100),
+                             proposal_resolutions=((128, 128, 128, 100), (256, 256, 256, 100)))
+    tr = KPlanesTrainer(cfg, R, dev)
+    tr.step = 6000  # steady-state schedule, IST active (iters_to_start_ist = 2000)
+    cams = synthetic.make_cameras(20, 960, 540)
+    data = synthetic.render_dataset(cams, synthetic.frame_times(100, 4), list(range(19)), dev, chunk_rows=540)
+    M, H, W = data["images"].shape[:3]
+    ist = compute_ist(data["images"], data["cam_id"], data["times"], ist_range=0.75)
+    batch = {"image": data["images"], "image_idx": torch.arange(M, device=dev), "ist_weights": ist, "iter_steps": 6000}
+    sampler = DynamicBasedPixelSampler(R, is_pixel_ratio=0.15, iters_to_start_ist=2000)
+    DynamicBasedPixelSampler.prepare(batch)
+
+    def step():
+        idx = sampler.sample_method(R, M, H, W, batch=batch, device=dev)
+        target = data["images"][idx[:, 0], idx[:, 1], idx[:, 2]].float() / 255.0
+        rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"], aabb=tr.aabb, near_plane=cfg.near_plane, training=True)
+        tr.train_step(rays, target)
+
+    for _ in range(max(args.warmup, 8)):
+        step()
+    cand = ["adam_planes.field", "kplanes_scatter_sorted.field", "kplanes_field_fwd", f"mlp_bwd.{32 * 6}x128x1"]
+    tr.enable_kernel_timing(cand)
+    tr.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    tr.synchronize()
+    dt = time.perf_counter() - t0
+    kt = tr.kernel_times_ms()
+    tr.disable_kernel_timing()
+    S2, ns, C = cfg.num_nerf_samples_per_ray, 6, cfg.feature_dim
+    gather = R * S2 * ns * 6 * 4 * C * 4
+    alg = {"adam_planes.field": (32 * tr.field_planes.numel, "plane_reg_kernel<32,true> (Adam + K-Planes regularisers, field planes): 32 B / parameter"),
+           "kplanes_scatter_sorted.field": (2 * gather, "pass B of the sorted scatter: read-modify-write of every touched texel"),
+           "kplanes_field_fwd": (gather + R * S2 * (16 + 2 * C * ns + 64), "field_fwd_kernel (gather + sigma_net + color_net fused)")}
+    ktl = {k: v for k, v in kt.items() if k in alg}
+    dom = max(ktl, key=lambda k: ktl[k][0] * ktl[k][1])
+    out = {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": args.mlp_operands,
+           "config": {"workload": "K-Planes multiscale-res 1-32 (6 scales x 6 planes, C = 32, spacetime_resolution (64,64,64,100)) + IST range 0.75, fps-downsample 4 "
+                                  "(19 cameras x 25 frames 960x540), 15 % importance rays, steady-state schedule (step 6000+), full train step incl. Adam",
+                      "params": int(tr.n_params), "images": int(M), "rays_per_gpu": R},
+           "roofline": _hbm_roofline(alg[dom][1], alg[dom][0], ktl[dom][0], ktl[dom][1],
+                                     other_kernels_ms={k: round(v[0], 4) for k, v in kt.items() if k != dom})}
+    del tr, data, ist, batch
+    torch.cuda.empty_cache()
+    return out
+
+
+def config4_leg(dev, args):
+    """BASELINE.json configs[3]: NeRFPlayer-nerfacto (hash grid + temporal decomposition; method_configs.py:616-660) on the stadium-players scene:
+    30 wide-angle training cameras high in the bleachers, aabb [-1,1]^3, fps_downsample 1 (stadiumwide_dataparser.py:94-112).  Rays are CAMERA rays of
+    the synthetic scene (synthetic.make_stadium_cameras / shade_stadium), uniform pixels as the preset's VanillaDataManager draws them.  A subset of
+    each camera's 100 frames is rendered (the timed kernels do not see how many images back the sampler); time stamps and the appearance-embedding
+    table are those of the full 3000-image set."""
+    from soccernerfs_amd import ops, synthetic
+    from soccernerfs_amd.nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R, steps = args.rays, args.leg_steps
+    torch.manual_seed(20231029)
+    n_cams, n_frames, frames_rendered = 30, 100, 8
+    cams = synthetic.make_stadium_cameras(n_cams, 6, 960, 540)
+    frame_ids = torch.linspace(0, n_frames - 1, frames_rendered).long()
+    data = synthetic.render_dataset(cams, frame_ids.float() / (n_frames - 1), list(range(n_cams)), dev, chunk_rows=540, variant="stadium")
+    M, H, W = data["images"].shape[:3]
+    full_index = (data["cam_id"] * n_frames + frame_ids.to(dev).repeat(n_cams)).contiguous()  # image m of the rendered subset -> its index among the 3000
+    mc = NerfplayerNerfactoModelConfig()
+    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev)
+    tr.step = 600  # past the learning-rate warm-up
+
+    def step():
+        idx, target = ops.sample_pixels_uniform(torch.rand(R, 3, device=dev), M, H, W, data["images"])
+        rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"])
+        tr.train_step(rays, full_index[idx[:, 0]].contiguous(), target)
+
+    for _ in range(max(args.warmup, 8)):
+        step()
+    tr.enable_kernel_timing(["adam_tv.field.table", "tgrid_fwd.field", "tgrid_bwd.field", "tgrid_fwd.prop", "tgrid_bwd.prop"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kt = tr.kernel_times_ms()
+    tr.disable_kernel_timing()
+    S2 = mc.num_nerf_samples_per_ray
+    L, Cl = mc.num_levels, mc.features_per_level
+    n_table = tr.enc.embeddings.numel()
+    # SURVEY 8d, config 4, BOTH byte conventions for the main table's gather: 8 corners x 3 live floats (two time rows of a column pair + ...) x 4 B per
+    # level = 1536 B per sample algorithmic; 8 corners x one 64-B sector per level = 8192 B per sample at sector granularity
+    tg_alg, tg_sector = R * S2 * L * 8 * 3 * 4, R * S2 * L * 8 * 64
+    sweep = kt.get("adam_tv.field.table")
+    roof = _hbm_roofline("adam_tv_kernel over the main temporal grid (Adam + temporal-TV, 32 B / parameter: p,g,m,v read, p,m,v written, g cleared)",
+                         32 * n_table, sweep[0], sweep[1]) if sweep else None
+    fwd = kt.get("tgrid_fwd.field")
+    out = {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32",
+           "config": {"workload": "nerfplayer-nerfacto preset (temporal hash grid L=16 C=2 log2T=19 temporal_dim 64, proposals L=5 log2T=17, samples 256/96/48) on the synthetic "
+                                  "stadium-players scene: 30 wide-angle training cameras in the bleachers, aabb [-1,1]^3, 100 frames (fps_downsample 1), camera rays, "
+                                  "uniform pixels; full train step incl. Adam over every table",
+                      "params": int(tr.n_params), "images_rendered": int(M), "images_in_dataset": n_cams * n_frames, "rays_per_gpu": R},
+           "roofline": roof,
+           "tgrid_fwd_main": None if fwd is None else {
+               "avg_launch_ms": fwd[0], "launches_timed": fwd[1],
+               "algorithmic": {"bytes_per_launch": tg_alg, "frac_of_hbm_peak": tg_alg / (fwd[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "convention": "SURVEY 8d: 16 levels x 8 corners x 3 floats x 4 B = 1536 B per sample"},
+               "sector_granular": {"bytes_per_launch": tg_sector, "frac_of_hbm_peak": tg_sector / (fwd[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   "convention": "SURVEY 8d: 16 levels x 8 corner rows x one 64-B sector = 8 KB per sample (no cache credit; above 1 means caches / "
+                                                 "run-length reuse removed traffic)"}},
+           "other_kernels_ms": {k: round(v[0], 4) for k, v in kt.items()}}
+    del tr, data
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -553,6 +687,18 @@ def main():
         if world == 1 and not args.no_standin:
             trainer.synchronize()
             line["reference_standin"] = reference_standin(dev, R, line["value"])
+        if world == 1 and not (args.no_config3 and args.no_config4):
+            # the other single-GPU configurations of BASELINE.json, each a full train step of its own preset, timed like the headline (never `value`)
+            trainer.synchronize()
+            del trainer, init_params
+            torch.cuda.empty_cache()
+            for key, leg, skip in (("config3", config3_leg, args.no_config3), ("config4", config4_leg, args.no_config4)):
+                if skip:
+                    continue
+                try:
+                    line[key] = leg(dev, args)
+                except Exception as e:  # a leg must not take the headline down; the failure is in the line
+                    line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps)
         for title, bd in (("per-step kernel time by group", breakdown), ("trained state, per-step kernel time by group", breakdown_trained)):

@@ -67,6 +67,15 @@ __device__ __forceinline__ float wave_inclusive_scan(float v, int lane) {
   return v;
 }
 
+// Workgroup barrier for data exchanged through LDS only: `__syncthreads()` is `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, i.e. it also waits
+// for the wave's outstanding GLOBAL loads and stores -- a register prefetch of the next tile issued in front of it is waited for on the spot.
+// This one orders LDS accesses only (ISA: s_waitcnt lgkmcnt(0); s_barrier).
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- deterministic gradient accumulation (KPlanesTrainConfig.deterministic) ----
 // Float atomics make a sum depend on the order in which wavefronts arrive.  In deterministic mode gradients are accumulated as 2^50-scaled
 // 64-bit integers instead (integer addition is associative: any order gives the same bits) and converted back once per step

@@ -18,6 +18,7 @@
 // The transposed copies cost nothing extra to write from an accumulator: a lane of the C layout holds 4 consecutive ROWS of one column,
 // i.e. 8 contiguous bytes of the transposed image.  Row stride = K + 8 elements (16-B aligned rows, conflict-free b128 reads).
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -996,9 +997,19 @@ bool mlp_bf16_supported(const snerf_mlp_desc* d) {
 bool mlp_rows_supported(const snerf_mlp_desc* d, const void* args);
 int mlp_rows_dispatch(const snerf_mlp_desc* d, const void* args, hipStream_t st);
 
+// wave-owns-rows backward of sigma_net (mlp_rows128.hip)
+bool mlp_rows128_supported(const snerf_mlp_desc* d, const void* args);
+int mlp_rows128_dispatch(const snerf_mlp_desc* d, const void* args, hipStream_t st);
+// SNERF_MLP_SIGMA_ROWS=0: dev A-B switch back to the workgroup-tile kernel for sigma_net's 16-bit-input backward (read per call)
+static bool sigma_rows_off() {
+  const char* e = getenv("SNERF_MLP_SIGMA_ROWS");
+  return e && atoi(e) == 0;
+}
+
 int mlp_bf16_dispatch(const snerf_mlp_desc* d, const void* args, bool bwd, hipStream_t st) {
   const MlpArgs& a = *static_cast<const MlpArgs*>(args);
   if (bwd && a.variant == 0 && mlp_rows_supported(d, args)) return mlp_rows_dispatch(d, args, st);
+  if (bwd && a.variant == 0 && !a.gWfx && mlp_rows128_supported(d, args) && !sigma_rows_off()) return mlp_rows128_dispatch(d, args, st);
   const int k0 = (d->d_in + 31) / 32 * 32;
 #define CASE(K0, H, NH)                                                                   \
   if (k0 == K0 && d->hidden == H && d->n_hidden == NH)                                    \

@@ -16,6 +16,12 @@
 
 #include "common.hpp"
 
+// No fused multiply-adds formed by contraction in this file: the run-length kernels below promise the per-sample kernels' results BIT FOR BIT, and
+// which a * b + c the compiler fuses depends on the code around it (the first run-length forward differed from tgrid_kernel<false> by 1 ulp in ray
+// mode for that reason alone).  With contraction off every kernel here evaluates the IEEE operations exactly as written.  These kernels are bound by
+// their table accesses; the few extra VALU instructions do not show.
+#pragma clang fp contract(off)
+
 namespace snerf {
 
 struct TgridArgs {
@@ -307,6 +313,131 @@ __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int se
   flush();
 }
 
+// ---- forward, run-length form (round 5): the same walk as tgrid_bwd_runs_kernel ----
+// tgrid_kernel<false> fetches 8 corner rows per (sample, level) even where consecutive samples of a ray stay in one cell: 3.50 GB of counter traffic for
+// 0.99 GB algorithmic on config 4 (profiles/r04_nerfplayer_fused_pmc.csv), each corner its own 64-B sector of a 264-B row for <= 3 live floats.  Here the
+// lane group that walks a segment of <= 32 consecutive samples keeps the eight corner values of the current cell in
+// registers and reloads them only when the cell or the live column changes.  Per sample the arithmetic is tgrid_kernel<false>'s own -- same weights, same
+// products, same order of the eight additions, the same pair sum of the a | b columns -- so the outputs are bit-identical (tests/test_gpu_tgrid.py).
+template <bool RAYS>
+__global__ __launch_bounds__(256) void tgrid_fwd_runs_kernel(TgridArgs a, int segs, int run) {
+  const int C = a.d.C, LPG = 2 * C;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t grp = gid / LPG;
+  const int k = (int)(gid - grp * LPG);
+  const int ch = k >> 1, ab = k & 1;
+  const int level = blockIdx.y;
+  // a group past the end keeps running with an empty segment: the pair sum below is a cross-lane operation of a full wave
+  int64_t b0 = 0, b1 = 0, r = 0;
+  if (RAYS) {
+    const int S = a.c.S;
+    r = grp / segs;
+    const int seg = (int)(grp - r * segs);
+    if (r < a.B / S) {
+      const int s0 = seg * run, s1 = (s0 + run) < S ? (s0 + run) : S;
+      b0 = r * S + s0; b1 = r * S + s1;
+    } else {
+      r = 0;
+    }
+  } else {
+    b0 = grp * run;
+    if (b0 < a.B) b1 = (b0 + run) < a.B ? (b0 + run) : a.B; else b0 = 0;
+  }
+  const int n_rows = a.d.grid_C - C - 1;
+  int col = 0;
+  float wt = 0.f;
+  if (RAYS) tg_slot_from_time(a.times[r], C, n_rows, ch, ab, col, wt);
+
+  const uint32_t off0 = (uint32_t)a.d.offsets[level];
+  const uint32_t hashmap_size = (uint32_t)(a.d.offsets[level + 1] - a.d.offsets[level]);
+  const float scale = exp2f((float)level * a.d.S) * (float)a.d.H - 1.0f;
+  const uint32_t resolution = (uint32_t)ceilf(scale) + 1;
+  const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+  uint32_t mult[3];
+  bool hashed;
+  {
+    uint32_t stride = 1;
+    for (int d = 0; d < 3 && stride <= hashmap_size; ++d) stride *= a.d.align_corners ? resolution : (resolution + 1);
+    hashed = a.d.gridtype == 0 && stride > hashmap_size;
+    uint32_t st = 1;
+    for (int d = 0; d < 3; ++d) {
+      mult[d] = hashed ? primes[d] : (st <= hashmap_size ? st : 0u);
+      if (st <= hashmap_size) st *= a.d.align_corners ? resolution : (resolution + 1);
+    }
+  }
+  const bool pow2 = (hashmap_size & (hashmap_size - 1u)) == 0u;
+  float o[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f}, inv[3] = {1.f, 1.f, 1.f};
+  const float* eb = nullptr;
+  if (RAYS) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      o[d] = a.c.origins[r * 3 + d];
+      dir[d] = a.c.dirs[r * 3 + d];
+      inv[d] = a.c.aabb_max[d] - a.c.aabb_min[d];
+    }
+    eb = a.c.ebins + r * (a.c.S + 1) - r * a.c.S;  // eb[b] = edge s of ray r for b = r S + s
+  }
+  const int ostride = a.d.L * C;
+  float* op = a.out + level * C + ch;
+
+  uint32_t ppg[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};  // no cell yet
+  int pcol = -1;
+  float val[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) val[i] = 0.f;
+  for (int64_t b = b0; b < b1; ++b) {
+    if (!RAYS) tg_slot_from_time(a.times[b / a.spr], C, n_rows, ch, ab, col, wt);
+    float pos[3];
+    uint32_t pg[3];
+    bool oob = false;
+    float mid = 0.f;
+    if (RAYS) mid = eb[b] + eb[b + 1];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float x;
+      if (RAYS) {
+        const float p = o[d] + (dir[d] * mid) / 2.f;
+        x = (p - a.c.aabb_min[d]) / inv[d];
+      } else {
+        x = a.c.pts[b * 3 + d];
+      }
+      oob |= (x < 0.f) || (x > 1.f);
+      pos[d] = x * scale + (a.d.align_corners ? 0.0f : 0.5f);
+      const float f = floorf(pos[d]);
+      pg[d] = (uint32_t)f;
+      pos[d] -= f;
+    }
+    float acc = 0.f;
+    if (!oob && wt != 0.f) {  // tgrid_kernel's `active`: an out-of-range sample reads nothing, a dead (channel, column) slot adds nothing
+      if (pg[0] != ppg[0] || pg[1] != ppg[1] || pg[2] != ppg[2] || col != pcol) {
+#pragma unroll
+        for (int idx = 0; idx < 8; ++idx) {
+          uint32_t index = 0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const uint32_t t = (pg[d] + ((idx >> d) & 1)) * mult[d];
+            index = hashed ? (index ^ t) : (index + t);
+          }
+          const uint32_t row = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
+          val[idx] = a.emb[((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)col];
+        }
+        ppg[0] = pg[0]; ppg[1] = pg[1]; ppg[2] = pg[2];
+        pcol = col;
+      }
+#pragma unroll
+      for (int idx = 0; idx < 8; ++idx) {
+        float w = 1.f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) w *= ((idx >> d) & 1) ? pos[d] : 1.f - pos[d];
+        const float v = val[idx] * wt;  // the temporal weight is applied per sample (explicit points: every sample has its own time), as tgrid_kernel does
+        acc += w * v;
+      }
+    }
+    acc += __shfl_xor(acc, 1, 64);  // column a + column b of this channel (segments of a wave's groups have the same length: see the launcher)
+    if (ab == 0) op[b * ostride] = oob ? 0.f : acc;
+  }
+}
+
 static int validate(const snerf_tgrid_desc* d, const snerf_coords* c, const float* trow, const float* times, int spr, int64_t B) {
   SNERF_REQUIRE(d && c, "tgrid: null descriptor");
   SNERF_REQUIRE(d->D >= 1 && d->D <= 3, "tgrid: D=%d unsupported (1..3)", d->D);
@@ -322,7 +453,7 @@ static int validate(const snerf_tgrid_desc* d, const snerf_coords* c, const floa
   return 0;
 }
 
-// SNERF_TGRID_RUNS=0: dev A-B switch back to the per-sample backward (read per call)
+// SNERF_TGRID_RUNS=0: dev A-B switch back to the per-sample kernels (read per call)
 static bool tgrid_runs_off() {
   const char* e = getenv("SNERF_TGRID_RUNS");
   return e && atoi(e) == 0;
@@ -357,6 +488,24 @@ static int launch(const TgridArgs& a, hipStream_t st) {
       const int64_t threads = ((a.B + TG_RUN - 1) / TG_RUN) * 2 * a.d.C;
       hipLaunchKernelGGL(tgrid_bwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, 1, TG_RUN);
       SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs, points)");
+      return 0;
+    }
+  }
+  if (!BWD && !a.dy_dx && a.d.D == 3 && a.times && !a.trow && !tgrid_runs_off()) {
+    // the forward walks the same segments.  The pair sum (__shfl_xor) needs both lanes of a (channel) pair in the same loop iteration: a pair
+    // shares its group and hence its segment, so its trip count -- whatever other groups of the wave do.
+    if (a.c.mode == 1 && a.spr == a.c.S && a.B % a.c.S == 0) {
+      const int S = a.c.S;
+      const int segs = (S + TG_RUN - 1) / TG_RUN, run = (S + segs - 1) / segs;
+      const int64_t threads = (a.B / S) * segs * 2 * a.d.C;
+      hipLaunchKernelGGL(tgrid_fwd_runs_kernel<true>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, segs, run);
+      SNERF_LAUNCH_CHECK("tgrid_encode_fwd (runs)");
+      return 0;
+    }
+    if (a.c.mode == 0) {
+      const int64_t threads = ((a.B + TG_RUN - 1) / TG_RUN) * 2 * a.d.C;
+      hipLaunchKernelGGL(tgrid_fwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, 1, TG_RUN);
+      SNERF_LAUNCH_CHECK("tgrid_encode_fwd (runs, points)");
       return 0;
     }
   }

@@ -349,3 +349,49 @@ def test_interpolation_matches_reference_hash_encoding(name):
     for explicit in (False, True):
         out = enc(x, t, explicit_rows=explicit)
         torch.testing.assert_close(out.cpu(), g[f"{name}_out"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode", ["rays", "points"])
+def test_run_length_forward_is_bit_identical_to_the_per_sample_kernel(mode):
+    """tgrid_fwd_runs_kernel (round 5: the eight corner values of the current cell stay in registers while consecutive samples of a ray remain in it)
+    against tgrid_kernel<false> (one gather of all corners per sample; SNERF_TGRID_RUNS=0 selects it): the same products summed in the same order, so the
+    outputs must agree BIT FOR BIT -- on the preset's main grid (16 levels, hashed above level 5) with ragged segments (S = 48 -> 2 x 24, S = 37 ->
+    2 x 19 / 18), rays that leave the box, and the explicit-point form the full NeRFPlayer feeds with deformed positions."""
+    import ctypes as C
+    import os
+
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.temporal_grid import TemporalGridEncoder
+
+    gen = torch.Generator().manual_seed(21)
+    enc = TemporalGridEncoder(input_dim=3, temporal_dim=64, num_levels=16, level_dim=2, log2_hashmap_size=15, desired_resolution=2048).to(DEV)
+    with torch.no_grad():
+        enc.embeddings.copy_((torch.rand(enc.embeddings.shape, generator=gen) - 0.5).to(DEV))
+    L = _lib.lib()
+    for R, S in ((300, 48), (129, 37)):
+        o = ((torch.rand(R, 3, generator=gen) * 2 - 1) * 0.9).to(DEV)
+        d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1).to(DEV)
+        # clustered samples (as after proposal resampling): runs of samples inside one cell on the coarse levels, new cells on the fine ones
+        edges = torch.sort(torch.rand(R, S + 1, generator=gen) ** 3 * 1.6, dim=-1).values.to(DEV).contiguous()
+        times = torch.rand(R, generator=gen).to(DEV)
+        times[0], times[1] = 0.0, 1.0
+        B = R * S
+        if mode == "rays":
+            co, spr, keep = ops.coords_from_rays(o, d, times, edges, [[-1.0] * 3, [1.0] * 3], False), S, None
+        else:
+            mid = (edges[:, :-1] + edges[:, 1:]) / 2
+            pts = (((o[:, None, :] + d[:, None, :] * mid[..., None]) + 1.0) / 2.0).reshape(B, 3).contiguous()
+            co, spr, keep = ops.coords_from_points(pts), S, pts
+        outs = []
+        for runs in ("1", "0"):
+            os.environ["SNERF_TGRID_RUNS"] = runs
+            try:
+                out = torch.full((B, enc.output_dim), 7.0, device=DEV)
+                _lib.check(L.snerf_tgrid_encode_fwd(C.byref(enc.desc), ops._ptr(enc.embeddings), C.byref(co), None, ops._ptr(times), spr, C.c_int64(B), ops._ptr(out),
+                                                    ops._stream()), "tgrid_encode_fwd")
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("SNERF_TGRID_RUNS", None)
+            outs.append(out)
+        assert float(outs[1].abs().max()) > 0 and bool((outs[1] == 0).all(dim=1).any())  # some samples lie outside the box (all-zero rows)
+        assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())

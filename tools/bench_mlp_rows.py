@@ -72,6 +72,38 @@ def main():
         row["rows_hbm_frac_of_8TBs"] = round(hbm / (row["rows_ms"] * 1e-3) / 8e12, 3)
         out[name] = row
         print(name, row)
+    # sigma_net from the 16-bit feature tile, with the quotient epilogue, as the trainer calls it: rows kernel (csrc/mlp_rows128.hip) vs tile kernel
+    for name, d_in in (("sigma_net 160->128->16 (config 2)", 160), ("sigma_net 192->128->16 (config 3)", 192)):
+        N = 4096 * 64
+        d = _lib.MlpDesc()
+        d.d_in, d.d_out, d.hidden, d.n_hidden, d.hidden_act, d.out_act, d.operands = d_in, 16, 128, 1, 1, 0, 1
+        W = ((torch.rand(L.snerf_mlp_param_count(C.byref(d)), device=DEV) - 0.5) * 0.2)
+        X16 = (torch.rand(N, d_in, device=DEV) - 0.3).to(torch.bfloat16)
+        gY = torch.rand(N, 16, device=DEV) - 0.5
+        gaux = torch.rand(N, device=DEV) - 0.5
+        G = torch.zeros(N, d_in, device=DEV)
+        gW = torch.zeros_like(W)
+        ws = torch.zeros(int(L.snerf_mlp_gw_workspace_floats(C.byref(d))), device=DEV)
+        fl = torch.zeros(2 * N, dtype=torch.int32, device=DEV)
+        cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
+        row = {}
+        for label, env in (("rows", None), ("tile", "0")):
+            if env is not None:
+                os.environ["SNERF_MLP_SIGMA_ROWS"] = env
+            try:
+                row[label + "_quotient_ws_ms"] = round(timed(lambda: _lib.check(L.snerf_mlp_bwd_x16_quotient_ws(
+                    C.byref(d), ops._ptr(W), ops._ptr(X16), d_in, C.c_int64(N), ops._ptr(gY), 16, 15, ops._ptr(gaux), ops._ptr(G), d_in, ops._ptr(fl), N,
+                    ops._ptr(cnt[0:1]), ops._ptr(cnt[1:2]), ops._ptr(ws), ops._stream()), label)), 4)
+                row[label + "_quotient_ms"] = round(timed(lambda: _lib.check(L.snerf_mlp_bwd_x16_quotient(
+                    C.byref(d), ops._ptr(W), ops._ptr(X16), d_in, C.c_int64(N), ops._ptr(gY), 16, 15, ops._ptr(gaux), ops._ptr(G), d_in, ops._ptr(fl), N,
+                    ops._ptr(cnt[0:1]), ops._ptr(cnt[1:2]), ops._ptr(gW), ops._stream()), label)), 4)
+            finally:
+                os.environ.pop("SNERF_MLP_SIGMA_ROWS", None)
+        hbm = N * (2 * d_in + 64 + 4 + 4 * d_in)
+        row["hbm_bytes"] = hbm
+        row["rows_ws_hbm_frac_of_8TBs"] = round(hbm / (row["rows_quotient_ws_ms"] * 1e-3) / 8e12, 3)
+        out[name] = row
+        print(name, row)
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 

@@ -38,17 +38,23 @@ def main():
     ap.add_argument("--out", default="gpurun_out/psnr_nerfplayer.json")
     ap.add_argument("--width", type=int, default=480)
     ap.add_argument("--frames", type=int, default=25)
+    ap.add_argument("--scene", default="clip", choices=["clip", "stadium"], help="stadium: synthetic.make_stadium_cameras / shade_stadium -- 30 wide-angle cameras high in "
+                    "the bleachers + 6 evaluation cameras near the players, aabb [-1,1]^3 (BASELINE.json configs[3]; stadiumwide_dataparser.py:94-112)")
+    ap.add_argument("--seed", type=int, default=20231029)
     args = ap.parse_args()
-    dev = torch.device("cuda:0"); torch.manual_seed(20231029)
+    dev = torch.device("cuda:0"); torch.manual_seed(args.seed)
     R = 4096
     Wd, Hd = args.width, args.width * 9 // 16
-    cams = synthetic.make_cameras(36, Wd, Hd)
+    stadium = args.scene == "stadium"
+    cams = synthetic.make_stadium_cameras(30, 6, Wd, Hd) if stadium else synthetic.make_cameras(36, Wd, Hd)
     times = synthetic.frame_times(100, 100 // args.frames)
-    train = synthetic.render_dataset(cams, times, list(range(30)), dev, chunk_rows=Hd)
-    held = synthetic.render_dataset(cams, times, list(range(30, 36)), dev, chunk_rows=Hd)
+    variant = "stadium" if stadium else "default"
+    train = synthetic.render_dataset(cams, times, list(range(30)), dev, chunk_rows=Hd, variant=variant)
+    held = synthetic.render_dataset(cams, times, list(range(30, 36)), dev, chunk_rows=Hd, variant=variant)
     M, H, W = train["images"].shape[:3]
-    tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, M, aabb_scale=1.5, device=dev, max_steps=args.steps)
-    log = {"config": f"nerfplayer-nerfacto preset, fused trainer, synthetic clip ({M} training images {W}x{H}, 6 cameras held out)", "evals": []}
+    tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, M, aabb_scale=1.0 if stadium else 1.5, device=dev, max_steps=args.steps)
+    log = {"config": f"nerfplayer-nerfacto preset, fused trainer, synthetic {'stadium-players scene' if stadium else 'clip'} ({M} training images {W}x{H}, "
+                     f"{len(times)} frames per camera, 6 cameras held out), seed {args.seed}", "scene": args.scene, "evals": []}
     t_train = 0.0
     for step in range(args.steps):
         if step % 500 == 0:
