@@ -27,7 +27,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
 DEFAULT_OPERANDS = "bf16"  # BASELINE.json configs[1]: "1xMI355X bf16"
-PROFILE_TAG = "r04"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
+PROFILE_TAG = "r05"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
 
 
 def parse():
@@ -671,14 +671,16 @@ def main():
         psnr = {}
         for op in ("bf16", "fp32", "standin"):
             # this round's file if it exists, else the last round's that does (the source is named in the line either way)
-            f = next((c for c in (os.path.join(ROOT, "profiles", f"{tag}_psnr_30k_{op}.json") for tag in (PROFILE_TAG, "r03")) if os.path.exists(c)), None)
+            f = next((c for c in (os.path.join(ROOT, "profiles", f"{tag}_psnr_30k_{op}.json") for tag in (PROFILE_TAG, "r04", "r03")) if os.path.exists(c)), None)
             if f is None:
                 continue
             try:
                 d = json.load(open(f))
                 what = ("oracle/torch_standin.StandinTrainer = the reference's algorithm in stock PyTorch, fp32, same scene / sampler / schedule / evaluation"
                         if op == "standin" else "tools/train_psnr.py: same preset, same synthetic scene")
-                psnr[op] = {"source": f"profiles/{os.path.basename(f)} ({what}, {len(d['runs'])} seed(s), eval frames per camera: {d.get('eval_frames', 'all')})",
+                early = [r["stopped_early_at_step"] for r in d["runs"] if r.get("stopped_early_at_step")]
+                psnr[op] = {"source": f"profiles/{os.path.basename(f)} ({what}, {len(d['runs'])} seed(s), eval frames per camera: {d.get('eval_frames', 'all')}"
+                                      + (f"; NOT 30 000 steps: the runs were stopped at steps {early} by the one-hour limit of a GPU call and evaluated there" if early else "") + ")",
                             **{k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in d["summary"].items()}}
             except Exception as e:  # a malformed file must not take the bench line down
                 psnr[op] = {"source": os.path.basename(f), "error": str(e)}

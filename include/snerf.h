@@ -515,6 +515,11 @@ int snerf_tgrid_input_bwd(const float* grad_out, const float* dy_dx, int64_t B, 
 int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,
                            const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings,
                            snerf_stream_t stream);
+/* ABI 12, deterministic mode: the same scatter ACCUMULATED into 2^50-scaled 64-bit integer cells [rows, grid_C] (integer addition is
+ * associative: the sum does not depend on the order the wavefronts arrive in); snerf_fx_to_float turns the cells into floats once per step. */
+int snerf_tgrid_encode_bwd_fx(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,
+                              const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, int64_t* grad_embeddings_fx,
+                              snerf_stream_t stream);
 
 /* TemporalGridEncoder.get_temporal_tv_loss (NS/field_components/temporal_grid.py:352-376): mean over table rows of
  * |E[r, col_a] - E[r, col_b]|.  fwd ADDS per-workgroup partial sums of |.| into partial[n_slots][16] (col 0; caller zeroes, then

@@ -198,6 +198,7 @@ EXPORTS = [
     "snerf_hashgrid_encode_fwd",
     "snerf_hashgrid_encode_bwd",
     "snerf_tgrid_encode_bwd",
+    "snerf_tgrid_encode_bwd_fx",
     "snerf_tgrid_encode_fwd_dydx",
     "snerf_tgrid_input_bwd",
     "snerf_ist_maps",

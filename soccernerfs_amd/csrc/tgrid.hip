@@ -36,7 +36,12 @@ struct TgridArgs {
   float* dy_dx;        // fwd, optional: [B, L, D, C] d out / d x (temporal_gridencoder.cu:204-273, calc_grad_inputs)
   const float* gout;   // bwd
   float* gemb;         // bwd
+  long long* gemb_fx;  // bwd, deterministic mode: 2^50-scaled fixed-point cells instead of gemb (common.hpp: integer addition is associative)
 };
+
+__device__ __forceinline__ void tg_grad_add(const TgridArgs& a, size_t e, float v) {
+  if (a.gemb_fx) fx_atomic_add(a.gemb_fx + e, v); else atomicAdd(a.gemb + e, v);
+}
 
 // (column, weight) of slot (ch, ab) at a time row; closed form of the reference's sampling_index table + get_temporal_index
 __device__ __forceinline__ void tg_slot_from_time(float t, int C, int n_rows, int ch, int ab, int& col, float& w) {
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
     if (active) {
       if (BWD) {
         float v = w * g;
-        if (v != 0.f) atomicAdd(a.gemb + e, v);
+        if (v != 0.f) tg_grad_add(a, e, v);
       } else {
         const float val = a.emb[e] * wt;
         acc += w * val;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int se
           index = hashed ? (index ^ t) : (index + t);
         }
         const uint32_t row = pow2 ? (index & (hashmap_size - 1u)) : (index % hashmap_size);
-        atomicAdd(a.gemb + ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)pcol, acc[idx]);
+        tg_grad_add(a, ((size_t)off0 + row) * (size_t)a.d.grid_C + (size_t)pcol, acc[idx]);
         acc[idx] = 0.f;
       }
     }
@@ -658,5 +663,19 @@ extern "C" int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_
   SNERF_REQUIRE(grad_out && grad_embeddings, "tgrid_encode_bwd: null buffer");
   TgridArgs a = {};
   a.d = *desc; a.c = *coords; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out; a.gemb = grad_embeddings;
+  return launch<true>(a, (hipStream_t)stream);
+}
+
+// deterministic mode: the same scatter into 2^50-scaled 64-bit integer cells (snerf_fx_to_float converts them once per step)
+extern "C" int snerf_tgrid_encode_bwd_fx(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,
+                                         const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, int64_t* grad_embeddings_fx,
+                                         snerf_stream_t stream) {
+  int rc = validate(desc, coords, temporal_row_index, times, samples_per_row, B);
+  if (rc) return rc;
+  if (B == 0) return 0;
+  SNERF_REQUIRE(grad_out && grad_embeddings_fx, "tgrid_encode_bwd_fx: null buffer");
+  TgridArgs a = {};
+  a.d = *desc; a.c = *coords; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
+  a.gemb_fx = reinterpret_cast<long long*>(grad_embeddings_fx);
   return launch<true>(a, (hipStream_t)stream);
 }

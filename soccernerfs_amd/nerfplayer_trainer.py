@@ -35,7 +35,10 @@ def _align4(n: int) -> int:
 
 class NerfplayerTrainer:
     def __init__(self, cfg: NerfplayerNerfactoModelConfig, num_rays: int, num_images: int, aabb_scale: float = 1.0, device="cuda:0",
-                 lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0):
+                 lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False):
+        """deterministic: every gradient scatter (temporal-grid tables, MLP weight gradients, appearance embedding) accumulates 2^50-scaled 64-bit
+        integers instead of float atomics (csrc/common.hpp: integer addition is associative), converted once per step: two runs from the same seed give
+        the same bits.  Costs 8 B per parameter and 64-bit atomics; off by default."""
         if not cfg.disable_scene_contraction or cfg.use_same_proposal_network or cfg.num_proposal_iterations != 2:
             raise NotImplementedError("NerfplayerTrainer covers the nerfplayer-nerfacto preset (AABB collider, two proposal networks)")
         self.cfg, self.R, self.dev = cfg, num_rays, torch.device(device)
@@ -77,13 +80,16 @@ class NerfplayerTrainer:
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
-        self.views, self.gviews = {}, {}
+        self.grads_fx = torch.zeros(off, dtype=torch.int64, device=self.dev) if deterministic else None
+        self.views, self.gviews, self.fxviews = {}, {}, {}
         for name, mod, attr, o, n in self.segments:
             p = getattr(mod, attr)
             self.params[o:o + n].copy_(p.detach().reshape(-1))
             p.data = self.params[o:o + n].view(p.shape)  # the module's parameter aliases its segment
             self.views[name] = p.data
             self.gviews[name] = self.grads[o:o + n].view(p.shape)
+            if deterministic:
+                self.fxviews[name] = self.grads_fx[o:o + n].view(p.shape)
         # ---- work buffers ----
         R = num_rays
         S0, S1 = cfg.num_proposal_samples_per_ray
@@ -139,8 +145,17 @@ class NerfplayerTrainer:
         _lib.check(self.lib.snerf_tgrid_encode_fwd(C.byref(enc.desc), self._p(table), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(out),
                                                    self._st), "tgrid_fwd")
 
+    def _fx_of(self, gview: torch.Tensor) -> torch.Tensor:
+        """The fixed-point cells behind a view of self.grads (deterministic mode)."""
+        o = gview.storage_offset() - self.grads.storage_offset()
+        return self.grads_fx[o:o + gview.numel()]
+
     def _tgrid_bwd(self, enc, co, times, S, N, gout, gtable):
       with self._span("tgrid_bwd.field" if enc is self.enc else "tgrid_bwd.prop"):
+        if self.grads_fx is not None:
+            _lib.check(self.lib.snerf_tgrid_encode_bwd_fx(C.byref(enc.desc), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(gout),
+                                                          self._p(self._fx_of(gtable)), self._st), "tgrid_bwd_fx")
+            return
         _lib.check(self.lib.snerf_tgrid_encode_bwd(C.byref(enc.desc), C.byref(co), None, self._p(times), S, C.c_int64(N), self._p(gout), self._p(gtable),
                                                    self._st), "tgrid_bwd")
 
@@ -149,6 +164,11 @@ class NerfplayerTrainer:
                                           self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
 
     def _mlp_bwd(self, net, gW, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
+        if self.grads_fx is not None:
+            _lib.check(self.lib.snerf_mlp_bwd_fx(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(gY) if gY is not None else None,
+                                                 ldgy, aux_col, self._p(gaux) if gaux is not None else None, self._p(gX) if gX is not None else None, ldgx,
+                                                 self._p(self._fx_of(gW)), self._st), "mlp_bwd_fx")
+            return
         _lib.check(self.lib.snerf_mlp_bwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(gY) if gY is not None else None,
                                           ldgy, aux_col, self._p(gaux) if gaux is not None else None, self._p(gX) if gX is not None else None, ldgx,
                                           self._p(gW), self._st), "mlp_bwd")
@@ -230,7 +250,11 @@ class NerfplayerTrainer:
         self._mlp_bwd(self.head, self.gviews["field.head"], b["hx"], 64, N2, b["grgb"], 3, -1, None, b["ghx"], 64)
         ghx = b["ghx"].view(R, S2, 64)
         b["gh"].view(R, S2, 16)[:, :, 1:16] = ghx[:, :, 16:31]  # column 0 (density) enters through gaux below
-        self.gviews["field.appearance"].index_add_(0, self.cams, ghx[:, :, 31:63].sum(1))
+        gapp = ghx[:, :, 31:63].sum(1)
+        if self.grads_fx is not None:  # integer index_add_: the atomics behind it commute
+            self.fxviews["field.appearance"].index_add_(0, self.cams, torch.round(gapp.double() * 2.0 ** 50).long())
+        else:
+            self.gviews["field.appearance"].index_add_(0, self.cams, gapp)
         self._mlp_bwd(self.decode, self.gviews["field.decode"], b["feat"], self.enc.output_dim, N2, b["gh"], 16, 0, b["gdens"][2], b["gfeat"],
                       self.enc.output_dim)
         self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])
@@ -283,6 +307,8 @@ class NerfplayerTrainer:
         snerf_adam_step_tv, which adds the temporal-TV gradient of their two columns on the fly."""
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
         off = {name: (o, n) for name, _, _, o, n in self.segments}
+        if self.grads_fx is not None:
+            ops.fx_to_float(self.grads_fx, self.grads, accumulate=True)  # fixed-point cells -> float gradients (cells cleared)
         tv = self.cfg.temporal_tv_weight > 0
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         # one plain sweep per run of segments between (and after) the tables; with the TV term each table gets its own sweep that adds

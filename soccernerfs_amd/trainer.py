@@ -662,10 +662,26 @@ class KPlanesTrainer:
         if self.sorted_scatter and self.grads_fx is None and self._sort_done is not None and r0 == 0 and r1 == self.R:
             torch.cuda.current_stream().wait_event(self._sort_done)
             ss = self._ss
+            ns = len(self.cfg.multiscale_res)
+            beside = bool(self.pass_b_beside_head and self._in_train_step and self.world == 1 and self.overlap and self.async_field_adam and self._reg_in_adam
+                          and not self.cfg.emulate_transports and not (self._sharded() and len(self._exchange) == 2))
+            passb_issued = False
             if self.quotient_scatter:
                 if not qg:
                     with self._span("kplanes_quotient_prepare"):
                         ss.quotient_prepare(b["gfeat"], b["feat"], self._st)
+                if beside:
+                    # (r05) pass B goes FIRST, on the sweep's stream, behind nothing but what it reads: G (the sigma_net backward, just queued) and the
+                    # sorted records.  The sweep's forerunners and the fix-up below used to sit between the sigma_net backward and pass B on the critical
+                    # chain (~35 us of tiny kernels and launch gaps per step, profiles/r05_timeline_step.txt); they only have to precede the SWEEP, which
+                    # waits for everything the caller's stream holds when it is launched (_adam_field_range).
+                    main = torch.cuda.current_stream()
+                    st = self._stream("adam")
+                    st.wait_event(main.record_event())
+                    st.wait_event(self._sort_done)
+                    with KPlanesTrainer._On(self, st):
+                        self._scatter_field_scales(co, 0, ns, fixup=False)
+                    passb_issued = True
                 if self.world == 1 and self._reg_in_adam:
                     # the optimiser sweep's two tiny forerunners (skip decision of the group, zeroed regulariser slots) depend on nothing pass B
                     # produces: issued here they are off the scatter -> sweep hand-over
@@ -678,7 +694,6 @@ class KPlanesTrainer:
               with self._span("kplanes_gradvec.field"):
                 _lib.check(self.lib.snerf_kplanes_gradvec(C.byref(ss.desc), self._p(self.field_planes.planes), C.byref(co), C.c_int64(ss.N),
                                                           self._p(b["gfeat"]), self._p(ss.gvec), ss.gvec_bf16, self._st), "gradvec")
-            ns = len(self.cfg.multiscale_res)
             if self._sharded() and len(self._exchange) == 2:
                 # finest scale first: its reduce-scatter (chunk 0) is on the links while the coarser scales are still being scattered
                 self._scatter_field_scales(co, ns - 1, ns)
@@ -687,19 +702,19 @@ class KPlanesTrainer:
                 self._start_field_grad_exchange(1)
                 self._exchange_started = True
                 return
-            if (self.pass_b_beside_head and self._in_train_step and self.world == 1 and self.overlap and self.async_field_adam and self._reg_in_adam
-                    and not self.cfg.emulate_transports):
+            if beside:
                 # only inside train_step: the one consumer of these gradients is then the sweep, queued behind pass B on the same stream (a
                 # caller of backward() may read the gradient buffer from ITS stream)
                 # The fix-up reads the sample coordinates (the caller's ray tensors, the nerf level's bin edges, which the next step's head overwrites):
-                # it stays on the caller's stream.  Pass B reads only the sorted records, G and the planes.
+                # it stays on the caller's stream; like pass B it only ADDS to the gradient planes, so the two may run side by side.
                 if self.quotient_scatter:
                     self._ss.quotient_fixup_scales(self.field_planes.planes, co, self.gviews["field.planes"], 0, ns, self._st)
-                main = torch.cuda.current_stream()
-                st = self._stream("adam")
-                st.wait_stream(main)  # G (sigma_net backward), the sort (joined above), the zeroed regulariser slots, the group's skip decision
-                with KPlanesTrainer._On(self, st):
-                    self._scatter_field_scales(co, 0, ns, fixup=False)
+                if not passb_issued:  # product form: pass B reads the gradient vectors gradvec has just written
+                    main = torch.cuda.current_stream()
+                    st = self._stream("adam")
+                    st.wait_stream(main)
+                    with KPlanesTrainer._On(self, st):
+                        self._scatter_field_scales(co, 0, ns, fixup=False)
             else:
                 self._scatter_field_scales(co, 0, ns)
         else:

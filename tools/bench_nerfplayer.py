@@ -18,6 +18,8 @@ ap.add_argument("--no-fuse-tv", action="store_true")
 ap.add_argument("--fused", action="store_true", help="soccernerfs_amd.nerfplayer_trainer.NerfplayerTrainer instead of the autograd model")
 ap.add_argument("--full", action="store_true", help="full NeRFPlayer (`nerfplayer` preset, soccernerfs_amd.nerfplayer.NerfplayerModel) instead of the nerfacto variant")
 ap.add_argument("--profile", action="store_true")
+ap.add_argument("--stadium", action="store_true", help="with --fused: camera rays of the synthetic stadium-players scene (30 cameras in the bleachers, aabb [-1,1]^3, uniform "
+                "pixels) instead of random rays through the box -- what bench.py's config-4 leg times")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -28,7 +30,23 @@ if args.fused:
     tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 36 * 100, device=dev)
     tr.step = 600  # past the learning-rate warm-up
 
+    if args.stadium:
+        from soccernerfs_amd import ops, synthetic
+
+        cams = synthetic.make_stadium_cameras(30, 6, 960, 540)
+        frame_ids = torch.linspace(0, 99, 8).long()
+        data = synthetic.render_dataset(cams, frame_ids.float() / 99, list(range(30)), dev, chunk_rows=540, variant="stadium")
+        M, H, W = data["images"].shape[:3]
+        full_index = (data["cam_id"] * 100 + frame_ids.to(dev).repeat(30)).contiguous()
+        tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 3000, aabb_scale=1.0, device=dev)
+        tr.step = 600
+
     def fstep():
+        if args.stadium:
+            idx, target = ops.sample_pixels_uniform(torch.rand(R, 3, device=dev), M, H, W, data["images"])
+            rays = ops.generate_rays(idx, data["fx"], data["fy"], data["cx"], data["cy"], data["c2w"], data["times"])
+            tr.train_step(rays, full_index[idx[:, 0]].contiguous(), target)
+            return
         o = (torch.rand(R, 3, device=dev) * 2 - 1) * 0.6
         d = torch.nn.functional.normalize(torch.rand(R, 3, device=dev) * 2 - 1, dim=-1)
         t = torch.rand(R, 1, device=dev)
@@ -46,7 +64,7 @@ if args.fused:
         fstep()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"config": "nerfplayer-nerfacto preset (fused trainer)", "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
+    print(json.dumps({"config": "nerfplayer-nerfacto preset (fused trainer)" + (", stadium-players camera rays" if args.stadium else ", random rays through the box"), "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
                       "rays_per_s": R * args.steps / dt}))
     sys.exit(0)
 if args.full:

@@ -4,19 +4,21 @@
 # usage: bash tools/collect_config4_profiles.sh <tag>    -> gpurun_out/<tag>_nerfplayer_fused_{bench.json,kernel_stats.csv,pmc.csv}
 set -u
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 fail() { echo "collect_config4_profiles.sh: $1" >&2; exit 1; }
 STEPS=30; WARM=5
-python tools/bench_nerfplayer.py --fused 2> $OUT/${TAG}_np_bench.err | tail -1 > $OUT/${TAG}_np_bench_line.json || fail "bench_nerfplayer.py --fused failed"
+python tools/bench_nerfplayer.py --fused --stadium 2> $OUT/${TAG}_np_bench.err | tail -1 > $OUT/${TAG}_np_bench_line.json || fail "bench_nerfplayer.py --fused --stadium failed"
+# the round-4 workload (random rays through the box) once more, for the comparison with profiles/r04_nerfplayer_fused_bench.json
+python tools/bench_nerfplayer.py --fused 2>/dev/null | tail -n 1 > $OUT/${TAG}_nerfplayer_fused_random_rays_bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_np_stats -- python3 $ROOT/tools/bench_nerfplayer.py --fused --steps $STEPS --warmup $WARM > $OUT/${TAG}_np_stats.log 2>&1 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_np_stats -- python3 $ROOT/tools/bench_nerfplayer.py --fused --stadium --steps $STEPS --warmup $WARM > $OUT/${TAG}_np_stats.log 2>&1 \
   || fail "rocprofv3 --stats pass failed (see $OUT/${TAG}_np_stats.log)"
 find $OUT/${TAG}_np_stats -name '*kernel_stats.csv' | grep -q . || fail "no kernel_stats.csv"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_np_pmc_$C -- python3 $ROOT/tools/bench_nerfplayer.py --fused --steps 6 --warmup 2 > $OUT/${TAG}_np_pmc_$C.log 2>&1 \
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_np_pmc_$C -- python3 $ROOT/tools/bench_nerfplayer.py --fused --stadium --steps 6 --warmup 2 > $OUT/${TAG}_np_pmc_$C.log 2>&1 \
     || fail "rocprofv3 --pmc $C pass failed (see $OUT/${TAG}_np_pmc_$C.log)"
   find $OUT/${TAG}_np_pmc_$C -name '*counter_collection.csv' | grep -q . || fail "no counter_collection.csv from the --pmc $C pass"
 done
@@ -26,7 +28,7 @@ import collections, csv, glob, json, os
 tag, out, steps = os.environ["TAG"], "gpurun_out", int(os.environ["STEPS"])
 rows = list(csv.DictReader(open(glob.glob(f"{out}/{tag}_np_stats/**/*kernel_stats.csv", recursive=True)[0])))
 with open(f"{out}/{tag}_nerfplayer_fused_kernel_stats.csv", "w") as g:
-    g.write(f"# rocprofv3 --kernel-trace --stats -- python3 tools/bench_nerfplayer.py --fused --steps 30 --warmup 5   ({steps} steps in the trace)\n")
+    g.write(f"# rocprofv3 --kernel-trace --stats -- python3 tools/bench_nerfplayer.py --fused --stadium --steps 30 --warmup 5   ({steps} steps in the trace)\n")
     w = csv.writer(g)
     w.writerow(rows[0].keys())
     for r in rows[:30]:
@@ -38,7 +40,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] == c:
                 pmc[r["Kernel_Name"].split("(")[0].replace("void ", "")][c].append(float(r["Counter_Value"]))
 with open(f"{out}/{tag}_nerfplayer_fused_pmc.csv", "w") as g:
-    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 tools/bench_nerfplayer.py --fused --steps 6 --warmup 2 (one counter per pass); SUM over the launches of one step\n")
+    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 tools/bench_nerfplayer.py --fused --stadium --steps 6 --warmup 2 (one counter per pass); SUM over the launches of one step\n")
     g.write("# KiB as reported; traffic = 2 x FETCH + WRITE (MI355X_MICROARCH.md's gfx950 correction; calibrated for 16-B-per-lane streams = the Adam kernels, a ratio-only figure for the scattered tgrid accesses)\n")
     g.write("kernel,launches_per_step,FETCH_SIZE_KiB_per_step,WRITE_SIZE_KiB_per_step,traffic_bytes_per_step\n")
     per_step = {}
@@ -53,7 +55,7 @@ R, P = line["rays"], line["params"]
 ms = lambda pat: sum(float(r["TotalDurationNs"]) for r in rows if pat in r["Name"]) / steps / 1e6
 tr = lambda pat: sum(v for k, v in per_step.items() if pat in k)
 adam_ms = ms("adam_tv_kernel") + ms("adam_kernel")
-fwd_ms, bwd_ms = ms("tgrid_kernel<false"), ms("tgrid_kernel<true") + ms("tgrid_bwd_runs_kernel")
+fwd_ms, bwd_ms = ms("tgrid_kernel<false") + ms("tgrid_fwd_runs_kernel"), ms("tgrid_kernel<true") + ms("tgrid_bwd_runs_kernel")
 alg_ray, sec_ray = 242688, 256 * 40 * 64 + 96 * 40 * 64 + 48 * 128 * 64  # algorithmic bytes / 64-B sectors touched per ray, forward
 line["roofline"] = {
     "bound": "hbm", "kernel": "optimiser sweep: adam_tv_kernel (temporal grids, TV term fused) + adam_kernel (MLPs): p, g, m, v read + p, m, v written + g cleared = 32 B / parameter",
@@ -65,7 +67,7 @@ line["roofline"] = {
         "algorithmic_bytes_per_step_forward": alg_ray * R, "sector_granular_bytes_per_step_forward": sec_ray * R,
         "forward_algorithmic_GBps": alg_ray * R / (fwd_ms * 1e-3) / 1e9, "forward_sector_granular_GBps": sec_ray * R / (fwd_ms * 1e-3) / 1e9,
         "backward_algorithmic_GBps_rmw": 2 * alg_ray * R / (bwd_ms * 1e-3) / 1e9, "backward_sector_granular_GBps_rmw": 2 * sec_ray * R / (bwd_ms * 1e-3) / 1e9,
-        "pmc_traffic_bytes_per_step": {"forward": tr("tgrid_kernel<false"), "backward": tr("tgrid_kernel<true") + tr("tgrid_bwd_runs_kernel")},
+        "pmc_traffic_bytes_per_step": {"forward": tr("tgrid_kernel<false") + tr("tgrid_fwd_runs_kernel"), "backward": tr("tgrid_kernel<true") + tr("tgrid_bwd_runs_kernel")},
         "conventions": "SURVEY 8d: per sample 16 levels x 8 corners x 3 floats x 4 B = 1536 B algorithmic (main) / 480 B (proposal levels); each corner row is its own 64-B sector: "
                        "128 / 40 sectors per sample.  Per ray 256 x 480 + 96 x 480 + 48 x 1536 = 242 688 B algorithmic, 1.29 MB sector-granular; the backward reads and writes them (x 2)"},
     "source": f"rocprofv3 --kernel-trace --stats over {steps} steps (profiles/{tag}_nerfplayer_fused_kernel_stats.csv) and separate --pmc passes (profiles/{tag}_nerfplayer_fused_pmc.csv)"}

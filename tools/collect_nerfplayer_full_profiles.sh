@@ -1,0 +1,40 @@
+#!/bin/bash
+# Full NeRFPlayer (`nerfplayer` preset, 458.6 M parameters, fused flat-buffer trainer): bench line, UNTRUNCATED rocprofv3 kernel stats, one step's timeline
+# and a `roofline` object for its dominant kernel (VERDICT r04 missing #6).  Run on the GPU box from the repo root.
+# usage: bash tools/collect_nerfplayer_full_profiles.sh <tag>   -> gpurun_out/<tag>_nerfplayer_full_{bench.json,kernel_stats.csv,timeline.txt,roofline.json}
+set -u
+set -o pipefail
+TAG=${1:-r05}
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
+fail() { echo "collect_nerfplayer_full_profiles.sh: $1" >&2; exit 1; }
+python tools/bench_nerfplayer_full.py > $OUT/${TAG}_npf_bench.log 2> $OUT/${TAG}_npf_bench.err || fail "bench_nerfplayer_full.py failed (see $OUT/${TAG}_npf_bench.err)"
+tail -n 1 $OUT/${TAG}_npf_bench.log > $OUT/${TAG}_nerfplayer_full_bench.json
+STEPS=30; WARM=5
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_npf_stats -- python3 $ROOT/tools/bench_nerfplayer_full.py --steps $STEPS --warmup $WARM > $OUT/${TAG}_npf_stats.log 2>&1 ) \
+  || fail "rocprofv3 --stats pass failed (see $OUT/${TAG}_npf_stats.log)"
+S=$(find $OUT/${TAG}_npf_stats -name '*kernel_stats.csv' | head -1); T=$(find $OUT/${TAG}_npf_stats -name '*kernel_trace.csv' | head -1)
+[ -n "$S" ] && [ -n "$T" ] || fail "no kernel_stats.csv / kernel_trace.csv"
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_nerfplayer_full.py --steps $STEPS --warmup $WARM   ($((STEPS + WARM)) steps in the trace; every row)"; cat "$S"; } > $OUT/${TAG}_nerfplayer_full_kernel_stats.csv
+python tools/timeline.py "$T" 3 1 spaced_bins_kernel > $OUT/${TAG}_nerfplayer_full_timeline.txt || fail "timeline.py failed"
+TAG=$TAG STEPS=$((STEPS + WARM)) python - <<'PY'
+import csv, json, os
+tag, out, steps = os.environ["TAG"], "gpurun_out", int(os.environ["STEPS"])
+bench = json.load(open(f"{out}/{tag}_nerfplayer_full_bench.json"))
+rows = [r for r in csv.DictReader(l for l in open(f"{out}/{tag}_nerfplayer_full_kernel_stats.csv") if not l.startswith("#"))]
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+sweep = [r for r in rows if "adam" in r["Name"]]
+# the optimiser sweep: Adam (+ temporal TV on the four temporal tables), 32 B per parameter (p, g, m, v read; p, m, v written; g cleared)
+sweep_ms = sum(float(r["TotalDurationNs"]) for r in sweep) / steps / 1e6
+alg = 32 * bench["params"]
+top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]
+roof = {"workload": bench["config"], "ms_per_step": bench["ms_per_step"], "rays_per_s": bench["rays_per_s"], "params": bench["params"],
+        "gpu_kernel_ms_per_step": tot / steps / 1e6,
+        "roofline": {"bound": "hbm", "kernel": "optimiser sweep over the flat buffer: " + ", ".join(sorted({r["Name"].split("(")[0][-40:] for r in sweep})) + " (32 B / parameter)",
+                     "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (sweep_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                     "algorithmic_per_step": alg, "ms_per_step": sweep_ms, "launches_per_step": sum(int(r["Calls"]) for r in sweep) / steps},
+        "top_kernels_ms_per_step": {r["Name"].split("(")[0][-60:]: round(float(r["TotalDurationNs"]) / steps / 1e6, 4) for r in top}}
+json.dump(roof, open(f"{out}/{tag}_nerfplayer_full_roofline.json", "w"), indent=1)
+print(json.dumps(roof)[:1500])
+PY
+rm -rf $OUT/${TAG}_npf_stats
+ls -la $OUT | grep ${TAG}_nerfplayer_full

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 n_ok=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $SET | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_k_$t" -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-standin --images 38 --no-steady-state "$@" > /dev/null 2>&1 && n_ok=$((n_ok + 1))
+  rocprofv3 --pmc $SET --kernel-trace --output-format csv -d "$OUT/pmc_k_$t" -- python3 "$ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --images 38 --no-steady-state "$@" > /dev/null 2>&1 && n_ok=$((n_ok + 1))
 done
 cd "$ROOT"
 if [ $n_ok -eq 0 ]; then echo "pmc_kernels.sh: every rocprofv3 pass failed" >&2; exit 1; fi

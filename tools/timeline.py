@@ -1,5 +1,5 @@
 """Timeline of one training step from a rocprofv3 --kernel-trace CSV (dev tool).
-usage: python tools/timeline.py <kernel_trace.csv> [step_index_from_end]"""
+usage: python tools/timeline.py <kernel_trace.csv> [step_index_from_end] [n_steps] [marker kernel substring (default raygen_kernel)]"""
 import csv, sys, collections
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -7,8 +7,9 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # consecutive steps to print (the optimiser sweep of step k runs under the head of step k + 1)
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].replace("snerf::", "").replace("void ", "")[:60]
-# a step starts at raygen_kernel
-starts = [i for i, r in enumerate(rows) if "raygen_kernel" in r["Kernel_Name"]]
+# a step starts at raygen_kernel (the NeRFPlayer tools feed random rays: their steps start at spaced_bins_kernel)
+marker = sys.argv[4] if len(sys.argv) > 4 else "raygen_kernel"
+starts = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 i0, i1 = starts[-back - 1], starts[-back - 1 + nsteps]
 step = rows[i0:i1]
 t0 = int(step[0]["Start_Timestamp"])

@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_tl" -- python3 "$ROOT/bench.py" --steps 30 --warmup 10 --no-cpu-baseline --no-standin --no-steady-state "$@" > "$OUT/${TAG}_timeline_run.log" 2>&1
+rocprofv3 --kernel-trace --output-format csv -d "$OUT/prof_tl" -- python3 "$ROOT/bench.py" --steps 30 --warmup 10 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-steady-state "$@" > "$OUT/${TAG}_timeline_run.log" 2>&1
 rc=$?
 cd "$ROOT"
 f=$(find "$OUT/prof_tl" -name "*kernel_trace.csv" | head -1)
