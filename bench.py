@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--no-fused-ray-loss", action="store_true", help="A-B: the nerf level's weights / render / MSE / distortion / weights-backward as five kernels instead of one")
+    ap.add_argument("--interleave-prop-levels", action="store_true", help="A/B: proposal backward interleaved by stage (both net backwards before the two plane scatters) instead of level by level")
     ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (K-Planes multiscale 1-32, IST range 0.75, fps-downsample 4; N = 1 only, ~15 s)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (nerfplayer-nerfacto preset on the synthetic stadium-players scene; N = 1 only, ~20 s)")
     ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of the config-3 / config-4 legs")
@@ -390,7 +391,8 @@ def main():
     torch.manual_seed(20231029 + rank)
     cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter,
                              fused_ray_loss=not args.no_fused_ray_loss, fused_proposal=not args.no_fused_proposal,
-                             quotient_epilogue=not args.no_quotient_epilogue, pass_b_beside_head=not args.pass_b_main_stream)  # the k-planes preset
+                             quotient_epilogue=not args.no_quotient_epilogue, pass_b_beside_head=not args.pass_b_main_stream,
+                             interleave_proposal_levels=args.interleave_prop_levels)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
     trainer.overlap = not args.no_overlap

@@ -78,6 +78,10 @@ class KPlanesTrainConfig:
     # weight gradients of the 16-bit MLP backward kernels through 16-replica workspaces (snerf_mlp_bwd_ws / snerf_mlp_gw_reduce): the flush of a
     # launch queues 16 same-address atomics instead of 256 (~25 us per launch), folded into the gradient buffer before the optimiser reads it
     mlp_grad_workspace: bool = True
+    # proposal backward on updated steps: the two levels' kernels interleaved by stage (both net backwards before the two plane scatters) instead of
+    # level by level.  Measured in round 5 (bench.py --interleave-prop-levels, same box, two runs each): 2.252 / 2.218 against 2.221 / 2.232 ms early
+    # schedule -- no difference outside the run-to-run noise, although the traced step suggested 0.4 ms on updated steps: off
+    interleave_proposal_levels: bool = False
     fix_capacity: Optional[int] = None  # quotient scatter: entries of the vanished-feature fix list (None: one per (sample, scale); ops.SortedScatter)
     exchange_chunks: int = 2          # world > 1, sharded: 2 = finest scale exchanged on its own, ahead of the rest (1: one exchange)
     grad_transport: str = "fp32"      # world > 1, sharded: "bf16" halves the reduce-scatter bytes (not the reference's fp32 DDP)
@@ -731,26 +735,36 @@ class KPlanesTrainer:
                                              self._p(b["gw"][lvl]) if with_grad else None, 1, self._st), "depth_loss")
 
     def _proposal_backward(self, proposal_grads: bool):
-        """Proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592)."""
-        for lvl in (0, 1):
-            self._proposal_backward_level(lvl, proposal_grads)
-
-    def _proposal_backward_level(self, lvl: int, proposal_grads: bool):
-        """One proposal level: interlevel loss (+ depth term) -> weights backward -> proposal net backward -> plane scatter.  The two levels
-        touch disjoint buffers and parameter segments."""
+        """Proposal supervision (interlevel loss); gradients only on `updated` steps (ray_samplers.py:573,587-592).  The two levels touch disjoint
+        buffers and parameter segments, so their kernels may be issued level by level (default) or interleaved by stage
+        (cfg.interleave_proposal_levels: both weights backwards, both net backwards, then the two plane scatters).  In the TRACED step
+        (profiles/r05_timeline_step.txt) level 1's net backward -- a 512-thread, 90-KB workgroup per CU -- lands under the field planes' optimiser
+        sweep, whose small workgroups leave it no room (0.65 ms for a 0.03-ms kernel), and the chain ends after the sweep; the untraced step did
+        not get faster with the interleaved order (see the config field), so the order stays as it was."""
         cfg, b, R, co = self.cfg, self.buf, self.R, self.cfg.loss_coefficients
-        S2, Sp = self.S[2], self.S[lvl]
-        _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
-                                             co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
-                                             self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
-        self._depth_loss(lvl, with_grad=proposal_grads)  # adds to the interlevel gradient just written
-        if proposal_grads:
-            N = R * Sp
-            _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, Sp,
-                                                  self._p(b["gdens"][lvl]), 0, self._p(self._dyn["proposal_networks"]), self._st), "weights_bwd")
-            self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, N, None, 1, 0, b["gdens"][lvl],
-                          b["gpfeat"][lvl], cfg.proposal_feature_dim)
-            self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], N, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.planes"])
+        S2 = self.S[2]
+        for lvl in (0, 1):
+            Sp = self.S[lvl]
+            _lib.check(self.lib.snerf_interlevel(self._p(b["sb"][2]), self._p(b["w"][2]), S2, self._p(b["sb"][lvl]), self._p(b["w"][lvl]), Sp, R,
+                                                 co["interlevel_loss"] / (R * S2), self._p(b["inter_rays"][lvl]),
+                                                 self._p(b["gw"][lvl]) if proposal_grads else None, self._st), "interlevel")
+            self._depth_loss(lvl, with_grad=proposal_grads)  # adds to the interlevel gradient just written
+        if not proposal_grads:
+            return
+        wb = lambda lvl: _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][lvl]), self._p(b["eb"][lvl]), self._p(b["gw"][lvl]), R, self.S[lvl],
+                                                               self._p(b["gdens"][lvl]), 0, self._p(self._dyn["proposal_networks"]), self._st), "weights_bwd")
+        nb = lambda lvl: self._mlp_bwd(self.prop_nets[lvl], f"prop{lvl}.mlp", b["pfeat"][lvl], cfg.proposal_feature_dim, R * self.S[lvl], None, 1, 0,
+                                       b["gdens"][lvl], b["gpfeat"][lvl], cfg.proposal_feature_dim)
+        sc = lambda lvl: self._scatter(self._desc_prop[lvl], self.prop_planes[lvl].planes, self._coords[lvl], R * self.S[lvl], b["gpfeat"][lvl],
+                                       self.gviews[f"prop{lvl}.planes"])
+        if cfg.interleave_proposal_levels:
+            for stage in (wb, nb, sc):
+                for lvl in (0, 1):
+                    stage(lvl)
+        else:
+            for lvl in (0, 1):
+                for stage in (wb, nb, sc):
+                    stage(lvl)
 
     def backward(self, target: torch.Tensor, rng: Dict[str, torch.Tensor], proposal_grads: bool, include_reg: bool = True,
                  defer_prop_join: bool = False, depth: Optional[torch.Tensor] = None):
