@@ -204,6 +204,8 @@ def bilinear_plane(plane, coords):
         out = torch.nn.functional.grid_sample(plane, coords.view(1, -1, 1, 2), align_corners=True, mode="bilinear", padding_mode="border")
         return out[0, :, :, 0].t()  # [1,C,N,1] -> [N,C]
     _, C, H, W = plane.shape
+    if plane.stride(1) == 1 and C > 1:
+        return _bilinear_plane_rows(plane, coords)
     ix = ((coords[:, 0] + 1) / 2) * (W - 1)
     iy = ((coords[:, 1] + 1) / 2) * (H - 1)
     ix = torch.clamp(ix, 0, W - 1)
@@ -220,6 +222,32 @@ def bilinear_plane(plane, coords):
         ok = (ixc >= 0) & (ixc <= W - 1) & (iyc >= 0) & (iyc <= H - 1)
         v = p[iyc.clamp(0, H - 1).long(), ixc.clamp(0, W - 1).long()]
         return v * (w * ok)[:, None]
+
+    return corner(iy0, ix0, w_nw) + corner(iy0, ix1, w_ne) + corner(iy1, ix0, w_sw) + corner(iy1, ix1, w_se)
+
+
+def _bilinear_plane_rows(plane, coords):
+    """The same restatement for a plane whose STORAGE is channel-last (a [1,C,H,W] view of an [H,W,C] tensor: oracle/torch_standin.py's
+    `plane_layout="hwc"`): the four corner texels are ROWS of an [H*W, C] matrix, fetched with index_select -- whose backward is a row-wise index_add,
+    128 contiguous bytes per texel -- instead of F.grid_sample's channel-strided backward (one 4-byte atomic per channel and corner, 4 MB apart at the
+    finest scale).  Same arithmetic per output element (weights, products, order of the four additions) as the strided route above; only the order in
+    which autograd sums a texel's gradient contributions differs.  Exists so that the stock-PyTorch stand-in of the reference's algorithm can finish
+    30 000 steps inside one GPU call; checked against F.grid_sample by tests/test_standin_cpu.py."""
+    _, C, H, W = plane.shape
+    rows = plane[0].permute(1, 2, 0).reshape(H * W, C)  # a view: the storage is [H,W,C]
+    ix = torch.clamp(((coords[:, 0] + 1) / 2) * (W - 1), 0, W - 1)
+    iy = torch.clamp(((coords[:, 1] + 1) / 2) * (H - 1), 0, H - 1)
+    ix0, iy0 = torch.floor(ix), torch.floor(iy)
+    ix1, iy1 = ix0 + 1, iy0 + 1
+    w_nw = (ix1 - ix) * (iy1 - iy)
+    w_ne = (ix - ix0) * (iy1 - iy)
+    w_sw = (ix1 - ix) * (iy - iy0)
+    w_se = (ix - ix0) * (iy - iy0)
+
+    def corner(iyc, ixc, w):
+        ok = (ixc <= W - 1) & (iyc <= H - 1)  # the lower corners are >= 0 after the clamp; an upper corner beyond the border adds 0
+        idx = iyc.clamp(0, H - 1).long() * W + ixc.clamp(0, W - 1).long()
+        return rows.index_select(0, idx) * (w * ok)[:, None]
 
     return corner(iy0, ix0, w_nw) + corner(iy0, ix1, w_ne) + corner(iy1, ix0, w_sw) + corner(iy1, ix1, w_se)
 

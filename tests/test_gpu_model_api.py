@@ -321,12 +321,16 @@ def test_unbounded_scene_contraction_matches_reference_golden():
     R = 64
     rb = RayBundle(origins=((torch.rand(R, 3, generator=gen) * 2 - 1) * 0.5).to(DEV), directions=torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1).to(DEV),
                    pixel_area=torch.ones(R, 1, device=DEV), camera_indices=torch.zeros(R, 1, dtype=torch.long, device=DEV), times=torch.rand(R, 1, generator=gen).to(DEV))
+    torch.manual_seed(3)  # the samplers draw on the device's default generator: seeded, the draws (and `far` below) are the same every run
     out = model(rb)
     batch = {"image": torch.rand(R, 3, generator=gen).to(DEV)}
     ld = model.get_loss_dict(out, batch, model.get_metrics_dict(out, batch))
     sum(ld.values()).backward()
     assert out["rgb"].shape == (R, 3) and bool(torch.isfinite(out["rgb"]).all())
+    # the piecewise initial sampler reaches far beyond the unit cube (whose diagonal is 3.5); those samples are contracted onto [-2, 2]^3.  The contract
+    # is on the INITIAL level, which spans near..far whatever the draws; the last level's largest end (16 PDF-resampled intervals per ray) is a draw-
+    # dependent quantity (9.5 ... 40 over unseeded runs) and only has to lie beyond the cube
+    assert float(out["ray_samples_list"][0].frustums.ends.max()) > 10.0
     far = float(out["ray_samples_list"][-1].frustums.ends.max())
-    assert far > 5.0  # the piecewise sampler reaches far beyond the unit cube (whose diagonal is 3.5); those samples are contracted onto [-2, 2]^3
-    #                   (the largest end of 64 rays x 16 resampled intervals depends on the draws: 9.5 ... 40 over repeated runs)
+    assert far > 3.5
     assert float(model.field.grids.planes.grad.abs().sum()) > 0 and all(float(p.grids.planes.grad.abs().sum()) > 0 for p in model.proposal_networks)

@@ -148,12 +148,20 @@ WINDOWS = [(5, 14), (14, 23), (23, 32), (32, 41), (41, 50)]  # steps whose means
 WINDOW_FACTOR = {"rgb_loss": 1.12, "interlevel_loss": 2.5, "distortion_loss": 1.9, "temporal_tv_loss": 1.05, "prob_loss": 1.6}
 
 
+N_RUNS = 4  # repeated runs of the 50 steps: the window means are asserted on their MEAN (the original bounds are the contract)
+
+
 def test_fifty_training_steps_track_the_reference_models_own_run():
     """G13b (oracle/gen_golden_nerfplayer_dynamics.py): 50 optimiser steps of the REFERENCE's NerfplayerModel on the CPU, run as its Trainer
     runs them (set_anneal -> forward -> losses -> backward -> Adam per group -> cosine schedule -> step_cb), every draw stored.  The fused
     HIP trainer, started from the same (G13) parameters and fed the same batch, draws and TV rows, must follow the reference's per-step loss
     terms, PSNR and mean rendered decomposition probabilities -- including the drift towards the static branch (0.20 -> 0.85 within 50
-    steps in the reference itself: the probability regulariser at work, not a defect of this build)."""
+    steps in the reference itself: the probability regulariser at work, not a defect of this build).
+
+    Steps 0-4 are compared value by value in EVERY run.  Beyond them the run is chaotic (float-atomic order: repeated runs of this trainer differ from
+    each other by 10-40 % per step, tools/g13b_spread.py), so what is compared is the course of the run -- window means -- and, since round 5, on the
+    MEAN over N_RUNS repeated runs with the bounds this test had before single outlier runs made round 4 widen them (probabilities within 0.12, the
+    run ending more than 0.7 static): averaging removes the run-to-run part of the deviation instead of the bound giving way to it."""
     from tests.conftest import load_golden
     from tests.test_gpu_hashgrid import _full_model
     from soccernerfs_amd.nerfplayer_full_trainer import NerfplayerFullTrainer
@@ -161,62 +169,69 @@ def test_fifty_training_steps_track_the_reference_models_own_run():
     g, gb = load_golden("g13_nerfplayer_full"), load_golden("g13b_nerfplayer_dynamics")
     model, _ = _full_model(g)
     R = int(g["R"])
-    tr = NerfplayerFullTrainer(model.config, R, aabb_scale=1.0, device=DEV, lr=float(gb["lr0"]), adam_eps=float(gb["eps"]), warm_up_end=int(gb["warm_up_end"]),
-                               max_steps=int(gb["max_steps"]), seed=0)
     pairs = _pairs(model)
-    assert set(pairs) == set(tr.views)
-    with torch.no_grad():
-        for name, p in pairs.items():
-            tr.views[name].copy_(p.detach().reshape(tr.views[name].shape))
     t = lambda k: g[k].to(DEV).contiguous()
     rays = {"origins": t("origins"), "directions": t("directions"), "times": t("times")}
     target = t("target")
     steps = int(gb["steps"])
     keys = ["rgb_loss", "interlevel_loss", "distortion_loss", "temporal_tv_loss", "prob_loss"]
-    worst = {k: 0.0 for k in keys + ["psnr", "probs"]}
-    history = {k: [] for k in keys + ["probs"]}
-    for step in range(steps):
-        rng = {"t_rand": gb["t_rand"][step].to(DEV), "u": [gb["u0"][step].to(DEV), gb["u1"][step].to(DEV)], "bg": gb["bg"][step].to(DEV)}
-        tr.tv_rows = [int(x) for x in gb["tv_rows"][step]]
-        tr.train_step(rays, target, rng)
-        ld = tr.loss_dict()
-        assert set(ld) == set(keys)
-        # early steps: fp32 agreement, value by value.  Later the two runs are 10-50 Adam steps apart from a common start: each step moves every
-        # parameter by ~lr whatever the gradient's size, so rounding-level differences (atomics order) grow, terms like the interlevel loss rise by
-        # four orders of magnitude within ten steps, and now and then a run takes a visibly different branch from step 4 on -- repeated runs of
-        # this trainer differ from EACH OTHER by 10-40 % per step there (tools/g13b_spread.py).  What is comparable is the course of the run: the
-        # mean of every term over windows of steps (below, after the loop)
-        for k in keys:
-            curve = gb["loss_" + k]
-            ref, got = float(curve[step]), float(ld[k])
-            floor = max(1e-2 * float(curve.abs().max()), 1e-7)  # a term four orders below its later size is noise
-            if step < 5:
-                rtol = 2e-3 if step == 0 else 5e-2
-                assert abs(got - ref) <= rtol * max(abs(ref), floor), (step, k, got, ref)
-            history[k].append(got)
-        probs = tr.rendered_probs().mean(0).cpu()
-        dp = float((probs - gb["probs_mean"][step]).abs().max())
-        psnr = float(-10.0 * torch.log10(ld["rgb_loss"]))
-        if step < 5:  # value by value while the runs are still together
-            assert dp <= (1e-4 if step == 0 else 2e-2), (step, probs, gb["probs_mean"][step])
-            assert abs(psnr - float(gb["psnr"][step])) <= (1e-2 if step == 0 else 0.1), (step, psnr, float(gb["psnr"][step]))
-        history["probs"].append(probs)
-    # the course of the run, window by window: this trainer's mean of each term against the reference's (spread of repeated runs: tools/g13b_spread.py)
+
+    def one_run():
+        tr = NerfplayerFullTrainer(model.config, R, aabb_scale=1.0, device=DEV, lr=float(gb["lr0"]), adam_eps=float(gb["eps"]), warm_up_end=int(gb["warm_up_end"]),
+                                   max_steps=int(gb["max_steps"]), seed=0)
+        assert set(pairs) == set(tr.views)
+        with torch.no_grad():
+            for name, p in pairs.items():
+                tr.views[name].copy_(p.detach().reshape(tr.views[name].shape))
+        history = {k: [] for k in keys + ["probs"]}
+        for step in range(steps):
+            rng = {"t_rand": gb["t_rand"][step].to(DEV), "u": [gb["u0"][step].to(DEV), gb["u1"][step].to(DEV)], "bg": gb["bg"][step].to(DEV)}
+            tr.tv_rows = [int(x) for x in gb["tv_rows"][step]]
+            tr.train_step(rays, target, rng)
+            ld = tr.loss_dict()
+            assert set(ld) == set(keys)
+            # early steps: fp32 agreement, value by value.  Later the two runs are 10-50 Adam steps apart from a common start: each step moves every
+            # parameter by ~lr whatever the gradient's size, so rounding-level differences (atomics order) grow, terms like the interlevel loss rise by
+            # four orders of magnitude within ten steps, and now and then a run takes a visibly different branch from step 4 on
+            for k in keys:
+                curve = gb["loss_" + k]
+                ref, got = float(curve[step]), float(ld[k])
+                floor = max(1e-2 * float(curve.abs().max()), 1e-7)  # a term four orders below its later size is noise
+                if step < 5:
+                    rtol = 2e-3 if step == 0 else 5e-2
+                    assert abs(got - ref) <= rtol * max(abs(ref), floor), (step, k, got, ref)
+                history[k].append(got)
+            probs = tr.rendered_probs().mean(0).cpu()
+            dp = float((probs - gb["probs_mean"][step]).abs().max())
+            psnr = float(-10.0 * torch.log10(ld["rgb_loss"]))
+            if step < 5:  # value by value while the runs are still together
+                assert dp <= (1e-4 if step == 0 else 2e-2), (step, probs, gb["probs_mean"][step])
+                assert abs(psnr - float(gb["psnr"][step])) <= (1e-2 if step == 0 else 0.1), (step, psnr, float(gb["psnr"][step]))
+            history["probs"].append(probs)
+        return history
+
+    runs = [one_run() for _ in range(N_RUNS)]
+    worst = {k: 0.0 for k in keys + ["probs"]}
+    # the course of the run, window by window: the mean over the runs of each term's window mean against the reference's
     for k in keys:
         curve = gb["loss_" + k]
         floor = max(1e-2 * float(curve.abs().max()), 1e-7)
         fac = WINDOW_FACTOR[k]
         for lo, hi in WINDOWS:
-            ref, got = float(curve[lo:hi].mean()), sum(history[k][lo:hi]) / (hi - lo)
+            ref = float(curve[lo:hi].mean())
+            got = sum(sum(h[k][lo:hi]) / (hi - lo) for h in runs) / N_RUNS
             assert ref / fac - floor <= got <= ref * fac + floor, (k, (lo, hi), got, ref)
             worst[k] = max(worst[k], abs(got - ref) / max(abs(ref), floor))
-    # the rendered decomposition probabilities drift towards "static" as the reference's do (0.20 -> 0.85 in 50 steps; repeated runs of this trainer
-    # end between 0.67 and 0.88 -- runs 11-13, in round 4, ended 0.1205 and 0.1249 away where the first ten had stayed within 0.12): window means within
-    # 0.2 of the reference's.  A sanity check of the drift's direction and size, not a parity claim: that is what steps 0-4 above are for
+    # the rendered decomposition probabilities drift towards "static" as the reference's do (0.20 -> 0.85 in 50 steps): mean over the runs of the window
+    # means within 0.12 of the reference's (single runs: up to 0.125 away, ending between 0.67 and 0.88 static)
     for lo, hi in WINDOWS:
-        got, ref = torch.stack(history["probs"][lo:hi]).mean(0), gb["probs_mean"][lo:hi].mean(0)
+        got = torch.stack([torch.stack(h["probs"][lo:hi]).mean(0) for h in runs]).mean(0)
+        ref = gb["probs_mean"][lo:hi].mean(0)
         worst["probs"] = max(worst["probs"], float((got - ref).abs().max()))
-        assert float((got - ref).abs().max()) <= 0.2, ((lo, hi), got, ref)
-    # the run ends where the reference's ends: loss lower than at the start, decomposition mostly static
-    assert float(ld["rgb_loss"]) < 0.8 * float(gb["loss_rgb_loss"][0]) and float(probs[0]) > 0.55  # (the reference ends at 0.85; this trainer's runs at 0.67 - 0.88)
-    print("G13b: worst deviation of the window means from the reference's run (steps 5..49):", {k: round(v, 4) for k, v in worst.items()})
+        assert float((got - ref).abs().max()) <= 0.12, ((lo, hi), got, ref)
+    # the runs end where the reference's ends: loss lower than at the start, decomposition mostly static (the reference ends at 0.85)
+    end_rgb = sum(h["rgb_loss"][-1] for h in runs) / N_RUNS
+    end_static = sum(float(h["probs"][-1][0]) for h in runs) / N_RUNS
+    assert end_rgb < 0.8 * float(gb["loss_rgb_loss"][0]) and end_static > 0.7, (end_rgb, end_static)
+    print(f"G13b: worst deviation of the mean (over {N_RUNS} runs) window means from the reference's run (steps 5..49):", {k: round(v, 4) for k, v in worst.items()},
+          "end static probability per run:", [round(float(h["probs"][-1][0]), 3) for h in runs])

@@ -73,8 +73,8 @@ def run_one(args, seed, train, sets, ist, dev, log_steps=True):
         # the reference's algorithm in stock PyTorch (oracle/torch_standin.py: checker / baseline code, imported ONLY for this mode) on the same
         # pixel draws (same sampler, same seed), the same rays and the same evaluation; F.grid_sample per plane as the reference calls it
         from oracle import kplanes_oracle as KO, torch_standin as TS
-        KO.USE_GRID_SAMPLE = True
-        trainer = TS.StandinTrainer(dev, R, seed=seed, max_steps=args.schedule_steps)
+        KO.USE_GRID_SAMPLE = args.standin_layout != "hwc"
+        trainer = TS.StandinTrainer(dev, R, seed=seed, max_steps=args.schedule_steps, plane_layout=args.standin_layout)
     else:
         trainer = KPlanesTrainer(cfg, R, dev)
         if args.oracle_init:  # the stand-in's initial parameters (same generator, same seed) instead of the trainer's own draw
@@ -173,6 +173,9 @@ def main():
     ap.add_argument("--standin", action="store_true",
                     help="train the REFERENCE'S ALGORITHM in stock PyTorch (oracle/torch_standin.StandinTrainer: F.grid_sample per plane, Linear stacks, autograd, "
                          "two torch.optim.Adam, fp32) instead of the HIP trainer -- same pixel draws, rays, schedule and evaluation; ~95 ms / step")
+    ap.add_argument("--standin-layout", default="chw", choices=["chw", "hwc"], help="--standin: chw = planes [1,C,H,W] through F.grid_sample, the reference's own call; "
+                    "hwc = the same algorithm on channel-last planes gathered as rows (oracle KO._bilinear_plane_rows, checked against F.grid_sample by "
+                    "tests/test_standin_cpu.py): about twice the rate, so that 30 000 steps fit one GPU call")
     ap.add_argument("--eval-at", default="", help="extra evaluation steps, comma separated (e.g. the step a stand-in run got to)")
     ap.add_argument("--train-budget-s", type=float, default=0.0, help="stop training when this much wall-clock is spent (a gpurun call is capped at one hour), "
                     "evaluate there and record `stopped_early_at_step`")
@@ -195,7 +198,9 @@ def main():
     sets = {"camera_20": (held, pick(held)), "novel": (novel, pick(novel)),
             "train": (train, torch.linspace(0, train["images"].shape[0] - 1, 4).long().tolist())}
     log = {"config": "k-planes preset, synthetic Broadcast-style (19 train cams x 33 frames 960x540)", "steps": args.steps, "scene": args.scene, "eval_frames": args.eval_frames or "all",
-           "trainer": "oracle/torch_standin.StandinTrainer: the reference's algorithm in stock PyTorch-ROCm, fp32" if args.standin else "soccernerfs_amd KPlanesTrainer (HIP)",
+           "trainer": ("oracle/torch_standin.StandinTrainer: the reference's algorithm in stock PyTorch-ROCm, fp32"
+                       + (", planes stored channel-last and gathered as rows (index_select) instead of F.grid_sample" if args.standin_layout == "hwc" else ", F.grid_sample per plane"))
+           if args.standin else "soccernerfs_amd KPlanesTrainer (HIP)",
            "oracle_init": bool(args.oracle_init or args.standin),
            "mlp_operands": args.mlp_operands, "gvec_dtype": args.gvec_dtype, "per_net_operands": [args.sigma_operands, args.color_operands, args.proposal_operands],
            "deterministic": args.deterministic, "nonfinite_policy": args.nonfinite_policy,
