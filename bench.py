@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--trained-until", type=int, default=5000, help="third leg: really train to this step (untimed, ~12 s), then time K steady-state steps (0 or --no-steady-state: skip)")
     ap.add_argument("--time-sorted-rays", action="store_true", help="A/B: every batch in order of frame time (ops.sort_rays_by_time); faster field forward, but 1.5 %% slower trained steps: profiles/r03_kernels.md section 11")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
+    ap.add_argument("--sort-before-field-fwd", action="store_true", help="A/B: the nerf level's sample sort before the wait for the sweep instead of after the field forward (measured slower: trainer.py)")
     ap.add_argument("--pass-b-main-stream", action="store_true", help="A/B: pass B of the field scatter on the caller's stream (round 3) instead of on the sweep's stream beside the next step's head")
     ap.add_argument("--no-fused-proposal", action="store_true", help="A/B: proposal levels as gather + net kernels instead of the fused density kernel (bit-identical densities)")
     ap.add_argument("--no-quotient-epilogue", action="store_true", help="A/B: round 3's flow -- G = gfeat .* feat from a separate pass over fp32 features instead of the sigma_net backward's epilogue")
@@ -391,7 +392,7 @@ def main():
     torch.manual_seed(20231029 + rank)
     cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter,
                              fused_ray_loss=not args.no_fused_ray_loss, fused_proposal=not args.no_fused_proposal,
-                             quotient_epilogue=not args.no_quotient_epilogue, pass_b_beside_head=not args.pass_b_main_stream,
+                             quotient_epilogue=not args.no_quotient_epilogue, pass_b_beside_head=not args.pass_b_main_stream, sort_before_field_fwd=args.sort_before_field_fwd,
                              interleave_proposal_levels=args.interleave_prop_levels)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)

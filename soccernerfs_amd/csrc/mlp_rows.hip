@@ -45,7 +45,11 @@ __host__ __device__ constexpr int rows_pi(int p) { return (p & ~31) + 16 * ((p >
 // touches in one ds_read_b64_tr_b16 (4 rows x 32 B per 16-lane group, two groups) fall on 8 disjoint sets of 8 banks
 __host__ __device__ constexpr int rows_img_ld(int width) { return width <= 16 ? 16 : (width <= 32 ? 48 : (width <= 64 ? 80 : 144)); }
 
-constexpr int ROWS_NW = 8;  // waves per workgroup (one workgroup per CU: two waves per SIMD at <= 256 registers)
+// Waves per workgroup: one 8-wave workgroup per CU (two waves per SIMD at <= 256 registers).  A 4-wave variant (two workgroups per CU, grid 512) was
+// measured in round 5 on the suspicion that the big workgroup starves beside kernels of small workgroups: alone 0.042 ms against 0.038 (colour net),
+// and in the untraced step the kernels were stretched exactly as before (proposal level 1: 0.24-0.27 ms beside the optimiser sweep, 0.03 alone;
+// profiles/r05_step_offsets_nw4.txt) -- the stretch is memory latency under an HBM-saturating neighbour, not workgroup slots.
+constexpr int ROWS_NW = 8;
 
 // local arrays picked at compile time without taking their address (keeps them in registers)
 template <bool SECOND, typename X, typename Y>

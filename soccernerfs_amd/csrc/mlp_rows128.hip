@@ -167,6 +167,7 @@ __global__ __launch_bounds__(NW * 64) void sigma_bwd_kernel(MlpArgs a, int64_t n
     gaq = gap[nn * ga_on];
   };
 
+  const bool gvec = a.gX && (a.ldgx & 3) == 0 && (reinterpret_cast<uintptr_t>(a.gX) & 15) == 0;
   int64_t tile = blockIdx.x;
   if (tile < n_tiles) fetch(tile);
   for (; tile < n_tiles; tile += gridDim.x) {
@@ -271,35 +272,36 @@ __global__ __launch_bounds__(NW * 64) void sigma_bwd_kernel(MlpArgs a, int64_t n
         // lane (g, c): features 16 kb + 4g .. +3 of sample 16 wave + c
         const int64_t n = n0 + 16 * wave + c;
         const int f0 = 16 * kb + 4 * g;
+        // (d_in == K0 for every shape this kernel serves -- the dispatcher checks it -- so every feature column is live: no per-column guards)
         if constexpr (QG) {
           const v4t xv = *reinterpret_cast<const v4t*>(XI + (16 * wave + c) * P::LX + f0);
-          f32x4 o4;
-          bool fix[4];
+          f32x4 o4, gx4;
+          bool anyfix = false;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float x = (float)xv[r], gx = acc[r] * (1.f / GS);
+            const float x = (float)xv[r];
+            gx4[r] = acc[r] * (1.f / GS);
             const bool vanished = fabsf(x) < QUOT_TINY;
-            o4[r] = vanished ? 0.f : gx * x;
-            fix[r] = vanished && gx != 0.f && f0 + r < a.d0;
+            o4[r] = vanished ? 0.f : gx4[r] * x;
+            anyfix |= vanished && gx4[r] != 0.f;
           }
           if (n < a.N) {
-            float* dst = a.G + n * a.ldg + f0;
-            if (f0 + 3 < a.d0) *reinterpret_cast<f32x4*>(dst) = o4;
-            else {
+            *reinterpret_cast<f32x4*>(a.G + n * a.ldg + f0) = o4;
+            if (__builtin_expect(anyfix, 0)) {  // ONE branch per block: a vanished feature with a live gradient is rare (never, in training so far)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                if (f0 + r < a.d0) dst[r] = o4[r];
+                if (fabsf((float)xv[r]) < QUOT_TINY && gx4[r] != 0.f) fix_append(a.fix_list, a.fix_capacity, a.fix_count, (int32_t)(n * a.ldg + f0 + r), gx4[r]);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (fix[r]) fix_append(a.fix_list, a.fix_capacity, a.fix_count, (int32_t)(n * a.ldg + f0 + r), acc[r] * (1.f / GS));
           }
         } else {
           if (n < a.N) {
             float* dst = a.gX + n * a.ldgx + f0;
+            const f32x4 o4 = {acc[0] * (1.f / GS), acc[1] * (1.f / GS), acc[2] * (1.f / GS), acc[3] * (1.f / GS)};
+            if (gvec) *reinterpret_cast<f32x4*>(dst) = o4;
+            else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (f0 + r < a.d0) dst[r] = acc[r] * (1.f / GS);
+              for (int r = 0; r < 4; ++r) dst[r] = o4[r];
+            }
           }
         }
       }

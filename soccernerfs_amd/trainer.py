@@ -123,6 +123,11 @@ class KPlanesTrainConfig:
     # generation, proposal levels) runs beside pass B (bound by float atomics) and has mostly finished when the sweep (bound by HBM) starts; and the
     # pass B -> sweep hand-over stays inside one stream.  False: pass B on the caller's stream (round 3; A-B).
     pass_b_beside_head: bool = True
+    # Round 5 (A-B, off): the nerf level's sample sort needs the sample COORDINATES only, so it can be issued before the wait for the field planes'
+    # optimiser sweep instead of after the field forward.  Measured: the colour-net backward it no longer runs beside drops from 0.17 to 0.065 ms in the
+    # untraced step, but the sort under the HBM-bound sweep takes 0.3-0.7 ms and stretches the sweep from 0.82 to 0.97 ms -- steady state 2.03 / 2.07 ms
+    # with it against 1.98 / 2.01 without (two runs each, one box; profiles/r05_step_offsets_early_sort.txt).
+    sort_before_field_fwd: bool = False
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -294,6 +299,7 @@ class KPlanesTrainer:
         if cfg.emulate_transports not in ("", "grad", "param", "both"):
             raise ValueError(f"emulate_transports must be '', 'grad', 'param' or 'both', got {cfg.emulate_transports!r}")
         self._sort_done = None
+        self._passb_done = None
         # (the proposal planes keep the sample-major scatter: they are small enough that their atomics are served by L2 -- 0.5 M of 19 M requests
         # reach memory -- while sorting 1.5 M samples x 6 planes cost ~0.6 ms: measured in round 1, the opt-in path was removed in round 3)
         self.step = 0                 # completed optimiser steps
@@ -535,12 +541,15 @@ class KPlanesTrainer:
                 self._mlp_fwd(self.prop_nets[lvl], b["pfeat"][lvl], cfg.proposal_feature_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
+                will_sort = bool(training and self.sorted_scatter and self.grads_fx is None and R == self.R)
+                sort_early = bool(will_sort and self.cfg.sort_before_field_fwd and self._field_adam_done is not None)
+                if sort_early:
+                    self._issue_sort(co)
                 self._wait_params()
                 # a training step's fused forward leaves the feature tile (16-bit), the sigma_net outputs and (quotient scatter) the fp32 features
                 # behind for the unfused backward kernels
                 self._fwd_fused = self.fused_field
                 keep = training
-                will_sort = bool(training and self.sorted_scatter and self.grads_fx is None and R == self.R)
                 # G comes out of the sigma_net backward's epilogue (quotient_epilogue): the fp32 features are then not needed at all
                 self._qg_step = bool(self._fwd_fused and self.quotient_epilogue and will_sort)
                 if self._fwd_fused:
@@ -553,15 +562,9 @@ class KPlanesTrainer:
                                    "kplanes_field_fwd")
                 else:
                     self._gather(self._desc_field, self.field_planes.planes, co, N, b["feat"])
-                if will_sort:
-                    # sort the nerf-level samples per (scale, plane) on a side stream.  Started AFTER the (memory-bound) gather so
-                    # that it runs under the MFMA-bound MLP forward / backward that follow on the main stream.
-                    main = torch.cuda.current_stream()
-                    st = self._stream("sort")
-                    st.wait_stream(main)
-                    with KPlanesTrainer._On(self, st), self._span("kplanes_sort"):
-                        self._ss.sort(co, self._st)
-                    self._sort_done = st.record_event()
+                if will_sort and not sort_early:
+                    # Started AFTER the (memory-bound) gather: it runs under the MLP backward kernels that follow on the main stream.
+                    self._issue_sort(co)
                 if not self._fwd_fused:
                     self._mlp_fwd(self.sigma_net, b["feat"], self.field_planes.out_dim, N, b["h"], 16, 15, b["dens"][2])
                     self._mlp_fwd(self.color_net, b["h"], 16, N, b["rgb"], 3)
@@ -580,6 +583,19 @@ class KPlanesTrainer:
         a.rgb_out, a.acc_out, a.depth_median = b["rgb_out"].data_ptr(), b["acc"].data_ptr(), b["depth"].data_ptr()
         _lib.check(self.lib.snerf_render_fwd(C.byref(a), self._st), "render_fwd")
         return b["rgb_out"][:R]
+
+    def _issue_sort(self, co):
+        """Sort the nerf-level samples per (scale, plane) on the "sort" stream, behind what the caller's stream holds (the sample coordinates) and
+        behind the last reader of the sorted records on another stream (pass B of the previous step, when it ran on the sweep's stream)."""
+        main = torch.cuda.current_stream()
+        st = self._stream("sort")
+        st.wait_stream(main)
+        if self._passb_done is not None:
+            st.wait_event(self._passb_done)
+            self._passb_done = None
+        with KPlanesTrainer._On(self, st), self._span("kplanes_sort"):
+            self._ss.sort(co, self._st)
+        self._sort_done = st.record_event()
 
     # ---- stream helpers: kernels bound by different units overlap on separate HIP streams ----
     class _On:
@@ -685,6 +701,7 @@ class KPlanesTrainer:
                     st.wait_event(self._sort_done)
                     with KPlanesTrainer._On(self, st):
                         self._scatter_field_scales(co, 0, ns, fixup=False)
+                    self._passb_done = st.record_event()
                     passb_issued = True
                 if self.world == 1 and self._reg_in_adam:
                     # the optimiser sweep's two tiny forerunners (skip decision of the group, zeroed regulariser slots) depend on nothing pass B
@@ -719,6 +736,7 @@ class KPlanesTrainer:
                     st.wait_stream(main)
                     with KPlanesTrainer._On(self, st):
                         self._scatter_field_scales(co, 0, ns, fixup=False)
+                    self._passb_done = st.record_event()
             else:
                 self._scatter_field_scales(co, 0, ns)
         else:
