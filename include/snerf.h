@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 12
+#define SNERF_ABI_VERSION 13
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -178,6 +178,10 @@ int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act, const flo
                     snerf_stream_t stream);
 int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
                     const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* ABI 13, deterministic mode: the same with gW accumulated into 2^50-scaled 64-bit cells [K,M] (see snerf_kplanes_gather_bwd_fx; gX is per-sample
+ * work and identical between runs either way). */
+int snerf_dense_bwd_fx(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                       const float* gY, int32_t ldgy, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream);
 
 /* Y[N,d_out] (row stride ldy) = MLP(X[N,d_in] (row stride ldx)).  If aux_out != NULL:
  * aux_out[n] = exp(raw output column aux_col) -- trunc_exp's forward (NS/field_components/activations.py:25-41),
@@ -566,6 +570,11 @@ int snerf_hashgrid_encode_fwd(const snerf_hashgrid_desc* desc, const float* tabl
 /* grad_table [rows, F] (may be NULL) and grad_x [B, D] (may be NULL; needs table) are ACCUMULATED into (atomic fp32): caller zeroes. */
 int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out,
                               float* grad_table, float* grad_x, snerf_stream_t stream);
+/* ABI 13, deterministic mode: grad_table_fx [rows, F] and grad_x_fx [B, D] (either may be NULL) are 2^50-scaled 64-bit cells (integer adds are
+ * associative: the table scatter's arrival order and the order in which the levels' workgroups reach a sample's coordinate gradient no longer
+ * matter); snerf_fx_to_float turns them into floats. */
+int snerf_hashgrid_encode_bwd_fx(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out,
+                                 int64_t* grad_table_fx, int64_t* grad_x_fx, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NeRFPlayer decomposition mixing (NerfplayerField.get_density, NS/fields/nerfplayer_field.py:365-372): probs[N,3] = softmax(logits[N,3])

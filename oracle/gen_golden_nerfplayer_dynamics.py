@@ -11,6 +11,11 @@ rate is 1e-2 for the whole run.
 
     python oracle/gen_golden_nerfplayer_dynamics.py        # build container only; writes tests/golden/g13b_nerfplayer_dynamics.npz
 
+How far can ANY other arithmetic follow this run value by value?  The reference's own run answers: SNERF_G13B_THREADS=<n> (torch.set_num_threads: another
+summation order inside ATen's reductions and GEMMs) and / or SNERF_G13B_PERTURB=<eps> (every initial parameter multiplied by 1 + eps * (+-1), eps ~ 1e-7 =
+one fp32 rounding) with SNERF_G13B_OUT=<path> write a second run elsewhere; tools/g13b_reference_spread.py compares it with the committed one
+(profiles/r05_g13b_reference_spread.json).
+
 TEST INFRASTRUCTURE ONLY (header as oracle/_refimport.py)."""
 import math
 import os
@@ -51,6 +56,8 @@ def main():
         f.stationary_field.params.copy_(torch.rand(f.stationary_field.params.shape, generator=gen) * 2 - 1)
         for l in f.deformation_field.layers:
             l.weight.mul_(1.5)
+    if os.environ.get("SNERF_G13B_THREADS"):
+        torch.set_num_threads(int(os.environ["SNERF_G13B_THREADS"]))
     R = 20
     o = (torch.rand(R, 3, generator=gen) * 2 - 1) * 0.4
     d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)
@@ -63,6 +70,13 @@ def main():
             assert np.array_equal(g13["param_" + name], p.detach().numpy()), name  # the run starts from the committed G13 parameters
     assert np.array_equal(g13["origins"], o.numpy()) and np.array_equal(g13["target"], target.numpy())
     rb = RayBundle(origins=o, directions=d, pixel_area=torch.ones(R, 1), camera_indices=cams, times=times)
+    eps_p = float(os.environ.get("SNERF_G13B_PERTURB", "0"))
+    if eps_p:  # AFTER the check against G13: a one-rounding perturbation of the start, to measure how fast the reference's own run forgets it
+        genp = torch.Generator().manual_seed(99)
+        with torch.no_grad():
+            for p_ in model.parameters():
+                if p_.requires_grad and p_.numel():
+                    p_.mul_(1.0 + eps_p * (torch.randint(0, 2, p_.shape, generator=genp).float() * 2 - 1))
 
     groups = model.get_param_groups()  # {"proposal_networks": [...], "fields": [...]}
     opts = {k: torch.optim.Adam(v, lr=LR, eps=EPS) for k, v in groups.items()}
@@ -118,7 +132,9 @@ def main():
         if p.requires_grad and p.numel():
             g["psum_" + name] = p.detach().double().sum()
             g["pabs_" + name] = p.detach().double().abs().sum()
-    path = os.path.join(ROOT, "tests", "golden", "g13b_nerfplayer_dynamics.npz")
+    path = os.environ.get("SNERF_G13B_OUT") or os.path.join(ROOT, "tests", "golden", "g13b_nerfplayer_dynamics.npz")
+    if os.environ.get("SNERF_G13B_THREADS") or eps_p:
+        assert os.environ.get("SNERF_G13B_OUT"), "a run with another thread count / a perturbed start must not overwrite the committed fixture"
     np.savez_compressed(path, **{k: npy(v) for k, v in g.items()})
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class KPlanesDesc(C.Structure):
@@ -172,6 +172,7 @@ EXPORTS = [
     "snerf_mlp_supported",
     "snerf_dense_fwd",
     "snerf_dense_bwd",
+    "snerf_dense_bwd_fx",
     "snerf_render_fwd",
     "snerf_ray_train_fwd_bwd",
     "snerf_render_bwd",
@@ -197,6 +198,7 @@ EXPORTS = [
     "snerf_hashgrid_layout",
     "snerf_hashgrid_encode_fwd",
     "snerf_hashgrid_encode_bwd",
+    "snerf_hashgrid_encode_bwd_fx",
     "snerf_tgrid_encode_bwd",
     "snerf_tgrid_encode_bwd_fx",
     "snerf_tgrid_encode_fwd_dydx",

@@ -27,6 +27,8 @@ struct HgArgs {
   const float* gout;    // bwd [B, L*F]
   float* gtable;        // bwd, may be null
   float* gx;            // bwd, may be null: [B, D], accumulated over levels
+  long long* gtable_fx; // deterministic mode: the same two accumulators as 2^50-scaled 64-bit cells (common.hpp: fx_atomic_add)
+  long long* gx_fx;
 };
 
 template <int F, bool BWD, int HG_CB>
@@ -98,11 +100,13 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
 #pragma unroll
       for (int f = 0; f < F; ++f) acc[f] += w * a.table[e + f];
     } else {
-      if (a.gtable) {
+      if (a.gtable || a.gtable_fx) {
         const float v = w * g;
-        if (v != 0.f) atomicAdd(a.gtable + e + fl, v);
+        if (v != 0.f) {
+          if (a.gtable_fx) fx_atomic_add(a.gtable_fx + e + fl, v); else atomicAdd(a.gtable + e + fl, v);
+        }
       }
-      if (a.gx) {
+      if (a.gx || a.gx_fx) {
         // dy/dx_d = scale * sum over corners of (+-1 along d) * prod_{e != d} w_e * value (grid.h dy_dx, linear interpolation)
         float dot = a.table[e + fl] * g;
 #pragma unroll
@@ -119,13 +123,15 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
   if (!BWD) {
 #pragma unroll
     for (int f = 0; f < F; ++f) a.out[b * (a.d.L * F) + level * F + f] = acc[f];
-  } else if (a.gx) {
+  } else if (a.gx || a.gx_fx) {
     for (int o = F; o < LPS; o <<= 1)
       for (int d = 0; d < D; ++d) gxd[d] += __shfl_xor(gxd[d], o, 64);  // the other corners' lanes
     if (li == 0) {
       for (int d = 0; d < D; ++d) {
         const float v = gxd[d] * scale;
-        if (v != 0.f) atomicAdd(a.gx + b * D + d, v);
+        if (v != 0.f) {
+          if (a.gx_fx) fx_atomic_add(a.gx_fx + b * D + d, v); else atomicAdd(a.gx + b * D + d, v);  // one add per level: the levels are separate workgroups
+        }
       }
     }
   }
@@ -214,5 +220,19 @@ extern "C" int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const 
   SNERF_REQUIRE(!grad_x || table, "hashgrid_encode_bwd: the coordinate gradient needs the table");
   HgArgs a = {};
   a.d = *desc; a.x = x; a.B = B; a.table = table; a.gout = grad_out; a.gtable = grad_table; a.gx = grad_x;
+  return launch<true>(a, (hipStream_t)stream);
+}
+
+// snerf.h (ABI 13): both accumulators as fixed-point cells
+extern "C" int snerf_hashgrid_encode_bwd_fx(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out,
+                                            int64_t* grad_table_fx, int64_t* grad_x_fx, snerf_stream_t stream) {
+  int rc = validate(desc, B);
+  if (rc) return rc;
+  if (B == 0) return 0;
+  SNERF_REQUIRE(x && grad_out && (grad_table_fx || grad_x_fx), "hashgrid_encode_bwd_fx: null buffer");
+  SNERF_REQUIRE(!grad_x_fx || table, "hashgrid_encode_bwd_fx: the coordinate gradient needs the table");
+  HgArgs a = {};
+  a.d = *desc; a.x = x; a.B = B; a.table = table; a.gout = grad_out;
+  a.gtable_fx = reinterpret_cast<long long*>(grad_table_fx); a.gx_fx = reinterpret_cast<long long*>(grad_x_fx);
   return launch<true>(a, (hipStream_t)stream);
 }

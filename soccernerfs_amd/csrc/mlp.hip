@@ -692,7 +692,7 @@ __global__ __launch_bounds__(dense_waves<MP>() * 64) void dense_bwd_kernel(MlpAr
     }
     if (tile + gridDim.x < n_tiles) xt.fetch(a, (tile + gridDim.x) * TS);
     __syncthreads();
-    if (a.gW) {
+    if (a.gW || a.gWfx) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int t = wave + NW * j;
@@ -1061,13 +1061,13 @@ extern "C" int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act
 
 // Backward of snerf_dense_fwd from the layer's stored output Y: gX[N,K] = dZ W^T (written; may be NULL), gW[K,M] += X^T dZ (atomic; may
 // be NULL), dZ = gY .* act'(Y).  Tiled like the forward: a K block writes its own columns of gX, later column blocks add to them.
-extern "C" int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
-                               const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+static int dense_bwd_impl(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                          const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, long long* gWfx, snerf_stream_t stream) {
   SNERF_REQUIRE(K >= 1 && K <= 4096 && M >= 1 && M <= 4096 && act >= 0 && act <= 2, "dense_bwd: K=%d M=%d act=%d (K, M <= 4096)", K, M, act);
   SNERF_REQUIRE(N >= 0 && ldx >= K && ldy >= M && ldgy >= M && (!gX || ldgx >= K), "dense_bwd: N=%lld ldx=%d ldy=%d ldgy=%d ldgx=%d", (long long)N, ldx,
                 ldy, ldgy, ldgx);
   if (N == 0) return 0;
-  SNERF_REQUIRE(W && X && Y && gY && (gX || gW), "dense_bwd: null buffer");
+  SNERF_REQUIRE(W && X && Y && gY && (gX || gW || gWfx), "dense_bwd: null buffer");
   for (int k0 = 0; k0 < K; k0 += 128)
     for (int j0 = 0; j0 < M; j0 += 128) {
       const int kb = K - k0 < 128 ? K - k0 : 128, mb = M - j0 < 128 ? M - j0 : 128;
@@ -1076,8 +1076,20 @@ extern "C" int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act
       a.Y = const_cast<float*>(Y) + j0; a.ldy = ldy; a.hidden_act = act == 1; a.out_act = act == 2;
       a.gY = gY + j0; a.ldgy = ldgy; a.gX = gX ? gX + k0 : nullptr; a.ldgx = ldgx; a.acc_gx = j0 > 0;
       a.gW = gW ? gW + (int64_t)k0 * M + j0 : nullptr;
+      a.gWfx = gWfx ? gWfx + (int64_t)k0 * M + j0 : nullptr;
       int rc = dispatch_dense(kb, mb, a, true, (hipStream_t)stream);
       if (rc) return rc;
     }
   return 0;
+}
+
+extern "C" int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                               const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream) {
+  return dense_bwd_impl(W, K, M, act, X, ldx, N, Y, ldy, gY, ldgy, gX, ldgx, gW, nullptr, stream);
+}
+
+// snerf.h (ABI 13): the weight gradient accumulated into fixed-point cells (any arrival order of the workgroups gives the same bits)
+extern "C" int snerf_dense_bwd_fx(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                                  const float* gY, int32_t ldgy, float* gX, int32_t ldgx, int64_t* gW_fx, snerf_stream_t stream) {
+  return dense_bwd_impl(W, K, M, act, X, ldx, N, Y, ldy, gY, ldgy, gX, ldgx, nullptr, reinterpret_cast<long long*>(gW_fx), stream);
 }

@@ -35,7 +35,11 @@ def _align4(n: int) -> int:
 
 class NerfplayerFullTrainer:
     def __init__(self, cfg: NerfplayerModelConfig, num_rays: int, aabb_scale: float = 1.0, device="cuda:0", lr: float = 1e-2,
-                 adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0):
+                 adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False):
+        """deterministic: every gradient accumulated across samples -- the temporal-grid and hash-grid table scatters, the hash grid's coordinate
+        gradient (one add per level and sample), the weight gradients of all seven nets -- goes into 2^50-scaled 64-bit cells
+        (snerf_*_bwd_fx; integer adds are associative) and is converted once per step: two runs from the same state and draws give the same bits.
+        Costs 8 bytes per parameter (3.7 GB at the preset) and 64-bit atomics."""
         if not cfg.disable_scene_contraction or cfg.use_same_proposal_network or cfg.num_proposal_iterations != 2 or not cfg.disable_viewing_dependent:
             raise NotImplementedError("NerfplayerFullTrainer covers the `nerfplayer` preset (AABB collider, two proposal networks, no view dependence)")
         self.cfg, self.R, self.dev = cfg, num_rays, torch.device(device)
@@ -86,6 +90,7 @@ class NerfplayerFullTrainer:
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
+        self.grads_fx = torch.zeros(off, dtype=torch.int64, device=self.dev) if deterministic else None
         self.views, self.gviews = {}, {}
         for name, mod, attr, o, n in self.segments:
             p = getattr(mod, attr)
@@ -120,6 +125,7 @@ class NerfplayerFullTrainer:
             "rgb_out": f(R, 3), "acc": f(R), "depth": f(R), "sqerr": z(R), "dist_rays": f(R), "inter_rays": [f(R), f(R)],
             "tv": z(4, 64, 16),
         }
+        self._gx_fx = torch.zeros(N * 3, dtype=torch.int64, device=self.dev) if deterministic else None  # the deformed half's coordinate gradient
         self._encs = [self.newness, self.decomp, self.prop_enc[0], self.prop_enc[1]]  # temporal-TV order of nerfplayer.py:329-333
         self._enc_names = ["field.newness", "field.decomp", "prop0.table", "prop1.table"]
         self._srow = [z(e.embeddings.shape[0]) for e in self._encs]
@@ -145,7 +151,22 @@ class NerfplayerFullTrainer:
         self._ck(self.lib.snerf_tgrid_encode_fwd(C.byref(enc.desc), self._p(enc.embeddings), C.byref(co), None, self._p(times), spr, C.c_int64(N), self._p(out),
                                                  self._st), "tgrid_fwd")
 
+    def _pfx(self, gview: torch.Tensor, off_cells: int = 0):
+        """The fixed-point cells behind a view of self.grads (deterministic mode), as a pointer."""
+        o = (gview.data_ptr() - self.grads.data_ptr()) // 4 + off_cells
+        return C.c_void_p(self.grads_fx.data_ptr() + 8 * o)
+
+    def gradients_to_float(self):
+        """Deterministic mode: fold the fixed-point cells into self.grads (cells cleared).  optimizer_step does this itself; callers that read
+        self.gviews after backward() call it first."""
+        if self.grads_fx is not None:
+            ops.fx_to_float(self.grads_fx, self.grads, accumulate=True)
+
     def _tgrid_bwd(self, enc, co, times, spr, N, gout, gtable):
+        if self.grads_fx is not None:
+            self._ck(self.lib.snerf_tgrid_encode_bwd_fx(C.byref(enc.desc), C.byref(co), None, self._p(times), spr, C.c_int64(N), self._p(gout),
+                                                        self._pfx(gtable), self._st), "tgrid_bwd_fx")
+            return
         self._ck(self.lib.snerf_tgrid_encode_bwd(C.byref(enc.desc), C.byref(co), None, self._p(times), spr, C.c_int64(N), self._p(gout), self._p(gtable),
                                                  self._st), "tgrid_bwd")
 
@@ -154,6 +175,11 @@ class NerfplayerFullTrainer:
                                         self._p(aux) if aux is not None else None, self._st), "mlp_fwd")
 
     def _mlp_bwd(self, net, gW, X, ldx, N, gY, ldgy, aux_col, gaux, gX, ldgx):
+        if self.grads_fx is not None:
+            self._ck(self.lib.snerf_mlp_bwd_fx(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(gY) if gY is not None else None,
+                                               ldgy, aux_col, self._p(gaux) if gaux is not None else None, self._p(gX) if gX is not None else None, ldgx,
+                                               self._pfx(gW), self._st), "mlp_bwd_fx")
+            return
         self._ck(self.lib.snerf_mlp_bwd(C.byref(net.desc), self._p(net.params), self._p(X), ldx, C.c_int64(N), self._p(gY) if gY is not None else None,
                                         ldgy, aux_col, self._p(gaux) if gaux is not None else None, self._p(gX) if gX is not None else None, ldgx,
                                         self._p(gW), self._st), "mlp_bwd")
@@ -183,9 +209,10 @@ class NerfplayerFullTrainer:
                 gx, ldgx_, go = gX, ldgx, gx_off
             else:
                 gx, ldgx_, go = scratch[l % 2], scratch[l % 2].stride(0), 0
-            self._ck(self.lib.snerf_dense_bwd(self._p(net.params, woffs[l]), K, M, _ACT[acts[l]], self._p(xin, xo), ldi, C.c_int64(N), self._p(outs[l]),
-                                              outs[l].stride(0), self._p(g), ldg, self._p(gx, go) if gx is not None else None, ldgx_, self._p(gW, woffs[l]),
-                                              self._st), "dense_bwd")
+            fx = self.grads_fx is not None
+            self._ck((self.lib.snerf_dense_bwd_fx if fx else self.lib.snerf_dense_bwd)(
+                self._p(net.params, woffs[l]), K, M, _ACT[acts[l]], self._p(xin, xo), ldi, C.c_int64(N), self._p(outs[l]), outs[l].stride(0), self._p(g), ldg,
+                self._p(gx, go) if gx is not None else None, ldgx_, self._pfx(gW, woffs[l]) if fx else self._p(gW, woffs[l]), self._st), "dense_bwd")
             g, ldg = gx, ldgx_
 
     def _resample(self, lvl, rand, anneal):
@@ -302,12 +329,20 @@ class NerfplayerFullTrainer:
                               b["gsx"], 36)
         b["genc2"].copy_(b["gsx"][:, :F])
         # static hash grid: table gradient from both halves, coordinate gradient only for the deformed half (x itself carries no gradient)
-        self._ck(self.lib.snerf_hashgrid_encode_bwd(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"]), C.c_int64(N), self._p(b["genc2"]),
-                                                    self._p(self.gviews["field.hash"]), None, self._st), "hashgrid_bwd")
-        b["gx2"][N:].zero_()
-        self._ck(self.lib.snerf_hashgrid_encode_bwd(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"], 3 * N), C.c_int64(N),
-                                                    self._p(b["genc2"], N * F), self._p(self.gviews["field.hash"]), self._p(b["gx2"], 3 * N), self._st),
-                 "hashgrid_bwd")
+        if self.grads_fx is not None:
+            gt = self._pfx(self.gviews["field.hash"])
+            self._ck(self.lib.snerf_hashgrid_encode_bwd_fx(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"]), C.c_int64(N), self._p(b["genc2"]),
+                                                           gt, None, self._st), "hashgrid_bwd_fx")
+            self._ck(self.lib.snerf_hashgrid_encode_bwd_fx(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"], 3 * N), C.c_int64(N),
+                                                           self._p(b["genc2"], N * F), gt, self._p(self._gx_fx), self._st), "hashgrid_bwd_fx")
+            ops.fx_to_float(self._gx_fx, b["gx2"][N:].view(-1))  # written, cells cleared
+        else:
+            self._ck(self.lib.snerf_hashgrid_encode_bwd(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"]), C.c_int64(N), self._p(b["genc2"]),
+                                                        self._p(self.gviews["field.hash"]), None, self._st), "hashgrid_bwd")
+            b["gx2"][N:].zero_()
+            self._ck(self.lib.snerf_hashgrid_encode_bwd(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"], 3 * N), C.c_int64(N),
+                                                        self._p(b["genc2"], N * F), self._p(self.gviews["field.hash"]), self._p(b["gx2"], 3 * N), self._st),
+                     "hashgrid_bwd")
         self._dense_chain_bwd(self.deform, "field.deform", ("relu", "relu", "relu", "none"), b["x2"], 3, 0, N, b["dh"] + [b["delta"]], b["gx2"][N:], 3,
                               b["gdh"], None, 0)
         # proposal supervision (interlevel loss, losses.py:106-121)
@@ -359,6 +394,7 @@ class NerfplayerFullTrainer:
         """Adam (lr x cosine schedule) over the flat buffer, gradient cleared in the sweep; the four temporal tables go through
         snerf_adam_step_tv, which adds the temporal-TV gradient of their two columns on the fly.  Every float is swept exactly once."""
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+        self.gradients_to_float()
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         plain = lambda lo, hi: ops.adam_step(self.params[lo:hi], self.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.step + 1, lr,
