@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--trained-until", type=int, default=5000, help="third leg: really train to this step (untimed, ~12 s), then time K steady-state steps (0 or --no-steady-state: skip)")
     ap.add_argument("--time-sorted-rays", action="store_true", help="A/B: every batch in order of frame time (ops.sort_rays_by_time); faster field forward, but 1.5 %% slower trained steps: profiles/r03_kernels.md section 11")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
+    ap.add_argument("--pipeline-sweep", default="coarse_first", choices=["coarse_first", "fine_first", "off"],
+                    help="pass B and the optimiser sweep of the field planes pipelined by scale (KPlanesTrainConfig.pipeline_sweep); off: one pass B, then one sweep (A/B)")
     ap.add_argument("--sort-before-field-fwd", action="store_true", help="A/B: the nerf level's sample sort before the wait for the sweep instead of after the field forward (measured slower: trainer.py)")
     ap.add_argument("--pass-b-main-stream", action="store_true", help="A/B: pass B of the field scatter on the caller's stream (round 3) instead of on the sweep's stream beside the next step's head")
     ap.add_argument("--no-fused-proposal", action="store_true", help="A/B: proposal levels as gather + net kernels instead of the fused density kernel (bit-identical densities)")
@@ -239,7 +241,9 @@ def config3_leg(dev, args):
     tr.disable_kernel_timing()
     S2, ns, C = cfg.num_nerf_samples_per_ray, 6, cfg.feature_dim
     gather = R * S2 * ns * 6 * 4 * C * 4
-    alg = {"adam_planes.field": (32 * tr.field_planes.numel, "plane_reg_kernel<32,true> (Adam + K-Planes regularisers, field planes): 32 B / parameter"),
+    nl = tr.field_sweep_launches  # 2: the sweep is pipelined with pass B by scale (finest scale's planes, then the rest): mean bytes per launch
+    alg = {"adam_planes.field": (32 * tr.field_planes.numel // nl, "plane_reg_kernel<32,true> (Adam + K-Planes regularisers, field planes): 32 B / parameter"
+                                 + (f"; {nl} launches per step (finest scale, then the coarser ones, pipelined with pass B): mean over both" if nl > 1 else "")),
            "kplanes_scatter_sorted.field": (2 * gather, "pass B of the sorted scatter: read-modify-write of every touched texel"),
            "kplanes_field_fwd": (gather + R * S2 * (16 + 2 * C * ns + 64), "field_fwd_kernel (gather + sigma_net + color_net fused)")}
     ktl = {k: v for k, v in kt.items() if k in alg}
@@ -274,7 +278,7 @@ def config4_leg(dev, args):
     M, H, W = data["images"].shape[:3]
     full_index = (data["cam_id"] * n_frames + frame_ids.to(dev).repeat(n_cams)).contiguous()  # image m of the rendered subset -> its index among the 3000
     mc = NerfplayerNerfactoModelConfig()
-    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev)
+    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev, async_field_sweep=True)
     tr.step = 600  # past the learning-rate warm-up
 
     def step():
@@ -301,7 +305,10 @@ def config4_leg(dev, args):
     tg_alg, tg_sector = R * S2 * L * 8 * 3 * 4, R * S2 * L * 8 * 64
     sweep = kt.get("adam_tv.field.table")
     roof = _hbm_roofline("adam_tv_kernel over the main temporal grid (Adam + temporal-TV, 32 B / parameter: p,g,m,v read, p,m,v written, g cleared)",
-                         32 * n_table, sweep[0], sweep[1]) if sweep else None
+                         32 * n_table, sweep[0], sweep[1],
+                         note="round 5: launched on a side stream right behind the table's gradient scatter (NerfplayerTrainer async_field_sweep): it runs beside the "
+                              "proposal networks' backward and the next step's ray generation / proposal levels, so its duration includes that sharing "
+                              "(alone: tools/bench_nerfplayer.py --fused --stadium --sync-sweep)") if sweep else None
     fwd = kt.get("tgrid_fwd.field")
     out = {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32",
            "config": {"workload": "nerfplayer-nerfacto preset (temporal hash grid L=16 C=2 log2T=19 temporal_dim 64, proposals L=5 log2T=17, samples 256/96/48) on the synthetic "
@@ -392,7 +399,7 @@ def main():
     torch.manual_seed(20231029 + rank)
     cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, fused_field=not args.no_fused_field, quotient_scatter=not args.no_quotient_scatter,
                              fused_ray_loss=not args.no_fused_ray_loss, fused_proposal=not args.no_fused_proposal,
-                             quotient_epilogue=not args.no_quotient_epilogue, pass_b_beside_head=not args.pass_b_main_stream, sort_before_field_fwd=args.sort_before_field_fwd,
+                             quotient_epilogue=not args.no_quotient_epilogue, pass_b_beside_head=not args.pass_b_main_stream, sort_before_field_fwd=args.sort_before_field_fwd, pipeline_sweep="" if args.pipeline_sweep == "off" else args.pipeline_sweep,
                              interleave_proposal_levels=args.interleave_prop_levels)  # the k-planes preset
     R = args.rays
     trainer = KPlanesTrainer(cfg, R, dev, process_group=pg)
@@ -483,6 +490,7 @@ def main():
     elapsed = timed(one_step, args.steps)
     kt = trainer.kernel_times_ms()
     trainer.disable_kernel_timing()
+    sweep_launches = trainer.field_sweep_launches  # 2 when the sweep is pipelined with pass B by scale (KPlanesTrainConfig.pipeline_sweep)
 
     def comm_report(kt_, n_steps):
         """world > 1: what one step puts on the links and how long the compute chain stood waiting for them (HIP events on the chain's
@@ -582,10 +590,13 @@ def main():
         # algorithmic bytes / flops of ONE launch (SURVEY.md §8d conventions: 4 texels per bilinear tap, no cache credit)
         gather = R * S2 * len(cfg.multiscale_res) * 6 * 4 * cfg.feature_dim * 4  # every texel of every tap, once
         F = cfg.feature_dim * len(cfg.multiscale_res)
+        fine_share = 1.0 - trainer._finest_offset() / max(trainer.field_planes.numel, 1)
         alg = {
             "adam_step": ("hbm", 32 * trainer.n_params, "adam_kernel: p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
-            "adam_planes.field": ("hbm", 32 * (trainer._field_seg[2] // world if trainer._sharded() else trainer.field_planes.numel),
-                                  "plane_reg_kernel<32,true> (Adam + K-Planes regularisers fused, field planes): p,g,m,v read + p,m,v written + g cleared = 32 B/param"),
+            "adam_planes.field": ("hbm", 32 * (trainer._field_seg[2] // world if trainer._sharded() else trainer.field_planes.numel) // sweep_launches,
+                                  "plane_reg_kernel<32,true> (Adam + K-Planes regularisers fused, field planes): p,g,m,v read + p,m,v written + g cleared = 32 B/param"
+                                  + (f"; {sweep_launches} launches per step (the finest scale's planes = {fine_share:.0%} of the floats, then the coarser scales', pipelined with "
+                                     "pass B of the sorted scatter): bytes and duration are means over both, as rocprofv3's per-kernel average is" if sweep_launches > 1 else "")),
             "kplanes_scatter_sorted.field": ("hbm", 2 * gather, "pass B of the sorted scatter (scatter_halfwave_kernel<6,QUOT>): read-modify-write of every touched texel"),
             "kplanes_gather_bwd.field": ("hbm", 2 * gather, "kplanes_gather_bwd_kernel<32,6>: read-modify-write of every touched texel"),
             "kplanes_gradvec.field": ("hbm", gather + R * S2 * 30 * cfg.feature_dim * 4, "gradvec_kernel<32,6>: texel reads + per-plane gradient vectors written"),
@@ -647,8 +658,8 @@ def main():
                          "avg_launch_ms": dom_ms, "near_ties": near_ties,
                          "launches_timed": timed_k[DOMINANT][1],
                          **({"alone": {"avg_launch_ms": round(alone[DOMINANT][0], 4),
-                                       "frac": round(alg[DOMINANT][1] / (alone[DOMINANT][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-                                       "note": "same kernel issued on the main stream (20 extra steps after the timed region): nothing of the NEXT step runs beside it; "
+                                       "frac": round(alg[DOMINANT][1] * (sweep_launches if DOMINANT == "adam_planes.field" else 1) / (alone[DOMINANT][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+                                       "note": "same kernel issued on the main stream as ONE launch over all field planes (20 extra steps after the timed region): nothing of the NEXT step runs beside it; "
                                                "in the timed region it shares the GPU with pass B of the coarser scales and the next step's first kernels"}}
                             if alone is not None and DOMINANT in alone else {}),
                          "other_kernels_ms": {k: round(v[0], 4) for k, v in sorted(timed_k.items(), key=lambda kv: -kv[1][0]) if k != DOMINANT},

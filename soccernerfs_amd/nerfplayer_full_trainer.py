@@ -35,8 +35,14 @@ def _align4(n: int) -> int:
 
 class NerfplayerFullTrainer:
     def __init__(self, cfg: NerfplayerModelConfig, num_rays: int, aabb_scale: float = 1.0, device="cuda:0", lr: float = 1e-2,
-                 adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False):
-        """deterministic: every gradient accumulated across samples -- the temporal-grid and hash-grid table scatters, the hash grid's coordinate
+                 adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
+                 async_table_sweeps: bool = False):
+        """async_table_sweeps (round 5): inside train_step the optimiser sweeps of the newness and decomposition tables (most of the parameters) go to a side
+        stream as soon as their gradients are complete (right behind their temporal-grid backward, early in the backward pass) and are joined in front of
+        the next forward's first read of those tables: they run beside the rest of the backward (hash-grid scatter, deformation net, proposal networks)
+        and the next step's proposal levels.  Same arithmetic (same bits in deterministic mode).  Readers of those tables outside forward() call
+        wait_params() / synchronize() first; off by default for that reason.
+        deterministic: every gradient accumulated across samples -- the temporal-grid and hash-grid table scatters, the hash grid's coordinate
         gradient (one add per level and sample), the weight gradients of all seven nets -- goes into 2^50-scaled 64-bit cells
         (snerf_*_bwd_fx; integer adds are associative) and is converted once per step: two runs from the same state and draws give the same bits.
         Costs 8 bytes per parameter (3.7 GB at the preset) and 64-bit atomics."""
@@ -138,6 +144,8 @@ class NerfplayerFullTrainer:
         self.tv_rows: Optional[List[int]] = None  # parity hook: fixed table rows [newness, decomp, prop0, prop1]
         self._tv_cols = [(0, 1)] * 4
         self.launches = 0  # libsnerf launches of the last step (diagnostics)
+        self.async_table_sweeps = bool(async_table_sweeps)
+        self._side, self._sweeps_done, self._swept, self._in_train_step = None, None, (), False
 
     # ---- helpers ----
     def _p(self, t, off_floats: int = 0):
@@ -146,6 +154,58 @@ class NerfplayerFullTrainer:
     def _ck(self, rc, what):
         self.launches += 1
         _lib.check(rc, what)
+
+    def wait_params(self):
+        """The current stream waits for the asynchronous table sweeps (no host block)."""
+        if self._sweeps_done is not None:
+            torch.cuda.current_stream().wait_event(self._sweeps_done)
+            self._sweeps_done = None
+
+    def synchronize(self):
+        self.wait_params()
+        torch.cuda.synchronize()
+
+    def _tv_sign(self, k: int):
+        """Value + per-row signed step of table k's temporal TV (order of nerfplayer.py:329-333); the row draw is the reference's randint."""
+        enc = self._encs[k]
+        row = self.tv_rows[k] if self.tv_rows is not None else int(torch.randint(0, len(enc._index_list_host), [1]).item())
+        ca, cb = enc._index_list_host[row]
+        self._tv_cols[k] = (ca, cb)
+        rows_, gc = enc.embeddings.shape
+        self._ck(self.lib.snerf_tgrid_tv_sign(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, float(self.cfg.temporal_tv_weight) / 4.0,
+                                              self._p(self.buf["tv"][k]), 64, self._p(self._srow[k]), self._st), "tv_sign")
+
+    def _sweep_table(self, k: int, lr: float, st):
+        """Adam over temporal table k on the current stream (st = its handle) with the TV gradient of its two columns added on the fly."""
+        o, n = next((o, n) for name, _, _, o, n in self.segments if name == self._enc_names[k])
+        enc = self._encs[k]
+        ca, cb = self._tv_cols[k]
+        rows_, gc = enc.embeddings.shape
+        sl = slice(o, o + n)
+        self._ck(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
+                                             C.c_int64(rows_), gc, ca, cb, self._p(self._srow[k]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
+                                             None, st), "adam_step_tv")
+
+    def _early_table_sweeps(self):
+        """async_table_sweeps: TV pass + Adam sweep of the newness (k = 0) and decomposition (k = 1) tables on the side stream, behind everything the
+        caller's stream holds (their gradient scatters)."""
+        for k in (0, 1):
+            self._tv_sign(k)
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(main)
+        lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+        with torch.cuda.stream(self._side):
+            st = C.c_void_p(self._side.cuda_stream)
+            for k in (0, 1):
+                if self.grads_fx is not None:
+                    gv = self.gviews[self._enc_names[k]]
+                    o = (gv.data_ptr() - self.grads.data_ptr()) // 4
+                    ops.fx_to_float(self.grads_fx[o:o + gv.numel()], gv.view(-1), accumulate=True)
+                self._sweep_table(k, lr, st)
+            self._sweeps_done = self._side.record_event()
+        self._swept = (0, 1)
 
     def _tgrid_fwd(self, enc, co, times, spr, N, out):
         self._ck(self.lib.snerf_tgrid_encode_fwd(C.byref(enc.desc), self._p(enc.embeddings), C.byref(co), None, self._p(times), spr, C.c_int64(N), self._p(out),
@@ -159,8 +219,15 @@ class NerfplayerFullTrainer:
     def gradients_to_float(self):
         """Deterministic mode: fold the fixed-point cells into self.grads (cells cleared).  optimizer_step does this itself; callers that read
         self.gviews after backward() call it first."""
-        if self.grads_fx is not None:
-            ops.fx_to_float(self.grads_fx, self.grads, accumulate=True)
+        if self.grads_fx is None:
+            return
+        lo = 0
+        for o, n in sorted((o, n) for name, _, _, o, n in self.segments if name in [self._enc_names[k] for k in self._swept]):
+            if o > lo:  # the tables swept on the side stream have been converted there (and are being written by it)
+                ops.fx_to_float(self.grads_fx[lo:o], self.grads[lo:o], accumulate=True)
+            lo = o + n
+        if lo < self.n_params:
+            ops.fx_to_float(self.grads_fx[lo:], self.grads[lo:], accumulate=True)
 
     def _tgrid_bwd(self, enc, co, times, spr, N, gout, gtable):
         if self.grads_fx is not None:
@@ -271,6 +338,7 @@ class NerfplayerFullTrainer:
         b["sx"][N:, F].copy_(b["tN"])                                       # cat([stationary_field(.), t]) (:349-351)
         self._dense_chain_fwd(self.stat_mlp, ("relu", "none"), b["sx"], 36, 0, 2 * N, [b["sh"], b["sv"]])
         self._pts = ops.coords_from_points(b["x2"])                         # explicit points for the temporal grids (pts [N,3], mode 0)
+        self.wait_params()  # the newness / decomposition tables' sweeps of the last step (async_table_sweeps)
         self._tgrid_fwd(self.newness, self._pts, b["tN"], 1, N, b["vnew"])
         self._tgrid_fwd(self.decomp, self._pts, b["tN"], 1, N, b["dfeat"])
         self._mlp_fwd(self.decomp_mlp, b["dfeat"], F, N, b["logits"], 3)
@@ -325,6 +393,11 @@ class NerfplayerFullTrainer:
         self._mlp_bwd(self.decomp_mlp, self.gviews["field.decomp_mlp"], b["dfeat"], F, N, b["glogits"], 3, -1, None, b["gdfeat"], F)
         self._tgrid_bwd(self.decomp, self._pts, b["tN"], 1, N, b["gdfeat"], self.gviews["field.decomp"])
         self._tgrid_bwd(self.newness, self._pts, b["tN"], 1, N, b["gvnew"], self.gviews["field.newness"])
+        early = bool(self.async_table_sweeps and self._in_train_step and cfg.temporal_tv_weight > 0)
+        if cfg.temporal_tv_weight > 0:
+            b["tv"].zero_()
+        if early:
+            self._early_table_sweeps()
         self._dense_chain_bwd(self.stat_mlp, "field.stat_mlp", ("relu", "none"), b["sx"], 36, 0, 2 * N, [b["sh"], b["sv"]], b["gsv"], F, [b["gsh"], b["gsh"]],
                               b["gsx"], 36)
         b["genc2"].copy_(b["gsx"][:, :F])
@@ -360,15 +433,9 @@ class NerfplayerFullTrainer:
                 self._tgrid_bwd(enc, self._coords[lvl], t, Sp, Np, b["gpfeat"][lvl], self.gviews[f"prop{lvl}.table"])
         # temporal TV of the four tables, weight / 4 (nerfplayer.py:329-333): values + per-row signed steps; the gradient is added in the Adam sweep
         if cfg.temporal_tv_weight > 0:
-            b["tv"].zero_()
-            wt = float(cfg.temporal_tv_weight) / 4.0
-            for k_, enc in enumerate(self._encs):
-                row = self.tv_rows[k_] if self.tv_rows is not None else int(torch.randint(0, len(enc._index_list_host), [1]).item())
-                ca, cb = enc._index_list_host[row]
-                self._tv_cols[k_] = (ca, cb)
-                rows_, gc = enc.embeddings.shape
-                self._ck(self.lib.snerf_tgrid_tv_sign(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, wt, self._p(b["tv"][k_]), 64,
-                                                      self._p(self._srow[k_]), self._st), "tv_sign")
+            for k_ in range(4):
+                if k_ not in self._swept:  # the same order of row draws either way
+                    self._tv_sign(k_)
 
     def materialize_tv_gradient(self):
         """Adds the temporal-TV gradient into self.grads explicitly (what the Adam sweep otherwise does on the fly); for parity tests."""
@@ -406,17 +473,13 @@ class NerfplayerFullTrainer:
                 if o > done:
                     plain(done, o)
                     self.launches += 1
-                enc = self._encs[k]
-                ca, cb = self._tv_cols[k]
-                rows_, gc = enc.embeddings.shape
-                sl = slice(o, o + n)
-                self._ck(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
-                                                     C.c_int64(rows_), gc, ca, cb, self._p(self._srow[k]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
-                                                     None, st), "adam_step_tv")
+                if k not in self._swept:
+                    self._sweep_table(k, lr, st)
                 done = o + n
         if done < self.n_params:
             plain(done, self.n_params)
             self.launches += 1
+        self._swept = ()
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:
@@ -432,8 +495,12 @@ class NerfplayerFullTrainer:
         sched = float(np.clip(np.interp(sstep, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1, cfg.proposal_update_every))
         updated = self._steps_since_update > sched or sstep < 10
         rng = rng if rng is not None else self.random_draws()
-        out = self.forward(rays, rng, anneal)
-        self.backward(target, rng, proposal_grads=updated)
+        self._in_train_step = True
+        try:
+            out = self.forward(rays, rng, anneal)
+            self.backward(target, rng, proposal_grads=updated)
+        finally:
+            self._in_train_step = False
         self.optimizer_step()
         if updated:
             self._steps_since_update = 0

@@ -35,8 +35,14 @@ def _align4(n: int) -> int:
 
 class NerfplayerTrainer:
     def __init__(self, cfg: NerfplayerNerfactoModelConfig, num_rays: int, num_images: int, aabb_scale: float = 1.0, device="cuda:0",
-                 lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False):
-        """deterministic: every gradient scatter (temporal-grid tables, MLP weight gradients, appearance embedding) accumulates 2^50-scaled 64-bit
+                 lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
+                 async_field_sweep: bool = False):
+        """async_field_sweep (round 5): inside train_step the optimiser sweep of the FIELD's table (most of the parameters) is launched on a side stream
+        as soon as that table's gradient is complete (right behind the field's temporal-grid backward) and is joined only in front of the NEXT forward's
+        field level: it runs beside the proposal networks' backward (atomic-bound) and the next step's ray generation and proposal levels, which read
+        the two small tables only.  Same arithmetic, same bits in deterministic mode.  Readers of the field table outside forward() call wait_params() /
+        synchronize() first; off by default for that reason (bench.py's config-4 leg and tools/bench_nerfplayer.py turn it on).
+        deterministic: every gradient scatter (temporal-grid tables, MLP weight gradients, appearance embedding) accumulates 2^50-scaled 64-bit
         integers instead of float atomics (csrc/common.hpp: integer addition is associative), converted once per step: two runs from the same seed give
         the same bits.  Costs 8 B per parameter and 64-bit atomics; off by default."""
         if not cfg.disable_scene_contraction or cfg.use_same_proposal_network or cfg.num_proposal_iterations != 2:
@@ -117,6 +123,8 @@ class NerfplayerTrainer:
         self._timing, self._timing_all = None, False
         self.tv_rows: Optional[List[int]] = None  # parity hook: fixed table rows [field, prop0, prop1] instead of the random draw
         self._tv_cols = [(0, 1)] * 3
+        self.async_field_sweep = bool(async_field_sweep)
+        self._side, self._field_sweep_done, self._field_swept, self._in_train_step = None, None, False, False
 
     # ---- helpers ----
     def _p(self, t):
@@ -139,6 +147,60 @@ class NerfplayerTrainer:
         from .trainer import KPlanesTrainer
 
         return KPlanesTrainer._Span(self, name)
+
+    def wait_params(self):
+        """The current stream waits for the field table's asynchronous sweep (no host block)."""
+        if self._field_sweep_done is not None:
+            torch.cuda.current_stream().wait_event(self._field_sweep_done)
+            self._field_sweep_done = None
+
+    def synchronize(self):
+        self.wait_params()
+        torch.cuda.synchronize()
+
+    def _tv_sign(self, k: int):
+        """Value + per-row signed step of table k's temporal TV (k: 0 field, 1 / 2 proposal tables); the row draw is the reference's randint."""
+        cfg, enc = self.cfg, (self.enc, self.prop_enc[0], self.prop_enc[1])[k]
+        row = self.tv_rows[k] if self.tv_rows is not None else int(torch.randint(0, len(enc._index_list_host), [1]).item())
+        ca, cb = enc._index_list_host[row]
+        self._tv_cols[k] = (ca, cb)
+        rows_, gc = enc.embeddings.shape
+        _lib.check(self.lib.snerf_tgrid_tv_sign(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, float(cfg.temporal_tv_weight),
+                                                self._p(self.buf["tv"][k]), 64, self._p(self._srow[k]), self._st), "tv_sign")
+
+    def _sweep_table(self, name: str, lr: float, st):
+        """Adam over one table on the current stream (st = its handle), with the temporal-TV gradient of its two columns added on the fly."""
+        o, n = next((o, n) for nm, _, _, o, n in self.segments if nm == name)
+        sl = slice(o, o + n)
+        if self.cfg.temporal_tv_weight <= 0:
+            ops.adam_step(self.params[sl], self.grads[sl], self.exp_avg[sl], self.exp_avg_sq[sl], self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
+            return
+        kk = {"field.table": 0, "prop0.table": 1, "prop1.table": 2}[name]
+        enc = self.enc if kk == 0 else self.prop_enc[kk - 1]
+        ca, cb = self._tv_cols[kk]
+        rows_, gc = enc.embeddings.shape
+        with self._span("adam_tv." + name):
+            _lib.check(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
+                                                   C.c_int64(rows_), gc, ca, cb, self._p(self._srow[kk]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
+                                                   None, st), "adam_step_tv")
+
+    def _field_table_sweep_async(self):
+        """async_field_sweep: the field table's TV pass, then its Adam sweep on the side stream, behind everything the caller's stream holds (the
+        table's gradient scatter)."""
+        if self.cfg.temporal_tv_weight > 0:
+            self._tv_sign(0)
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        self._side.wait_stream(main)
+        lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+        with torch.cuda.stream(self._side):
+            if self.grads_fx is not None:
+                gv = self.gviews["field.table"]
+                ops.fx_to_float(self._fx_of(gv), gv.view(-1), accumulate=True)
+            self._sweep_table("field.table", lr, C.c_void_p(self._side.cuda_stream))
+            self._field_sweep_done = self._side.record_event()
+        self._field_swept = True
 
     def _tgrid_fwd(self, enc, table, co, times, S, N, out):
       with self._span("tgrid_fwd.field" if enc is self.enc else "tgrid_fwd.prop"):
@@ -213,6 +275,7 @@ class NerfplayerTrainer:
                 self._mlp_fwd(net, b["pfeat"][lvl], enc.output_dim, N, b["pout"][lvl], 1, 0, b["dens"][lvl])
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
+                self.wait_params()  # the field table's sweep of the last step (async_field_sweep) must be complete before the table is read
                 self._tgrid_fwd(self.enc, self.enc.embeddings, co, t, S, N, b["feat"])
                 self._mlp_fwd(self.decode, b["feat"], self.enc.output_dim, N, b["h"], 16, 0, b["dens"][2])
                 hx = b["hx"].view(R, S, 64)
@@ -258,6 +321,11 @@ class NerfplayerTrainer:
         self._mlp_bwd(self.decode, self.gviews["field.decode"], b["feat"], self.enc.output_dim, N2, b["gh"], 16, 0, b["gdens"][2], b["gfeat"],
                       self.enc.output_dim)
         self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])
+        if cfg.temporal_tv_weight > 0:
+            b["tv"].zero_()
+        early = bool(self.async_field_sweep and self._in_train_step)
+        if early:
+            self._field_table_sweep_async()
         # proposal supervision (interlevel loss, losses.py:106-121)
         for lvl in range(2):
             Sp, Np = self.S[lvl], R * self.S[lvl]
@@ -274,14 +342,9 @@ class NerfplayerTrainer:
         # temporal TV of the three tables (temporal_grid.py:352-376; nerfplayer_nerfacto.py:311-316): one pass over two columns per table
         # gives the value and the per-row signed step; the gradient itself is added inside the Adam sweep (optimizer_step)
         if cfg.temporal_tv_weight > 0:
-            b["tv"].zero_()
-            for k, enc in enumerate((self.enc, self.prop_enc[0], self.prop_enc[1])):
-                row = self.tv_rows[k] if self.tv_rows is not None else int(torch.randint(0, len(enc._index_list_host), [1]).item())
-                ca, cb = enc._index_list_host[row]
-                self._tv_cols[k] = (ca, cb)
-                rows_, gc = enc.embeddings.shape
-                _lib.check(self.lib.snerf_tgrid_tv_sign(self._p(enc.embeddings), C.c_int64(rows_), gc, ca, cb, float(cfg.temporal_tv_weight),
-                                                        self._p(b["tv"][k]), 64, self._p(self._srow[k]), self._st), "tv_sign")
+            for k in range(3):
+                if not (early and k == 0):  # the same order of row draws either way: field, proposal 0, proposal 1
+                    self._tv_sign(k)
 
     def materialize_tv_gradient(self):
         """Adds the temporal-TV gradient into self.grads explicitly (what the Adam sweep otherwise does on the fly); for parity tests."""
@@ -307,32 +370,31 @@ class NerfplayerTrainer:
         snerf_adam_step_tv, which adds the temporal-TV gradient of their two columns on the fly."""
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
         off = {name: (o, n) for name, _, _, o, n in self.segments}
-        if self.grads_fx is not None:
-            ops.fx_to_float(self.grads_fx, self.grads, accumulate=True)  # fixed-point cells -> float gradients (cells cleared)
-        tv = self.cfg.temporal_tv_weight > 0
+        swept = self._field_swept  # async_field_sweep: the field table has been stepped (and its cells converted) on the side stream already
+        fo, fn = off["field.table"]
+        if self.grads_fx is not None:  # fixed-point cells -> float gradients (cells cleared)
+            if swept:
+                ops.fx_to_float(self.grads_fx[:fo], self.grads[:fo], accumulate=True)
+                ops.fx_to_float(self.grads_fx[fo + fn:], self.grads[fo + fn:], accumulate=True)
+            else:
+                ops.fx_to_float(self.grads_fx, self.grads, accumulate=True)
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         # one plain sweep per run of segments between (and after) the tables; with the TV term each table gets its own sweep that adds
         # the TV gradient of its two columns.  Every parameter is stepped exactly once (`done` = first float not yet swept).
         done = 0
         plain = lambda lo, hi: ops.adam_step(self.params[lo:hi], self.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.step + 1, lr,
                                              eps=self.adam_eps, zero_grad=True)
-        if tv:
-            for name in ("prop0.table", "prop1.table", "field.table"):
-                o, n = off[name]
-                if o > done:  # the small segments in front of this table
-                    plain(done, o)
-                kk = {"field.table": 0, "prop0.table": 1, "prop1.table": 2}[name]
-                enc = self.enc if kk == 0 else self.prop_enc[kk - 1]
-                ca, cb = self._tv_cols[kk]
-                rows_, gc = enc.embeddings.shape
-                sl = slice(o, o + n)
-                with self._span("adam_tv." + name):
-                  _lib.check(self.lib.snerf_adam_step_tv(self._p(self.params[sl]), self._p(self.grads[sl]), self._p(self.exp_avg[sl]), self._p(self.exp_avg_sq[sl]),
-                                                       C.c_int64(rows_), gc, ca, cb, self._p(self._srow[kk]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
-                                                       None, st), "adam_step_tv")
-                done = o + n
+        tables = ("prop0.table", "prop1.table", "field.table") if self.cfg.temporal_tv_weight > 0 else (("field.table",) if swept else ())
+        for name in sorted(tables, key=lambda nm: off[nm][0]):
+            o, n = off[name]
+            if o > done:  # the small segments in front of this table
+                plain(done, o)
+            if not (swept and name == "field.table"):
+                self._sweep_table(name, lr, st)
+            done = o + n
         if done < self.n_params:
             plain(done, self.n_params)
+        self._field_swept = False
         self.step += 1
 
     def random_draws(self) -> Dict[str, torch.Tensor]:
@@ -348,8 +410,12 @@ class NerfplayerTrainer:
         sched = float(np.clip(np.interp(sstep, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1, cfg.proposal_update_every))
         updated = self._steps_since_update > sched or sstep < 10
         rng = rng if rng is not None else self.random_draws()
-        out = self.forward(rays, cams, rng, anneal)
-        self.backward(target, rng, proposal_grads=updated)
+        self._in_train_step = True
+        try:
+            out = self.forward(rays, cams, rng, anneal)
+            self.backward(target, rng, proposal_grads=updated)
+        finally:
+            self._in_train_step = False
         self.optimizer_step()
         if updated:
             self._steps_since_update = 0

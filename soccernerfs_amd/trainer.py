@@ -128,6 +128,13 @@ class KPlanesTrainConfig:
     # untraced step, but the sort under the HBM-bound sweep takes 0.3-0.7 ms and stretches the sweep from 0.82 to 0.97 ms -- steady state 2.03 / 2.07 ms
     # with it against 1.98 / 2.01 without (two runs each, one box; profiles/r05_step_offsets_early_sort.txt).
     sort_before_field_fwd: bool = False
+    # Round 5: pass B and the optimiser sweep of the field planes PIPELINED by scale (single GPU, inside train_step).  Pass B scatters one part of the
+    # scales first; the sweep of those planes then starts on the idle "sort" stream while pass B goes on with the other part on the sweep's stream, whose
+    # planes are swept behind it.  "coarse_first": scales 0..n-2, then the finest (~72 % of the floats at the preset) -- the small sweep runs beside the
+    # finest scale's short scatter and the big sweep follows with only the next step's head beside it; "fine_first": the finest scale first, its big sweep
+    # beside the coarser scales' scatter (both lean on the memory system: pass B of the coarser scales stretches from 0.39 to 0.85 ms and the sweep from
+    # 0.60 to 0.74 ms, profiles/r05_step_offsets_pipelined_fine_first.txt); "": one pass B, then one sweep (A-B).
+    pipeline_sweep: str = "coarse_first"
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -300,6 +307,8 @@ class KPlanesTrainer:
             raise ValueError(f"emulate_transports must be '', 'grad', 'param' or 'both', got {cfg.emulate_transports!r}")
         self._sort_done = None
         self._passb_done = None
+        self._passb_fine_done = None
+        self.field_sweep_launches = 1  # launches of the field planes' sweep in the last optimiser step (2 when pipelined with pass B: cfg.pipeline_sweep)
         # (the proposal planes keep the sample-major scatter: they are small enough that their atomics are served by L2 -- 0.5 M of 19 M requests
         # reach memory -- while sorting 1.5 M samples x 6 planes cost ~0.6 ms: measured in round 1, the opt-in path was removed in round 3)
         self.step = 0                 # completed optimiser steps
@@ -700,7 +709,14 @@ class KPlanesTrainer:
                     st.wait_event(main.record_event())
                     st.wait_event(self._sort_done)
                     with KPlanesTrainer._On(self, st):
-                        self._scatter_field_scales(co, 0, ns, fixup=False)
+                        if self.cfg.pipeline_sweep and ns > 1 and not self.cfg.emulate_transports:
+                            fine_first = self.cfg.pipeline_sweep == "fine_first"
+                            first, second = ((ns - 1, ns), (0, ns - 1)) if fine_first else ((0, ns - 1), (ns - 1, ns))
+                            self._scatter_field_scales(co, *first, fixup=False)  # the sweep of these scales' planes starts when this is done
+                            self._passb_fine_done = (st.record_event(), fine_first)
+                            self._scatter_field_scales(co, *second, fixup=False)
+                        else:
+                            self._scatter_field_scales(co, 0, ns, fixup=False)
                     self._passb_done = st.record_event()
                     passb_issued = True
                 if self.world == 1 and self._reg_in_adam:
@@ -1103,9 +1119,10 @@ class KPlanesTrainer:
         """First float of the finest scale's planes inside the field-plane segment (planes are laid out scale-major)."""
         return int(self._desc_field.off[len(self.cfg.multiscale_res) - 1][0])
 
-    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool, role: str = "adam", span: str = "adam_planes.field"):
+    def _adam_field_range(self, lo: int, hi: Optional[int], side: bool, role: str = "adam", span: str = "adam_planes.field", after=None):
         """Fused Adam + regularisers over floats [lo, hi) of the field planes, old -> other half of the ping-pong pair.  side=True:
-        on the side stream `role`, ordered after everything issued so far on the current stream (the scatter of those planes)."""
+        on the side stream `role`, ordered after everything issued so far on the current stream (the scatter of those planes) and after
+        the event `after` (pass B of those planes, when it ran on another stream)."""
         cfg, co = self.cfg, self.cfg.loss_coefficients
         lr = cfg.lr * cosine_lr_factor(self.step, cfg.warm_up_end, cfg.max_steps, cfg.lr_alpha)
         n4 = _align4(self.field_planes.numel)
@@ -1123,6 +1140,8 @@ class KPlanesTrainer:
         cur = torch.cuda.current_stream()
         st = self._stream(role)
         st.wait_stream(cur)
+        if after is not None:
+            st.wait_event(after)
         with KPlanesTrainer._On(self, st), self._span(span):
             ops.adam_planes_step(*args, **kw)
 
@@ -1172,7 +1191,22 @@ class KPlanesTrainer:
         if emu in ("grad", "both"):
             gv = self.gviews["field.planes"]
             gv.copy_(gv.to(torch.bfloat16))
-        self._adam_field_range(0, None, side=async_field)
+        if async_field and self._passb_fine_done is not None:
+            # pipelined with pass B (cfg.pipeline_sweep): the planes of the scales scattered first on the "sort" stream (idle between this step's sort
+            # and the next one's) as soon as their scatter is complete; the others' on the sweep's stream, behind the rest of pass B
+            cut = self._finest_offset()
+            ev, fine_first = self._passb_fine_done
+            first, second = ((cut, None), (0, cut)) if fine_first else ((0, cut), (cut, None))
+            self._adam_field_range(*first, side=True, role="sort", after=ev)
+            fine_done = self._stream("sort").record_event()
+            self._adam_field_range(*second, side=True)
+            self._stream("adam").wait_event(fine_done)  # _field_adam_done (below) then stands for both
+            self._passb_fine_done = None
+            self.field_sweep_launches = 2
+        else:
+            self._passb_fine_done = None
+            self._adam_field_range(0, None, side=async_field)
+            self.field_sweep_launches = 1
         if emu in ("param", "both"):  # new = old + bf16(new - old) on the field planes, on the stream that ran the sweep
             o_, n_ = next((o, n) for name, _, _, o, n in self.segments if name == "field.planes")
             with KPlanesTrainer._On(self, self._stream("adam") if async_field else torch.cuda.current_stream()):

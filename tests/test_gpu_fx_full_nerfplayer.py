@@ -83,7 +83,7 @@ def test_dense_backward_fixed_point_equals_float_and_repeats(K, M, act):
     assert torch.equal(fx, cells[1])
 
 
-def _g13b_run(deterministic, steps=None):
+def _g13b_run(deterministic, steps=None, async_sweeps=False):
     from tests.conftest import load_golden
     from tests.test_gpu_hashgrid import _full_model
     from tests.test_gpu_nerfplayer_full_trainer import _pairs
@@ -97,7 +97,7 @@ def _g13b_run(deterministic, steps=None):
     rays = {"origins": t("origins"), "directions": t("directions"), "times": t("times")}
     target = t("target")
     tr = NerfplayerFullTrainer(model.config, R, aabb_scale=1.0, device=DEV, lr=float(gb["lr0"]), adam_eps=float(gb["eps"]), warm_up_end=int(gb["warm_up_end"]),
-                               max_steps=int(gb["max_steps"]), seed=0, deterministic=deterministic)
+                               max_steps=int(gb["max_steps"]), seed=0, deterministic=deterministic, async_table_sweeps=async_sweeps)
     with torch.no_grad():
         for name, p in pairs.items():
             tr.views[name].copy_(p.detach().reshape(tr.views[name].shape))
@@ -108,6 +108,7 @@ def _g13b_run(deterministic, steps=None):
         out = tr.train_step(rays, target, rng).clone()
         ld = tr.loss_dict()
         hist.append({"rgb_out": out, "probs": tr.rendered_probs().mean(0).clone(), **{k: v.clone() for k, v in ld.items() if k != "temporal_tv_loss"}})
+    tr.synchronize()  # async_table_sweeps: the last step's table sweeps may still be running on the side stream
     return tr, hist, gb
 
 
@@ -130,9 +131,23 @@ def test_deterministic_full_trainer_repeats_bit_for_bit_over_g13b():
             ref, got = float(hd[step][k]), float(ha[step][k])
             floor = max(1e-2 * float(gb["loss_" + k].abs().max()), 1e-7)
             assert abs(got - ref) <= (1e-4 if step == 0 else 5e-2) * max(abs(ref), floor), (step, k, got, ref)
-    # the course of the deterministic run against the reference's: reported (it is ONE sample of the spread the N_RUNS test averages over)
+    # The course of the deterministic run against the reference's, step by step.  This run is ONE reproducible sample (same binary, same GPU model: the
+    # same bits), so the bound needs no allowance for run-to-run spread -- only for what separates two arithmetics of the same algorithm, and that the
+    # reference measures on itself: restarted from parameters perturbed by one fp32 rounding its own mean probabilities move by up to 0.053 within the 50 steps
+    # and its loss terms by > 100 % from step 13 on (profiles/r05_g13b_reference_spread.json).  Probabilities within 0.08 of the reference's at EVERY step,
+    # the run ending within 0.08 of the reference's 0.85 static.
     dev = [float((h["probs"].cpu() - gb["probs_mean"][s]).abs().max()) for s, h in enumerate(ha)]
-    print("deterministic G13b run: |mean probabilities - reference's| by step:", [round(x, 3) for x in dev[::5]], "end static", round(float(ha[-1]["probs"][0]), 3))
+    loss_dev = []
+    for s, h in enumerate(ha):
+        w = 0.0
+        for k in ("rgb_loss", "interlevel_loss", "distortion_loss", "prob_loss"):
+            c = gb["loss_" + k]
+            w = max(w, abs(float(h[k]) - float(c[s])) / max(abs(float(c[s])), 1e-2 * float(c.abs().max()), 1e-7))
+        loss_dev.append(w)
+    print("deterministic G13b run: |mean probabilities - reference's| by step:", [round(x, 3) for x in dev], "end static", round(float(ha[-1]["probs"][0]), 3))
+    print("deterministic G13b run: worst loss-term relative deviation by step:", [round(x, 4) for x in loss_dev])
+    assert max(dev) <= 0.08, dev
+    assert abs(float(ha[-1]["probs"][0]) - float(gb["probs_mean"][-1][0])) <= 0.08
 
 
 def test_deterministic_gradients_equal_default_mode():
@@ -157,3 +172,15 @@ def test_deterministic_gradients_equal_default_mode():
         a, b = tr_d.gviews[name], tr_f.gviews[name]
         assert float(b.abs().max()) > 0, name
         torch.testing.assert_close(a, b, rtol=1e-3, atol=2e-6 * float(b.abs().max()), msg=lambda m: f"{name}: {m}")
+
+
+def test_async_table_sweeps_give_the_same_bits_over_g13b():
+    """async_table_sweeps=True (the newness / decomposition tables' optimiser sweeps on a side stream right behind their gradient scatters, joined in front of
+    the next forward's first read of them) against the in-order step, both deterministic: G13b's 50 steps, every step's colours / losses / probabilities and
+    the final parameters and Adam moments bit for bit."""
+    tr_a, ha, _ = _g13b_run(True, async_sweeps=True)
+    tr_b, hb, _ = _g13b_run(True, async_sweeps=False)
+    for step, (a, b) in enumerate(zip(ha, hb)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (step, k)
+    assert torch.equal(tr_a.params, tr_b.params) and torch.equal(tr_a.exp_avg, tr_b.exp_avg) and torch.equal(tr_a.exp_avg_sq, tr_b.exp_avg_sq)

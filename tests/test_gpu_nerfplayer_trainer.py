@@ -207,3 +207,39 @@ def test_deterministic_mode_two_runs_bit_identical_and_close_to_the_default():
     # orders; everything else agrees closely
     assert float((d > 1e-4).float().mean()) < 2e-3, float((d > 1e-4).float().mean())
     assert abs(la["rgb_loss"] - lc["rgb_loss"]) <= 2e-3 * abs(lc["rgb_loss"])
+
+
+@pytest.mark.parametrize("tv", [1.0, 0.0])
+def test_async_field_sweep_gives_the_same_bits(tv):
+    """async_field_sweep=True (the field table's optimiser sweep on a side stream right behind its gradient scatter, joined in front of the next forward's
+    field level) against the in-order step, both in deterministic mode so that the comparison is bit for bit: 14 steps crossing updated and non-updated
+    proposal steps; parameters, both Adam moments and the loss terms of every step are identical, and an evaluation forward right after the last step
+    (which must wait for the sweep by itself) renders the same colours."""
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R, n_img, steps = 128, 9, 14
+    cfg = _cfg()
+    cfg.temporal_tv_weight = tv
+
+    def run(async_sweep):
+        tr = NerfplayerTrainer(cfg, R, n_img, aabb_scale=1.0, device=DEV, seed=5, deterministic=True, warm_up_end=4, async_field_sweep=async_sweep)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(1)
+            for name in ("field.table", "prop0.table", "prop1.table"):
+                tr.views[name].copy_((torch.rand(tr.views[name].shape, generator=g) * 2 - 1).to(DEV))
+        tr.tv_rows = [2, 1, 3]
+        losses = []
+        for k in range(steps):
+            rays, cams, target, rng = _batch(R, n_img, 100 + k)
+            tr.train_step(rays, cams, target, rng)
+            losses.append({k_: float(v) for k_, v in tr.loss_dict().items() if k_ != "temporal_tv_loss"})
+        rays, cams, target, rng = _batch(R, n_img, 999)
+        rgb = tr.forward(rays, None, rng, 1.0, training=False).clone()  # no explicit join: forward() waits for the side stream itself
+        tr.synchronize()
+        return tr.params.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), losses, rgb
+
+    a, b = run(True), run(False)
+    assert a[3] == b[3]
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[4], b[4]) and bool(torch.isfinite(a[4]).all())

@@ -43,7 +43,8 @@ kt = tr.kernel_times_ms()
 tr.disable_kernel_timing()
 S2, ns, C = 64, 6, 32
 gather = R * S2 * ns * 6 * 4 * C * 4
-alg = {"adam_planes.field": 32 * tr.field_planes.numel, "kplanes_scatter_sorted.field": 2 * gather, "kplanes_field_fwd": gather + R * S2 * (16 + 2 * C * ns + 64),
+alg = {"adam_planes.field": 32 * tr.field_planes.numel // tr.field_sweep_launches,  # 2 launches per step when pipelined with pass B: mean bytes per launch
+        "kplanes_scatter_sorted.field": 2 * gather, "kplanes_field_fwd": gather + R * S2 * (16 + 2 * C * ns + 64),
        "kplanes_quotient_prepare": 3 * R * S2 * C * ns * 4}
 kt = {k: v for k, v in kt.items() if k in alg}
 dom = max(kt, key=lambda k: kt[k][0] * kt[k][1])

@@ -20,11 +20,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--sync-sweeps", action="store_true", help="A/B: the newness / decomposition tables' optimiser sweeps in order on the main stream (round 4) instead of on a side stream")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 R = args.rays
-tr = NerfplayerFullTrainer(NerfplayerModelConfig(), R, aabb_scale=1.0, device=dev, max_steps=30000, seed=0)
+tr = NerfplayerFullTrainer(NerfplayerModelConfig(), R, aabb_scale=1.0, device=dev, max_steps=30000, seed=0, async_table_sweeps=not args.sync_sweeps)
 tr.step = 600
 
 
@@ -44,4 +45,5 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"config": "nerfplayer preset, full NeRFPlayer (fused flat-buffer trainer)", "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
-                  "rays_per_s": R * args.steps / dt, "launches_per_step": tr.launches}))
+                  "rays_per_s": R * args.steps / dt, "launches_per_step": tr.launches,
+                  "async_table_sweeps": not args.sync_sweeps}))

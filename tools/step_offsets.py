@@ -21,11 +21,12 @@ def main():
     ap.add_argument("--start-step", type=int, default=20)
     ap.add_argument("--interleave-prop-levels", action="store_true")
     ap.add_argument("--sort-before-field-fwd", action="store_true")
+    ap.add_argument("--pipeline-sweep", default="coarse_first", choices=["coarse_first", "fine_first", "off"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     R = 4096
-    cfg = KPlanesTrainConfig(interleave_proposal_levels=args.interleave_prop_levels, sort_before_field_fwd=args.sort_before_field_fwd)
+    cfg = KPlanesTrainConfig(interleave_proposal_levels=args.interleave_prop_levels, sort_before_field_fwd=args.sort_before_field_fwd, pipeline_sweep="" if args.pipeline_sweep == "off" else args.pipeline_sweep)
     tr = KPlanesTrainer(cfg, R, dev)
     tr.step = args.start_step
     cams = synthetic.make_cameras(20, 960, 540)
