@@ -59,13 +59,17 @@ def parse():
     ap.add_argument("--trained-until", type=int, default=5000, help="third leg: really train to this step (untimed, ~12 s), then time K steady-state steps (0 or --no-steady-state: skip)")
     ap.add_argument("--time-sorted-rays", action="store_true", help="A/B: every batch in order of frame time (ops.sort_rays_by_time); faster field forward, but 1.5 %% slower trained steps: profiles/r03_kernels.md section 11")
     ap.add_argument("--no-fused-field", action="store_true", help="A/B: unfused forward (gather, sigma_net, color_net as three kernels); default is the fused forward kernel (csrc/field_fused.hip) with the unfused backward")
-    ap.add_argument("--pipeline-sweep", default="coarse_first", choices=["coarse_first", "fine_first", "off"],
+    ap.add_argument("--pipeline-sweep", default="off", choices=["coarse_first", "fine_first", "off"],
                     help="pass B and the optimiser sweep of the field planes pipelined by scale (KPlanesTrainConfig.pipeline_sweep); off: one pass B, then one sweep (A/B)")
+    ap.add_argument("--pipeline-sweep-config3", default="off", choices=["coarse_first", "fine_first", "off"],
+                    help="the same for the config-3 leg (measured: 4.57 / 4.63 ms pipelined, 4.60 / 4.64 ms not)")
     ap.add_argument("--sort-before-field-fwd", action="store_true", help="A/B: the nerf level's sample sort before the wait for the sweep instead of after the field forward (measured slower: trainer.py)")
     ap.add_argument("--pass-b-main-stream", action="store_true", help="A/B: pass B of the field scatter on the caller's stream (round 3) instead of on the sweep's stream beside the next step's head")
     ap.add_argument("--no-fused-proposal", action="store_true", help="A/B: proposal levels as gather + net kernels instead of the fused density kernel (bit-identical densities)")
     ap.add_argument("--no-quotient-epilogue", action="store_true", help="A/B: round 3's flow -- G = gfeat .* feat from a separate pass over fp32 features instead of the sigma_net backward's epilogue")
     ap.add_argument("--no-quotient-scatter", action="store_true", help="A/B: product form of the field's sorted scatter (gradvec + 1 GB of per-plane gradient vectors) instead of the quotient form")
+    ap.add_argument("--no-alone", action="store_true", help="skip the 20 extra steps that time the optimiser sweep alone as ONE launch (profiling passes: every step of the run "
+                    "then launches the sweep the same way, so rocprofv3's per-kernel averages are means over like launches)")
     ap.add_argument("--no-steady-state", action="store_true", help="skip the second timed region (steady-state schedule + IST importance sampler)")
     ap.add_argument("--cpu-steps", type=int, default=4, help="oracle train steps timed for cpu_baseline")
     ap.add_argument("--no-fused-ray-loss", action="store_true", help="A-B: the nerf level's weights / render / MSE / distortion / weights-backward as five kernels instead of one")
@@ -193,6 +197,21 @@ def launch_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def _merge_sweep_spans(kt, tr):
+    """KPlanesTrainConfig.pipeline_sweep launches the field planes' optimiser sweep twice per step (the finest scale's planes / the coarser scales').  Their
+    HIP-event spans are folded into ONE "adam_planes.field" entry = mean over all launches (what rocprofv3's per-kernel average of plane_reg_kernel<32,true>
+    is) and returned separately as well, each with its own algorithmic bytes (32 B / parameter of its range)."""
+    parts = {k: kt.pop(k) for k in ("adam_planes.field.fine", "adam_planes.field.coarse") if k in kt}
+    if not parts:
+        return None
+    n = sum(v[1] for v in parts.values())
+    kt["adam_planes.field"] = (sum(v[0] * v[1] for v in parts.values()) / n, n)
+    cut, tot = tr._finest_offset(), tr.field_planes.numel
+    nbytes = {"adam_planes.field.fine": 32 * (tot - cut), "adam_planes.field.coarse": 32 * cut}
+    return {k.rsplit(".", 1)[1]: {"avg_launch_ms": round(v[0], 4), "launches_timed": v[1], "algorithmic_per_launch": nbytes[k],
+                                   "frac": round(nbytes[k] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)} for k, v in parts.items()}
+
+
 def _hbm_roofline(kernel, alg_bytes, ms, launches, **extra):
     ach = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -210,7 +229,8 @@ def config3_leg(dev, args):
     R, steps = args.rays, args.leg_steps
     torch.manual_seed(20231029)
     cfg = KPlanesTrainConfig(mlp_operands=args.mlp_operands, multiscale_res=(1, 2, 4, 8, 16, 32), spacetime_resolution=(64, 64, 64, 100),
-                             proposal_resolutions=((128, 128, 128, 100), (256, 256, 256, 100)))
+                             proposal_resolutions=((128, 128, 128, 100), (256, 256, 256, 100)),
+                             pipeline_sweep=args.pipeline_sweep_config3 if args.pipeline_sweep_config3 != "off" else "")
     tr = KPlanesTrainer(cfg, R, dev)
     tr.step = 6000  # steady-state schedule, IST active (iters_to_start_ist = 2000)
     cams = synthetic.make_cameras(20, 960, 540)
@@ -229,7 +249,7 @@ def config3_leg(dev, args):
 
     for _ in range(max(args.warmup, 8)):
         step()
-    cand = ["adam_planes.field", "kplanes_scatter_sorted.field", "kplanes_field_fwd", f"mlp_bwd.{32 * 6}x128x1"]
+    cand = ["adam_planes.field", "adam_planes.field.fine", "adam_planes.field.coarse", "kplanes_scatter_sorted.field", "kplanes_field_fwd", f"mlp_bwd.{32 * 6}x128x1"]
     tr.enable_kernel_timing(cand)
     tr.synchronize()
     t0 = time.perf_counter()
@@ -239,6 +259,7 @@ def config3_leg(dev, args):
     dt = time.perf_counter() - t0
     kt = tr.kernel_times_ms()
     tr.disable_kernel_timing()
+    sweep_parts = _merge_sweep_spans(kt, tr)
     S2, ns, C = cfg.num_nerf_samples_per_ray, 6, cfg.feature_dim
     gather = R * S2 * ns * 6 * 4 * C * 4
     nl = tr.field_sweep_launches  # 2: the sweep is pipelined with pass B by scale (finest scale's planes, then the rest): mean bytes per launch
@@ -253,7 +274,8 @@ def config3_leg(dev, args):
                                   "(19 cameras x 25 frames 960x540), 15 % importance rays, steady-state schedule (step 6000+), full train step incl. Adam",
                       "params": int(tr.n_params), "images": int(M), "rays_per_gpu": R},
            "roofline": _hbm_roofline(alg[dom][1], alg[dom][0], ktl[dom][0], ktl[dom][1],
-                                     other_kernels_ms={k: round(v[0], 4) for k, v in kt.items() if k != dom})}
+                                     other_kernels_ms={k: round(v[0], 4) for k, v in kt.items() if k != dom},
+                                     **({"launch_breakdown": sweep_parts} if sweep_parts and dom == "adam_planes.field" else {}))}
     del tr, data, ist, batch
     torch.cuda.empty_cache()
     return out
@@ -483,7 +505,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     # candidates for "the dominant kernel" (single kernels; HIP events around each launch inside the timed region)
-    CAND = ["adam_planes.field", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
+    CAND = ["adam_planes.field", "adam_planes.field.fine", "adam_planes.field.coarse", "adam_step", "kplanes_scatter_sorted.field", "kplanes_gradvec.field", "kplanes_gather_bwd.field", "mlp_bwd.160x128x1",
             "kplanes_gather_fwd.field", "kplanes_gather_bwd.prop", "kplanes_field_fwd", "kplanes_quotient_prepare"]
     COMM = list(trainer.COMM_WAIT_SPANS) if world > 1 else []
     trainer.enable_kernel_timing(CAND + COMM)
@@ -491,6 +513,7 @@ def main():
     kt = trainer.kernel_times_ms()
     trainer.disable_kernel_timing()
     sweep_launches = trainer.field_sweep_launches  # 2 when the sweep is pipelined with pass B by scale (KPlanesTrainConfig.pipeline_sweep)
+    sweep_parts = _merge_sweep_spans(kt, trainer)
 
     def comm_report(kt_, n_steps):
         """world > 1: what one step puts on the links and how long the compute chain stood waiting for them (HIP events on the chain's
@@ -545,7 +568,7 @@ def main():
     # the optimiser sweep runs on its own stream under the next step's first kernels (async_field_adam): its launch duration in the timed
     # region includes that sharing.  For context, time it ALONE as well (a few extra steps with the sweep back on the main stream).
     alone = None
-    if trainer.async_field_adam and not trainer._sharded():
+    if trainer.async_field_adam and not trainer._sharded() and not args.no_alone:
         trainer.async_field_adam = False
         trainer.enable_kernel_timing(["adam_planes.field"])
         for _ in range(20):
@@ -656,6 +679,7 @@ def main():
             "roofline": {"bound": bound, "kernel": kdesc, "achieved": achieved, "peak": peak, "unit": "GB/s" if bound == "hbm" else "GFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_source, "algorithmic_per_launch": alg_bytes,
                          "avg_launch_ms": dom_ms, "near_ties": near_ties,
+                         **({"launch_breakdown": sweep_parts} if sweep_parts and DOMINANT == "adam_planes.field" else {}),
                          "launches_timed": timed_k[DOMINANT][1],
                          **({"alone": {"avg_launch_ms": round(alone[DOMINANT][0], 4),
                                        "frac": round(alg[DOMINANT][1] * (sweep_launches if DOMINANT == "adam_planes.field" else 1) / (alone[DOMINANT][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),

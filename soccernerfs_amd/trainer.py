@@ -128,13 +128,15 @@ class KPlanesTrainConfig:
     # untraced step, but the sort under the HBM-bound sweep takes 0.3-0.7 ms and stretches the sweep from 0.82 to 0.97 ms -- steady state 2.03 / 2.07 ms
     # with it against 1.98 / 2.01 without (two runs each, one box; profiles/r05_step_offsets_early_sort.txt).
     sort_before_field_fwd: bool = False
-    # Round 5: pass B and the optimiser sweep of the field planes PIPELINED by scale (single GPU, inside train_step).  Pass B scatters one part of the
-    # scales first; the sweep of those planes then starts on the idle "sort" stream while pass B goes on with the other part on the sweep's stream, whose
-    # planes are swept behind it.  "coarse_first": scales 0..n-2, then the finest (~72 % of the floats at the preset) -- the small sweep runs beside the
-    # finest scale's short scatter and the big sweep follows with only the next step's head beside it; "fine_first": the finest scale first, its big sweep
-    # beside the coarser scales' scatter (both lean on the memory system: pass B of the coarser scales stretches from 0.39 to 0.85 ms and the sweep from
-    # 0.60 to 0.74 ms, profiles/r05_step_offsets_pipelined_fine_first.txt); "": one pass B, then one sweep (A-B).
-    pipeline_sweep: str = "coarse_first"
+    # Round 5 (A-B, off): pass B and the optimiser sweep of the field planes PIPELINED by scale (single GPU, inside train_step).  Pass B scatters one part
+    # of the scales first; the sweep of those planes then starts on the idle "sort" stream while pass B goes on with the other part on the sweep's stream,
+    # whose planes are swept behind it.  "coarse_first": scales 0..n-2, then the finest (~72 % of the floats at the preset); "fine_first": the finest scale
+    # first, its big sweep beside the coarser scales' scatter.  Measured on one box (profiles/r05_bench_final.json vs r05_bench_pipelined.json): early
+    # schedule 2.140 ms against 2.208 (-3 %), steady state 2.097 against 2.068 and trained state 1.813 against 1.817 (no gain where the proposal networks
+    # update every 5th step); config 3 4.57 / 4.63 against 4.60 / 4.64.  Both kernels lean on the memory system, so what one gains the other loses: beside
+    # the sweep pass B of the coarser scales stretches from 0.39 to 0.85 ms (fine_first), beside pass B the coarse sweep runs at 0.46 of the HBM peak instead
+    # of 0.79 (coarse_first; profiles/r05_step_offsets_pipelined_*.txt).  Off: the gain is confined to the early schedule and inside the box-to-box spread.
+    pipeline_sweep: str = ""
 
 
 def anneal_value(step: int, max_iters: int, slope: float) -> float:
@@ -1197,9 +1199,10 @@ class KPlanesTrainer:
             cut = self._finest_offset()
             ev, fine_first = self._passb_fine_done
             first, second = ((cut, None), (0, cut)) if fine_first else ((0, cut), (cut, None))
-            self._adam_field_range(*first, side=True, role="sort", after=ev)
+            names = ("adam_planes.field.fine", "adam_planes.field.coarse") if fine_first else ("adam_planes.field.coarse", "adam_planes.field.fine")
+            self._adam_field_range(*first, side=True, role="sort", after=ev, span=names[0])
             fine_done = self._stream("sort").record_event()
-            self._adam_field_range(*second, side=True)
+            self._adam_field_range(*second, side=True, span=names[1])
             self._stream("adam").wait_event(fine_done)  # _field_adam_done (below) then stands for both
             self._passb_fine_done = None
             self.field_sweep_launches = 2

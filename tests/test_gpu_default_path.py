@@ -95,9 +95,11 @@ def test_default_step_matches_reference_golden():
     print(f"default path vs G11: worst gradient checksum deviation {worst:.2e}")
 
 
-def test_default_train_steps_match_oracle():
+@pytest.mark.parametrize("pipeline_sweep", ["", "coarse_first", "fine_first"])
+def test_default_train_steps_match_oracle(pipeline_sweep):
     """Three `train_step`s with every default (16-bit operands, fused forward, quotient scatter, regularisers inside the sweep) against
-    the CPU oracle's autograd + Adam on the same rays and draws."""
+    the CPU oracle's autograd + Adam on the same rays and draws.  Also with pass B and the optimiser sweep pipelined by scale
+    (KPlanesTrainConfig.pipeline_sweep, an A-B switch: two scatter launches, two sweep launches on two streams) -- same bounds."""
     from oracle import kplanes_oracle as KO
     from soccernerfs_amd.trainer import KPlanesTrainer, anneal_value, cosine_lr_factor
 
@@ -108,7 +110,7 @@ def test_default_train_steps_match_oracle():
     for x in leaves:
         x.requires_grad_(True)
     R = 40
-    cfg = _default_cfg(E, num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=16, warm_up_end=2)
+    cfg = _default_cfg(E, num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=16, warm_up_end=2, pipeline_sweep=pipeline_sweep)
     tr = KPlanesTrainer(cfg, R, DEV)
     _assert_default(tr)
     tr.load_oracle_params(P)
@@ -138,6 +140,7 @@ def test_default_train_steps_match_oracle():
         # parameter by up to 2 lr): the rendered colour keeps SURVEY 8d's bound at step 0 and twice that afterwards
         torch.testing.assert_close(rgb.cpu(), out["rgb"].detach(), rtol=0, atol=4e-3 if step == 0 else 8e-3)
         torch.testing.assert_close(sum(tr.loss_dict().values()).cpu(), loss.detach(), rtol=3e-2, atol=1e-7)
+        assert tr.field_sweep_launches == (2 if pipeline_sweep else 1)
     tr.synchronize()
     # Adam's update is ~lr * sign(g) this early: a parameter whose tiny gradient changes sign under 16-bit rounding lands 2 lr away, all
     # others follow the oracle closely -> bound the mean and the fraction of outliers instead of the maximum

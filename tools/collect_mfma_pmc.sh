@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 n_ok=0
 for SET in "SQ_VALU_MFMA_BUSY_CYCLES" "SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU"; do
   t=$(echo $SET | tr ' ' '_' | cut -c1-40)
-  if rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/${TAG}_pmcm_$t -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --images 38 --no-steady-state "$@" > $OUT/${TAG}_pmcm_$t.log 2>&1 \
+  if rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/${TAG}_pmcm_$t -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-alone --images 38 --no-steady-state "$@" > $OUT/${TAG}_pmcm_$t.log 2>&1 \
      && find $OUT/${TAG}_pmcm_$t -name '*counter_collection.csv' | grep -q .; then n_ok=$((n_ok + 1)); else echo "collect_mfma_pmc.sh: pass '$SET' failed (see $OUT/${TAG}_pmcm_$t.log)" >&2; fi
 done
 cd $ROOT
@@ -27,7 +27,7 @@ for f in glob.glob(f"{out}/{tag}_pmcm_*/**/*counter_collection.csv", recursive=T
 cols = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
         "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_VALU"]
 with open(f"{out}/{tag}_mfma_pmc.csv", "w") as g:
-    g.write(f"# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --images 38 --no-steady-state {os.environ['ARGS']}   (one counter set per pass; mean per launch)\n")
+    g.write(f"# rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-alone --images 38 --no-steady-state {os.environ['ARGS']}   (one counter set per pass; mean per launch)\n")
     g.write("# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE / 8): share of the chip's matrix pipes busy while the kernel runs\n")
     g.write("# (GRBM_GUI_ACTIVE is summed over the 8 XCDs).  wait_frac / lds_wait_frac / issue_frac = SQ_WAIT_ANY / SQ_WAIT_INST_LDS / SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES\n")
     g.write("# (MI355X_MICROARCH.md: WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES); waves_per_simd = SQ_WAVE_CYCLES / SQ_BUSY_CYCLES x (SQ_BUSY_CYCLES counts per SE: a relative figure)\n")

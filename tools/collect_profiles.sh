@@ -12,11 +12,11 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || fail "bench
 python bench.py --no-cpu-baseline --no-standin --no-config3 --no-config4 --breakdown --no-overlap --steps 60 2> $OUT/${TAG}_breakdown_serial.txt > /dev/null || fail "bench.py --breakdown failed"
 cd /tmp && export TMPDIR=/tmp
 # every pass: exit code AND the CSV it must leave behind are checked -- a failed pass must not pass stale or empty numbers on
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --no-config3 --no-config4 --trained-until 0 > $OUT/${TAG}_stats.log 2>&1 \
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-alone --trained-until 0 > $OUT/${TAG}_stats.log 2>&1 \
   || fail "rocprofv3 --stats pass failed (see $OUT/${TAG}_stats.log)"
 ls $OUT/${TAG}_stats/*/*kernel_stats.csv > /dev/null 2>&1 || ls $OUT/${TAG}_stats/*kernel_stats.csv > /dev/null 2>&1 || fail "no kernel_stats.csv from the --stats pass"
 for C in FETCH_SIZE WRITE_SIZE TCC_EA0_ATOMIC_sum; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --images 38 --trained-until 0 > $OUT/${TAG}_pmc_$C.log 2>&1 \
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$C -- python3 $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-alone --images 38 --trained-until 0 > $OUT/${TAG}_pmc_$C.log 2>&1 \
     || fail "rocprofv3 --pmc $C pass failed (see $OUT/${TAG}_pmc_$C.log)"
   find $OUT/${TAG}_pmc_$C -name '*counter_collection.csv' | grep -q . || fail "no counter_collection.csv from the --pmc $C pass"
 done
@@ -30,7 +30,7 @@ f = glob.glob(f"{out}/{tag}_stats/**/*kernel_stats.csv", recursive=True)
 if f:
     rows = list(csv.reader(open(f[0])))
     with open(f"{out}/{tag}_kernel_stats.csv", "w") as g:
-        g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --no-config3 --no-config4 --trained-until 0\n")
+        g.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-alone --trained-until 0\n")
         csv.writer(g).writerows(rows[:45])
 # pmc
 acc = collections.defaultdict(dict)
@@ -45,7 +45,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_ATOMIC_sum"):
     for k, v in tmp.items():
         acc[k][c] = sum(v) / len(v)
 with open(f"{out}/{tag}_pmc_counters.csv", "w") as g:
-    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --images 38 --trained-until 0  (one counter per pass)\n")
+    g.write("# rocprofv3 --pmc <C> --kernel-trace -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-standin --no-config3 --no-config4 --no-alone --images 38 --trained-until 0  (one counter per pass)\n")
     g.write("# mean per launch; FETCH_SIZE/WRITE_SIZE in KiB as reported (gfx950: FETCH_SIZE reads 1/2 of a coalesced stream -> traffic = 2*FETCH + WRITE)\n")
     g.write("kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,TCC_EA0_ATOMIC_requests,traffic_bytes\n")
     for k, v in sorted(acc.items(), key=lambda kv: -(2 * kv[1].get("FETCH_SIZE", 0) + kv[1].get("WRITE_SIZE", 0))):

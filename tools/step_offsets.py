@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--start-step", type=int, default=20)
     ap.add_argument("--interleave-prop-levels", action="store_true")
     ap.add_argument("--sort-before-field-fwd", action="store_true")
-    ap.add_argument("--pipeline-sweep", default="coarse_first", choices=["coarse_first", "fine_first", "off"])
+    ap.add_argument("--pipeline-sweep", default="off", choices=["coarse_first", "fine_first", "off"])
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
