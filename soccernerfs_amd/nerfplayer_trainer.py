@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
+from .streams import side_stream
 from .nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
 from .sh import sh4_from_unit_dirs
 from .tcnn_compat import Network
@@ -191,7 +192,7 @@ class NerfplayerTrainer:
             self._tv_sign(0)
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.dev)
+            self._side = side_stream(self.dev, "adam")  # the process-wide sweep stream (streams.py)
         self._side.wait_stream(main)
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
         with torch.cuda.stream(self._side):

@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib, ops
+from .streams import side_stream
 from .plane_set import PlaneSet
 from .tcnn_compat import Network
 
@@ -630,7 +631,7 @@ class KPlanesTrainer:
         normal-priority streams onto 3 hardware queues beside the null stream's -- tools/debug_queues.py -- and chains sharing a queue do
         not overlap; a high-priority stream would get a fifth queue, which made every step slower -- profiles/r02_kernels.md section 8)."""
         if role not in self._side:
-            self._side[role] = torch.cuda.Stream(device=self.dev)
+            self._side[role] = side_stream(self.dev, role)  # one stream per role for the whole PROCESS (streams.py: hardware queues are few)
         return self._side[role]
 
     def _reg_sweep(self):
