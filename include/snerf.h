@@ -178,6 +178,14 @@ int snerf_dense_fwd(const float* W, int32_t K, int32_t M, int32_t act, const flo
                     snerf_stream_t stream);
 int snerf_dense_bwd(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
                     const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, snerf_stream_t stream);
+/* ABI 13: the same single layers with 16-bit MFMA operands (operands: 1 = bf16; fp32 accumulation; X, W, dY rounded while staged into LDS, outputs
+ * and gradients fp32) -- csrc/dense_lp.hip.  K, M <= 128 (the full NeRFPlayer's nets: NS/fields/nerfplayer_field.py:231-316, which the reference runs
+ * in tcnn's fp16).  gW (float atomics) or gW_fx (fixed-point cells), not both; either may be NULL.  snerf_dense_lp_supported: 1 iff built for the shape. */
+int snerf_dense_lp_supported(int32_t K, int32_t M, int32_t operands);
+int snerf_dense_fwd_lp(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, float* Y, int32_t ldy,
+                       int32_t operands, snerf_stream_t stream);
+int snerf_dense_bwd_lp(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,
+                       const float* gY, int32_t ldgy, float* gX, int32_t ldgx, float* gW, int64_t* gW_fx, int32_t operands, snerf_stream_t stream);
 /* ABI 13, deterministic mode: the same with gW accumulated into 2^50-scaled 64-bit cells [K,M] (see snerf_kplanes_gather_bwd_fx; gX is per-sample
  * work and identical between runs either way). */
 int snerf_dense_bwd_fx(const float* W, int32_t K, int32_t M, int32_t act, const float* X, int32_t ldx, int64_t N, const float* Y, int32_t ldy,

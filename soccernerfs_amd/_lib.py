@@ -173,6 +173,9 @@ EXPORTS = [
     "snerf_dense_fwd",
     "snerf_dense_bwd",
     "snerf_dense_bwd_fx",
+    "snerf_dense_lp_supported",
+    "snerf_dense_fwd_lp",
+    "snerf_dense_bwd_lp",
     "snerf_render_fwd",
     "snerf_ray_train_fwd_bwd",
     "snerf_render_bwd",

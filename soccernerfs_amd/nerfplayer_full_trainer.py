@@ -37,8 +37,11 @@ def _align4(n: int) -> int:
 class NerfplayerFullTrainer:
     def __init__(self, cfg: NerfplayerModelConfig, num_rays: int, aabb_scale: float = 1.0, device="cuda:0", lr: float = 1e-2,
                  adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
-                 async_table_sweeps: bool = False):
-        """async_table_sweeps (round 5): inside train_step the optimiser sweeps of the newness and decomposition tables (most of the parameters) go to a side
+                 async_table_sweeps: bool = False, mlp_operands: str = "fp32"):
+        """mlp_operands: "fp32" (exact: every net on the fp32 matrix instructions -- the parity path, what G13 / G13b pin) or "bf16" (round 5: bf16 MFMA
+        operands with fp32 accumulation in every net -- the fused kernels for the shapes in their table, csrc/dense_lp.hip's single layers for the
+        deformation net, the 33 -> 64 -> 32 MLP and the colour head; the reference itself runs all of them in tcnn's fp16).
+        async_table_sweeps (round 5): inside train_step the optimiser sweeps of the newness and decomposition tables (most of the parameters) go to a side
         stream as soon as their gradients are complete (right behind their temporal-grid backward, early in the backward pass) and are joined in front of
         the next forward's first read of those tables: they run beside the rest of the backward (hash-grid scatter, deformation net, proposal networks)
         and the next step's proposal levels.  Same arithmetic (same bits in deterministic mode).  Readers of those tables outside forward() call
@@ -54,8 +57,18 @@ class NerfplayerFullTrainer:
         a = aabb_scale
         self.aabb = [[-a, -a, -a], [a, a, a]]
         torch.manual_seed(seed)
+        if mlp_operands not in ("fp32", "bf16"):
+            raise ValueError(f"mlp_operands must be 'fp32' or 'bf16', got {mlp_operands!r}")
+        self.mlp_operands = mlp_operands
+        self._dense_operands = {"fp32": 0, "bf16": 1}[mlp_operands]
         fc = {"otype": "FullyFusedMLP", "activation": "ReLU"}
-        net = lambda din, dout, h, nh, act: Network(din, dout, {**fc, "output_activation": act, "n_neurons": h, "n_hidden_layers": nh})
+
+        def net(din, dout, h, nh, act):
+            cfg_ = {**fc, "output_activation": act, "n_neurons": h, "n_hidden_layers": nh}
+            d = _lib.MlpDesc()
+            d.d_in, d.d_out, d.hidden, d.n_hidden, d.hidden_act, d.out_act, d.operands = din, dout, h, nh, 1, int(act == "Sigmoid"), self._dense_operands
+            fused16 = self._dense_operands != 0 and bool(_lib.lib().snerf_mlp_supported(C.byref(d)))
+            return Network(din, dout, cfg_, operands=mlp_operands if fused16 else "fp32")  # layer-chained nets pick their kernels in _dense_chain_*
         F = cfg.num_levels * cfg.features_per_level
         self.F = F
         # ---- modules exactly as the fields build them (nerfplayer_nerfacto_field.py:83-104; nerfplayer_field.py:223-316) ----
@@ -257,8 +270,12 @@ class NerfplayerFullTrainer:
         woff, cur, ld, xo = 0, X, ldx, x_off
         for l, y in enumerate(outs):
             K, M = net.dims[l], net.dims[l + 1]
-            self._ck(self.lib.snerf_dense_fwd(self._p(net.params, woff), K, M, _ACT[acts[l]], self._p(cur, xo), ld, C.c_int64(N), self._p(y), y.stride(0),
-                                              self._st), "dense_fwd")
+            if self._dense_operands:
+                self._ck(self.lib.snerf_dense_fwd_lp(self._p(net.params, woff), K, M, _ACT[acts[l]], self._p(cur, xo), ld, C.c_int64(N), self._p(y), y.stride(0),
+                                                     self._dense_operands, self._st), "dense_fwd_lp")
+            else:
+                self._ck(self.lib.snerf_dense_fwd(self._p(net.params, woff), K, M, _ACT[acts[l]], self._p(cur, xo), ld, C.c_int64(N), self._p(y), y.stride(0),
+                                                  self._st), "dense_fwd")
             woff += K * M
             cur, ld, xo = y, y.stride(0), 0
 
@@ -278,6 +295,13 @@ class NerfplayerFullTrainer:
             else:
                 gx, ldgx_, go = scratch[l % 2], scratch[l % 2].stride(0), 0
             fx = self.grads_fx is not None
+            if self._dense_operands:
+                self._ck(self.lib.snerf_dense_bwd_lp(
+                    self._p(net.params, woffs[l]), K, M, _ACT[acts[l]], self._p(xin, xo), ldi, C.c_int64(N), self._p(outs[l]), outs[l].stride(0), self._p(g), ldg,
+                    self._p(gx, go) if gx is not None else None, ldgx_, None if fx else self._p(gW, woffs[l]), self._pfx(gW, woffs[l]) if fx else None,
+                    self._dense_operands, self._st), "dense_bwd_lp")
+                g, ldg = gx, ldgx_
+                continue
             self._ck((self.lib.snerf_dense_bwd_fx if fx else self.lib.snerf_dense_bwd)(
                 self._p(net.params, woffs[l]), K, M, _ACT[acts[l]], self._p(xin, xo), ldi, C.c_int64(N), self._p(outs[l]), outs[l].stride(0), self._p(g), ldg,
                 self._p(gx, go) if gx is not None else None, ldgx_, self._pfx(gW, woffs[l]) if fx else self._p(gW, woffs[l]), self._st), "dense_bwd")

@@ -20,12 +20,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--warmup", type=int, default=5)
 ap.add_argument("--rays", type=int, default=4096)
+ap.add_argument("--mlp-operands", default="bf16", choices=["fp32", "bf16"], help="fp32: every net on the fp32 matrix instructions (the parity path); bf16: 16-bit MFMA operands everywhere")
 ap.add_argument("--sync-sweeps", action="store_true", help="A/B: the newness / decomposition tables' optimiser sweeps in order on the main stream (round 4) instead of on a side stream")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 R = args.rays
-tr = NerfplayerFullTrainer(NerfplayerModelConfig(), R, aabb_scale=1.0, device=dev, max_steps=30000, seed=0, async_table_sweeps=not args.sync_sweeps)
+tr = NerfplayerFullTrainer(NerfplayerModelConfig(), R, aabb_scale=1.0, device=dev, max_steps=30000, seed=0, async_table_sweeps=not args.sync_sweeps, mlp_operands=args.mlp_operands)
 tr.step = 600
 
 
@@ -46,4 +47,4 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"config": "nerfplayer preset, full NeRFPlayer (fused flat-buffer trainer)", "rays": R, "params": int(tr.n_params), "ms_per_step": dt / args.steps * 1e3,
                   "rays_per_s": R * args.steps / dt, "launches_per_step": tr.launches,
-                  "async_table_sweeps": not args.sync_sweeps}))
+                  "async_table_sweeps": not args.sync_sweeps, "mlp_operands": args.mlp_operands}))
