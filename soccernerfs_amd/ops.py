@@ -364,19 +364,23 @@ class _DenseNet(torch.autograd.Function):
     kernels are not instantiated for.  params: one flat vector, layer l row-major [d_l][d_{l+1}] (tcnn_compat.Network's layout)."""
 
     @staticmethod
-    def forward(ctx, x, params, dims, acts):
+    def forward(ctx, x, params, dims, acts, operands=0):
         N = x.shape[0]
         l = _lib.lib()
         saved, h, off = [x], x, 0
         for i in range(len(dims) - 1):
             K, M = dims[i], dims[i + 1]
             y = torch.empty(N, M, dtype=torch.float32, device=x.device)
-            _lib.check(l.snerf_dense_fwd(C.c_void_p(params.data_ptr() + 4 * off), K, M, acts[i], _ptr(h), h.stride(0), C.c_int64(N), _ptr(y), M,
-                                         _stream()), "dense_fwd")
+            if operands:  # 16-bit MFMA operands (csrc/dense_lp.hip)
+                _lib.check(l.snerf_dense_fwd_lp(C.c_void_p(params.data_ptr() + 4 * off), K, M, acts[i], _ptr(h), h.stride(0), C.c_int64(N), _ptr(y), M,
+                                                operands, _stream()), "dense_fwd_lp")
+            else:
+                _lib.check(l.snerf_dense_fwd(C.c_void_p(params.data_ptr() + 4 * off), K, M, acts[i], _ptr(h), h.stride(0), C.c_int64(N), _ptr(y), M,
+                                             _stream()), "dense_fwd")
             saved.append(y)
             h = y
             off += K * M
-        ctx.dims, ctx.acts = dims, acts
+        ctx.dims, ctx.acts, ctx.operands = dims, acts, operands
         ctx.save_for_backward(params, *saved)
         return h
 
@@ -396,21 +400,26 @@ class _DenseNet(torch.autograd.Function):
             x, y = saved[i], saved[i + 1]
             need_gx = i > 0 or ctx.needs_input_grad[0]
             gx = torch.empty(N, K, dtype=torch.float32, device=g.device) if need_gx else None
-            _lib.check(l.snerf_dense_bwd(C.c_void_p(params.data_ptr() + 4 * offs[i]), K, M, acts[i], _ptr(x), x.stride(0), C.c_int64(N), _ptr(y), M,
-                                         _ptr(g), M, _ptr(gx) if gx is not None else None, K, C.c_void_p(gw.data_ptr() + 4 * offs[i]), _stream()),
-                       "dense_bwd")
+            if ctx.operands:
+                _lib.check(l.snerf_dense_bwd_lp(C.c_void_p(params.data_ptr() + 4 * offs[i]), K, M, acts[i], _ptr(x), x.stride(0), C.c_int64(N), _ptr(y), M,
+                                                _ptr(g), M, _ptr(gx) if gx is not None else None, K, C.c_void_p(gw.data_ptr() + 4 * offs[i]), None,
+                                                ctx.operands, _stream()), "dense_bwd_lp")
+            else:
+                _lib.check(l.snerf_dense_bwd(C.c_void_p(params.data_ptr() + 4 * offs[i]), K, M, acts[i], _ptr(x), x.stride(0), C.c_int64(N), _ptr(y), M,
+                                             _ptr(g), M, _ptr(gx) if gx is not None else None, K, C.c_void_p(gw.data_ptr() + 4 * offs[i]), _stream()),
+                           "dense_bwd")
             g = gx
-        return g, gw, None, None
+        return g, gw, None, None, None
 
 
-def dense_net_forward(x, params, dims, hidden_act: str, out_act: str):
+def dense_net_forward(x, params, dims, hidden_act: str, out_act: str, operands: int = 0):
     if not x.is_cuda or x.dtype != torch.float32:
         raise RuntimeError("mlp: expected a float32 HIP device tensor (the HIP library is the only product path)")
     if x.dim() != 2 or x.stride(1) != 1:
         x = x.reshape(-1, x.shape[-1]).contiguous()
     n = len(dims) - 1
     acts = tuple(_ACT_ID[out_act] if i == n - 1 else _ACT_ID[hidden_act] for i in range(n))
-    return _DenseNet.apply(x, _f32c(params, "mlp params"), tuple(dims), acts)
+    return _DenseNet.apply(x, _f32c(params, "mlp params"), tuple(dims), acts, int(operands))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -29,8 +29,11 @@ _OUT = {"None": 0, "Sigmoid": 1}
 
 
 class Network(nn.Module):
-    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337, device=None, operands: str = "fp32"):
-        """operands: "fp32" (exact, the parity path), "bf16" or "fp16" (16-bit MFMA operands, fp32 accumulation; fp16 is tcnn's own)."""
+    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337, device=None, operands: str = "fp32",
+                 chained_16bit: bool = False):
+        """operands: "fp32" (exact, the parity path), "bf16" or "fp16" (16-bit MFMA operands, fp32 accumulation; fp16 is tcnn's own).
+        chained_16bit: a shape outside the fused 16-bit kernels' table is an error by default (the fused trainers rely on that); True accepts it as a
+        layer-chained net on csrc/dense_lp.hip's bf16 single layers (widths <= 128)."""
         super().__init__()
         otype = network_config.get("otype", "FullyFusedMLP")
         if otype not in ("FullyFusedMLP", "CutlassMLP"):
@@ -44,14 +47,20 @@ class Network(nn.Module):
         if operands not in ("fp32", "bf16", "fp16"):
             raise ValueError(f"operands must be 'fp32', 'bf16' or 'fp16', got {operands!r}")
         d.operands = {"fp32": 0, "bf16": 1, "fp16": 2}[operands]
-        if d.operands != 0 and not _lib.lib().snerf_mlp_supported(C.byref(d)):
-            raise ValueError(f"16-bit operands are built for d_in <= 160 -> 128 | d_in <= 32 -> 64 (one hidden layer) and d_in <= 64 -> 64 -> 64; "
-                             f"got {n_input_dims} -> {d.hidden} x {d.n_hidden}")
+        self.dims = [n_input_dims] + [d.hidden] * d.n_hidden + [n_output_dims]
+        fused16 = d.operands == 0 or bool(_lib.lib().snerf_mlp_supported(C.byref(d)))
+        # shapes outside the fused 16-bit table run layer by layer: csrc/dense_lp.hip has bf16 single layers up to 128 wide (round 5)
+        self.dense_operands = 0
+        if not fused16:
+            if not chained_16bit or not all(_lib.lib().snerf_dense_lp_supported(k, m, d.operands) for k, m in zip(self.dims[:-1], self.dims[1:])):
+                raise ValueError(f"16-bit operands: fused kernels for d_in <= 160 -> 128 | d_in <= 32 -> 64 (one hidden layer) and d_in <= 64 -> 64 -> 64, bf16 single "
+                                 f"layers up to 128 wide for everything else; got {operands} for {n_input_dims} -> {d.hidden} x {d.n_hidden} -> {n_output_dims}")
+            self.dense_operands = d.operands
+            d.operands = 0  # the descriptor describes the fused kernels; this net never reaches them
         self.desc = d
         self.operands = operands
         self.hidden_act, self.out_act = network_config["activation"], network_config["output_activation"]
-        self.fused = bool(_lib.lib().snerf_mlp_supported(C.byref(d)))
-        self.dims = [n_input_dims] + [d.hidden] * d.n_hidden + [n_output_dims]
+        self.fused = bool(_lib.lib().snerf_mlp_supported(C.byref(d))) and self.dense_operands == 0
         gen = torch.Generator().manual_seed(seed)
         chunks = []
         for i in range(len(self.dims) - 1):
@@ -80,7 +89,7 @@ class Network(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.fused:
             return ops.mlp_forward(x, self.params, self.desc)
-        return ops.dense_net_forward(x, self.params, self.dims, self.hidden_act, self.out_act)
+        return ops.dense_net_forward(x, self.params, self.dims, self.hidden_act, self.out_act, self.dense_operands)
 
     def forward_with_exp_head(self, x: torch.Tensor, col: int):
         """Returns (y, exp(raw y[:, col])) -- the fused trunc_exp density head (kplanes_field.py:308-311)."""
