@@ -300,7 +300,7 @@ def config4_leg(dev, args):
     M, H, W = data["images"].shape[:3]
     full_index = (data["cam_id"] * n_frames + frame_ids.to(dev).repeat(n_cams)).contiguous()  # image m of the rendered subset -> its index among the 3000
     mc = NerfplayerNerfactoModelConfig()
-    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev, async_field_sweep=True)
+    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev, async_field_sweep=True, mlp_operands=args.mlp_operands if args.mlp_operands in ("fp32", "bf16") else "fp32")
     tr.step = 600  # past the learning-rate warm-up
 
     def step():
@@ -332,7 +332,9 @@ def config4_leg(dev, args):
                               "proposal networks' backward and the next step's ray generation / proposal levels, so its duration includes that sharing "
                               "(alone: tools/bench_nerfplayer.py --fused --stadium --sync-sweep)") if sweep else None
     fwd = kt.get("tgrid_fwd.field")
-    out = {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32",
+    out = {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32" if tr.mlp_operands == "fp32" else tr.mlp_operands,
+           "dtype_note": "tables, sampling, compositing, losses, gradient accumulation and the optimiser f32; " + ("every net exact f32" if tr.mlp_operands == "fp32" else
+                         "bf16 MFMA operands with f32 accumulation in the decode net and the colour head (the proposal nets' 16-wide shape has no 16-bit kernel: f32); the reference runs its nets in tcnn fp16"),
            "config": {"workload": "nerfplayer-nerfacto preset (temporal hash grid L=16 C=2 log2T=19 temporal_dim 64, proposals L=5 log2T=17, samples 256/96/48) on the synthetic "
                                   "stadium-players scene: 30 wide-angle training cameras in the bleachers, aabb [-1,1]^3, 100 frames (fps_downsample 1), camera rays, "
                                   "uniform pixels; full train step incl. Adam over every table",

@@ -37,8 +37,10 @@ def _align4(n: int) -> int:
 class NerfplayerTrainer:
     def __init__(self, cfg: NerfplayerNerfactoModelConfig, num_rays: int, num_images: int, aabb_scale: float = 1.0, device="cuda:0",
                  lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
-                 async_field_sweep: bool = False):
-        """async_field_sweep (round 5): inside train_step the optimiser sweep of the FIELD's table (most of the parameters) is launched on a side stream
+                 async_field_sweep: bool = False, mlp_operands: str = "fp32"):
+        """mlp_operands: "fp32" (exact: the parity path, what G12 pins) or "bf16" (bf16 MFMA operands, fp32 accumulation, for every net whose shape the
+        16-bit fused kernels are built for -- the decode net and the colour head of the preset; the reference runs all of them in tcnn's fp16).
+        async_field_sweep (round 5): inside train_step the optimiser sweep of the FIELD's table (most of the parameters) is launched on a side stream
         as soon as that table's gradient is complete (right behind the field's temporal-grid backward) and is joined only in front of the NEXT forward's
         field level: it runs beside the proposal networks' backward (atomic-bound) and the next step's ray generation and proposal levels, which read
         the two small tables only.  Same arithmetic, same bits in deterministic mode.  Readers of the field table outside forward() call wait_params() /
@@ -53,8 +55,16 @@ class NerfplayerTrainer:
         a = aabb_scale
         self.aabb = [[-a, -a, -a], [a, a, a]]
         torch.manual_seed(seed)
-        mlp = lambda din, dout, h, nh, act: Network(din, dout, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act,
-                                                               "n_neurons": h, "n_hidden_layers": nh})
+        if mlp_operands not in ("fp32", "bf16"):
+            raise ValueError(f"mlp_operands must be 'fp32' or 'bf16', got {mlp_operands!r}")
+        self.mlp_operands = mlp_operands
+
+        def mlp(din, dout, h, nh, act):
+            d = _lib.MlpDesc()
+            d.d_in, d.d_out, d.hidden, d.n_hidden, d.hidden_act, d.out_act, d.operands = din, dout, h, nh, 1, int(act == "Sigmoid"), int(mlp_operands == "bf16")
+            op = mlp_operands if (d.operands and _lib.lib().snerf_mlp_supported(C.byref(d))) else "fp32"
+            return Network(din, dout, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": act, "n_neurons": h, "n_hidden_layers": nh}, operands=op)
+
         # ---- modules exactly as the fields build them (nerfplayer_nerfacto_field.py:83-104, 238-311) ----
         self.prop_enc: List[TemporalGridEncoder] = []
         self.prop_mlp: List[Network] = []
