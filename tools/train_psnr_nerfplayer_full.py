@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--frames", type=int, default=25)
     ap.add_argument("--prob-reg", type=float, default=0.1, help="prob_reg_loss_mult (preset: 0.1)")
     ap.add_argument("--seed", type=int, default=20231029)
+    ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16"], help="NerfplayerFullTrainer(mlp_operands=...)")
+    ap.add_argument("--async-sweeps", action="store_true", help="NerfplayerFullTrainer(async_table_sweeps=True)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(args.seed)
@@ -81,9 +83,11 @@ def main():
     novel = synthetic.render_dataset(synthetic.make_novel_cameras(3, Wd, Hd, n_train_cams=36), times, [0, 1, 2], dev, chunk_rows=Hd)
     M, H, W = train["images"].shape[:3]
     cfg = NerfplayerModelConfig(prob_reg_loss_mult=args.prob_reg)
-    tr = NerfplayerFullTrainer(cfg, R, aabb_scale=1.5, device=dev, max_steps=args.steps, seed=args.seed)
+    tr = NerfplayerFullTrainer(cfg, R, aabb_scale=1.5, device=dev, max_steps=args.steps, seed=args.seed, mlp_operands=args.mlp_operands,
+                               async_table_sweeps=args.async_sweeps)
     log = {"config": f"nerfplayer preset (full NeRFPlayer), fused flat-buffer trainer, synthetic clip ({M} training images {W}x{H} from 36 cameras; "
-                     f"3 evaluation-only cameras between them), prob_reg_loss_mult {args.prob_reg}", "params": int(tr.n_params), "evals": []}
+                     f"3 evaluation-only cameras between them), prob_reg_loss_mult {args.prob_reg}", "params": int(tr.n_params), "mlp_operands": args.mlp_operands,
+           "async_table_sweeps": bool(args.async_sweeps), "evals": []}
     torch.cuda.synchronize()
     t0 = time.time()
     for step in range(args.steps):
