@@ -596,6 +596,16 @@ int snerf_nerfplayer_mix_bwd(const float* probs, const float* v_static, const fl
                              const float* g_probs, int64_t N, int32_t F, float* g_static, float* g_deform, float* g_new, float* g_logits,
                              snerf_stream_t stream);
 
+/* ABI 13: the colour head's input of the NeRFPlayer-nerfacto field (NS/fields/nerfplayer_nerfacto_field.py:350-384), one launch each way instead of ~35
+ * ATen kernels.  fwd: hx[R*S, 64] = [SH degree 4 of dirs[ray] (16, the expressions of tcnn's SphericalHarmonics on unit vectors) | h[n, 1:16] (15) |
+ * appearance[cams[ray]] (32; cams NULL: row 0 of `appearance` for every ray -- an average embedding; appearance NULL: zeros) | 0].
+ * bwd: g_h[n, 1:16] = g_hx[n, 16:31] (the other columns of g_h are left alone) and, if asked for, the appearance gradient: for every ray the sum over its
+ * samples of g_hx[n, 31:63] is ADDED to row cams[ray] of g_appearance [num_images, 32] (float atomics) or g_appearance_fx (fixed-point cells); not both. */
+int snerf_nerfacto_head_input_fwd(const float* dirs, const float* h, const float* appearance, const int64_t* cams, int32_t S, int64_t R, float* hx,
+                                  snerf_stream_t stream);
+int snerf_nerfacto_head_input_bwd(const float* g_hx, const int64_t* cams, int32_t S, int64_t R, float* g_h, float* g_appearance,
+                                  int64_t* g_appearance_fx, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * KPlanesField's linear decoder, the pointwise pieces (NS/fields/kplanes_field.py:305-311, :349-354; the dense layers are snerf_dense_*):
  * trunc_exp (NS/field_components/activations.py:25-41): y = exp(x);  gx = g * exp(clamp(x, -15, 15)).

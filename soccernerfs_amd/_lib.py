@@ -235,6 +235,8 @@ EXPORTS = [
     "snerf_kplanes_quotient_fixup",
     "snerf_nerfplayer_mix_fwd",
     "snerf_nerfplayer_mix_bwd",
+    "snerf_nerfacto_head_input_fwd",
+    "snerf_nerfacto_head_input_bwd",
     "snerf_trunc_exp_fwd",
     "snerf_trunc_exp_bwd",
     "snerf_basis_rgb_fwd",

@@ -62,9 +62,101 @@ __global__ __launch_bounds__(256) void mix_bwd_kernel(const float* __restrict__ 
   *reinterpret_cast<float4*>(gvn + n * F + cg * 4) = make_float4(p2 * g.x, p2 * g.y, p2 * g.z, p2 * g.w);
 }
 
+// ---------------------------------------------------------------------------------------------
+// NeRFPlayer-nerfacto colour head input (NerfplayerNerfactoField.get_outputs, NS/fields/nerfplayer_nerfacto_field.py:350-384): per sample
+//   hx = [ SH degree 4 of the ray direction (16) | geometry features h[:, 1:16] (15) | appearance embedding of the ray's camera (32) | 0 ]
+// The reference builds it from ~35 ATen launches (the spherical harmonics alone are 25 elementwise kernels on [R] tensors, then stack / expand /
+// cat); here one launch each way.  The SH expressions are soccernerfs_amd/sh.py's, evaluated in its order with contraction off, so the values are
+// the bits the torch expressions give.  Backward: gh[:, 1:16] = ghx[:, 16:31] and the appearance gradient = sum over the ray's samples of
+// ghx[:, 31:63], added to the camera's row (float atomics, or fixed-point cells).
+// ---------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+__device__ __forceinline__ float sh4_coeff(int k, float x, float y, float z) {
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  switch (k) {
+    case 0: return 0.28209479177387814f;
+    case 1: return -0.48860251190291987f * y;
+    case 2: return 0.48860251190291987f * z;
+    case 3: return -0.48860251190291987f * x;
+    case 4: return 1.0925484305920792f * xy;
+    case 5: return -1.0925484305920792f * yz;
+    case 6: return 0.94617469575755997f * z2 - 0.31539156525251999f;
+    case 7: return -1.0925484305920792f * xz;
+    case 8: return 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    case 9: return (0.59004358992664352f * y) * (-3.0f * x2 + y2);
+    case 10: return (2.8906114426405538f * xy) * z;
+    case 11: return (0.45704579946446572f * y) * (1.0f - 5.0f * z2);
+    case 12: return (0.3731763325901154f * z) * (5.0f * z2 - 3.0f);
+    case 13: return (0.45704579946446572f * x) * (1.0f - 5.0f * z2);
+    case 14: return (1.4453057213202769f * z) * (x2 - y2);
+    default: return (0.59004358992664352f * x) * (-x2 + 3.0f * y2);
+  }
+}
+
+// one thread per (sample, column of hx); rows of hx are 64 floats
+__global__ __launch_bounds__(256) void head_input_fwd_kernel(const float* __restrict__ dirs, const float* __restrict__ h, const float* __restrict__ app,
+                                                            const int64_t* __restrict__ cams, int S, int64_t N, float* __restrict__ hx) {
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = gid >> 6;
+  const int c = (int)(gid & 63);
+  if (n >= N) return;
+  const int64_t ray = n / S;
+  float v = 0.f;
+  if (c < 16) v = sh4_coeff(c, dirs[ray * 3], dirs[ray * 3 + 1], dirs[ray * 3 + 2]);
+  else if (c < 31) v = h[n * 16 + (c - 15)];
+  else if (c < 63 && app) v = app[(cams ? cams[ray] : 0) * 32 + (c - 31)];
+  hx[n * 64 + c] = v;
+}
+
+// one 64-thread group per ray: lanes 0..31 sum the appearance columns over the ray's samples (in sample order), lanes 32..46 copy the geometry columns
+__global__ __launch_bounds__(256) void head_input_bwd_kernel(const float* __restrict__ ghx, const int64_t* __restrict__ cams, int S, int64_t R,
+                                                            float* __restrict__ gh, float* __restrict__ gapp, long long* __restrict__ gapp_fx) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int l = threadIdx.x & 63;
+  if (ray >= R) return;
+  const float* g = ghx + ray * S * 64;
+  if (l < 32) {
+    if (!gapp && !gapp_fx) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += g[s * 64 + 31 + l];
+    const int64_t e = cams[ray] * 32 + l;
+    if (gapp_fx) fx_atomic_add(gapp_fx + e, acc); else if (acc != 0.f) atomicAdd(gapp + e, acc);
+  } else if (l < 47) {
+    const int j = l - 32;  // geometry column 1 + j of h
+    for (int s = 0; s < S; ++s) gh[(ray * S + s) * 16 + 1 + j] = g[s * 64 + 16 + j];
+  }
+}
+#pragma clang fp contract(fast)
+
 }  // namespace snerf
 
 using namespace snerf;
+
+// snerf.h (ABI 13)
+extern "C" int snerf_nerfacto_head_input_fwd(const float* dirs, const float* h, const float* appearance, const int64_t* cams, int32_t S, int64_t R,
+                                             float* hx, snerf_stream_t stream) {
+  SNERF_REQUIRE(S >= 1 && R >= 0, "nerfacto_head_input_fwd: S=%d R=%lld", S, (long long)R);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(dirs && h && hx, "nerfacto_head_input_fwd: null buffer");
+  SNERF_REQUIRE(!cams || appearance, "nerfacto_head_input_fwd: camera indices without an embedding table");
+  const int64_t N = R * S, threads = N * 64;
+  hipLaunchKernelGGL(head_input_fwd_kernel, dim3((unsigned)ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, dirs, h, appearance, cams, S, N, hx);
+  SNERF_LAUNCH_CHECK("nerfacto_head_input_fwd");
+  return 0;
+}
+
+extern "C" int snerf_nerfacto_head_input_bwd(const float* g_hx, const int64_t* cams, int32_t S, int64_t R, float* g_h, float* g_appearance,
+                                             int64_t* g_appearance_fx, snerf_stream_t stream) {
+  SNERF_REQUIRE(S >= 1 && R >= 0, "nerfacto_head_input_bwd: S=%d R=%lld", S, (long long)R);
+  if (R == 0) return 0;
+  SNERF_REQUIRE(g_hx && g_h, "nerfacto_head_input_bwd: null buffer");
+  SNERF_REQUIRE(!(g_appearance && g_appearance_fx), "nerfacto_head_input_bwd: give g_appearance or g_appearance_fx, not both");
+  SNERF_REQUIRE(cams || !(g_appearance || g_appearance_fx), "nerfacto_head_input_bwd: the appearance gradient needs the camera indices");
+  hipLaunchKernelGGL(head_input_bwd_kernel, dim3((unsigned)ceil_div(R * 64, 256)), dim3(256), 0, (hipStream_t)stream, g_hx, cams, S, R, g_h, g_appearance,
+                     reinterpret_cast<long long*>(g_appearance_fx));
+  SNERF_LAUNCH_CHECK("nerfacto_head_input_bwd");
+  return 0;
+}
 
 extern "C" int snerf_nerfplayer_mix_fwd(const float* logits, const float* v_static, const float* v_deform, const float* v_new, int64_t N, int32_t F,
                                         float* probs, float* v, snerf_stream_t stream) {

@@ -24,7 +24,6 @@ import torch
 from . import _lib, ops
 from .streams import side_stream
 from .nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
-from .sh import sh4_from_unit_dirs
 from .tcnn_compat import Network
 from .temporal_grid import TemporalGridEncoder
 from .trainer import anneal_value, cosine_lr_factor
@@ -270,6 +269,8 @@ class NerfplayerTrainer:
         o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
         rays = dict(rays)
         rays["nears"], rays["fars"] = ops.aabb_collide(o, d, self.aabb, 0.0, training)  # AABBBoxCollider(scene_box): near_plane 0
+        if cams is not None and (cams.dtype != torch.int64 or not cams.is_contiguous()):
+            cams = cams.to(torch.int64).contiguous()
         self.rays, self.cams = rays, cams
         t_rand = rng["t_rand"] if training else None
         _lib.check(self.lib.snerf_spaced_bins(self._p(rays["nears"]), self._p(rays["fars"]), self._p(t_rand) if t_rand is not None else None,
@@ -289,15 +290,16 @@ class NerfplayerTrainer:
                 self.wait_params()  # the field table's sweep of the last step (async_field_sweep) must be complete before the table is read
                 self._tgrid_fwd(self.enc, self.enc.embeddings, co, t, S, N, b["feat"])
                 self._mlp_fwd(self.decode, b["feat"], self.enc.output_dim, N, b["h"], 16, 0, b["dens"][2])
-                hx = b["hx"].view(R, S, 64)
-                hx[:, :, 0:16] = sh4_from_unit_dirs(d)[:, None, :]
-                hx[:, :, 16:31] = b["h"].view(R, S, 16)[:, :, 1:16]
+                # colour head input [SH 16 | geo 15 | appearance 32 | 0] in one launch (csrc/nerfplayer.hip; ~35 ATen kernels before round 5)
                 if training:
-                    hx[:, :, 31:63] = self.appearance.weight[cams][:, None, :]
+                    app, cm = self.appearance.weight, cams
                 elif cfg.use_average_appearance_embedding:
-                    hx[:, :, 31:63] = self.appearance.weight.mean(0)[None, None, :]
+                    app, cm = self.appearance.weight.mean(0, keepdim=True).contiguous(), None
                 else:
-                    hx[:, :, 31:63] = 0.0
+                    app, cm = None, None
+                dd = d if d.is_contiguous() else d.contiguous()
+                _lib.check(self.lib.snerf_nerfacto_head_input_fwd(self._p(dd), self._p(b["h"]), self._p(app) if app is not None else None,
+                                                                  self._p(cm) if cm is not None else None, S, R, self._p(b["hx"]), self._st), "head_input_fwd")
                 self._mlp_fwd(self.head, b["hx"], 64, N, b["rgb"], 3)
                 _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, S, self._p(b["w"][2]), self._st), "weights_fwd")
         a = _lib.RenderArgs()
@@ -322,13 +324,12 @@ class NerfplayerTrainer:
                                               self._st), "weights_bwd")
         # colour head: gX = [dSH (unused) | d geo | d appearance | pad]
         self._mlp_bwd(self.head, self.gviews["field.head"], b["hx"], 64, N2, b["grgb"], 3, -1, None, b["ghx"], 64)
-        ghx = b["ghx"].view(R, S2, 64)
-        b["gh"].view(R, S2, 16)[:, :, 1:16] = ghx[:, :, 16:31]  # column 0 (density) enters through gaux below
-        gapp = ghx[:, :, 31:63].sum(1)
-        if self.grads_fx is not None:  # integer index_add_: the atomics behind it commute
-            self.fxviews["field.appearance"].index_add_(0, self.cams, torch.round(gapp.double() * 2.0 ** 50).long())
-        else:
-            self.gviews["field.appearance"].index_add_(0, self.cams, gapp)
+        # gh[:, 1:16] = ghx[:, 16:31] (column 0, the density, enters through gaux below); appearance gradient = per-ray sums of ghx[:, 31:63] added to the
+        # cameras' rows -- fixed-point cells in deterministic mode
+        fx = self.grads_fx is not None
+        _lib.check(self.lib.snerf_nerfacto_head_input_bwd(self._p(b["ghx"]), self._p(self.cams), S2, R, self._p(b["gh"]),
+                                                          None if fx else self._p(self.gviews["field.appearance"]),
+                                                          self._p(self.fxviews["field.appearance"]) if fx else None, self._st), "head_input_bwd")
         self._mlp_bwd(self.decode, self.gviews["field.decode"], b["feat"], self.enc.output_dim, N2, b["gh"], 16, 0, b["gdens"][2], b["gfeat"],
                       self.enc.output_dim)
         self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])

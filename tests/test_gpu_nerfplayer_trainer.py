@@ -293,3 +293,55 @@ def test_bf16_operands_close_to_fp32_and_train():
                 first[op] = float(tr.loss_dict()["rgb_loss"])
         last[op] = float(tr.loss_dict()["rgb_loss"])
     assert last["bf16"] < 0.8 * first["bf16"] and abs(last["bf16"] - last["fp32"]) <= 0.25 * last["fp32"], (first, last)
+
+
+def test_head_input_kernels_match_the_torch_expressions():
+    """snerf_nerfacto_head_input_fwd / _bwd against the ~35 torch ops they replace: the SH block is the bits soccernerfs_amd.sh.sh4_from_unit_dirs gives, the
+    copies are exact, the appearance gradient is the per-ray sum added to the cameras' rows (float and fixed-point accumulators)."""
+    import ctypes as C
+
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.sh import sh4_from_unit_dirs
+
+    L = _lib.lib()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    gen = torch.Generator().manual_seed(4)
+    R, S, M = 333, 7, 11
+    d = torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1).to(DEV)
+    h = torch.rand(R * S, 16, generator=gen).to(DEV)
+    app = torch.rand(M, 32, generator=gen).to(DEV)
+    cams = torch.randint(0, M, (R,), generator=gen).to(DEV)
+    st = ops._stream()
+    hx = torch.full((R * S, 64), 9.0, device=DEV)
+    _lib.check(L.snerf_nerfacto_head_input_fwd(p(d), p(h), p(app), p(cams), S, C.c_int64(R), p(hx), st), "fwd")
+    v = hx.view(R, S, 64)
+    assert torch.equal(v[:, :, 0:16], sh4_from_unit_dirs(d)[:, None, :].expand(R, S, 16))
+    assert torch.equal(v[:, :, 16:31], h.view(R, S, 16)[:, :, 1:16]) and torch.equal(v[:, :, 31:63], app[cams][:, None, :].expand(R, S, 32))
+    assert bool((v[:, :, 63] == 0).all())
+    # evaluation variants: one constant row for every ray / no embedding at all
+    avg = app.mean(0, keepdim=True).contiguous()
+    _lib.check(L.snerf_nerfacto_head_input_fwd(p(d), p(h), p(avg), None, S, C.c_int64(R), p(hx), st), "fwd avg")
+    assert torch.equal(hx.view(R, S, 64)[:, :, 31:63], avg[None].expand(R, S, 32))
+    _lib.check(L.snerf_nerfacto_head_input_fwd(p(d), p(h), None, None, S, C.c_int64(R), p(hx), st), "fwd zero")
+    assert bool((hx.view(R, S, 64)[:, :, 31:] == 0).all())
+    assert L.snerf_nerfacto_head_input_fwd(p(d), p(h), None, p(cams), S, C.c_int64(R), p(hx), st) != 0  # indices without a table
+    # backward
+    ghx = (torch.rand(R * S, 64, generator=gen) - 0.5).to(DEV)
+    gh = torch.full((R * S, 16), 3.0, device=DEV)
+    gapp = torch.zeros(M, 32, device=DEV)
+    _lib.check(L.snerf_nerfacto_head_input_bwd(p(ghx), p(cams), S, C.c_int64(R), p(gh), p(gapp), None, st), "bwd")
+    g3 = ghx.view(R, S, 64)
+    assert torch.equal(gh.view(R, S, 16)[:, :, 1:16], g3[:, :, 16:31]) and bool((gh[:, 0] == 3.0).all())
+    ref = torch.zeros(M, 32, device=DEV, dtype=torch.float64).index_add_(0, cams, g3[:, :, 31:63].double().sum(1))
+    torch.testing.assert_close(gapp.double(), ref, rtol=1e-5, atol=1e-5)
+    cells = []
+    for _ in range(2):
+        fx = torch.zeros(M * 32, dtype=torch.int64, device=DEV)
+        _lib.check(L.snerf_nerfacto_head_input_bwd(p(ghx), p(cams), S, C.c_int64(R), p(gh), None, p(fx), st), "bwd fx")
+        cells.append(fx)
+    assert torch.equal(cells[0], cells[1])
+    out = torch.empty(M * 32, device=DEV)
+    ops.fx_to_float(cells[0], out)
+    torch.testing.assert_close(out.view(M, 32).double(), ref, rtol=1e-5, atol=1e-5)
+    assert L.snerf_nerfacto_head_input_bwd(p(ghx), p(cams), S, C.c_int64(R), p(gh), p(gapp), p(cells[0]), st) != 0  # both accumulators
+    assert L.snerf_nerfacto_head_input_bwd(p(ghx), None, S, C.c_int64(R), p(gh), None, None, st) == 0             # geometry columns only
