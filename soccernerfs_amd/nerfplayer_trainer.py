@@ -134,7 +134,7 @@ class NerfplayerTrainer:
         self.tv_rows: Optional[List[int]] = None  # parity hook: fixed table rows [field, prop0, prop1] instead of the random draw
         self._tv_cols = [(0, 1)] * 3
         self.async_field_sweep = bool(async_field_sweep)
-        self._side, self._field_sweep_done, self._field_swept, self._in_train_step = None, None, False, False
+        self._side, self._field_sweep_done, self._field_swept, self._in_train_step, self._tv0_done = None, None, False, False, None
 
     # ---- helpers ----
     def _p(self, t):
@@ -194,15 +194,27 @@ class NerfplayerTrainer:
                                                    C.c_int64(rows_), gc, ca, cb, self._p(self._srow[kk]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
                                                    None, st), "adam_step_tv")
 
-    def _field_table_sweep_async(self):
-        """async_field_sweep: the field table's TV pass, then its Adam sweep on the side stream, behind everything the caller's stream holds (the
-        table's gradient scatter)."""
-        if self.cfg.temporal_tv_weight > 0:
-            self._tv_sign(0)
+    def _field_tv_early(self):
+        """async_field_sweep: the field table's TV pass reads parameters only, so it goes to the side stream at the START of the backward instead of between the
+        table's gradient scatter and its sweep (~0.1 ms off the chain scatter -> sweep -> next forward)."""
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = side_stream(self.dev, "adam")  # the process-wide sweep stream (streams.py)
-        self._side.wait_stream(main)
+        self._side.wait_stream(main)  # b["tv"] zeroed; the forward's reads of everything else are irrelevant to it
+        keep = self._st
+        with torch.cuda.stream(self._side):
+            self._st = C.c_void_p(self._side.cuda_stream)
+            try:
+                self._tv_sign(0)
+            finally:
+                self._st = keep
+            self._tv0_done = self._side.record_event()
+
+    def _field_table_sweep_async(self):
+        """async_field_sweep: the field table's Adam sweep on the side stream, behind everything the caller's stream holds (the table's gradient scatter)
+        and behind its TV pass (same stream)."""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)  # (the table's TV pass has been on this stream since the start of the backward: _field_tv_early)
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
         with torch.cuda.stream(self._side):
             if self.grads_fx is not None:
@@ -316,6 +328,11 @@ class NerfplayerTrainer:
         S2, N2 = self.S[2], R * self.S[2]
         t = self.rays["times"].reshape(-1)
         target = target if target.is_contiguous() else target.contiguous()
+        early = bool(self.async_field_sweep and self._in_train_step)
+        if cfg.temporal_tv_weight > 0:
+            b["tv"].zero_()
+            if early:
+                self._field_tv_early()
         _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
                                                  2.0 / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]), self._st), "render_mse_bwd")
         _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, cfg.distortion_loss_mult / R, self._p(b["dist_rays"]),
@@ -333,10 +350,9 @@ class NerfplayerTrainer:
         self._mlp_bwd(self.decode, self.gviews["field.decode"], b["feat"], self.enc.output_dim, N2, b["gh"], 16, 0, b["gdens"][2], b["gfeat"],
                       self.enc.output_dim)
         self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])
-        if cfg.temporal_tv_weight > 0:
-            b["tv"].zero_()
-        early = bool(self.async_field_sweep and self._in_train_step)
         if early:
+            if self._side is None:
+                self._side = side_stream(self.dev, "adam")
             self._field_table_sweep_async()
         # proposal supervision (interlevel loss, losses.py:106-121)
         for lvl in range(2):
@@ -357,6 +373,8 @@ class NerfplayerTrainer:
             for k in range(3):
                 if not (early and k == 0):  # the same order of row draws either way: field, proposal 0, proposal 1
                     self._tv_sign(k)
+            if early:
+                torch.cuda.current_stream().wait_event(self._tv0_done)  # loss_dict reads the field table's TV value on the caller's stream
 
     def materialize_tv_gradient(self):
         """Adds the temporal-TV gradient into self.grads explicitly (what the Adam sweep otherwise does on the fly); for parity tests."""
