@@ -159,7 +159,7 @@ class NerfplayerFullTrainer:
         self._tv_cols = [(0, 1)] * 4
         self.launches = 0  # libsnerf launches of the last step (diagnostics)
         self.async_table_sweeps = bool(async_table_sweeps)
-        self._side, self._sweeps_done, self._swept, self._in_train_step = None, None, (), False
+        self._side, self._sweeps_done, self._swept, self._in_train_step, self._tv01_done = None, None, (), False, None
 
     # ---- helpers ----
     def _p(self, t, off_floats: int = 0):
@@ -200,15 +200,28 @@ class NerfplayerFullTrainer:
                                              C.c_int64(rows_), gc, ca, cb, self._p(self._srow[k]), lr, 0.9, 0.999, self.adam_eps, self.step + 1, 1.0, 1,
                                              None, st), "adam_step_tv")
 
-    def _early_table_sweeps(self):
-        """async_table_sweeps: TV pass + Adam sweep of the newness (k = 0) and decomposition (k = 1) tables on the side stream, behind everything the
-        caller's stream holds (their gradient scatters)."""
-        for k in (0, 1):
-            self._tv_sign(k)
+    def _early_tv(self):
+        """async_table_sweeps: the TV passes of the newness (k = 0) and decomposition (k = 1) tables read parameters only -- on the side stream at the START of
+        the backward instead of on the caller's stream (the critical path of this model) between the tables' gradient scatters and their sweeps."""
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = side_stream(self.dev, "adam")  # the process-wide sweep stream (streams.py)
         self._side.wait_stream(main)
+        keep = self._st
+        with torch.cuda.stream(self._side):
+            self._st = C.c_void_p(self._side.cuda_stream)
+            try:
+                for k in (0, 1):
+                    self._tv_sign(k)
+            finally:
+                self._st = keep
+            self._tv01_done = self._side.record_event()
+
+    def _early_table_sweeps(self):
+        """async_table_sweeps: TV pass + Adam sweep of the newness (k = 0) and decomposition (k = 1) tables on the side stream, behind everything the
+        caller's stream holds (their gradient scatters)."""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)  # (the two tables' TV passes have been on this stream since the start of the backward: _early_tv)
         lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
         with torch.cuda.stream(self._side):
             st = C.c_void_p(self._side.cuda_stream)
@@ -395,6 +408,11 @@ class NerfplayerFullTrainer:
         S2, N = self.S[2], R * self.S[2]
         t = self.rays["times"].reshape(-1)
         target = ops._f32c(target, "target")
+        early = bool(self.async_table_sweeps and self._in_train_step and cfg.temporal_tv_weight > 0)
+        if cfg.temporal_tv_weight > 0:
+            b["tv"].zero_()
+        if early:
+            self._early_tv()
         self._ck(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
                                                2.0 / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]), self._st), "render_mse_bwd")
         self._ck(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, cfg.distortion_loss_mult / R, self._p(b["dist_rays"]),
@@ -418,9 +436,6 @@ class NerfplayerFullTrainer:
         self._mlp_bwd(self.decomp_mlp, self.gviews["field.decomp_mlp"], b["dfeat"], F, N, b["glogits"], 3, -1, None, b["gdfeat"], F)
         self._tgrid_bwd(self.decomp, self._pts, b["tN"], 1, N, b["gdfeat"], self.gviews["field.decomp"])
         self._tgrid_bwd(self.newness, self._pts, b["tN"], 1, N, b["gvnew"], self.gviews["field.newness"])
-        early = bool(self.async_table_sweeps and self._in_train_step and cfg.temporal_tv_weight > 0)
-        if cfg.temporal_tv_weight > 0:
-            b["tv"].zero_()
         if early:
             self._early_table_sweeps()
         self._dense_chain_bwd(self.stat_mlp, "field.stat_mlp", ("relu", "none"), b["sx"], 36, 0, 2 * N, [b["sh"], b["sv"]], b["gsv"], F, [b["gsh"], b["gsh"]],
@@ -461,6 +476,8 @@ class NerfplayerFullTrainer:
             for k_ in range(4):
                 if k_ not in self._swept:  # the same order of row draws either way
                     self._tv_sign(k_)
+            if early:
+                torch.cuda.current_stream().wait_event(self._tv01_done)  # loss_dict reads those tables' TV values on the caller's stream
 
     def materialize_tv_gradient(self):
         """Adds the temporal-TV gradient into self.grads explicitly (what the Adam sweep otherwise does on the fly); for parity tests."""
