@@ -32,7 +32,7 @@ PROFILE_TAG = "r05"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psn
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launcher's WORLD_SIZE when one started this script, else 1")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU per step (k-planes preset: 4096)")
@@ -355,6 +355,10 @@ def config4_leg(dev, args):
 
 def main():
     args = parse()
+    if args.gpus is None:
+        # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's rank count is the request; an EXPLICIT --gpus that
+        # disagrees with the launcher stays fatal below
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -30,7 +30,7 @@ typedef void* snerf_stream_t; /* hipStream_t */
 #define SNERF_ERR_UNSUPPORTED (-2)
 
 #define SNERF_MAX_SCALES 8
-#define SNERF_ABI_VERSION 13
+#define SNERF_ABI_VERSION 14
 
 /* Library identity / diagnostics. */
 int snerf_abi_version(void);
@@ -532,6 +532,50 @@ int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_coords* coo
 int snerf_tgrid_encode_bwd_fx(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index,
                               const float* times, int32_t samples_per_row, int64_t B, const float* grad_out, int64_t* grad_embeddings_fx,
                               snerf_stream_t stream);
+
+/* ABI 14: the backward w.r.t. the table in OWNER-COMPUTES form, for D = 3 grids with per-sample / per-ray `times` (csrc/tgrid_tiles.hip).  Replaces the
+ * same reference kernel (kernel_grid_backward, temporal_gridencoder.cu:283-370) and, in its fused form, the torch.optim.Adam step of the table that
+ * follows it (NS/configs/method_configs.py:648-657) together with the temporal-TV gradient (NS/field_components/temporal_grid.py:352-376).  The table is
+ * cut into tiles of 2^tile_rows_log2 consecutive rows; snerf_tgrid_bwd_bin files every (sample, level, corner) under the tile its row belongs to (a
+ * counting sort without global atomics), and one workgroup per tile then sums the tile's gradient rows in LDS and either adds them into the dense
+ * gradient buffer with plain stores (snerf_tgrid_bwd_tiles: same result as snerf_tgrid_encode_bwd up to the association order of the float sums) or
+ * runs Adam for its rows straight from LDS (snerf_tgrid_bwd_tiles_adam: the dense gradient buffer is not touched).  Levels [0, first_tiled_level) --
+ * few rows, thousands of samples per row -- are NOT binned: the caller runs snerf_tgrid_encode_bwd restricted to them (snerf_tgrid_encode_bwd_levels)
+ * into grad_embeddings, which the fused form reads and clears for those levels' rows. */
+typedef struct {
+  int32_t tile_rows_log2;     /* rows per tile = 1 << tile_rows_log2 */
+  int32_t n_tiles;            /* over all levels = tile_start[L] */
+  int32_t n_chunks;           /* sample chunks of the binning passes = ceil(B / chunk) */
+  int32_t chunk;              /* samples per chunk */
+  int32_t first_tiled_level;  /* levels below it go through the atomic kernel */
+  int32_t lds_bytes;          /* dynamic LDS of a tile workgroup */
+  int32_t tile_start[33];     /* first tile of each level */
+  int32_t _pad;
+  int64_t count_ints;         /* int32 elements of `counts` */
+  int64_t record_capacity;    /* uint32 elements of `records` = B * (L - first_tiled_level) * 8 */
+} snerf_tgrid_tile_plan;
+/* Host arithmetic only.  tile_rows_log2 <= 0: the largest tile that lets two workgroups share a CU's LDS; first_tiled_level < 0: levels with fewer than
+ * 2^16 rows stay atomic. */
+int snerf_tgrid_tile_plan_make(const snerf_tgrid_desc* desc, int64_t B, int32_t tile_rows_log2, int32_t first_tiled_level, snerf_tgrid_tile_plan* plan);
+/* counts [count_ints] and tile_base [n_tiles + 1] are workspaces (no initialisation needed); records [record_capacity].  B < 2^28. */
+int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
+                        int32_t samples_per_row, int64_t B, const float* grad_out, int32_t* counts, int32_t* tile_base, uint32_t* records,
+                        snerf_stream_t stream);
+/* grad_embeddings [rows, grid_C] += the gradient of the tiled levels (16-byte aligned). */
+int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
+                          int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
+                          float* grad_embeddings, snerf_stream_t stream);
+/* Adam (torch.optim.Adam: bias-corrected, eps outside the square root; step is 1-based) over the WHOLE table with gradient = tiled scatter + what
+ * grad_embeddings holds for the rows of levels [0, first_tiled_level) (read and cleared; may be NULL when first_tiled_level = 0) + the temporal-TV
+ * term srow[row] on column col_a and -srow[row] on col_b (col_a < 0: none; srow from snerf_tgrid_tv_sign).  A non-finite gradient element is dropped. */
+int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
+                               int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
+                               float* grad_embeddings, float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, int32_t step,
+                               int32_t col_a, int32_t col_b, const float* srow, snerf_stream_t stream);
+/* snerf_tgrid_encode_bwd for levels [level_begin, level_end) only (the coarse levels beside the tiled form). */
+int snerf_tgrid_encode_bwd_levels(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index, const float* times,
+                                  int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings, int32_t level_begin,
+                                  int32_t level_end, snerf_stream_t stream);
 
 /* TemporalGridEncoder.get_temporal_tv_loss (NS/field_components/temporal_grid.py:352-376): mean over table rows of
  * |E[r, col_a] - E[r, col_b]|.  fwd ADDS per-workgroup partial sums of |.| into partial[n_slots][16] (col 0; caller zeroes, then

@@ -9,7 +9,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libsnerf.so")
 
 MAX_SCALES = 8
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class KPlanesDesc(C.Structure):
@@ -89,6 +89,12 @@ class TgridDesc(C.Structure):
                 ("align_corners", C.c_int32), ("S", C.c_float), ("offsets", C.c_int32 * 33)]
 
 
+class TgridTilePlan(C.Structure):
+    """snerf_tgrid_tile_plan (ABI 14): the tiling of a temporal-grid table for the owner-computes backward (csrc/tgrid_tiles.hip)."""
+    _fields_ = [("tile_rows_log2", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("chunk", C.c_int32), ("first_tiled_level", C.c_int32),
+                ("lds_bytes", C.c_int32), ("tile_start", C.c_int32 * 33), ("_pad", C.c_int32), ("count_ints", C.c_int64), ("record_capacity", C.c_int64)]
+
+
 class HashgridDesc(C.Structure):
     _fields_ = [("D", C.c_int32), ("F", C.c_int32), ("L", C.c_int32), ("scale", C.c_float * 32), ("resolution", C.c_int32 * 32),
                 ("offsets", C.c_int32 * 33)]
@@ -140,6 +146,11 @@ def lib():
     l.snerf_tgrid_tv_bwd.argtypes = [P, L, I, I, I, P, P, P]
     l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_tgrid_tv_sign.argtypes = [P, L, I, I, I, F, P, I, P, P]
+    l.snerf_tgrid_tile_plan_make.argtypes = [P, L, I, I, P]
+    l.snerf_tgrid_bwd_bin.argtypes = [P, P, P, P, I, L, P, P, P, P, P]
+    l.snerf_tgrid_bwd_tiles.argtypes = [P, P, P, P, I, L, P, P, P, P, P]
+    l.snerf_tgrid_bwd_tiles_adam.argtypes = [P, P, P, P, I, L, P, P, P, P, P, P, P, F, F, F, F, I, I, I, P, P]
+    l.snerf_tgrid_encode_bwd_levels.argtypes = [P, P, P, P, I, L, P, P, I, I, P]
     l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P, P]
     l.snerf_isg_maps.argtypes = [P, I, I, I, I, I, P, P, P, I, F, P, P, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
@@ -206,6 +217,11 @@ EXPORTS = [
     "snerf_tgrid_encode_bwd_fx",
     "snerf_tgrid_encode_fwd_dydx",
     "snerf_tgrid_input_bwd",
+    "snerf_tgrid_tile_plan_make",
+    "snerf_tgrid_bwd_bin",
+    "snerf_tgrid_bwd_tiles",
+    "snerf_tgrid_bwd_tiles_adam",
+    "snerf_tgrid_encode_bwd_levels",
     "snerf_ist_maps",
     "snerf_ist_sample",
     "snerf_kplanes_sort_workspace",

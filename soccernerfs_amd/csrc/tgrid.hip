@@ -14,7 +14,7 @@
 //  * sample coordinates can be derived in-kernel from rays (snerf_coords mode 1), as for the K-Planes gather.
 #include <stdlib.h>
 
-#include "common.hpp"
+#include "tgrid_common.hpp"  // tg_slot_from_time (shared with tgrid_tiles.hip)
 
 // No fused multiply-adds formed by contraction in this file: the run-length kernels below promise the per-sample kernels' results BIT FOR BIT, and
 // which a * b + c the compiler fuses depends on the code around it (the first run-length forward differed from tgrid_kernel<false> by 1 ulp in ray
@@ -36,27 +36,12 @@ struct TgridArgs {
   float* dy_dx;        // fwd, optional: [B, L, D, C] d out / d x (temporal_gridencoder.cu:204-273, calc_grad_inputs)
   const float* gout;   // bwd
   float* gemb;         // bwd
+  int level0, level1;  // levels [level0, level1) of this launch (level1 = 0: all; snerf_tgrid_encode_bwd_levels, dev switch SNERF_TGRID_LEVELS)
   long long* gemb_fx;  // bwd, deterministic mode: 2^50-scaled fixed-point cells instead of gemb (common.hpp: integer addition is associative)
 };
 
 __device__ __forceinline__ void tg_grad_add(const TgridArgs& a, size_t e, float v) {
   if (a.gemb_fx) fx_atomic_add(a.gemb_fx + e, v); else atomicAdd(a.gemb + e, v);
-}
-
-// (column, weight) of slot (ch, ab) at a time row; closed form of the reference's sampling_index table + get_temporal_index
-__device__ __forceinline__ void tg_slot_from_time(float t, int C, int n_rows, int ch, int ab, int& col, float& w) {
-  const float v = t * (float)(n_rows - 1);
-  int r = (int)v;  // floor for t >= 0
-  if (t == 1.f) r = n_rows - 1;
-  auto occ = [&](int q) { return r > q ? C + q + C * ((r - 1 - q) / C) : q; };
-  const int p = r % C;
-  if (ch == p) {
-    if (ab == 0) { col = occ(p); w = (float)(r + 1) - v; }
-    else { col = C + r; w = v - (float)r; }
-  } else {
-    col = occ(ch);
-    w = ab == 0 ? 1.f : 0.f;
-  }
 }
 
 template <bool BWD, bool DYDX = false>
@@ -67,7 +52,7 @@ __global__ __launch_bounds__(256) void tgrid_kernel(TgridArgs a) {
   const int64_t b = gid / LPG;
   const int k = (int)(gid - b * LPG);
   const int ch = k >> 1, ab = k & 1;
-  const int level = blockIdx.y;
+  const int level = blockIdx.y + a.level0;
   const bool live = b < a.B;
   const int64_t bb = live ? b : a.B - 1;
 
@@ -203,7 +188,7 @@ __global__ __launch_bounds__(256) void tgrid_bwd_runs_kernel(TgridArgs a, int se
   const int64_t grp = gid / LPG;
   const int k = (int)(gid - grp * LPG);
   const int ch = k >> 1, ab = k & 1;
-  const int level = blockIdx.y;
+  const int level = blockIdx.y + a.level0;
   int64_t b0, b1, r = 0;
   if (RAYS) {
     const int S = a.c.S;
@@ -331,7 +316,7 @@ __global__ __launch_bounds__(256) void tgrid_fwd_runs_kernel(TgridArgs a, int se
   const int64_t grp = gid / LPG;
   const int k = (int)(gid - grp * LPG);
   const int ch = k >> 1, ab = k & 1;
-  const int level = blockIdx.y;
+  const int level = blockIdx.y + a.level0;
   // a group past the end keeps running with an empty segment: the pair sum below is a cross-lane operation of a full wave
   int64_t b0 = 0, b1 = 0, r = 0;
   if (RAYS) {
@@ -477,21 +462,34 @@ __global__ __launch_bounds__(256) void tgrid_input_bwd_kernel(const float* __res
   grad_inputs[t] = r;
 }
 
+// SNERF_TGRID_LEVELS=lo:hi -- dev switch (tools/tgrid_levels.py): only levels [lo, hi) are launched; read per call
+static void tgrid_level_range(int L, int& lo, int& hi) {
+  lo = 0; hi = L;
+  const char* e = getenv("SNERF_TGRID_LEVELS");
+  if (e) { int x = 0, y = L; if (sscanf(e, "%d:%d", &x, &y) == 2 && x >= 0 && y <= L && x < y) { lo = x; hi = y; } }
+}
+
 template <bool BWD>
-static int launch(const TgridArgs& a, hipStream_t st) {
+static int launch(const TgridArgs& a_in, hipStream_t st) {
+  TgridArgs a = a_in;
+  int lv_lo, lv_hi;
+  tgrid_level_range(a.d.L, lv_lo, lv_hi);
+  if (a.level1 > 0) { lv_lo = a.level0; lv_hi = a.level1; }
+  a.level0 = lv_lo;
+  const unsigned n_lv = (unsigned)(lv_hi - lv_lo);
   if (BWD && a.d.D == 3 && a.times && !a.trow && !tgrid_runs_off()) {
     // times instead of explicit temporal rows (every caller but the reference-shaped API test): the run-length form
     if (a.c.mode == 1 && a.spr == a.c.S && a.B % a.c.S == 0) {  // rays: segments inside a ray
       const int S = a.c.S;
       const int segs = (S + TG_RUN - 1) / TG_RUN, run = (S + segs - 1) / segs;  // (segments of 8 ... 256 samples: 4.03 - 4.07 ms per step of config 4, no trend)
       const int64_t threads = (a.B / S) * segs * 2 * a.d.C;
-      hipLaunchKernelGGL(tgrid_bwd_runs_kernel<true>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, segs, run);
+      hipLaunchKernelGGL(tgrid_bwd_runs_kernel<true>, dim3((unsigned)ceil_div(threads, 256), n_lv), dim3(256), 0, st, a, segs, run);
       SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs)");
       return 0;
     }
     if (a.c.mode == 0) {  // explicit points in sample order
       const int64_t threads = ((a.B + TG_RUN - 1) / TG_RUN) * 2 * a.d.C;
-      hipLaunchKernelGGL(tgrid_bwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, 1, TG_RUN);
+      hipLaunchKernelGGL(tgrid_bwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), n_lv), dim3(256), 0, st, a, 1, TG_RUN);
       SNERF_LAUNCH_CHECK("tgrid_encode_bwd (runs, points)");
       return 0;
     }
@@ -503,19 +501,19 @@ static int launch(const TgridArgs& a, hipStream_t st) {
       const int S = a.c.S;
       const int segs = (S + TG_RUN - 1) / TG_RUN, run = (S + segs - 1) / segs;
       const int64_t threads = (a.B / S) * segs * 2 * a.d.C;
-      hipLaunchKernelGGL(tgrid_fwd_runs_kernel<true>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, segs, run);
+      hipLaunchKernelGGL(tgrid_fwd_runs_kernel<true>, dim3((unsigned)ceil_div(threads, 256), n_lv), dim3(256), 0, st, a, segs, run);
       SNERF_LAUNCH_CHECK("tgrid_encode_fwd (runs)");
       return 0;
     }
     if (a.c.mode == 0) {
       const int64_t threads = ((a.B + TG_RUN - 1) / TG_RUN) * 2 * a.d.C;
-      hipLaunchKernelGGL(tgrid_fwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), (unsigned)a.d.L), dim3(256), 0, st, a, 1, TG_RUN);
+      hipLaunchKernelGGL(tgrid_fwd_runs_kernel<false>, dim3((unsigned)ceil_div(threads, 256), n_lv), dim3(256), 0, st, a, 1, TG_RUN);
       SNERF_LAUNCH_CHECK("tgrid_encode_fwd (runs, points)");
       return 0;
     }
   }
   const int64_t threads = a.B * 2 * a.d.C;
-  dim3 grid((unsigned)ceil_div(threads, 256), (unsigned)a.d.L);
+  dim3 grid((unsigned)ceil_div(threads, 256), n_lv);
   if (!BWD && a.dy_dx) hipLaunchKernelGGL((tgrid_kernel<false, true>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(tgrid_kernel<BWD>, grid, dim3(256), 0, st, a);
   SNERF_LAUNCH_CHECK(BWD ? "tgrid_encode_bwd" : "tgrid_encode_fwd");
@@ -663,6 +661,20 @@ extern "C" int snerf_tgrid_encode_bwd(const snerf_tgrid_desc* desc, const snerf_
   SNERF_REQUIRE(grad_out && grad_embeddings, "tgrid_encode_bwd: null buffer");
   TgridArgs a = {};
   a.d = *desc; a.c = *coords; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out; a.gemb = grad_embeddings;
+  return launch<true>(a, (hipStream_t)stream);
+}
+
+extern "C" int snerf_tgrid_encode_bwd_levels(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index, const float* times,
+                                             int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings, int32_t level_begin,
+                                             int32_t level_end, snerf_stream_t stream) {
+  int rc = validate(desc, coords, temporal_row_index, times, samples_per_row, B);
+  if (rc) return rc;
+  SNERF_REQUIRE(level_begin >= 0 && level_begin <= level_end && level_end <= desc->L, "tgrid_encode_bwd_levels: levels [%d, %d) of %d", level_begin, level_end, desc->L);
+  if (B == 0 || level_begin == level_end) return 0;
+  SNERF_REQUIRE(grad_out && grad_embeddings, "tgrid_encode_bwd_levels: null buffer");
+  TgridArgs a = {};
+  a.d = *desc; a.c = *coords; a.trow = temporal_row_index; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out; a.gemb = grad_embeddings;
+  a.level0 = level_begin; a.level1 = level_end;
   return launch<true>(a, (hipStream_t)stream);
 }
 

@@ -1,0 +1,434 @@
+// Temporal hash grid, backward w.r.t. the table in OWNER-COMPUTES form (round 6), optionally with the optimiser step of the table fused in.
+//
+// What it replaces: NS/field_components/cuda/csrc/temporal_gridencoder.cu:283-370 (kernel_grid_backward: one atomicAdd per sample, level, corner and
+// live column) followed by torch.optim.Adam over the dense table (NS/configs/method_configs.py:648-657) and, in between, the temporal-TV gradient of two
+// columns (NS/field_components/temporal_grid.py:352-376).
+//
+// Why: on camera rays tgrid_bwd_runs_kernel (tgrid.hip) already runs AT the chip-wide rate of memory-side float atomics -- 22 M 64-B atomic requests of
+// 12 useful bytes each in 1.26 ms for config 4's main grid (profiles/r06_tgrid_levels.json) -- and above the coarsest levels no two samples share a cell
+// (196 608 samples -> 196 5xx distinct cells per level from level 11 on), so combining across rays cannot remove requests.  What can go is the atomic
+// itself: every table row gets ONE owner.
+//
+//   1. bin (count, two scans, fill): every (sample, level, corner pair) is filed under the TILE of 2^k consecutive table rows its corner rows fall into
+//      -- a counting sort with one LDS histogram per (sample chunk, level) workgroup and NO global atomics (per-chunk counts go into a [chunks, tiles]
+//      matrix whose column prefix sums are the write offsets).  A record is 4 bytes: sample index, which (y, z) corner pair, which of its two x corners.
+//   2. tiles: one workgroup per tile holds the tile's gradient rows in LDS (256 rows x 66 columns x 4 B = 67.6 KB: two workgroups per CU), walks the
+//      tile's records (re-deriving cell, weights and the <= C + 1 live columns from the ray and its time, exactly as the scatter kernels do), adds with
+//      LDS atomics, and then either
+//        MODE 0: adds the tile into the dense gradient buffer with plain loads / stores (it is the only writer of those rows), or
+//        MODE 1: runs Adam for its rows straight from LDS -- p, m, v are read and written once, the dense gradient buffer is not touched at all
+//                (32 -> 24 B per parameter for the sweep, and the scatter's read-modify-write traffic is gone).
+//
+// The coarsest levels (few rows, thousands of samples per row: one tile would receive 10^4..10^5 records) stay with the run-length atomic kernel, where
+// consecutive samples of a ray share cells and requests are few; in MODE 1 their tiles read (and clear) what that kernel left in the gradient buffer.
+#include <stdlib.h>
+
+#include "plane_adam_common.hpp"  // adam_float4, ldnt4 / stnt4: compiled with the optimiser sweep's own contraction setting
+#include "tgrid_common.hpp"       // no contraction from here on: cells and weights exactly as tgrid.hip derives them
+
+namespace snerf {
+
+constexpr int TT_NT = 512;                  // threads of a tile workgroup
+constexpr int TT_BIN_NT = 256;              // threads of a binning workgroup
+constexpr int TT_MAX_LEVEL_TILES = 8192;    // LDS histogram of the binning kernels: 2 ints per tile of one level
+
+struct TileArgs {
+  snerf_tgrid_desc d;
+  snerf_coords c;
+  snerf_tgrid_tile_plan pl;
+  const float* times;
+  int spr;
+  int64_t B;
+  const float* gout;
+  int32_t* counts;     // [n_chunks][n_tiles]: per-chunk record counts, then (scan) the chunk's write offset inside the tile
+  int32_t* tile_base;  // [n_tiles + 1]
+  uint32_t* records;
+  float* gemb;         // MODE 0: accumulated into; MODE 1: optional contribution of the coarse levels (read and cleared)
+  float* p; float* m; float* v;
+  float step_size, b1, b2, inv_sqrt_bc2, eps;
+  int col_a, col_b;    // temporal-TV columns (MODE 1; col_a < 0: none)
+  const float* srow;   // [rows]: signed TV step per table row
+  int tile0;           // first tile of the launch
+};
+
+// the records of sample b at one level: (tile in level, record) per (y, z) corner pair -- its two x corners share a tile unless a tile boundary lies between
+// their rows (hashed levels: rows r and r ^ 1 mostly), then one record each
+template <int C, typename F>
+__device__ __forceinline__ void tt_for_records(const TileArgs& a, const TgLevel& lv, int level, int64_t b, F&& emit) {
+  float x[3];
+  if (tg_sample_x(a.c, b, x)) return;
+  const float* g = a.gout + b * (a.d.L * C) + level * C;
+  bool any = false;
+#pragma unroll
+  for (int ch = 0; ch < C; ++ch) any |= g[ch] != 0.f;
+  if (!any) return;  // nothing to add for this (sample, level)
+  uint32_t pg[3];
+  float fr[3];
+  tg_cell(lv, a.d.align_corners != 0, x, pg, fr);
+#pragma unroll
+  for (int yz = 0; yz < 4; ++yz) {
+    const uint32_t cy = pg[1] + (uint32_t)(yz & 1), cz = pg[2] + (uint32_t)(yz >> 1);
+    const uint32_t t0 = lv.row_of(pg[0], cy, cz) >> a.pl.tile_rows_log2, t1 = lv.row_of(pg[0] + 1u, cy, cz) >> a.pl.tile_rows_log2;
+    const uint32_t base = ((uint32_t)b << 4) | ((uint32_t)yz << 2);
+    if (t0 == t1) emit(t0, base | 3u);
+    else { emit(t0, base | 1u); emit(t1, base | 2u); }
+  }
+}
+
+// count (FILL = false) / fill (FILL = true): grid (chunks, tiled levels)
+template <int C, bool FILL>
+__global__ __launch_bounds__(TT_BIN_NT) void tt_bin_kernel(TileArgs a) {
+  extern __shared__ int tt_hist[];
+  const int level = (int)blockIdx.y + a.pl.first_tiled_level, chunk = (int)blockIdx.x;
+  const int T0 = a.pl.tile_start[level], nt = a.pl.tile_start[level + 1] - T0;
+  int* hist = tt_hist;
+  int* base = tt_hist + nt;
+  int32_t* mine = a.counts + (int64_t)chunk * a.pl.n_tiles + T0;
+  for (int i = threadIdx.x; i < nt; i += TT_BIN_NT) {
+    hist[i] = 0;
+    if (FILL) base[i] = a.tile_base[T0 + i] + mine[i];
+  }
+  __syncthreads();
+  const TgLevel lv = tg_level(a.d, level);
+  const int64_t b0 = (int64_t)chunk * a.pl.chunk;
+  const int64_t b1 = b0 + a.pl.chunk < a.B ? b0 + a.pl.chunk : a.B;
+  for (int64_t b = b0 + threadIdx.x; b < b1; b += TT_BIN_NT)
+    tt_for_records<C>(a, lv, level, b, [&](uint32_t t, uint32_t rec) {
+      const int rank = atomicAdd(&hist[t], 1);
+      if (FILL) a.records[base[t] + rank] = rec;
+    });
+  if (!FILL) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += TT_BIN_NT) mine[i] = hist[i];
+  }
+}
+
+// per tile: counts[chunk][tile] -> the chunk's offset inside the tile (exclusive prefix over the chunks); totals[tile] = the tile's records
+__global__ __launch_bounds__(256) void tt_scan_chunks_kernel(int32_t* __restrict__ counts, int n_chunks, int n_tiles, int t_first, int32_t* __restrict__ totals) {
+  const int t = t_first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t >= n_tiles) return;
+  int run = 0;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int v = counts[(int64_t)c * n_tiles + t];
+    counts[(int64_t)c * n_tiles + t] = run;
+    run += v;
+  }
+  totals[t] = run;
+}
+
+// exclusive prefix over the tiles (one workgroup): tile_base[t] = records in front of tile t; tile_base[n_tiles] = all of them.  In place.
+__global__ __launch_bounds__(1024) void tt_scan_tiles_kernel(int32_t* __restrict__ tile_base, int n_tiles, int t_first) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int t = tid; t < t_first; t += 1024) tile_base[t] = 0;  // tiles of the coarse (atomic) levels hold no records
+  const int n = n_tiles - t_first;
+  const int per = (n + 1023) / 1024;
+  const int i0 = t_first + tid * per;
+  int local = 0;
+  for (int k = 0; k < per; ++k)
+    if (i0 + k < n_tiles) local += tile_base[i0 + k];
+  int incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) wsum[w] = incl;
+  __syncthreads();
+  int before = 0;
+  for (int k = 0; k < w; ++k) before += wsum[k];
+  int run = before + incl - local;
+  for (int k = 0; k < per; ++k)
+    if (i0 + k < n_tiles) {
+      const int v = tile_base[i0 + k];
+      tile_base[i0 + k] = run;
+      run += v;
+    }
+  if (tid == 1023) {
+    int total = 0;
+    for (int k = 0; k < 16; ++k) total += wsum[k];
+    tile_base[n_tiles] = total;
+  }
+}
+
+// MODE 0: dense gradient += tile; MODE 1: Adam (+ temporal TV) for the tile's rows
+template <int C, int MODE>
+__global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
+  extern __shared__ float tt_acc[];
+  const int tile = (int)blockIdx.x + a.tile0;
+  int level = 0;
+  while (level + 1 < a.d.L && tile >= a.pl.tile_start[level + 1]) ++level;
+  const TgLevel lv = tg_level(a.d, level);
+  const int sh = a.pl.tile_rows_log2;
+  const uint32_t row0 = (uint32_t)(tile - a.pl.tile_start[level]) << sh;
+  const uint32_t nrows = (lv.rows - row0) < (1u << sh) ? (lv.rows - row0) : (1u << sh);
+  const int gc = a.d.grid_C;
+  const int64_t gb = ((int64_t)lv.off0 + row0) * gc, ge = gb + (int64_t)nrows * gc;  // this tile's floats of the table
+  const int64_t q0 = gb >> 2;
+  const int nq = (int)(((ge + 3) >> 2) - q0);  // float4 groups that overlap the tile; the first / last may belong to a neighbour in part
+  const int ph = (int)(gb - (q0 << 2));
+  for (int q = threadIdx.x; q < nq; q += TT_NT) *reinterpret_cast<float4*>(tt_acc + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+  lds_barrier();
+
+  // ---- the tile's records ----
+  const int rec0 = a.tile_base[tile], rec1 = a.tile_base[tile + 1];
+  const int n_trows = gc - C - 1;
+  const int gstride = a.d.L * C;
+  for (int i = rec0 + (int)threadIdx.x; i < rec1; i += TT_NT) {
+    const uint32_t rec = a.records[i];
+    const int64_t b = (int64_t)(rec >> 4);
+    const int yz = (int)(rec >> 2) & 3, xm = (int)(rec & 3u);
+    float x[3];
+    tg_sample_x(a.c, b, x);
+    uint32_t pg[3];
+    float fr[3];
+    tg_cell(lv, a.d.align_corners != 0, x, pg, fr);
+    const float t = a.times[(uint32_t)b / (uint32_t)a.spr];
+    const float tv = t * (float)(n_trows - 1);
+    int r = (int)tv;
+    if (t == 1.f) r = n_trows - 1;
+    const int pch = r % C;
+    const float wa_p = (float)(r + 1) - tv, wb_p = tv - (float)r;  // tg_slot_from_time: the blending channel's two weights
+    const float* g = a.gout + b * gstride + level * C;
+    float gch[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) gch[ch] = g[ch];
+    const uint32_t cy = pg[1] + (uint32_t)(yz & 1), cz = pg[2] + (uint32_t)(yz >> 1);
+#pragma unroll
+    for (int xb = 0; xb < 2; ++xb) {
+      if (!((xm >> xb) & 1)) continue;
+      float w = 1.f;  // the corner's weight, factors in axis order as tgrid_kernel multiplies them
+      w *= xb ? fr[0] : 1.f - fr[0];
+      w *= (yz & 1) ? fr[1] : 1.f - fr[1];
+      w *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+      const uint32_t row = lv.row_of(pg[0] + (uint32_t)xb, cy, cz);
+      float* rowp = tt_acc + ph + (int)(row - row0) * gc;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        const int occ = r > ch ? C + ch + C * ((r - 1 - ch) / C) : ch;
+        const float wt = ch == pch ? wa_p : 1.f;
+        if (wt != 0.f) {
+          const float val = w * (gch[ch] * wt);
+          if (val != 0.f) atomicAdd(rowp + occ, val);
+        }
+        if (ch == pch && wb_p != 0.f) {
+          const float val = w * (gch[ch] * wb_p);
+          if (val != 0.f) atomicAdd(rowp + C + r, val);
+        }
+      }
+    }
+  }
+  lds_barrier();
+
+  if (MODE == 1 && a.col_a >= 0) {
+    // temporal TV (temporal_grid.py:352-376): srow[row] = weight / rows * sign(E[row, a] - E[row, b]) from the OLD table (tgrid_tv_sign_kernel)
+    for (uint32_t lr = threadIdx.x; lr < nrows; lr += TT_NT) {
+      const float s = a.srow[(int64_t)lv.off0 + row0 + lr];
+      if (s != 0.f) {
+        tt_acc[ph + (int)lr * gc + a.col_a] += s;
+        tt_acc[ph + (int)lr * gc + a.col_b] -= s;
+      }
+    }
+    lds_barrier();
+  }
+
+  // ---- epilogue over the float4 groups; a group that straddles the tile's first / last float is handled element by element ----
+  const bool coarse = level < a.pl.first_tiled_level;  // its gradient came through the atomic kernel into gemb
+  const DynConsts dc = {a.step_size, a.inv_sqrt_bc2, 0};
+  for (int q = threadIdx.x; q < nq; q += TT_NT) {
+    const int64_t f0 = (q0 + q) << 2;
+    float4 gq = *reinterpret_cast<const float4*>(tt_acc + 4 * q);
+    const bool full = f0 >= gb && f0 + 4 <= ge;
+    if (MODE == 0) {
+      if (gq.x == 0.f && gq.y == 0.f && gq.z == 0.f && gq.w == 0.f) continue;
+      if (full) {
+        float4 o = ld4(a.gemb + f0);
+        o.x += gq.x; o.y += gq.y; o.z += gq.z; o.w += gq.w;
+        *reinterpret_cast<float4*>(a.gemb + f0) = o;
+      } else {
+        const float* G = &gq.x;
+        for (int k = 0; k < 4; ++k)
+          if (f0 + k >= gb && f0 + k < ge && G[k] != 0.f) a.gemb[f0 + k] += G[k];
+      }
+    } else {
+      if (full) {
+        float4 pp = ldnt4(a.p + f0), mm = ldnt4(a.m + f0), vv = ldnt4(a.v + f0);
+        float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (coarse && a.gemb) {
+          extra = ldnt4(a.gemb + f0);
+          if (extra.x != 0.f || extra.y != 0.f || extra.z != 0.f || extra.w != 0.f) stnt4(a.gemb + f0, make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+        adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
+        stnt4(a.p + f0, pp);
+        stnt4(a.m + f0, mm);
+        stnt4(a.v + f0, vv);
+      } else {
+        float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp, extra = pp;
+        float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; float* E = &extra.x;
+        for (int k = 0; k < 4; ++k)
+          if (f0 + k >= gb && f0 + k < ge) {
+            P[k] = a.p[f0 + k]; M[k] = a.m[f0 + k]; V[k] = a.v[f0 + k];
+            if (coarse && a.gemb) { E[k] = a.gemb[f0 + k]; if (E[k] != 0.f) a.gemb[f0 + k] = 0.f; }
+          }
+        adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
+        for (int k = 0; k < 4; ++k)
+          if (f0 + k >= gb && f0 + k < ge) { a.p[f0 + k] = P[k]; a.m[f0 + k] = M[k]; a.v[f0 + k] = V[k]; }
+      }
+    }
+  }
+}
+
+static int tiles_lds_bytes(const snerf_tgrid_desc* d, int sh) { return (((1 << sh) * d->grid_C + 6) / 4 + 1) * 16; }
+
+static int validate_tiles(const snerf_tgrid_desc* d, const snerf_tgrid_tile_plan* pl, const snerf_coords* c, const float* times, int spr, int64_t B) {
+  SNERF_REQUIRE(d && pl && c, "tgrid tiles: null descriptor");
+  SNERF_REQUIRE(d->D == 3, "tgrid tiles: D=%d (3 only)", d->D);
+  SNERF_REQUIRE(d->C == 1 || d->C == 2 || d->C == 4 || d->C == 8, "tgrid tiles: level_dim C=%d unsupported (1,2,4,8)", d->C);
+  SNERF_REQUIRE(d->L >= 1 && d->L <= 32 && d->grid_C > d->C + 1 && (d->grid_C & 1) == 0, "tgrid tiles: L=%d grid_C=%d (even row length needed)", d->L, d->grid_C);
+  SNERF_REQUIRE(times && spr >= 1 && B >= 0 && B < (1LL << 28), "tgrid tiles: times / samples_per_row / B=%lld (< 2^28)", (long long)B);
+  SNERF_REQUIRE(c->mode == 0 || c->mode == 1, "tgrid tiles: coords.mode=%d", c->mode);
+  if (c->mode == 0) SNERF_REQUIRE(c->pts || B == 0, "tgrid tiles: pts is null");
+  if (c->mode == 1) SNERF_REQUIRE(c->S >= 1 && B % c->S == 0 && c->origins && c->dirs && c->ebins, "tgrid tiles: bad ray coords");
+  SNERF_REQUIRE(pl->tile_rows_log2 >= 2 && pl->tile_rows_log2 <= 16 && pl->n_tiles == pl->tile_start[d->L] && pl->chunk >= 1 &&
+                    pl->n_chunks == (int)((B + pl->chunk - 1) / pl->chunk) && pl->first_tiled_level >= 0 && pl->first_tiled_level <= d->L,
+                "tgrid tiles: the plan does not belong to this descriptor / batch (snerf_tgrid_tile_plan_make)");
+  return 0;
+}
+
+template <int C>
+static int bin_launch(const TileArgs& a, hipStream_t st) {
+  const int L = a.d.L, Lc = a.pl.first_tiled_level;
+  if (Lc >= L || a.B == 0) {
+    hipLaunchKernelGGL(tt_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles, a.pl.n_tiles);
+    SNERF_LAUNCH_CHECK("tgrid_bwd_bin (empty)");
+    return 0;
+  }
+  int max_nt = 0;
+  for (int l = Lc; l < L; ++l) max_nt = a.pl.tile_start[l + 1] - a.pl.tile_start[l] > max_nt ? a.pl.tile_start[l + 1] - a.pl.tile_start[l] : max_nt;
+  const size_t lds = (size_t)max_nt * 2 * sizeof(int);
+  const dim3 grid((unsigned)a.pl.n_chunks, (unsigned)(L - Lc));
+  const int t_first = a.pl.tile_start[Lc];
+  hipLaunchKernelGGL((tt_bin_kernel<C, false>), grid, dim3(TT_BIN_NT), lds, st, a);
+  hipLaunchKernelGGL(tt_scan_chunks_kernel, dim3((unsigned)ceil_div(a.pl.n_tiles - t_first, 256)), dim3(256), 0, st, a.counts, a.pl.n_chunks, a.pl.n_tiles, t_first,
+                     a.tile_base);
+  hipLaunchKernelGGL(tt_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles, t_first);
+  hipLaunchKernelGGL((tt_bin_kernel<C, true>), grid, dim3(TT_BIN_NT), lds, st, a);
+  SNERF_LAUNCH_CHECK("tgrid_bwd_bin");
+  return 0;
+}
+
+template <int C, int MODE>
+static int tiles_launch(TileArgs& a, hipStream_t st) {
+  const int lds = tiles_lds_bytes(&a.d, a.pl.tile_rows_log2);
+  SNERF_ALLOW_LDS((tt_tiles_kernel<C, MODE>), lds);
+  a.tile0 = MODE == 0 ? a.pl.tile_start[a.pl.first_tiled_level] : 0;  // MODE 0: tiles of the coarse levels hold no records
+  const int n = a.pl.n_tiles - a.tile0;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL((tt_tiles_kernel<C, MODE>), dim3((unsigned)n), dim3(TT_NT), (size_t)lds, st, a);
+  SNERF_LAUNCH_CHECK(MODE == 0 ? "tgrid_bwd_tiles" : "tgrid_bwd_tiles_adam");
+  return 0;
+}
+
+#define TT_DISPATCH_C(C_, CALL)          \
+  switch (C_) {                          \
+    case 1: return CALL(1);              \
+    case 2: return CALL(2);              \
+    case 4: return CALL(4);              \
+    default: return CALL(8);             \
+  }
+
+}  // namespace snerf
+
+using namespace snerf;
+
+extern "C" int snerf_tgrid_tile_plan_make(const snerf_tgrid_desc* desc, int64_t B, int32_t tile_rows_log2, int32_t first_tiled_level,
+                                          snerf_tgrid_tile_plan* plan) {
+  SNERF_REQUIRE(desc && plan, "tgrid_tile_plan_make: null argument");
+  SNERF_REQUIRE(desc->L >= 1 && desc->L <= 32 && desc->grid_C >= 2 && B >= 0, "tgrid_tile_plan_make: L=%d grid_C=%d B=%lld", desc->L, desc->grid_C, (long long)B);
+  int64_t max_rows = 0;
+  for (int l = 0; l < desc->L; ++l) max_rows = desc->offsets[l + 1] - desc->offsets[l] > max_rows ? desc->offsets[l + 1] - desc->offsets[l] : max_rows;
+  int sh = tile_rows_log2;
+  if (sh <= 0) {
+    // the largest tile whose LDS image lets two workgroups share a CU's 160 KB, but no more tiles per level than the binning histogram holds
+    sh = 2;
+    while (sh < 16 && tiles_lds_bytes(desc, sh + 1) <= 72 * 1024) ++sh;
+  }
+  while (sh < 16 && ((max_rows + (1LL << sh) - 1) >> sh) > TT_MAX_LEVEL_TILES) ++sh;
+  SNERF_REQUIRE(sh >= 2 && sh <= 16 && tiles_lds_bytes(desc, sh) <= 156 * 1024, "tgrid_tile_plan_make: a tile of 2^%d rows x %d columns does not fit LDS", sh, desc->grid_C);
+  plan->tile_rows_log2 = sh;
+  int t = 0;
+  for (int l = 0; l < desc->L; ++l) {
+    plan->tile_start[l] = t;
+    t += (int)((desc->offsets[l + 1] - desc->offsets[l] + (1LL << sh) - 1) >> sh);
+  }
+  for (int l = desc->L; l < 33; ++l) plan->tile_start[l] = t;
+  plan->n_tiles = t;
+  plan->chunk = 4096;
+  plan->n_chunks = (int)((B + plan->chunk - 1) / plan->chunk);
+  int lc = first_tiled_level;
+  if (lc < 0) {
+    // levels with fewer than 2^16 rows (the coarsest dense ones: 10^4..10^5 records per tile) stay with the run-length atomic kernel
+    lc = 0;
+    while (lc < desc->L && desc->offsets[lc + 1] - desc->offsets[lc] < (1 << 16)) ++lc;
+  }
+  plan->first_tiled_level = lc > desc->L ? desc->L : lc;
+  plan->lds_bytes = tiles_lds_bytes(desc, sh);
+  plan->count_ints = (int64_t)(plan->n_chunks > 0 ? plan->n_chunks : 1) * plan->n_tiles;
+  plan->record_capacity = B * (desc->L - plan->first_tiled_level) * 8;
+  return 0;
+}
+
+extern "C" int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
+                                   int32_t samples_per_row, int64_t B, const float* grad_out, int32_t* counts, int32_t* tile_base, uint32_t* records,
+                                   snerf_stream_t stream) {
+  int rc = validate_tiles(desc, plan, coords, times, samples_per_row, B);
+  if (rc) return rc;
+  SNERF_REQUIRE(counts && tile_base && (records || plan->record_capacity == 0) && (grad_out || B == 0), "tgrid_bwd_bin: null buffer");
+  TileArgs a = {};
+  a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
+  a.counts = counts; a.tile_base = tile_base; a.records = records;
+#define TT_CALL(C_) bin_launch<C_>(a, (hipStream_t)stream)
+  TT_DISPATCH_C(desc->C, TT_CALL)
+#undef TT_CALL
+}
+
+extern "C" int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
+                                     int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
+                                     float* grad_embeddings, snerf_stream_t stream) {
+  int rc = validate_tiles(desc, plan, coords, times, samples_per_row, B);
+  if (rc) return rc;
+  if (B == 0) return 0;
+  SNERF_REQUIRE(tile_base && records && grad_out && grad_embeddings, "tgrid_bwd_tiles: null buffer");
+  SNERF_REQUIRE(((uintptr_t)grad_embeddings & 15) == 0, "tgrid_bwd_tiles: grad_embeddings must be 16-byte aligned");
+  TileArgs a = {};
+  a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
+  a.tile_base = const_cast<int32_t*>(tile_base); a.records = const_cast<uint32_t*>(records); a.gemb = grad_embeddings;
+  a.col_a = -1;
+#define TT_CALL(C_) tiles_launch<C_, 0>(a, (hipStream_t)stream)
+  TT_DISPATCH_C(desc->C, TT_CALL)
+#undef TT_CALL
+}
+
+extern "C" int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
+                                          int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
+                                          float* grad_embeddings, float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, int32_t step,
+                                          int32_t col_a, int32_t col_b, const float* srow, snerf_stream_t stream) {
+  int rc = validate_tiles(desc, plan, coords, times, samples_per_row, B);
+  if (rc) return rc;
+  SNERF_REQUIRE(tile_base && (records || B == 0) && (grad_out || B == 0) && p && m && v, "tgrid_bwd_tiles_adam: null buffer");
+  SNERF_REQUIRE(step >= 1, "tgrid_bwd_tiles_adam: step=%d (1-based)", step);
+  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad_embeddings) & 15) == 0, "tgrid_bwd_tiles_adam: buffers must be 16-byte aligned");
+  SNERF_REQUIRE(plan->first_tiled_level == 0 || grad_embeddings, "tgrid_bwd_tiles_adam: levels [0, %d) go through the atomic kernel: pass their gradient buffer",
+                plan->first_tiled_level);
+  SNERF_REQUIRE(col_a < 0 || (srow && col_b >= 0 && col_a < desc->grid_C && col_b < desc->grid_C && col_a != col_b), "tgrid_bwd_tiles_adam: TV columns (%d,%d)", col_a,
+                col_b);
+  TileArgs a = {};
+  a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
+  a.tile_base = const_cast<int32_t*>(tile_base); a.records = const_cast<uint32_t*>(records); a.gemb = grad_embeddings;
+  a.p = p; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+  adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
+  a.col_a = col_a; a.col_b = col_b; a.srow = srow;
+#define TT_CALL(C_) tiles_launch<C_, 1>(a, (hipStream_t)stream)
+  TT_DISPATCH_C(desc->C, TT_CALL)
+#undef TT_CALL
+}

@@ -171,9 +171,10 @@ class NerfplayerFullTrainer:
 
     def wait_params(self):
         """The current stream waits for the asynchronous table sweeps (no host block)."""
+        # the event is KEPT until the next sweep replaces it: waiting for a completed event is free, and a later reader on ANOTHER stream (a checkpoint
+        # save, a side-stream evaluation) that calls wait_params() is then ordered behind the sweep too (ADVICE r05)
         if self._sweeps_done is not None:
             torch.cuda.current_stream().wait_event(self._sweeps_done)
-            self._sweeps_done = None
 
     def synchronize(self):
         self.wait_params()
@@ -408,6 +409,9 @@ class NerfplayerFullTrainer:
         S2, N = self.S[2], R * self.S[2]
         t = self.rays["times"].reshape(-1)
         target = ops._f32c(target, "target")
+        # a backward that raised after its asynchronous sweeps were issued never reached optimizer_step(): start from clean flags, or this step's TV pass
+        # and sweep of those tables would be skipped
+        self._swept, self._tv01_done = (), None
         early = bool(self.async_table_sweeps and self._in_train_step and cfg.temporal_tv_weight > 0)
         if cfg.temporal_tv_weight > 0:
             b["tv"].zero_()

@@ -160,9 +160,10 @@ class NerfplayerTrainer:
 
     def wait_params(self):
         """The current stream waits for the field table's asynchronous sweep (no host block)."""
+        # the event is KEPT until the next sweep replaces it: waiting for a completed event is free, and a later reader on ANOTHER stream (a checkpoint
+        # save, a side-stream evaluation) that calls wait_params() is then ordered behind the sweep too (ADVICE r05)
         if self._field_sweep_done is not None:
             torch.cuda.current_stream().wait_event(self._field_sweep_done)
-            self._field_sweep_done = None
 
     def synchronize(self):
         self.wait_params()
@@ -328,6 +329,9 @@ class NerfplayerTrainer:
         S2, N2 = self.S[2], R * self.S[2]
         t = self.rays["times"].reshape(-1)
         target = target if target.is_contiguous() else target.contiguous()
+        # a backward that raised after its asynchronous sweep was issued never reached optimizer_step(): start from clean flags, or this step's TV pass and
+        # sweep of the field table would be skipped
+        self._field_swept, self._tv0_done = False, None
         early = bool(self.async_field_sweep and self._in_train_step)
         if cfg.temporal_tv_weight > 0:
             b["tv"].zero_()

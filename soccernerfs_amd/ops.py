@@ -115,13 +115,13 @@ class SortedScatter:
             rows = N * len(ps.resolutions)
             self.G = torch.empty(N, ps.out_dim, dtype=torch.float32, device=device)       # gfeat .* feat
             # fix list: {element index, feature gradient} per vanished feature with a non-zero gradient (2 int32 per entry).  In training it
-            # stays empty (planes initialised in [0.1, 0.5] / [1, 1]: no feature is exactly 0), so the default holds one entry per (sample,
-            # scale) -- 10 MB at the preset instead of the worst case's 335 MB (N x C n_scales: EVERY feature vanished, e.g. imported all-zero
-            # planes; pass fix_capacity=N * ps.out_dim for that).  Entries beyond the capacity are NOT lost silently: the fix-up kernel records
-            # the demanded count in fix_peak and check_fix_overflow() / the trainer raise on it.
-            self.fix_capacity = max(int(fix_capacity) if fix_capacity is not None else N * len(ps.resolutions), 1)
-            if self.fix_capacity > N * ps.out_dim:
-                self.fix_capacity = max(N * ps.out_dim, 1)
+            # stays empty (planes initialised in [0.1, 0.5] / [1, 1]: no feature is exactly 0), but imported planes (a checkpoint, restart(params),
+            # all-zero planes) can make EVERY feature vanish, and an entry that does not fit is a lost gradient term.  (r06, ADVICE) The default
+            # therefore holds the worst case again -- N x C n_scales entries: 335 MB at the preset, 0.1 % of the HBM -- so that no input can
+            # overflow it; a smaller fix_capacity is an explicit choice of a memory-constrained caller, and then the fix-up kernel records the
+            # demanded count in fix_peak and check_fix_overflow() / the trainer (every optimizer_step) raise on it.
+            worst = max(N * ps.out_dim, 1)
+            self.fix_capacity = worst if fix_capacity is None else min(max(int(fix_capacity), 1), worst)
             self.fix_list = torch.empty(2 * self.fix_capacity, dtype=torch.int32, device=device)
             self.fix_peak = torch.zeros(1, dtype=torch.int32, device=device)  # sticky: the largest entry count that did not fit
             self.fix_counts = torch.zeros(2, dtype=torch.int32, device=device)  # used alternately: a prepare resets the other one for the next step
@@ -173,11 +173,18 @@ class SortedScatter:
         counter (synchronises) unless the caller hands over a value it copied itself."""
         if not self.quotient:
             return
+        if self.fix_capacity >= self.N * self.ps.out_dim:
+            return  # worst-case list (the default): cannot overflow
         peak = int(self.fix_peak.item()) if peak is None else int(peak)
         if peak > self.fix_capacity:
             raise RuntimeError(f"quotient scatter: {peak} vanished-feature entries in one step but the fix list holds {self.fix_capacity}: the gradient terms "
                                f"of the rest were dropped.  Construct SortedScatter / the trainer with fix_capacity >= {peak} (worst case N * C * n_scales = "
                                f"{self.N * self.ps.out_dim}), or use the product-form scatter (quotient_scatter=False) for planes with this many exact zeros")
+
+    def clear_fix_overflow(self):
+        """Forget a recorded overflow (the counter is sticky): restart() / a parameter import start a new run."""
+        if self.quotient:
+            self.fix_peak.zero_()
 
     def quotient_pass_b_scales(self, planes, gplanes, scale_begin: int, scale_end: int, stream=None):
         """Pass B for scales [scale_begin, scale_end): reads only the sorted records, G and the planes -- never the ray buffers."""

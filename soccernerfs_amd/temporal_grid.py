@@ -182,3 +182,53 @@ class TemporalGridEncoder(nn.Module):
             row_idx = int(torch.randint(0, len(self.index_list), [1]).item())
         a, b = self.index_list[row_idx].tolist()
         return (self.embeddings[:, a] - self.embeddings[:, b]).abs().mean()
+
+
+class TiledTableBackward:
+    """Owner-computes backward of one TemporalGridEncoder table for a fixed batch size (csrc/tgrid_tiles.hip, ABI 14): `bin` files the batch's (sample,
+    level, corner) touches under tiles of consecutive table rows, then either `scatter` adds the tiles into a dense gradient buffer (= what
+    snerf_tgrid_encode_bwd leaves there, up to the association order of the float sums) or `scatter_adam` runs torch.optim.Adam for the whole table
+    straight from the tiles' LDS images (+ the temporal-TV step), without a dense gradient.  Levels below plan.first_tiled_level go through the run-length
+    atomic kernel into the gradient buffer (in both forms).  Replaces NS/field_components/cuda/csrc/temporal_gridencoder.cu:283-370 + the optimiser step."""
+
+    def __init__(self, enc: "TemporalGridEncoder", B: int, tile_rows_log2: int = 0, first_tiled_level: int = -1):
+        self.enc, self.B = enc, int(B)
+        self.plan = _lib.TgridTilePlan()
+        _lib.check(_lib.lib().snerf_tgrid_tile_plan_make(C.byref(enc.desc), C.c_int64(B), tile_rows_log2, first_tiled_level, C.byref(self.plan)), "tile_plan_make")
+        dev = enc.embeddings.device
+        self.counts = torch.empty(max(int(self.plan.count_ints), 1), dtype=torch.int32, device=dev)
+        self.tile_base = torch.empty(self.plan.n_tiles + 1, dtype=torch.int32, device=dev)
+        self.records = torch.empty(max(int(self.plan.record_capacity), 1), dtype=torch.int32, device=dev)
+
+    def _coarse(self, coords, times, spr, gout, gtable, st):
+        lc = self.plan.first_tiled_level
+        if lc > 0:
+            _lib.check(_lib.lib().snerf_tgrid_encode_bwd_levels(C.byref(self.enc.desc), C.byref(coords), None, ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
+                                                                ops._ptr(gtable), 0, lc, st), "tgrid_encode_bwd_levels")
+
+    def bin(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, stream=None):
+        st = stream if stream is not None else ops._stream()
+        _lib.check(_lib.lib().snerf_tgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
+                                                  ops._ptr(self.counts), ops._ptr(self.tile_base), ops._ptr(self.records), st), "tgrid_bwd_bin")
+
+    def scatter(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
+        """gtable += d loss / d table (after `bin` of the same batch)."""
+        st = stream if stream is not None else ops._stream()
+        self._coarse(coords, times, spr, gout, gtable, st)
+        _lib.check(_lib.lib().snerf_tgrid_bwd_tiles(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
+                                                    ops._ptr(self.tile_base), ops._ptr(self.records), ops._ptr(gtable), st), "tgrid_bwd_tiles")
+
+    def coarse_levels(self, coords, times, spr, gout, gtable, stream=None):
+        """The atomic part of the fused form (levels [0, first_tiled_level) into gtable); reads the ray buffers, so it belongs on their stream."""
+        self._coarse(coords, times, spr, gout, gtable, stream if stream is not None else ops._stream())
+
+    def scatter_adam(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, gtable: Optional[torch.Tensor], p: torch.Tensor, m: torch.Tensor,
+                     v: torch.Tensor, lr: float, step: int, eps: float, tv_cols=None, srow: Optional[torch.Tensor] = None, betas=(0.9, 0.999), stream=None):
+        """Adam step `step` (1-based) of the whole table with gradient = tiles + gtable's coarse-level rows (cleared) + the TV term; after `bin` and
+        `coarse_levels` of the same batch."""
+        st = stream if stream is not None else ops._stream()
+        ca, cb = tv_cols if tv_cols is not None else (-1, -1)
+        _lib.check(_lib.lib().snerf_tgrid_bwd_tiles_adam(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B),
+                                                         ops._ptr(gout), ops._ptr(self.tile_base), ops._ptr(self.records),
+                                                         ops._ptr(gtable) if gtable is not None else None, ops._ptr(p), ops._ptr(m), ops._ptr(v), lr, betas[0], betas[1],
+                                                         eps, step, ca, cb, ops._ptr(srow) if srow is not None else None, st), "tgrid_bwd_tiles_adam")

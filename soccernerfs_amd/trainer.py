@@ -978,6 +978,9 @@ class KPlanesTrainer:
             d.zero_()
         self.step = self._dyn_step = 0
         self._steps_since_update = 0
+        if getattr(self, "_fix_peak_host", None) is not None:  # a new run: the sticky overflow record of the old one is void
+            self._ss.clear_fix_overflow()
+            self._fix_peak_host.zero_()
         torch.cuda.synchronize(self.dev)
 
     def _start_field_grad_exchange(self, k: int):
@@ -1022,6 +1025,17 @@ class KPlanesTrainer:
         self._prepared.clear()
         self.step += 1
         self._dyn_step = self.step
+        self._poll_fix_overflow()
+
+    def _poll_fix_overflow(self):
+        """A fix list SMALLER than the worst case (cfg.fix_capacity set by the caller; the default cannot overflow) is watched from every optimiser
+        step -- train_step's and a direct optimizer_step() caller's alike -- without ever blocking: every 8th step looks at the counter value copied
+        into the pinned word 8 steps earlier and starts the next copy, so dropped gradient terms end the run within 16 steps (was: 128, and only
+        through train_step).  synchronize() checks the device counter itself."""
+        if self._fix_peak_host is None or self._ss.fix_capacity >= self._ss.N * self._ss.ps.out_dim or (self.step & 7) != 0:
+            return
+        self._ss.check_fix_overflow(int(self._fix_peak_host[0]))
+        self._fix_peak_host.copy_(self._ss.fix_peak, non_blocking=True)
 
     def _convert_fx(self, lo: int = 0, hi: Optional[int] = None):
         """Deterministic mode: fixed-point cells [lo, hi) -> self.grads (added; the cells are cleared)."""
@@ -1279,11 +1293,6 @@ class KPlanesTrainer:
         if updated:
             self._steps_since_update = 0
         self._steps_since_update += 1  # step_cb (ray_samplers.py:554-557)
-        if self._fix_peak_host is not None and (self.step & 63) == 0:
-            # fix-list overflow (ops.SortedScatter.check_fix_overflow) without ever blocking: look at the value copied 64 steps ago,
-            # then start the next copy into the pinned word
-            self._ss.check_fix_overflow(int(self._fix_peak_host[0]))
-            self._fix_peak_host.copy_(self._ss.fix_peak, non_blocking=True)
         return out
 
     # ---- nerfstudio checkpoint files (trainer.py:331-380 of the reference; formats in soccernerfs_amd/checkpoint.py) ----

@@ -46,3 +46,17 @@ def test_more_gpus_than_devices_refuses_before_spawning():
     out = _run(["--gpus", "8", "--steps", "1", "--warmup", "0"], HIP_VISIBLE_DEVICES="")
     assert out.returncode == 4 and "HIP device(s) visible" in out.stderr, out.stderr[-2000:]
     assert "starting 8 ranks" not in out.stderr
+
+
+def test_launcher_without_gpus_flag_takes_the_launchers_rank_count():
+    # `torchrun --nproc-per-node 2 bench.py` with no --gpus: the launcher's WORLD_SIZE is the request; no abort, n_gpus = 2
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(PYTHONPATH=ROOT, SNERF_BENCH_ONE_DEVICE="1", SNERF_BENCH_BACKEND="gloo", SNERF_BENCH_RANK_CHECK_ONLY="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          "29653", BENCH, "--steps", "1", "--warmup", "0"], env=e, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    # and with no launcher and no flag: one rank
+    out = _run(["--steps", "1", "--warmup", "0"], SNERF_BENCH_RANK_CHECK_ONLY="1")
+    assert out.returncode == 0 and json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1

@@ -280,3 +280,58 @@ def test_default_operands_fall_back_to_fp32_for_shapes_without_16_bit_kernels():
     assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(tr.params).all()) and tr.step == 3
     with pytest.raises(ValueError):
         KPlanesTrainer(KPlanesTrainConfig(**small, sigma_operands="bf16"), R, DEV)
+
+
+def test_fix_list_default_cannot_overflow_and_a_small_one_ends_the_run_from_optimizer_step():
+    """imported planes with exact zeros make every feature vanish.  The default fix list holds the worst case, so the step's
+    gradient stays exact (equal to the product-form scatter's); a caller-chosen small list must end the run soon -- also for callers that drive
+    forward / backward / optimizer_step themselves -- and restart() clears the sticky record."""
+    from oracle import kplanes_oracle as KO
+    from soccernerfs_amd.trainer import KPlanesTrainer
+
+    E = dict(base_res=(16, 16, 16, 4), multiscale=(1, 2), feat_dim=32, prop_res=((24, 24, 24, 4), (32, 32, 32, 4)), prop_feat=8,
+             sigma_hidden=128, color_hidden=64, aabb_scale=1.5, seed=5)
+    P = KO.make_kplanes_params(**E)
+    for sc in P["field_grids"]:
+        sc[0].zero_()  # the XY plane of every scale all-zero: every feature of every sample vanishes
+    R = 40
+    gen = torch.Generator().manual_seed(3)
+    dv = lambda z: z.to(DEV).contiguous()
+    rays = {"origins": dv((torch.rand(R, 3, generator=gen) * 2 - 1) * 1.2), "directions": dv(torch.nn.functional.normalize(torch.rand(R, 3, generator=gen) * 2 - 1, dim=-1)),
+            "times": dv(torch.rand(R, 1, generator=gen))}
+    target = dv(torch.rand(R, 3, generator=gen))
+    rng = {"t_rand": dv(torch.rand(R, 65, generator=gen)), "u": [dv(torch.rand(R, 33, generator=gen)), dv(torch.rand(R, 17, generator=gen))],
+           "bg": dv(torch.rand(R, 3, generator=gen))}
+    kw = dict(num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=16, warm_up_end=2)
+
+    def grads(tr):
+        tr.load_oracle_params(P)
+        tr.forward(rays, rng, 1.0, training=True)
+        tr.backward(target, rng, proposal_grads=True, include_reg=True)
+        torch.cuda.synchronize()
+        return tr.gviews["field.planes"].clone()
+
+    full = KPlanesTrainer(_default_cfg(E, **kw), R, DEV)
+    assert full._ss.fix_capacity == full._ss.N * full._ss.ps.out_dim
+    product = KPlanesTrainer(_default_cfg(E, quotient_scatter=False, **kw), R, DEV)
+    g_q, g_p = grads(full), grads(product)
+    assert float(g_p.abs().max()) > 0
+    torch.testing.assert_close(g_q, g_p, rtol=1e-3, atol=2e-6 * float(g_p.abs().max()))
+    full.optimizer_step()
+    full.synchronize()  # no overflow possible
+
+    small = KPlanesTrainer(_default_cfg(E, fix_capacity=4, **kw), R, DEV)
+    small.load_oracle_params(P)
+    with pytest.raises(RuntimeError, match="fix list holds"):
+        for _ in range(17):  # forward / backward / optimizer_step driven by the caller: no train_step, no synchronize()
+            small.forward(rays, rng, 1.0, training=True)
+            small.backward(target, rng, proposal_grads=True, include_reg=True)
+            small.optimizer_step()
+            torch.cuda.synchronize()  # (the pinned copy of the counter lands; the poll itself never blocks)
+    P2 = KO.make_kplanes_params(**E)  # positive planes: nothing vanishes
+    small._ss.fix_peak.fill_(10 ** 6)  # a stale record of the old run
+    small.restart()
+    small.load_oracle_params(P2)
+    for _ in range(17):
+        small.train_step(rays, target, rng)
+    small.synchronize()

@@ -230,10 +230,11 @@ def test_quotient_scatter_equals_direct_scatter(ms, N, zeros):
     _lib.check(L.snerf_kplanes_gather_bwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(goutd), ops._ptr(direct), ops._stream()))
     feat = torch.empty(N, ps.out_dim, device=dev)
     _lib.check(L.snerf_kplanes_gather_fwd(Ct.byref(desc), ops._ptr(ps.planes), Ct.byref(co), Ct.c_int64(N), ops._ptr(feat), ops._stream()))
-    # planted zeros make thousands of features vanish at once: the list is sized for the worst case there (the default holds one entry
-    # per (sample, scale), which training never comes near)
-    ss = ops.SortedScatter(ps, N, dev, quotient=True, fix_capacity=N * ps.out_dim if zeros else None)
-    assert ss.gvec is None and ss.fix_capacity == (N * ps.out_dim if zeros else N * len(ms))
+    # planted zeros make thousands of features vanish at once.  (r06, ADVICE) The DEFAULT list holds the worst case (every feature of every sample),
+    # so no input -- imported all-zero planes included -- can overflow it; a smaller list is the caller's explicit choice
+    ss = ops.SortedScatter(ps, N, dev, quotient=True)
+    assert ss.gvec is None and ss.fix_capacity == N * ps.out_dim
+    assert ops.SortedScatter(ps, N, dev, quotient=True, fix_capacity=7).fix_capacity == 7
     ss.sort(co)
     got = torch.zeros_like(ps.planes)
     ss.scatter_quotient(ps.planes, co, goutd, feat, got)

@@ -12,7 +12,8 @@ fail() { echo "collect_config4_profiles.sh: $1" >&2; exit 1; }
 STEPS=30; WARM=5
 python tools/bench_nerfplayer.py --fused --stadium 2> $OUT/${TAG}_np_bench.err | tail -1 > $OUT/${TAG}_np_bench_line.json || fail "bench_nerfplayer.py --fused --stadium failed"
 # the round-4 workload (random rays through the box) once more, for the comparison with profiles/r04_nerfplayer_fused_bench.json
-python tools/bench_nerfplayer.py --fused 2>/dev/null | tail -n 1 > $OUT/${TAG}_nerfplayer_fused_random_rays_bench.json
+python tools/bench_nerfplayer.py --fused 2> $OUT/${TAG}_np_random_rays_bench.err | tail -n 1 > $OUT/${TAG}_nerfplayer_fused_random_rays_bench.json \
+  || fail "bench_nerfplayer.py --fused (random rays) failed (see $OUT/${TAG}_np_random_rays_bench.err)"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_np_stats -- python3 $ROOT/tools/bench_nerfplayer.py --fused --stadium --steps $STEPS --warmup $WARM > $OUT/${TAG}_np_stats.log 2>&1 \
   || fail "rocprofv3 --stats pass failed (see $OUT/${TAG}_np_stats.log)"
