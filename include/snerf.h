@@ -557,21 +557,21 @@ typedef struct {
 /* Host arithmetic only.  tile_rows_log2 <= 0: the largest tile that lets two workgroups share a CU's LDS; first_tiled_level < 0: levels with fewer than
  * 2^16 rows stay atomic. */
 int snerf_tgrid_tile_plan_make(const snerf_tgrid_desc* desc, int64_t B, int32_t tile_rows_log2, int32_t first_tiled_level, snerf_tgrid_tile_plan* plan);
-/* counts [count_ints] and tile_base [n_tiles + 1] are workspaces (no initialisation needed); records [record_capacity].  B < 2^28. */
+/* counts [count_ints] and tile_base [n_tiles + 1] are workspaces (no initialisation needed); records [record_capacity]; pos4 [B,4] (16-byte aligned)
+ * receives (x, y, z, time) per sample -- the later passes read ONLY pos4, grad_out, tile_base and records, never `coords`, so they may run on another
+ * stream while the caller's ray buffers are rewritten.  B < 2^28. */
 int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
-                        int32_t samples_per_row, int64_t B, const float* grad_out, int32_t* counts, int32_t* tile_base, uint32_t* records,
+                        int32_t samples_per_row, int64_t B, const float* grad_out, float* pos4, int32_t* counts, int32_t* tile_base, uint32_t* records,
                         snerf_stream_t stream);
 /* grad_embeddings [rows, grid_C] += the gradient of the tiled levels (16-byte aligned). */
-int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
-                          int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
-                          float* grad_embeddings, snerf_stream_t stream);
+int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, int64_t B, const float* grad_out, const float* pos4,
+                          const int32_t* tile_base, const uint32_t* records, float* grad_embeddings, snerf_stream_t stream);
 /* Adam (torch.optim.Adam: bias-corrected, eps outside the square root; step is 1-based) over the WHOLE table with gradient = tiled scatter + what
  * grad_embeddings holds for the rows of levels [0, first_tiled_level) (read and cleared; may be NULL when first_tiled_level = 0) + the temporal-TV
  * term srow[row] on column col_a and -srow[row] on col_b (col_a < 0: none; srow from snerf_tgrid_tv_sign).  A non-finite gradient element is dropped. */
-int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
-                               int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
-                               float* grad_embeddings, float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, int32_t step,
-                               int32_t col_a, int32_t col_b, const float* srow, snerf_stream_t stream);
+int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, int64_t B, const float* grad_out, const float* pos4,
+                               const int32_t* tile_base, const uint32_t* records, float* grad_embeddings, float* p, float* m, float* v, float lr,
+                               float beta1, float beta2, float eps, int32_t step, int32_t col_a, int32_t col_b, const float* srow, snerf_stream_t stream);
 /* snerf_tgrid_encode_bwd for levels [level_begin, level_end) only (the coarse levels beside the tiled form). */
 int snerf_tgrid_encode_bwd_levels(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index, const float* times,
                                   int32_t samples_per_row, int64_t B, const float* grad_out, float* grad_embeddings, int32_t level_begin,

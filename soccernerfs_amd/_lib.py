@@ -147,9 +147,9 @@ def lib():
     l.snerf_tgrid_tv_fwd_bwd.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_tgrid_tv_sign.argtypes = [P, L, I, I, I, F, P, I, P, P]
     l.snerf_tgrid_tile_plan_make.argtypes = [P, L, I, I, P]
-    l.snerf_tgrid_bwd_bin.argtypes = [P, P, P, P, I, L, P, P, P, P, P]
-    l.snerf_tgrid_bwd_tiles.argtypes = [P, P, P, P, I, L, P, P, P, P, P]
-    l.snerf_tgrid_bwd_tiles_adam.argtypes = [P, P, P, P, I, L, P, P, P, P, P, P, P, F, F, F, F, I, I, I, P, P]
+    l.snerf_tgrid_bwd_bin.argtypes = [P, P, P, P, I, L, P, P, P, P, P, P]
+    l.snerf_tgrid_bwd_tiles.argtypes = [P, P, L, P, P, P, P, P, P]
+    l.snerf_tgrid_bwd_tiles_adam.argtypes = [P, P, L, P, P, P, P, P, P, P, P, F, F, F, F, I, I, I, P, P]
     l.snerf_tgrid_encode_bwd_levels.argtypes = [P, P, P, P, I, L, P, P, I, I, P]
     l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P, P]
     l.snerf_isg_maps.argtypes = [P, I, I, I, I, I, P, P, P, I, F, P, P, P]

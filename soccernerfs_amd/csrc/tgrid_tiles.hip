@@ -40,6 +40,8 @@ struct TileArgs {
   int spr;
   int64_t B;
   const float* gout;
+  float4* pos4;        // [B]: (x, y, z in [0,1]^3 as tg_sample_x derives them, time) -- written by the binning entry, read by every later pass, so that the
+                       // tile kernels never touch the caller's ray buffers (they may run on another stream while the next step's head rewrites those)
   int32_t* counts;     // [n_chunks][n_tiles]: per-chunk record counts, then (scan) the chunk's write offset inside the tile
   int32_t* tile_base;  // [n_tiles + 1]
   uint32_t* records;
@@ -55,8 +57,9 @@ struct TileArgs {
 // their rows (hashed levels: rows r and r ^ 1 mostly), then one record each
 template <int C, typename F>
 __device__ __forceinline__ void tt_for_records(const TileArgs& a, const TgLevel& lv, int level, int64_t b, F&& emit) {
-  float x[3];
-  if (tg_sample_x(a.c, b, x)) return;
+  const float4 ps = a.pos4[b];
+  const float x[3] = {ps.x, ps.y, ps.z};
+  if ((x[0] < 0.f) || (x[0] > 1.f) || (x[1] < 0.f) || (x[1] > 1.f) || (x[2] < 0.f) || (x[2] > 1.f)) return;  // .cu:119-124
   const float* g = a.gout + b * (a.d.L * C) + level * C;
   bool any = false;
 #pragma unroll
@@ -73,6 +76,14 @@ __device__ __forceinline__ void tt_for_records(const TileArgs& a, const TgLevel&
     if (t0 == t1) emit(t0, base | 3u);
     else { emit(t0, base | 1u); emit(t1, base | 2u); }
   }
+}
+
+__global__ __launch_bounds__(256) void tt_positions_kernel(TileArgs a) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  float x[3];
+  tg_sample_x(a.c, b, x);
+  a.pos4[b] = make_float4(x[0], x[1], x[2], a.times[(uint32_t)b / (uint32_t)a.spr]);
 }
 
 // count (FILL = false) / fill (FILL = true): grid (chunks, tiled levels)
@@ -167,6 +178,28 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
   const int64_t q0 = gb >> 2;
   const int nq = (int)(((ge + 3) >> 2) - q0);  // float4 groups that overlap the tile; the first / last may belong to a neighbour in part
   const int ph = (int)(gb - (q0 << 2));
+  // the float4 groups that lie wholly inside the tile: [qa, qb)
+  const int qa = ph ? 1 : 0, qb = nq - ((ge & 3) ? 1 : 0);
+  const bool coarse = level < a.pl.first_tiled_level;  // its gradient came through the atomic kernel into gemb
+  // MODE 1, streaming part (below), software-pipelined: TT_U groups per thread and stage, the next stage's 3 x TT_U loads in flight while this one is
+  // computed and stored; the FIRST stage is requested here, in front of the record walk, so that the memory system works while the tile is being summed
+  constexpr int TT_U = 2;
+  constexpr int STRIDE = TT_U * TT_NT;
+  float4 PA[TT_U], MA[TT_U], VA[TT_U], PB[TT_U], MB[TT_U], VB[TT_U];
+  auto load = [&](float4* P, float4* M, float4* V, int qbase) {
+#pragma unroll
+    for (int u = 0; u < TT_U; ++u) {
+      const int q = qbase + u * TT_NT;
+      if (q < qb) {
+        const int64_t f0 = (q0 + q) << 2;
+        P[u] = ldnt4(a.p + f0); M[u] = ldnt4(a.m + f0); V[u] = ldnt4(a.v + f0);
+      }
+    }
+  };
+  const bool stream = MODE == 1 && !(coarse && a.gemb);
+  int cur = qa + (int)threadIdx.x;
+  if (stream) load(PA, MA, VA, cur);
+
   for (int q = threadIdx.x; q < nq; q += TT_NT) *reinterpret_cast<float4*>(tt_acc + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
   lds_barrier();
 
@@ -178,12 +211,12 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
     const uint32_t rec = a.records[i];
     const int64_t b = (int64_t)(rec >> 4);
     const int yz = (int)(rec >> 2) & 3, xm = (int)(rec & 3u);
-    float x[3];
-    tg_sample_x(a.c, b, x);
+    const float4 ps = a.pos4[b];
+    const float x[3] = {ps.x, ps.y, ps.z};
     uint32_t pg[3];
     float fr[3];
     tg_cell(lv, a.d.align_corners != 0, x, pg, fr);
-    const float t = a.times[(uint32_t)b / (uint32_t)a.spr];
+    const float t = ps.w;
     const float tv = t * (float)(n_trows - 1);
     int r = (int)tv;
     if (t == 1.f) r = n_trows - 1;
@@ -233,15 +266,13 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
   }
 
   // ---- epilogue over the float4 groups; a group that straddles the tile's first / last float is handled element by element ----
-  const bool coarse = level < a.pl.first_tiled_level;  // its gradient came through the atomic kernel into gemb
   const DynConsts dc = {a.step_size, a.inv_sqrt_bc2, 0};
-  for (int q = threadIdx.x; q < nq; q += TT_NT) {
-    const int64_t f0 = (q0 + q) << 2;
-    float4 gq = *reinterpret_cast<const float4*>(tt_acc + 4 * q);
-    const bool full = f0 >= gb && f0 + 4 <= ge;
-    if (MODE == 0) {
+  if (MODE == 0) {
+    for (int q = threadIdx.x; q < nq; q += TT_NT) {
+      const int64_t f0 = (q0 + q) << 2;
+      const float4 gq = *reinterpret_cast<const float4*>(tt_acc + 4 * q);
       if (gq.x == 0.f && gq.y == 0.f && gq.z == 0.f && gq.w == 0.f) continue;
-      if (full) {
+      if (f0 >= gb && f0 + 4 <= ge) {
         float4 o = ld4(a.gemb + f0);
         o.x += gq.x; o.y += gq.y; o.z += gq.z; o.w += gq.w;
         *reinterpret_cast<float4*>(a.gemb + f0) = o;
@@ -250,45 +281,76 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
         for (int k = 0; k < 4; ++k)
           if (f0 + k >= gb && f0 + k < ge && G[k] != 0.f) a.gemb[f0 + k] += G[k];
       }
-    } else {
-      if (full) {
-        float4 pp = ldnt4(a.p + f0), mm = ldnt4(a.m + f0), vv = ldnt4(a.v + f0);
-        float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (coarse && a.gemb) {
-          extra = ldnt4(a.gemb + f0);
-          if (extra.x != 0.f || extra.y != 0.f || extra.z != 0.f || extra.w != 0.f) stnt4(a.gemb + f0, make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    return;
+  }
+  if (!stream) {
+    for (int q = qa + (int)threadIdx.x; q < qb; q += TT_NT) {
+      const int64_t f0 = (q0 + q) << 2;
+      const float4 gq = *reinterpret_cast<const float4*>(tt_acc + 4 * q);
+      float4 pp = ldnt4(a.p + f0), mm = ldnt4(a.m + f0), vv = ldnt4(a.v + f0);
+      const float4 extra = ldnt4(a.gemb + f0);
+      if (extra.x != 0.f || extra.y != 0.f || extra.z != 0.f || extra.w != 0.f) stnt4(a.gemb + f0, make_float4(0.f, 0.f, 0.f, 0.f));
+      adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
+      stnt4(a.p + f0, pp);
+      stnt4(a.m + f0, mm);
+      stnt4(a.v + f0, vv);
+    }
+  } else {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto step = [&](float4* P, float4* M, float4* V, int qbase) {
+#pragma unroll
+      for (int u = 0; u < TT_U; ++u) {
+        const int q = qbase + u * TT_NT;
+        if (q < qb) {
+          const int64_t f0 = (q0 + q) << 2;
+          const float4 gq = *reinterpret_cast<const float4*>(tt_acc + 4 * q);
+          adam_float4(P[u], M[u], V[u], gq, zero, 1.f, a.b1, a.b2, a.eps, dc);
+          stnt4(a.p + f0, P[u]);
+          stnt4(a.m + f0, M[u]);
+          stnt4(a.v + f0, V[u]);
         }
-        adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
-        stnt4(a.p + f0, pp);
-        stnt4(a.m + f0, mm);
-        stnt4(a.v + f0, vv);
-      } else {
-        float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp, extra = pp;
-        float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; float* E = &extra.x;
-        for (int k = 0; k < 4; ++k)
-          if (f0 + k >= gb && f0 + k < ge) {
-            P[k] = a.p[f0 + k]; M[k] = a.m[f0 + k]; V[k] = a.v[f0 + k];
-            if (coarse && a.gemb) { E[k] = a.gemb[f0 + k]; if (E[k] != 0.f) a.gemb[f0 + k] = 0.f; }
-          }
-        adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
-        for (int k = 0; k < 4; ++k)
-          if (f0 + k >= gb && f0 + k < ge) { a.p[f0 + k] = P[k]; a.m[f0 + k] = M[k]; a.v[f0 + k] = V[k]; }
       }
+    };
+    while (cur < qb) {
+      load(PB, MB, VB, cur + STRIDE);
+      step(PA, MA, VA, cur);
+      cur += STRIDE;
+      if (cur >= qb) break;
+      load(PA, MA, VA, cur + STRIDE);
+      step(PB, MB, VB, cur);
+      cur += STRIDE;
+    }
+  }
+  // the (at most two) groups shared with a neighbouring tile: element by element, this tile's floats only
+  if (threadIdx.x < 2) {
+    const int q = threadIdx.x == 0 ? 0 : nq - 1;
+    const bool partial = threadIdx.x == 0 ? (qa == 1) : (qb == nq - 1 && nq - 1 >= qa);
+    if (partial && (threadIdx.x == 0 || nq > 1 || qa == 0)) {
+      const int64_t f0 = (q0 + q) << 2;
+      const float4 gq = *reinterpret_cast<const float4*>(tt_acc + 4 * q);
+      float4 pp = make_float4(0.f, 0.f, 0.f, 0.f), mm = pp, vv = pp, extra = pp;
+      float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; float* E = &extra.x;
+      for (int k = 0; k < 4; ++k)
+        if (f0 + k >= gb && f0 + k < ge) {
+          P[k] = a.p[f0 + k]; M[k] = a.m[f0 + k]; V[k] = a.v[f0 + k];
+          if (coarse && a.gemb) { E[k] = a.gemb[f0 + k]; if (E[k] != 0.f) a.gemb[f0 + k] = 0.f; }
+        }
+      adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
+      for (int k = 0; k < 4; ++k)
+        if (f0 + k >= gb && f0 + k < ge) { a.p[f0 + k] = P[k]; a.m[f0 + k] = M[k]; a.v[f0 + k] = V[k]; }
     }
   }
 }
 
 static int tiles_lds_bytes(const snerf_tgrid_desc* d, int sh) { return (((1 << sh) * d->grid_C + 6) / 4 + 1) * 16; }
 
-static int validate_tiles(const snerf_tgrid_desc* d, const snerf_tgrid_tile_plan* pl, const snerf_coords* c, const float* times, int spr, int64_t B) {
-  SNERF_REQUIRE(d && pl && c, "tgrid tiles: null descriptor");
+static int validate_tiles(const snerf_tgrid_desc* d, const snerf_tgrid_tile_plan* pl, int64_t B) {
+  SNERF_REQUIRE(d && pl, "tgrid tiles: null descriptor");
   SNERF_REQUIRE(d->D == 3, "tgrid tiles: D=%d (3 only)", d->D);
   SNERF_REQUIRE(d->C == 1 || d->C == 2 || d->C == 4 || d->C == 8, "tgrid tiles: level_dim C=%d unsupported (1,2,4,8)", d->C);
   SNERF_REQUIRE(d->L >= 1 && d->L <= 32 && d->grid_C > d->C + 1 && (d->grid_C & 1) == 0, "tgrid tiles: L=%d grid_C=%d (even row length needed)", d->L, d->grid_C);
-  SNERF_REQUIRE(times && spr >= 1 && B >= 0 && B < (1LL << 28), "tgrid tiles: times / samples_per_row / B=%lld (< 2^28)", (long long)B);
-  SNERF_REQUIRE(c->mode == 0 || c->mode == 1, "tgrid tiles: coords.mode=%d", c->mode);
-  if (c->mode == 0) SNERF_REQUIRE(c->pts || B == 0, "tgrid tiles: pts is null");
-  if (c->mode == 1) SNERF_REQUIRE(c->S >= 1 && B % c->S == 0 && c->origins && c->dirs && c->ebins, "tgrid tiles: bad ray coords");
+  SNERF_REQUIRE(B >= 0 && B < (1LL << 28), "tgrid tiles: B=%lld (< 2^28)", (long long)B);
   SNERF_REQUIRE(pl->tile_rows_log2 >= 2 && pl->tile_rows_log2 <= 16 && pl->n_tiles == pl->tile_start[d->L] && pl->chunk >= 1 &&
                     pl->n_chunks == (int)((B + pl->chunk - 1) / pl->chunk) && pl->first_tiled_level >= 0 && pl->first_tiled_level <= d->L,
                 "tgrid tiles: the plan does not belong to this descriptor / batch (snerf_tgrid_tile_plan_make)");
@@ -298,6 +360,7 @@ static int validate_tiles(const snerf_tgrid_desc* d, const snerf_tgrid_tile_plan
 template <int C>
 static int bin_launch(const TileArgs& a, hipStream_t st) {
   const int L = a.d.L, Lc = a.pl.first_tiled_level;
+  if (a.B > 0) hipLaunchKernelGGL(tt_positions_kernel, dim3((unsigned)ceil_div(a.B, 256)), dim3(256), 0, st, a);
   if (Lc >= L || a.B == 0) {
     hipLaunchKernelGGL(tt_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles, a.pl.n_tiles);
     SNERF_LAUNCH_CHECK("tgrid_bwd_bin (empty)");
@@ -379,29 +442,33 @@ extern "C" int snerf_tgrid_tile_plan_make(const snerf_tgrid_desc* desc, int64_t 
 }
 
 extern "C" int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
-                                   int32_t samples_per_row, int64_t B, const float* grad_out, int32_t* counts, int32_t* tile_base, uint32_t* records,
-                                   snerf_stream_t stream) {
-  int rc = validate_tiles(desc, plan, coords, times, samples_per_row, B);
+                                   int32_t samples_per_row, int64_t B, const float* grad_out, float* pos4, int32_t* counts, int32_t* tile_base,
+                                   uint32_t* records, snerf_stream_t stream) {
+  int rc = validate_tiles(desc, plan, B);
   if (rc) return rc;
-  SNERF_REQUIRE(counts && tile_base && (records || plan->record_capacity == 0) && (grad_out || B == 0), "tgrid_bwd_bin: null buffer");
+  SNERF_REQUIRE(coords && times && samples_per_row >= 1, "tgrid_bwd_bin: coords / times / samples_per_row");
+  SNERF_REQUIRE(coords->mode == 0 || coords->mode == 1, "tgrid_bwd_bin: coords.mode=%d", coords->mode);
+  if (coords->mode == 0) SNERF_REQUIRE(coords->pts || B == 0, "tgrid_bwd_bin: pts is null");
+  if (coords->mode == 1) SNERF_REQUIRE(coords->S >= 1 && B % coords->S == 0 && coords->origins && coords->dirs && coords->ebins, "tgrid_bwd_bin: bad ray coords");
+  SNERF_REQUIRE(counts && tile_base && (pos4 || B == 0) && (records || plan->record_capacity == 0) && (grad_out || B == 0), "tgrid_bwd_bin: null buffer");
+  SNERF_REQUIRE(((uintptr_t)pos4 & 15) == 0, "tgrid_bwd_bin: pos4 must be 16-byte aligned");
   TileArgs a = {};
   a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
-  a.counts = counts; a.tile_base = tile_base; a.records = records;
+  a.pos4 = reinterpret_cast<float4*>(pos4); a.counts = counts; a.tile_base = tile_base; a.records = records;
 #define TT_CALL(C_) bin_launch<C_>(a, (hipStream_t)stream)
   TT_DISPATCH_C(desc->C, TT_CALL)
 #undef TT_CALL
 }
 
-extern "C" int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
-                                     int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
-                                     float* grad_embeddings, snerf_stream_t stream) {
-  int rc = validate_tiles(desc, plan, coords, times, samples_per_row, B);
+extern "C" int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, int64_t B, const float* grad_out, const float* pos4,
+                                     const int32_t* tile_base, const uint32_t* records, float* grad_embeddings, snerf_stream_t stream) {
+  int rc = validate_tiles(desc, plan, B);
   if (rc) return rc;
   if (B == 0) return 0;
-  SNERF_REQUIRE(tile_base && records && grad_out && grad_embeddings, "tgrid_bwd_tiles: null buffer");
-  SNERF_REQUIRE(((uintptr_t)grad_embeddings & 15) == 0, "tgrid_bwd_tiles: grad_embeddings must be 16-byte aligned");
+  SNERF_REQUIRE(tile_base && records && grad_out && pos4 && grad_embeddings, "tgrid_bwd_tiles: null buffer");
+  SNERF_REQUIRE((((uintptr_t)grad_embeddings | (uintptr_t)pos4) & 15) == 0, "tgrid_bwd_tiles: grad_embeddings / pos4 must be 16-byte aligned");
   TileArgs a = {};
-  a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
+  a.d = *desc; a.pl = *plan; a.B = B; a.gout = grad_out; a.pos4 = reinterpret_cast<float4*>(const_cast<float*>(pos4));
   a.tile_base = const_cast<int32_t*>(tile_base); a.records = const_cast<uint32_t*>(records); a.gemb = grad_embeddings;
   a.col_a = -1;
 #define TT_CALL(C_) tiles_launch<C_, 0>(a, (hipStream_t)stream)
@@ -409,21 +476,22 @@ extern "C" int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_t
 #undef TT_CALL
 }
 
-extern "C" int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
-                                          int32_t samples_per_row, int64_t B, const float* grad_out, const int32_t* tile_base, const uint32_t* records,
-                                          float* grad_embeddings, float* p, float* m, float* v, float lr, float beta1, float beta2, float eps, int32_t step,
-                                          int32_t col_a, int32_t col_b, const float* srow, snerf_stream_t stream) {
-  int rc = validate_tiles(desc, plan, coords, times, samples_per_row, B);
+extern "C" int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, int64_t B, const float* grad_out, const float* pos4,
+                                          const int32_t* tile_base, const uint32_t* records, float* grad_embeddings, float* p, float* m, float* v, float lr,
+                                          float beta1, float beta2, float eps, int32_t step, int32_t col_a, int32_t col_b, const float* srow,
+                                          snerf_stream_t stream) {
+  int rc = validate_tiles(desc, plan, B);
   if (rc) return rc;
-  SNERF_REQUIRE(tile_base && (records || B == 0) && (grad_out || B == 0) && p && m && v, "tgrid_bwd_tiles_adam: null buffer");
+  SNERF_REQUIRE(tile_base && (records || B == 0) && (grad_out || B == 0) && (pos4 || B == 0) && p && m && v, "tgrid_bwd_tiles_adam: null buffer");
   SNERF_REQUIRE(step >= 1, "tgrid_bwd_tiles_adam: step=%d (1-based)", step);
-  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad_embeddings) & 15) == 0, "tgrid_bwd_tiles_adam: buffers must be 16-byte aligned");
+  SNERF_REQUIRE((((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad_embeddings | (uintptr_t)pos4) & 15) == 0,
+                "tgrid_bwd_tiles_adam: buffers must be 16-byte aligned");
   SNERF_REQUIRE(plan->first_tiled_level == 0 || grad_embeddings, "tgrid_bwd_tiles_adam: levels [0, %d) go through the atomic kernel: pass their gradient buffer",
                 plan->first_tiled_level);
   SNERF_REQUIRE(col_a < 0 || (srow && col_b >= 0 && col_a < desc->grid_C && col_b < desc->grid_C && col_a != col_b), "tgrid_bwd_tiles_adam: TV columns (%d,%d)", col_a,
                 col_b);
   TileArgs a = {};
-  a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;
+  a.d = *desc; a.pl = *plan; a.B = B; a.gout = grad_out; a.pos4 = reinterpret_cast<float4*>(const_cast<float*>(pos4));
   a.tile_base = const_cast<int32_t*>(tile_base); a.records = const_cast<uint32_t*>(records); a.gemb = grad_embeddings;
   a.p = p; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
   adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);

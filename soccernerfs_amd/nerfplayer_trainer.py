@@ -36,7 +36,7 @@ def _align4(n: int) -> int:
 class NerfplayerTrainer:
     def __init__(self, cfg: NerfplayerNerfactoModelConfig, num_rays: int, num_images: int, aabb_scale: float = 1.0, device="cuda:0",
                  lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
-                 async_field_sweep: bool = False, mlp_operands: str = "fp32"):
+                 async_field_sweep: bool = False, mlp_operands: str = "fp32", tiled_field_backward: bool = False, tiled_first_level: int = 0):
         """mlp_operands: "fp32" (exact: the parity path, what G12 pins) or "bf16" (bf16 MFMA operands, fp32 accumulation, for every net whose shape the
         16-bit fused kernels are built for -- the decode net and the colour head of the preset; the reference runs all of them in tcnn's fp16).
         async_field_sweep (round 5): inside train_step the optimiser sweep of the FIELD's table (most of the parameters) is launched on a side stream
@@ -44,6 +44,13 @@ class NerfplayerTrainer:
         field level: it runs beside the proposal networks' backward (atomic-bound) and the next step's ray generation and proposal levels, which read
         the two small tables only.  Same arithmetic, same bits in deterministic mode.  Readers of the field table outside forward() call wait_params() /
         synchronize() first; off by default for that reason (bench.py's config-4 leg and tools/bench_nerfplayer.py turn it on).
+        tiled_field_backward (round 6): inside train_step the FIELD table's gradient scatter and its Adam sweep are one owner-computes pass
+        (temporal_grid.TiledTableBackward, csrc/tgrid_tiles.hip): the batch's (sample, level, corner) touches are binned by tile of 256 table rows, one
+        workgroup per tile sums its rows in LDS and steps them with Adam straight from there -- no float atomics (the run-length kernel ran AT the chip's
+        atomic rate: 1.26 ms per step on camera rays) and no dense gradient for this table (24 instead of 32 B per parameter in the sweep).  Same
+        mathematics; float sums in another association order.  The fused pass goes where the asynchronous sweep goes (side stream with
+        async_field_sweep, else the caller's stream).  backward() called outside train_step, and deterministic mode, keep the atomic scatter into
+        self.grads.  tiled_first_level: levels below it stay with the atomic kernel (0: every level tiled).
         deterministic: every gradient scatter (temporal-grid tables, MLP weight gradients, appearance embedding) accumulates 2^50-scaled 64-bit
         integers instead of float atomics (csrc/common.hpp: integer addition is associative), converted once per step: two runs from the same seed give
         the same bits.  Costs 8 B per parameter and 64-bit atomics; off by default."""
@@ -134,6 +141,12 @@ class NerfplayerTrainer:
         self.tv_rows: Optional[List[int]] = None  # parity hook: fixed table rows [field, prop0, prop1] instead of the random draw
         self._tv_cols = [(0, 1)] * 3
         self.async_field_sweep = bool(async_field_sweep)
+        self.tiled_field_backward = bool(tiled_field_backward) and not deterministic
+        self._tiled = None
+        if self.tiled_field_backward:
+            from .temporal_grid import TiledTableBackward
+
+            self._tiled = TiledTableBackward(self.enc, R * S2, first_tiled_level=tiled_first_level)
         self._side, self._field_sweep_done, self._field_swept, self._in_train_step, self._tv0_done = None, None, False, False, None
 
     # ---- helpers ----
@@ -223,6 +236,31 @@ class NerfplayerTrainer:
                 ops.fx_to_float(self._fx_of(gv), gv.view(-1), accumulate=True)
             self._sweep_table("field.table", lr, C.c_void_p(self._side.cuda_stream))
             self._field_sweep_done = self._side.record_event()
+        self._field_swept = True
+
+    def _field_table_fused_adam(self, on_side: bool):
+        """tiled_field_backward: the field table's scatter + temporal TV + Adam as one owner-computes pass over the tiles filed by `bin`; on the side stream
+        (async_field_sweep) it reads only the tiler's own buffers and gfeat, which the next step rewrites after wait_params() at the earliest."""
+        lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+        o, n = next((o, n) for nm, _, _, o, n in self.segments if nm == "field.table")
+        sl = slice(o, o + n)
+        tv = self._tv_cols[0] if self.cfg.temporal_tv_weight > 0 else None
+        gt = self.gviews["field.table"] if self._tiled.plan.first_tiled_level > 0 else None
+
+        def run(st):
+            with self._span("tgrid_tiles_adam.field"):
+                self._tiled.scatter_adam(self.buf["gfeat"], gt, self.params[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, self.step + 1, self.adam_eps, tv_cols=tv,
+                                         srow=self._srow[0] if tv is not None else None, stream=st)
+
+        if on_side:
+            if self._side is None:
+                self._side = side_stream(self.dev, "adam")
+            self._side.wait_stream(torch.cuda.current_stream())  # (the table's TV pass has been on this stream since the start of the backward)
+            with torch.cuda.stream(self._side):
+                run(C.c_void_p(self._side.cuda_stream))
+                self._field_sweep_done = self._side.record_event()
+        else:
+            run(self._st)
         self._field_swept = True
 
     def _tgrid_fwd(self, enc, table, co, times, S, N, out):
@@ -353,11 +391,20 @@ class NerfplayerTrainer:
                                                           self._p(self.fxviews["field.appearance"]) if fx else None, self._st), "head_input_bwd")
         self._mlp_bwd(self.decode, self.gviews["field.decode"], b["feat"], self.enc.output_dim, N2, b["gh"], 16, 0, b["gdens"][2], b["gfeat"],
                       self.enc.output_dim)
-        self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])
-        if early:
-            if self._side is None:
-                self._side = side_stream(self.dev, "adam")
-            self._field_table_sweep_async()
+        if self._tiled is not None and self._in_train_step:
+            # owner-computes form: bin on this stream (it reads the ray buffers), then scatter + Adam of the table as ONE pass where the sweep would go
+            with self._span("tgrid_bin.field"):
+                self._tiled.bin(self._coords[2], t, S2, b["gfeat"], self._st)
+                self._tiled.coarse_levels(self._coords[2], t, S2, b["gfeat"], self.gviews["field.table"], self._st)
+            if cfg.temporal_tv_weight > 0 and not early:
+                self._tv_sign(0)  # the fused pass adds the TV step itself: its per-row signs must exist first (row draw order unchanged: field first)
+            self._field_table_fused_adam(early)
+        else:
+            self._tgrid_bwd(self.enc, self._coords[2], t, S2, N2, b["gfeat"], self.gviews["field.table"])
+            if early:
+                if self._side is None:
+                    self._side = side_stream(self.dev, "adam")
+                self._field_table_sweep_async()
         # proposal supervision (interlevel loss, losses.py:106-121)
         for lvl in range(2):
             Sp, Np = self.S[lvl], R * self.S[lvl]
@@ -375,7 +422,7 @@ class NerfplayerTrainer:
         # gives the value and the per-row signed step; the gradient itself is added inside the Adam sweep (optimizer_step)
         if cfg.temporal_tv_weight > 0:
             for k in range(3):
-                if not (early and k == 0):  # the same order of row draws either way: field, proposal 0, proposal 1
+                if not ((early or (self._tiled is not None and self._in_train_step)) and k == 0):  # the same order of row draws either way: field, proposal 0, proposal 1
                     self._tv_sign(k)
             if early:
                 torch.cuda.current_stream().wait_event(self._tv0_done)  # loss_dict reads the field table's TV value on the caller's stream

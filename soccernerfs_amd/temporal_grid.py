@@ -189,7 +189,8 @@ class TiledTableBackward:
     level, corner) touches under tiles of consecutive table rows, then either `scatter` adds the tiles into a dense gradient buffer (= what
     snerf_tgrid_encode_bwd leaves there, up to the association order of the float sums) or `scatter_adam` runs torch.optim.Adam for the whole table
     straight from the tiles' LDS images (+ the temporal-TV step), without a dense gradient.  Levels below plan.first_tiled_level go through the run-length
-    atomic kernel into the gradient buffer (in both forms).  Replaces NS/field_components/cuda/csrc/temporal_gridencoder.cu:283-370 + the optimiser step."""
+    atomic kernel into the gradient buffer (`coarse_levels`, in both forms).  After `bin` the tile passes read only this object's buffers and `gout`.
+    Replaces NS/field_components/cuda/csrc/temporal_gridencoder.cu:283-370 + the optimiser step of the table."""
 
     def __init__(self, enc: "TemporalGridEncoder", B: int, tile_rows_log2: int = 0, first_tiled_level: int = -1):
         self.enc, self.B = enc, int(B)
@@ -199,36 +200,34 @@ class TiledTableBackward:
         self.counts = torch.empty(max(int(self.plan.count_ints), 1), dtype=torch.int32, device=dev)
         self.tile_base = torch.empty(self.plan.n_tiles + 1, dtype=torch.int32, device=dev)
         self.records = torch.empty(max(int(self.plan.record_capacity), 1), dtype=torch.int32, device=dev)
-
-    def _coarse(self, coords, times, spr, gout, gtable, st):
-        lc = self.plan.first_tiled_level
-        if lc > 0:
-            _lib.check(_lib.lib().snerf_tgrid_encode_bwd_levels(C.byref(self.enc.desc), C.byref(coords), None, ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
-                                                                ops._ptr(gtable), 0, lc, st), "tgrid_encode_bwd_levels")
+        self.pos4 = torch.empty(max(self.B, 1), 4, dtype=torch.float32, device=dev)
 
     def bin(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, stream=None):
         st = stream if stream is not None else ops._stream()
         _lib.check(_lib.lib().snerf_tgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
-                                                  ops._ptr(self.counts), ops._ptr(self.tile_base), ops._ptr(self.records), st), "tgrid_bwd_bin")
+                                                  ops._ptr(self.pos4), ops._ptr(self.counts), ops._ptr(self.tile_base), ops._ptr(self.records), st), "tgrid_bwd_bin")
 
-    def scatter(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
-        """gtable += d loss / d table (after `bin` of the same batch)."""
+    def coarse_levels(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
+        """Levels [0, first_tiled_level) through the run-length atomic kernel into gtable; reads the ray buffers, so it belongs on their stream."""
+        lc = self.plan.first_tiled_level
+        if lc > 0:
+            st = stream if stream is not None else ops._stream()
+            _lib.check(_lib.lib().snerf_tgrid_encode_bwd_levels(C.byref(self.enc.desc), C.byref(coords), None, ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
+                                                                ops._ptr(gtable), 0, lc, st), "tgrid_encode_bwd_levels")
+
+    def scatter(self, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
+        """gtable += the tiled levels' share of d loss / d table (after `bin` of the same batch; `coarse_levels` adds the rest)."""
         st = stream if stream is not None else ops._stream()
-        self._coarse(coords, times, spr, gout, gtable, st)
-        _lib.check(_lib.lib().snerf_tgrid_bwd_tiles(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
+        _lib.check(_lib.lib().snerf_tgrid_bwd_tiles(C.byref(self.enc.desc), C.byref(self.plan), C.c_int64(self.B), ops._ptr(gout), ops._ptr(self.pos4),
                                                     ops._ptr(self.tile_base), ops._ptr(self.records), ops._ptr(gtable), st), "tgrid_bwd_tiles")
 
-    def coarse_levels(self, coords, times, spr, gout, gtable, stream=None):
-        """The atomic part of the fused form (levels [0, first_tiled_level) into gtable); reads the ray buffers, so it belongs on their stream."""
-        self._coarse(coords, times, spr, gout, gtable, stream if stream is not None else ops._stream())
-
-    def scatter_adam(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, gtable: Optional[torch.Tensor], p: torch.Tensor, m: torch.Tensor,
-                     v: torch.Tensor, lr: float, step: int, eps: float, tv_cols=None, srow: Optional[torch.Tensor] = None, betas=(0.9, 0.999), stream=None):
+    def scatter_adam(self, gout: torch.Tensor, gtable: Optional[torch.Tensor], p: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, eps: float,
+                     tv_cols=None, srow: Optional[torch.Tensor] = None, betas=(0.9, 0.999), stream=None):
         """Adam step `step` (1-based) of the whole table with gradient = tiles + gtable's coarse-level rows (cleared) + the TV term; after `bin` and
         `coarse_levels` of the same batch."""
         st = stream if stream is not None else ops._stream()
         ca, cb = tv_cols if tv_cols is not None else (-1, -1)
-        _lib.check(_lib.lib().snerf_tgrid_bwd_tiles_adam(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B),
-                                                         ops._ptr(gout), ops._ptr(self.tile_base), ops._ptr(self.records),
-                                                         ops._ptr(gtable) if gtable is not None else None, ops._ptr(p), ops._ptr(m), ops._ptr(v), lr, betas[0], betas[1],
-                                                         eps, step, ca, cb, ops._ptr(srow) if srow is not None else None, st), "tgrid_bwd_tiles_adam")
+        _lib.check(_lib.lib().snerf_tgrid_bwd_tiles_adam(C.byref(self.enc.desc), C.byref(self.plan), C.c_int64(self.B), ops._ptr(gout), ops._ptr(self.pos4),
+                                                         ops._ptr(self.tile_base), ops._ptr(self.records), ops._ptr(gtable) if gtable is not None else None,
+                                                         ops._ptr(p), ops._ptr(m), ops._ptr(v), lr, betas[0], betas[1], eps, step, ca, cb,
+                                                         ops._ptr(srow) if srow is not None else None, st), "tgrid_bwd_tiles_adam")

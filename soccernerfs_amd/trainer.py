@@ -248,6 +248,13 @@ class KPlanesTrainer:
             else:
                 off += _align4(n)
         self.n_params = off
+        from .exchange_plan import kplanes_segment_sizes
+
+        # the tensor-free restatement of this layout (what tests/test_exchange_plan_cpu.py checks at world 2 / 4 / 8) must describe THIS buffer
+        sz = kplanes_segment_sizes(base, cfg.multiscale_res, cfg.feature_dim, cfg.proposal_resolutions, cfg.proposal_feature_dim,
+                                   {"prop": self.prop_nets[0].params.numel(), "sigma": self.sigma_net.params.numel(), "color": self.color_net.params.numel()}, self.world)
+        assert (sz["n_params"], sz["n_proposal_params"], sz["field_offset"], sz["field_floats"], sz["field_padded"]) == \
+            (self.n_params, self.n_proposal_params) + tuple(self._field_seg), (sz, self.n_params, self._field_seg)
         self.params = torch.zeros(off, dtype=torch.float32, device=self.dev)
         self.grads = torch.zeros_like(self.params)
         self.exp_avg = torch.zeros_like(self.params)
@@ -342,19 +349,15 @@ class KPlanesTrainer:
         scale (the tail of the segment: planes are laid out scale-major; ~72 % of the floats at the preset), scattered first; chunk 1 =
         everything in front of it.  Inside a chunk rank r owns floats [lo + r * len / world, lo + (r + 1) * len / world).
         cfg.exchange_chunks = 1 restores the single exchange (A-B)."""
+        from .exchange_plan import exchange_chunks
+
         _, n, npad = self._field_seg
-        q = 4 * self.world
-        cuts = [0, npad]
-        ns = len(self.cfg.multiscale_res)
-        if self.cfg.exchange_chunks > 1 and ns > 1:
-            b = (self._finest_offset() + q - 1) // q * q  # the boundary rounded UP: chunk 0 lies wholly inside the finest scale
-            if 0 < b < npad:
-                cuts = [0, b, npad]
         f = lambda k, dt=torch.float32: torch.zeros(k, dtype=dt, device=self.dev)
         self._exchange = []
-        for lo, hi in reversed(list(zip(cuts[:-1], cuts[1:]))):  # finest first
-            shard = (hi - lo) // self.world
-            self._exchange.append({"lo": lo, "hi": hi, "shard": shard, "g_shard": f(shard), "p_shard": f(shard), "rs": None, "ag": None,
+        # the arithmetic lives in exchange_plan.py (checked on the CPU at world 2 / 4 / 8 on the preset's sizes: tests/test_exchange_plan_cpu.py)
+        for ch in exchange_chunks(npad, self._finest_offset(), self.world, self.cfg.exchange_chunks, len(self.cfg.multiscale_res)):
+            shard = ch["shard"]
+            self._exchange.append({"lo": ch["lo"], "hi": ch["hi"], "shard": shard, "g_shard": f(shard), "p_shard": f(shard), "rs": None, "ag": None,
                                    "g16": None, "g16_shard": None, "d16_full": None, "d16_shard": None})
 
     def _repoint(self, flat: torch.Tensor):
@@ -416,21 +419,9 @@ class KPlanesTrainer:
         """Bytes this rank SENDS over the links per optimiser step (= bytes it receives), by collective, from the segment sizes:
         reduce-scatter and all-gather of n elements move (W-1)/W * n * elt each, an all-reduce twice that (ring or direct: the same
         per-rank volume).  World 1: all zero."""
-        W = self.world
-        if W <= 1:
-            return {"total": 0.0}
-        f = (W - 1) / W
-        o, n, npad = self._field_seg
-        if self._sharded():
-            eg = 2 if self.grad_transport == "bf16" else 4
-            ep = 2 if self.param_transport == "bf16" else 4
-            small = self.n_params - npad
-            d = {"reduce_scatter.field": f * npad * eg, "all_gather.field": f * npad * ep, "all_reduce.small_segments": 2 * f * small * 4,
-                 "all_reduce.flags_and_reg_values": 2 * f * (2 * 4 + self.buf["reg"][0].numel() * 4)}
-        else:
-            d = {"all_reduce.flat_gradient": 2 * f * self.n_params * 4, "all_reduce.flags": 2 * f * 2 * 4}
-        d["total"] = float(sum(d.values()))
-        return d
+        from .exchange_plan import link_bytes
+
+        return link_bytes(self.world, self.n_params, self._field_seg[2], self.buf["reg"][0].numel(), self._sharded(), self.grad_transport, self.param_transport)
 
     def _p(self, t):
         return C.c_void_p(t.data_ptr())

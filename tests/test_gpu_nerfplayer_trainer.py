@@ -345,3 +345,67 @@ def test_head_input_kernels_match_the_torch_expressions():
     torch.testing.assert_close(out.view(M, 32).double(), ref, rtol=1e-5, atol=1e-5)
     assert L.snerf_nerfacto_head_input_bwd(p(ghx), p(cams), S, C.c_int64(R), p(gh), p(gapp), p(cells[0]), st) != 0  # both accumulators
     assert L.snerf_nerfacto_head_input_bwd(p(ghx), None, S, C.c_int64(R), p(gh), None, None, st) == 0             # geometry columns only
+
+
+@pytest.mark.parametrize("async_sweep", [True, False])
+@pytest.mark.parametrize("tv,first_level", [(1.0, 0), (0.0, 0), (1.0, 2)])
+def test_tiled_field_backward_is_the_same_step(tv, first_level, async_sweep):
+    """tiled_field_backward=True (round 6: the field table's gradient scatter, temporal-TV step and Adam sweep as ONE owner-computes pass over tiles of table
+    rows, csrc/tgrid_tiles.hip) against the atomic scatter + dense sweep, from the same state on the same batches and draws.  After ONE step the field
+    table's first moment IS the gradient (m = 0.1 g) and the second its square: both equal to summation-order accuracy, every other segment bit for bit
+    (nothing else changed); over 14 steps crossing updated and non-updated proposal steps the loss terms stay together (two runs of either form differ by
+    the order of their float sums), and an evaluation forward right after the last step waits for the side-stream pass by itself."""
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R, n_img, steps = 128, 9, 14
+    cfg = _cfg()
+    cfg.temporal_tv_weight = tv
+
+    def make(tiled):
+        tr = NerfplayerTrainer(cfg, R, n_img, aabb_scale=1.0, device=DEV, seed=5, warm_up_end=4, async_field_sweep=async_sweep, tiled_field_backward=tiled,
+                               tiled_first_level=first_level)
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(1)
+            for name in ("field.table", "prop0.table", "prop1.table"):
+                tr.views[name].copy_((torch.rand(tr.views[name].shape, generator=g) * 2 - 1).to(DEV))
+        tr.tv_rows = [2, 1, 3]
+        return tr
+
+    a, b = make(True), make(False)
+    assert a._tiled is not None and b._tiled is None
+    assert a._tiled.plan.first_tiled_level == first_level
+    off = {name: (o, n) for name, _, _, o, n in a.segments}
+    fo, fn = off["field.table"]
+    rays, cams, target, rng = _batch(R, n_img, 100)
+    for tr in (a, b):
+        tr.train_step(rays, cams, target, rng)
+        tr.synchronize()
+    assert float(a.grads.abs().max()) == 0.0 and float(b.grads.abs().max()) == 0.0  # both leave cleared gradients (the tiled form never wrote the table's)
+    ma, mb = a.exp_avg[fo:fo + fn], b.exp_avg[fo:fo + fn]
+    assert float(mb.abs().max()) > 0
+    torch.testing.assert_close(ma, mb, rtol=1e-4, atol=1e-6 * float(mb.abs().max()))
+    assert bool(((ma != 0) == (mb != 0)).all())
+    torch.testing.assert_close(a.exp_avg_sq[fo:fo + fn], b.exp_avg_sq[fo:fo + fn], rtol=2e-4, atol=1e-12 * float(mb.abs().max()) ** 2)
+    mask = torch.ones(a.n_params, dtype=torch.bool, device=DEV)
+    mask[fo:fo + fn] = False
+    for x, y in ((a.params, b.params), (a.exp_avg, b.exp_avg), (a.exp_avg_sq, b.exp_avg_sq)):
+        # the other segments' kernels are untouched; their float atomics (MLP weight gradients, proposal tables) are order-dependent in both forms
+        torch.testing.assert_close(x[mask], y[mask], rtol=1e-3, atol=1e-6)
+    # Adam's first step moves every touched parameter by ~lr * sign(g): equal wherever the gradient is not at rounding distance from zero
+    moved = (a.params[fo:fo + fn] - b.params[fo:fo + fn]).abs() > 1e-6
+    assert float(moved.float().mean()) < 1e-3
+    la_all, lb_all = [], []
+    for k in range(1, steps):
+        rays, cams, target, rng = _batch(R, n_img, 100 + k)
+        for tr, acc in ((a, la_all), (b, lb_all)):
+            tr.train_step(rays, cams, target, rng)
+            acc.append({k_: float(v) for k_, v in tr.loss_dict().items()})
+    for la, lb in zip(la_all, lb_all):
+        for k_ in lb:
+            assert abs(la[k_] - lb[k_]) <= 3e-2 * abs(lb[k_]) + 1e-7, (k_, la[k_], lb[k_])
+    rays, cams, target, rng = _batch(R, n_img, 999)
+    ra = a.forward(rays, None, rng, 1.0, training=False).clone()  # no explicit join: forward() waits for the side stream itself
+    rb = b.forward(rays, None, rng, 1.0, training=False).clone()
+    a.synchronize(); b.synchronize()
+    assert bool(torch.isfinite(ra).all()) and float((ra - rb).abs().max()) < 5e-2
+    assert float((a.params[fo:fo + fn] - b.params[fo:fo + fn]).abs().mean()) < 2e-3

@@ -42,8 +42,8 @@ def _per_sample_bwd(enc, co, times, spr, B, gout):
 
 
 CASES = [
-    # the preset's main grid at a small table (dense levels, hashed levels, 66-float rows), default split: coarse levels atomic
-    (dict(input_dim=3, temporal_dim=64, num_levels=16, level_dim=2, log2_hashmap_size=15, desired_resolution=2048), 0, -1),
+    # the preset's main grid at a smaller table (dense levels, hashed levels, 66-float rows), default split: levels below 2^16 rows atomic
+    (dict(input_dim=3, temporal_dim=64, num_levels=16, level_dim=2, log2_hashmap_size=17, desired_resolution=2048), 0, -1),
     # every level tiled, small tiles (tile boundaries inside dense levels whose row count is not a multiple of the tile)
     (dict(input_dim=3, temporal_dim=64, num_levels=16, level_dim=2, log2_hashmap_size=15, desired_resolution=2048), 5, 0),
     # a proposal grid of the preset (34-float rows), C = 4 and C = 8 tables, a tiled (non-hashed) grid type
@@ -70,18 +70,24 @@ def test_tiled_scatter_equals_the_per_sample_atomic_kernel(kw, sh, lc, mode):
         ref = _per_sample_bwd(enc, co, times, S, B, gout)
         tb = TiledTableBackward(enc, B, tile_rows_log2=sh, first_tiled_level=lc)
         assert tb.plan.n_tiles == tb.plan.tile_start[enc.num_levels] and (sh == 0 or tb.plan.tile_rows_log2 == sh)
-        got = torch.full_like(ref, 0.25)       # accumulates: the buffer's content stays
+        got = torch.zeros_like(ref)
         tb.bin(co, times, S, gout)
-        tb.scatter(co, times, S, gout, got)
+        tb.coarse_levels(co, times, S, gout, got)
+        tb.scatter(gout, got)
         torch.cuda.synchronize()
         n_rec = int(tb.tile_base[-1])
-        assert 0 < n_rec <= tb.plan.record_capacity
+        assert n_rec <= tb.plan.record_capacity and (n_rec > 0) == (tb.plan.first_tiled_level < enc.num_levels)
         scale = float(ref.abs().max())
         assert scale > 0
         # the same products (w * (g * wt), factors in the same order) summed in another order: a few ulps of the largest partial sum
-        torch.testing.assert_close(got - 0.25, ref, rtol=1e-5, atol=2e-6 * scale)
-        assert float((got - 0.25 - ref).norm() / ref.norm()) < 1e-6
-        assert bool(((got - 0.25 != 0) == (ref != 0)).all())  # exactly the same entries are touched
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6 * scale)
+        assert float((got - ref).norm() / ref.norm()) < 1e-6
+        assert bool(((got != 0) == (ref != 0)).all())  # exactly the same entries are touched
+        # it ACCUMULATES: a second pass over the same records doubles the tiled levels' share, whatever the buffer held
+        again = got.clone()
+        tb.coarse_levels(co, times, S, gout, again)
+        tb.scatter(gout, again)
+        torch.testing.assert_close(again, 2 * ref, rtol=1e-5, atol=4e-6 * scale)
 
 
 @pytest.mark.parametrize("tv", [False, True])
@@ -121,7 +127,7 @@ def test_fused_adam_equals_scatter_then_tv_then_adam(kw, sh, lc, tv):
             _lib.check(L.snerf_tgrid_tv_sign(ops._ptr(p_new), C.c_int64(rows), gc, ca, cb, 0.1, ops._ptr(part), 64, ops._ptr(srow), ops._stream()))
         tb.bin(co, times, S, gout)
         tb.coarse_levels(co, times, S, gout, g_new)
-        tb.scatter_adam(co, times, S, gout, g_new, p_new, m_new, v_new, lr, step, eps, tv_cols=(ca, cb) if tv else None, srow=srow if tv else None)
+        tb.scatter_adam(gout, g_new, p_new, m_new, v_new, lr, step, eps, tv_cols=(ca, cb) if tv else None, srow=srow if tv else None)
         torch.cuda.synchronize()
         assert float(g_new.abs().max()) == 0.0 and float(g_ref.abs().max()) == 0.0  # both leave a cleared gradient buffer
         # Adam's first steps move a parameter by ~lr whatever the gradient's size, so an element whose tiny gradient differs in its last bits (another

@@ -20,6 +20,8 @@ ap.add_argument("--full", action="store_true", help="full NeRFPlayer (`nerfplaye
 ap.add_argument("--profile", action="store_true")
 ap.add_argument("--mlp-operands", default="bf16", choices=["fp32", "bf16"], help="--fused: fp32 = every net exact (the parity path); bf16 = 16-bit MFMA operands where the fused kernels have them")
 ap.add_argument("--sync-sweep", action="store_true", help="A/B (--fused): the field table's optimiser sweep in order on the main stream instead of on a side stream behind its gradient scatter")
+ap.add_argument("--tiled", action="store_true", help="with --fused: the field table through the owner-computes backward + fused Adam (csrc/tgrid_tiles.hip)")
+ap.add_argument("--tiled-first-level", type=int, default=0)
 ap.add_argument("--stadium", action="store_true", help="with --fused: camera rays of the synthetic stadium-players scene (30 cameras in the bleachers, aabb [-1,1]^3, uniform "
                 "pixels) instead of random rays through the box -- what bench.py's config-4 leg times")
 args = ap.parse_args()
@@ -29,7 +31,7 @@ if args.fused:
     from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
 
     R = args.rays
-    tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 36 * 100, device=dev, async_field_sweep=not args.sync_sweep, mlp_operands=args.mlp_operands)
+    tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 36 * 100, device=dev, async_field_sweep=not args.sync_sweep, mlp_operands=args.mlp_operands, tiled_field_backward=args.tiled, tiled_first_level=args.tiled_first_level)
     tr.step = 600  # past the learning-rate warm-up
 
     if args.stadium:
@@ -40,7 +42,7 @@ if args.fused:
         data = synthetic.render_dataset(cams, frame_ids.float() / 99, list(range(30)), dev, chunk_rows=540, variant="stadium")
         M, H, W = data["images"].shape[:3]
         full_index = (data["cam_id"] * 100 + frame_ids.to(dev).repeat(30)).contiguous()
-        tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 3000, aabb_scale=1.0, device=dev, async_field_sweep=not args.sync_sweep, mlp_operands=args.mlp_operands)
+        tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 3000, aabb_scale=1.0, device=dev, async_field_sweep=not args.sync_sweep, mlp_operands=args.mlp_operands, tiled_field_backward=args.tiled, tiled_first_level=args.tiled_first_level)
         tr.step = 600
 
     def fstep():
