@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--interleave-prop-levels", action="store_true", help="A/B: proposal backward interleaved by stage (both net backwards before the two plane scatters) instead of level by level")
     ap.add_argument("--no-config3", action="store_true", help="skip the config-3 leg (K-Planes multiscale 1-32, IST range 0.75, fps-downsample 4; N = 1 only, ~15 s)")
     ap.add_argument("--no-config4", action="store_true", help="skip the config-4 leg (nerfplayer-nerfacto preset on the synthetic stadium-players scene; N = 1 only, ~20 s)")
+    ap.add_argument("--no-tiled-config4", action="store_true", help="A/B: config 4 with the round-5 form (run-length atomic scatter + dense Adam sweep of the main table) instead of "
+                    "the owner-computes pass (csrc/tgrid_tiles.hip)")
     ap.add_argument("--leg-steps", type=int, default=20, help="timed steps of the config-3 / config-4 legs")
     return ap.parse_args()
 
@@ -300,7 +302,9 @@ def config4_leg(dev, args):
     M, H, W = data["images"].shape[:3]
     full_index = (data["cam_id"] * n_frames + frame_ids.to(dev).repeat(n_cams)).contiguous()  # image m of the rendered subset -> its index among the 3000
     mc = NerfplayerNerfactoModelConfig()
-    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev, async_field_sweep=True, mlp_operands=args.mlp_operands if args.mlp_operands in ("fp32", "bf16") else "fp32")
+    tiled = not args.no_tiled_config4
+    tr = NerfplayerTrainer(mc, R, n_cams * n_frames, aabb_scale=1.0, device=dev, async_field_sweep=True, mlp_operands=args.mlp_operands if args.mlp_operands in ("fp32", "bf16") else "fp32",
+                           tiled_field_backward=tiled)
     tr.step = 600  # past the learning-rate warm-up
 
     def step():
@@ -310,7 +314,7 @@ def config4_leg(dev, args):
 
     for _ in range(max(args.warmup, 8)):
         step()
-    tr.enable_kernel_timing(["adam_tv.field.table", "tgrid_fwd.field", "tgrid_bwd.field", "tgrid_fwd.prop", "tgrid_bwd.prop"])
+    tr.enable_kernel_timing(["adam_tv.field.table", "tgrid_tiles_adam.field", "tgrid_bin.field", "tgrid_fwd.field", "tgrid_bwd.field", "tgrid_fwd.prop", "tgrid_bwd.prop"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -325,12 +329,26 @@ def config4_leg(dev, args):
     # SURVEY 8d, config 4, BOTH byte conventions for the main table's gather: 8 corners x 3 live floats (two time rows of a column pair + ...) x 4 B per
     # level = 1536 B per sample algorithmic; 8 corners x one 64-B sector per level = 8192 B per sample at sector granularity
     tg_alg, tg_sector = R * S2 * L * 8 * 3 * 4, R * S2 * L * 8 * 64
-    sweep = kt.get("adam_tv.field.table")
-    roof = _hbm_roofline("adam_tv_kernel over the main temporal grid (Adam + temporal-TV, 32 B / parameter: p,g,m,v read, p,m,v written, g cleared)",
-                         32 * n_table, sweep[0], sweep[1],
-                         note="round 5: launched on a side stream right behind the table's gradient scatter (NerfplayerTrainer async_field_sweep): it runs beside the "
-                              "proposal networks' backward and the next step's ray generation / proposal levels, so its duration includes that sharing "
-                              "(alone: tools/bench_nerfplayer.py --fused --stadium --sync-sweep)") if sweep else None
+    sweep = kt.get("tgrid_tiles_adam.field") if tiled else kt.get("adam_tv.field.table")
+    if tiled:
+        # round 6: scatter + temporal TV + Adam of the main table as ONE owner-computes pass (csrc/tgrid_tiles.hip).  Algorithmic bytes per launch: p, m, v
+        # read and written once = 24 B per parameter (the dense gradient is neither read nor cleared: it does not exist for this table), plus the
+        # per-step records (4 B written by the binning pass, 4 B read here) and what a record's walk reads (16 B position + time, 8 B of gfeat)
+        n_rec = int(tr._tiled.tile_base[-1])
+        roof = _hbm_roofline("tt_tiles_kernel<2,1> over the main temporal grid: gradient scatter (LDS, one owner per 256-row tile) + temporal TV + Adam in one pass; "
+                             "24 B / parameter (p, m, v read and written; no dense gradient) + 28 B per binned record",
+                             24 * n_table + 28 * n_rec, sweep[0], sweep[1],
+                             records_per_launch=n_rec,
+                             note="launched on a side stream right behind the binning pass (NerfplayerTrainer async_field_sweep + tiled_field_backward): it runs beside "
+                                  "the proposal networks' backward and the next step's ray generation / proposal levels, so its duration includes that sharing "
+                                  "(alone: tools/bench_tgrid_tiles.py).  Replaces tgrid_bwd_runs_kernel (1.26 ms at the float-atomic rate) + adam_tv_kernel "
+                                  "(32 B / parameter): bench.py --no-tiled-config4 times that form") if sweep else None
+    else:
+        roof = _hbm_roofline("adam_tv_kernel over the main temporal grid (Adam + temporal-TV, 32 B / parameter: p,g,m,v read, p,m,v written, g cleared)",
+                             32 * n_table, sweep[0], sweep[1],
+                             note="round 5: launched on a side stream right behind the table's gradient scatter (NerfplayerTrainer async_field_sweep): it runs beside the "
+                                  "proposal networks' backward and the next step's ray generation / proposal levels, so its duration includes that sharing "
+                                  "(alone: tools/bench_nerfplayer.py --fused --stadium --sync-sweep)") if sweep else None
     fwd = kt.get("tgrid_fwd.field")
     out = {"value": R * steps / dt, "unit": "rays/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f32" if tr.mlp_operands == "fp32" else tr.mlp_operands,
            "dtype_note": "tables, sampling, compositing, losses, gradient accumulation and the optimiser f32; " + ("every net exact f32" if tr.mlp_operands == "fp32" else

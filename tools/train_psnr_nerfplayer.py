@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20231029)
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16"], help="NerfplayerTrainer(mlp_operands=...): bf16 MFMA operands in the decode net and the colour head")
     ap.add_argument("--async-sweep", action="store_true", help="NerfplayerTrainer(async_field_sweep=True): the main table's optimiser sweep on a side stream")
+    ap.add_argument("--tiled", action="store_true", help="NerfplayerTrainer(tiled_field_backward=True): the main table's scatter + TV + Adam as one owner-computes pass (round 6)")
     args = ap.parse_args()
     dev = torch.device("cuda:0"); torch.manual_seed(args.seed)
     R = 4096
@@ -55,10 +56,10 @@ def main():
     held = synthetic.render_dataset(cams, times, list(range(30, 36)), dev, chunk_rows=Hd, variant=variant)
     M, H, W = train["images"].shape[:3]
     tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, M, aabb_scale=1.0 if stadium else 1.5, device=dev, max_steps=args.steps,
-                           mlp_operands=args.mlp_operands, async_field_sweep=args.async_sweep)
+                           mlp_operands=args.mlp_operands, async_field_sweep=args.async_sweep, tiled_field_backward=args.tiled)
     log = {"config": f"nerfplayer-nerfacto preset, fused trainer, synthetic {'stadium-players scene' if stadium else 'clip'} ({M} training images {W}x{H}, "
                      f"{len(times)} frames per camera, 6 cameras held out), seed {args.seed}", "scene": args.scene, "mlp_operands": args.mlp_operands,
-           "async_field_sweep": bool(args.async_sweep), "evals": []}
+           "async_field_sweep": bool(args.async_sweep), "tiled_field_backward": bool(args.tiled), "evals": []}
     t_train = 0.0
     for step in range(args.steps):
         if step % 500 == 0:
