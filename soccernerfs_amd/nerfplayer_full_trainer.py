@@ -37,7 +37,7 @@ def _align4(n: int) -> int:
 class NerfplayerFullTrainer:
     def __init__(self, cfg: NerfplayerModelConfig, num_rays: int, aabb_scale: float = 1.0, device="cuda:0", lr: float = 1e-2,
                  adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
-                 async_table_sweeps: bool = False, mlp_operands: str = "fp32"):
+                 async_table_sweeps: bool = False, mlp_operands: str = "fp32", tiled_table_backward: bool = False):
         """mlp_operands: "fp32" (exact: every net on the fp32 matrix instructions -- the parity path, what G13 / G13b pin) or "bf16" (round 5: bf16 MFMA
         operands with fp32 accumulation in every net -- the fused kernels for the shapes in their table, csrc/dense_lp.hip's single layers for the
         deformation net, the 33 -> 64 -> 32 MLP and the colour head; the reference itself runs all of them in tcnn's fp16).
@@ -46,6 +46,10 @@ class NerfplayerFullTrainer:
         the next forward's first read of those tables: they run beside the rest of the backward (hash-grid scatter, deformation net, proposal networks)
         and the next step's proposal levels.  Same arithmetic (same bits in deterministic mode).  Readers of those tables outside forward() call
         wait_params() / synchronize() first; off by default for that reason.
+        tiled_table_backward (round 6): inside train_step the newness and decomposition tables' gradient scatter, temporal-TV step and Adam sweep are ONE
+        owner-computes pass each (temporal_grid.TiledTableBackward, csrc/tgrid_tiles.hip): no float atomics on the deformed positions (tgrid_bwd_runs_kernel
+        <false> ran at the atomic rate, 2.0 ms per step) and no dense gradient for the two tables (24 instead of 32 B per parameter).  Same mathematics, float
+        sums in another order.  Needs temporal_tv_weight > 0 (the preset); not with `deterministic`; backward() outside train_step keeps the atomic scatter.
         deterministic: every gradient accumulated across samples -- the temporal-grid and hash-grid table scatters, the hash grid's coordinate
         gradient (one add per level and sample), the weight gradients of all seven nets -- goes into 2^50-scaled 64-bit cells
         (snerf_*_bwd_fx; integer adds are associative) and is converted once per step: two runs from the same state and draws give the same bits.
@@ -159,6 +163,11 @@ class NerfplayerFullTrainer:
         self._tv_cols = [(0, 1)] * 4
         self.launches = 0  # libsnerf launches of the last step (diagnostics)
         self.async_table_sweeps = bool(async_table_sweeps)
+        self._tiled = None
+        if tiled_table_backward and not deterministic and cfg.temporal_tv_weight > 0:
+            from .temporal_grid import TiledTableBackward
+
+            self._tiled = [TiledTableBackward(self.newness, N, first_tiled_level=0), TiledTableBackward(self.decomp, N, first_tiled_level=0)]
         self._side, self._sweeps_done, self._swept, self._in_train_step, self._tv01_done = None, None, (), False, None
 
     # ---- helpers ----
@@ -233,6 +242,29 @@ class NerfplayerFullTrainer:
                     ops.fx_to_float(self.grads_fx[o:o + gv.numel()], gv.view(-1), accumulate=True)
                 self._sweep_table(k, lr, st)
             self._sweeps_done = self._side.record_event()
+        self._swept = (0, 1)
+
+    def _tiled_fused_adam(self, gouts, on_side: bool):
+        """tiled_table_backward: scatter + temporal TV + Adam of the newness (k = 0) and decomposition (k = 1) tables, one owner-computes pass each, over the
+        tiles filed by `bin`; on the side stream (async_table_sweeps) it reads only the tilers' own buffers and the two feature-gradient buffers, which the
+        next step rewrites after wait_params() at the earliest."""
+        lr = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+
+        def run(st):
+            for k in (0, 1):
+                o, n = next((o, n) for name, _, _, o, n in self.segments if name == self._enc_names[k])
+                sl = slice(o, o + n)
+                self._tiled[k].scatter_adam(gouts[k], None, self.params[sl], self.exp_avg[sl], self.exp_avg_sq[sl], lr, self.step + 1, self.adam_eps,
+                                            tv_cols=self._tv_cols[k], srow=self._srow[k], stream=st)
+                self.launches += 1
+
+        if on_side:
+            self._side.wait_stream(torch.cuda.current_stream())  # (the two tables' TV passes have been on this stream since the start of the backward)
+            with torch.cuda.stream(self._side):
+                run(C.c_void_p(self._side.cuda_stream))
+                self._sweeps_done = self._side.record_event()
+        else:
+            run(self._st)
         self._swept = (0, 1)
 
     def _tgrid_fwd(self, enc, co, times, spr, N, out):
@@ -438,10 +470,21 @@ class NerfplayerFullTrainer:
                                                    self._p(b["gprobs"]), C.c_int64(N), F, self._p(b["gsv"]), self._p(b["gsv"], N * F), self._p(b["gvnew"]),
                                                    self._p(b["glogits"]), self._st), "mix_bwd")
         self._mlp_bwd(self.decomp_mlp, self.gviews["field.decomp_mlp"], b["dfeat"], F, N, b["glogits"], 3, -1, None, b["gdfeat"], F)
-        self._tgrid_bwd(self.decomp, self._pts, b["tN"], 1, N, b["gdfeat"], self.gviews["field.decomp"])
-        self._tgrid_bwd(self.newness, self._pts, b["tN"], 1, N, b["gvnew"], self.gviews["field.newness"])
-        if early:
-            self._early_table_sweeps()
+        if self._tiled is not None and self._in_train_step:
+            # owner-computes form: bin both tables' touches here (the pass reads the deformed positions), then scatter + TV + Adam per table as one pass
+            gouts = (b["gvnew"], b["gdfeat"])
+            for k in (0, 1):
+                self._tiled[k].bin(self._pts, b["tN"], 1, gouts[k], self._st)
+                self.launches += 5
+            if not early:
+                for k in (0, 1):
+                    self._tv_sign(k)  # the fused pass adds the TV step itself (row draw order unchanged: newness, decomposition first)
+            self._tiled_fused_adam(gouts, early)
+        else:
+            self._tgrid_bwd(self.decomp, self._pts, b["tN"], 1, N, b["gdfeat"], self.gviews["field.decomp"])
+            self._tgrid_bwd(self.newness, self._pts, b["tN"], 1, N, b["gvnew"], self.gviews["field.newness"])
+            if early:
+                self._early_table_sweeps()
         self._dense_chain_bwd(self.stat_mlp, "field.stat_mlp", ("relu", "none"), b["sx"], 36, 0, 2 * N, [b["sh"], b["sv"]], b["gsv"], F, [b["gsh"], b["gsh"]],
                               b["gsx"], 36)
         b["genc2"].copy_(b["gsx"][:, :F])

@@ -235,3 +235,54 @@ def test_fifty_training_steps_track_the_reference_models_own_run():
     assert end_rgb < 0.8 * float(gb["loss_rgb_loss"][0]) and end_static > 0.7, (end_rgb, end_static)
     print(f"G13b: worst deviation of the mean (over {N_RUNS} runs) window means from the reference's run (steps 5..49):", {k: round(v, 4) for k, v in worst.items()},
           "end static probability per run:", [round(float(h["probs"][-1][0]), 3) for h in runs])
+
+
+@pytest.mark.parametrize("async_sweeps", [True, False])
+def test_tiled_table_backward_is_the_same_step(async_sweeps):
+    """tiled_table_backward=True (round 6: the newness and decomposition tables' gradient scatter on the DEFORMED positions, temporal-TV step and Adam sweep as
+    one owner-computes pass each, csrc/tgrid_tiles.hip) against the atomic scatter + dense sweeps from the same state, batch and draws: after one step both
+    tables' first moments (= 0.1 x gradient, TV term included) and second moments agree to summation-order accuracy, the same entries are touched, the
+    gradient buffer is left cleared; six more steps keep the loss terms together and an evaluation forward waits for the side-stream pass by itself."""
+    from soccernerfs_amd.nerfplayer_full_trainer import NerfplayerFullTrainer
+
+    R = 96
+    cfg = _cfg(1.0)
+
+    def make(tiled):
+        tr = NerfplayerFullTrainer(cfg, R, aabb_scale=1.0, device=DEV, seed=3, async_table_sweeps=async_sweeps, tiled_table_backward=tiled)
+        gen = torch.Generator(device=DEV).manual_seed(5)
+        with torch.no_grad():
+            for name in ("field.hash", "field.newness", "field.decomp", "prop0.table", "prop1.table"):
+                tr.views[name].copy_(torch.rand(tr.views[name].shape, device=DEV, generator=gen) * 2 - 1)
+        tr.tv_rows = [2, 1, 3, 0]
+        return tr
+
+    a, b = make(True), make(False)
+    assert a._tiled is not None and b._tiled is None
+    rays, target, rng = _batch(R, 11)
+    for tr in (a, b):
+        tr.train_step(rays, target, rng)
+        tr.synchronize()
+    assert float(a.grads.abs().max()) == 0.0 and float(b.grads.abs().max()) == 0.0
+    off = {name: (o, n) for name, _, _, o, n in a.segments}
+    for name in ("field.newness", "field.decomp"):
+        o, n = off[name]
+        ma, mb = a.exp_avg[o:o + n], b.exp_avg[o:o + n]
+        scale = float(mb.abs().max())
+        assert scale > 0
+        torch.testing.assert_close(ma, mb, rtol=1e-4, atol=2e-6 * scale)
+        assert float(((ma != 0) != (mb != 0)).float().mean()) < 1e-5  # (a sum that cancels to exactly 0 in one association order only)
+        torch.testing.assert_close(a.exp_avg_sq[o:o + n], b.exp_avg_sq[o:o + n], rtol=4e-4, atol=1e-11 * scale * scale)
+    la_all, lb_all = [], []
+    for k in range(6):
+        rays, target, rng = _batch(R, 20 + k)
+        for tr, acc in ((a, la_all), (b, lb_all)):
+            tr.train_step(rays, target, rng)
+            acc.append({k_: float(v) for k_, v in tr.loss_dict().items()})
+    for la, lb in zip(la_all[:3], lb_all[:3]):  # (this model's trajectories separate within ~5 steps whatever the arithmetic: DESIGN section 5)
+        for k_ in lb:
+            assert abs(la[k_] - lb[k_]) <= 5e-2 * abs(lb[k_]) + 1e-6, (k_, la[k_], lb[k_])
+    rays, target, rng = _batch(R, 99)
+    ra = a.forward(rays, None, 1.0, training=False).clone()
+    a.synchronize(); b.synchronize()
+    assert bool(torch.isfinite(ra).all()) and bool(torch.isfinite(a.params).all())

@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20231029)
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16"], help="NerfplayerFullTrainer(mlp_operands=...)")
     ap.add_argument("--async-sweeps", action="store_true", help="NerfplayerFullTrainer(async_table_sweeps=True)")
+    ap.add_argument("--tiled", action="store_true", help="NerfplayerFullTrainer(tiled_table_backward=True) (round 6)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(args.seed)
@@ -84,7 +85,7 @@ def main():
     M, H, W = train["images"].shape[:3]
     cfg = NerfplayerModelConfig(prob_reg_loss_mult=args.prob_reg)
     tr = NerfplayerFullTrainer(cfg, R, aabb_scale=1.5, device=dev, max_steps=args.steps, seed=args.seed, mlp_operands=args.mlp_operands,
-                               async_table_sweeps=args.async_sweeps)
+                               async_table_sweeps=args.async_sweeps, tiled_table_backward=args.tiled)
     log = {"config": f"nerfplayer preset (full NeRFPlayer), fused flat-buffer trainer, synthetic clip ({M} training images {W}x{H} from 36 cameras; "
                      f"3 evaluation-only cameras between them), prob_reg_loss_mult {args.prob_reg}", "params": int(tr.n_params), "mlp_operands": args.mlp_operands,
            "async_table_sweeps": bool(args.async_sweeps), "evals": []}
