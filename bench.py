@@ -334,7 +334,7 @@ def config4_leg(dev, args):
         # round 6: scatter + temporal TV + Adam of the main table as ONE owner-computes pass (csrc/tgrid_tiles.hip).  Algorithmic bytes per launch: p, m, v
         # read and written once = 24 B per parameter (the dense gradient is neither read nor cleared: it does not exist for this table), plus the
         # per-step records (4 B written by the binning pass, 4 B read here) and what a record's walk reads (16 B position + time, 8 B of gfeat)
-        n_rec = int(tr._tiled.tile_base[-1])
+        n_rec = int(tr._tiled.tile_base[tr._tiled.plan.n_tiles])
         roof = _hbm_roofline("tt_tiles_kernel<2,1> over the main temporal grid: gradient scatter (LDS, one owner per 256-row tile) + temporal TV + Adam in one pass; "
                              "24 B / parameter (p, m, v read and written; no dense gradient) + 28 B per binned record",
                              24 * n_table + 28 * n_rec, sweep[0], sweep[1],

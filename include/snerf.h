@@ -557,7 +557,8 @@ typedef struct {
 /* Host arithmetic only.  tile_rows_log2 <= 0: the largest tile that lets two workgroups share a CU's LDS; first_tiled_level < 0: levels with fewer than
  * 2^16 rows stay atomic. */
 int snerf_tgrid_tile_plan_make(const snerf_tgrid_desc* desc, int64_t B, int32_t tile_rows_log2, int32_t first_tiled_level, snerf_tgrid_tile_plan* plan);
-/* counts [count_ints] and tile_base [n_tiles + 1] are workspaces (no initialisation needed); records [record_capacity]; pos4 [B,4] (16-byte aligned)
+/* counts [count_ints] and tile_base [n_tiles + 3] are workspaces (no initialisation needed: n_tiles + 1 prefix sums, then two words the fused tile pass
+ * uses to hand out tiles); records [record_capacity]; pos4 [B,4] (16-byte aligned)
  * receives (x, y, z, time) per sample -- the later passes read ONLY pos4, grad_out, tile_base and records, never `coords`, so they may run on another
  * stream while the caller's ray buffers are rewritten.  B < 2^28. */
 int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
@@ -570,7 +571,7 @@ int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_p
  * grad_embeddings holds for the rows of levels [0, first_tiled_level) (read and cleared; may be NULL when first_tiled_level = 0) + the temporal-TV
  * term srow[row] on column col_a and -srow[row] on col_b (col_a < 0: none; srow from snerf_tgrid_tv_sign).  A non-finite gradient element is dropped. */
 int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, int64_t B, const float* grad_out, const float* pos4,
-                               const int32_t* tile_base, const uint32_t* records, float* grad_embeddings, float* p, float* m, float* v, float lr,
+                               int32_t* tile_base, const uint32_t* records, float* grad_embeddings, float* p, float* m, float* v, float lr,
                                float beta1, float beta2, float eps, int32_t step, int32_t col_a, int32_t col_b, const float* srow, snerf_stream_t stream);
 /* snerf_tgrid_encode_bwd for levels [level_begin, level_end) only (the coarse levels beside the tiled form). */
 int snerf_tgrid_encode_bwd_levels(const snerf_tgrid_desc* desc, const snerf_coords* coords, const float* temporal_row_index, const float* times,

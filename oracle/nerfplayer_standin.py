@@ -1,0 +1,229 @@
+"""Stock-PyTorch NeRFPlayer-nerfacto train step -- the reference-ALGORITHM stand-in for BASELINE config 4's PSNR.  BASELINE / TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+The reference's CUDA stack (its own temporal_gridencoder.cu, tiny-cuda-nn) cannot run on an MI355X, so "matched PSNR" for config 4 is anchored the way
+config 2's is (oracle/torch_standin.py): the same algorithm in stock PyTorch-ROCm ops, trained on the same scene with the same schedule, next to the HIP trainer.
+
+What one `train_step` does follows Trainer.train_iteration (NS/engine/trainer.py:383-412) for the `nerfplayer-nerfacto` preset (NS/configs/method_configs.py:616-660):
+NerfplayerNerfactoModel.get_outputs / get_metrics_dict / get_loss_dict (NS/models/nerfplayer_nerfacto.py:206-318) -- AABB collider (near 0), piecewise sampler with a
+single jitter, two temporal-hash-grid proposal networks (TemporalHashMLPDensityField, NS/fields/nerfplayer_nerfacto_field.py:107-146), the main field (:313-409:
+temporal grid -> 32->64->16 MLP, trunc_exp density, [SH4(dir) | 15 geo | appearance(cam)] -> 63->64->64->3 sigmoid), weights, rgb with a random background, MSE +
+interlevel + 1e-3 distortion + temporal TV of the three tables (random row each) -> autograd -> Adam (lr 1e-2 x cosine with 512 warm-up steps, eps 1e-12) with the
+proposal-weight annealing and the proposal update schedule of NS/models/nerfacto.py:235-264.
+
+The temporal grid is the oracle's restatement (oracle/tgrid_oracle.py: channel table, get_temporal_index, hash / dense row index, trilinear corners -- pinned there
+against the reference's known-answer test and its own HashEncoding), vectorised over the eight corners so that it runs on the device; `tests/test_standin_cpu.py`
+checks this file's encoder against tgrid_oracle.encode value for value.  Each level's table is its own leaf tensor (autograd then builds one level-sized gradient
+per level instead of sixteen table-sized ones); values and layout are the reference's [rows, level_dim + temporal_dim].
+
+Interface = what tools/train_psnr_nerfplayer.py uses of NerfplayerTrainer: R, step, train_step(rays, cams, target), forward(rays, None, rng, anneal, training=False),
+loss_dict()."""
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import kplanes_oracle as KO
+from . import tgrid_oracle as TO
+
+P1, P2 = 2654435761, 805459861  # temporal_gridencoder.cu:49
+
+
+class TorchTemporalGrid:
+    """One TemporalGridEncoder (NS/field_components/temporal_grid.py:159-376) on per-level leaf tensors; D = 3."""
+
+    def __init__(self, embeddings: torch.Tensor, offsets: List[int], log2_scale: float, base_res: int, level_dim: int, gridtype: int = 0):
+        self.offsets, self.C, self.gc = list(offsets), level_dim, embeddings.shape[1]
+        self.L = len(offsets) - 1
+        self.levels = [embeddings[offsets[l]:offsets[l + 1]].detach().clone().requires_grad_(True) for l in range(self.L)]
+        self.rows_total = offsets[-1]
+        self.meta = []
+        for l in range(self.L):
+            rows = offsets[l + 1] - offsets[l]
+            scale = float(np.float32(np.exp2(np.float32(l * log2_scale))) * np.float32(base_res) - np.float32(1.0))  # temporal_gridencoder.cu:146-148 in fp32
+            resolution = int(math.ceil(scale)) + 1
+            stride, strides = 1, []
+            for _ in range(3):  # get_grid_index, .cu:62-88: axes beyond the overflowing stride do not contribute
+                strides.append(stride if stride <= rows else 0)
+                if stride <= rows:
+                    stride *= resolution + 1
+            self.meta.append((scale, rows, gridtype == 0 and stride > rows, strides))
+        T = self.gc - level_dim
+        self.n_trows = max(T - 1, 1)
+        self.index_ab = TO.channel_table(T, level_dim)["index_ab"].tolist()
+        self._corner = None
+
+    def table(self) -> torch.Tensor:
+        return torch.cat([t.detach() for t in self.levels], 0)
+
+    def encode(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """x [B,3] in [0,1], t [B] in [0,1] -> [B, L*C] (kernel_grid, temporal_gridencoder.cu:107-203 with get_temporal_index, temporal_grid.py:320-330)."""
+        dev, C, B = x.device, self.C, x.shape[0]
+        if self._corner is None or self._corner.device != dev:
+            self._corner = torch.tensor([[(i >> d) & 1 for d in range(3)] for i in range(8)], device=dev)  # [8,3], x fastest
+        cb = self._corner
+        n = self.n_trows - 1
+        v = t * n
+        r = v.long()
+        r = torch.where(t == 1, torch.full_like(r, n), r)
+        p = r % C
+        q = torch.arange(C, device=dev)[None, :]
+        occ = torch.where(r[:, None] > q, C + q + C * torch.div(r[:, None] - 1 - q, C, rounding_mode="floor"), q.expand(B, C))  # the closed form of channel_table
+        blend = q == p[:, None]
+        wa = torch.where(blend, (r + 1 - v)[:, None], torch.ones(B, C, device=dev, dtype=x.dtype))
+        wb = (v - r)  # weight of the entering column C + r in channel p
+        cols = torch.cat([occ, (C + r)[:, None]], 1)  # [B, C+1]
+        oob = ((x < 0) | (x > 1)).any(-1)
+        outs = []
+        for l, (scale, rows, hashed, strides) in enumerate(self.meta):
+            pos = x * scale + 0.5
+            pg = torch.floor(pos)
+            frac = pos - pg
+            pgc = pg.long()[:, None, :] + cb[None]                                  # [B,8,3]
+            w3 = torch.where(cb[None].bool(), frac[:, None, :], 1 - frac[:, None, :])   # [B,8,3]
+            w = w3[..., 0] * w3[..., 1] * w3[..., 2]                                # factors in axis order, as the kernel multiplies them
+            if hashed:
+                idx = (pgc[..., 0] & 0xFFFFFFFF) ^ ((pgc[..., 1] * P1) & 0xFFFFFFFF) ^ ((pgc[..., 2] * P2) & 0xFFFFFFFF)
+            else:
+                idx = (pgc[..., 0] * strides[0] + pgc[..., 1] * strides[1] + pgc[..., 2] * strides[2]) & 0xFFFFFFFF
+            row = idx % rows                                                        # [B,8]
+            row = torch.where(oob[:, None], torch.zeros_like(row), row)              # (an out-of-range sample reads nothing: masked below)
+            vals = self.levels[l][row[:, :, None], cols[:, None, :]]                 # [B,8,C+1]
+            va, vb = vals[..., :C], vals[..., C]
+            per_corner = va * wa[:, None, :] + blend[:, None, :] * (vb * wb[:, None])[..., None]
+            res = (w[..., None] * per_corner).sum(1)                                 # [B,C]
+            outs.append(torch.where(oob[:, None], torch.zeros_like(res), res))
+        return torch.stack(outs, 1).reshape(B, self.L * C)
+
+    def tv_loss(self, row: int) -> torch.Tensor:
+        """get_temporal_tv_loss (temporal_grid.py:352-376): mean over ALL table rows of |E[:, A] - E[:, B]| for the drawn row of the index list."""
+        a, b = self.index_ab[row]
+        return sum((e[:, a] - e[:, b]).abs().sum() for e in self.levels) / self.rows_total
+
+
+class NerfplayerStandinTrainer:
+    """Starts from the parameters of a freshly constructed soccernerfs_amd.nerfplayer_trainer.NerfplayerTrainer (tables, MLP weights in Linear layout, appearance
+    embedding: both arms of the comparison begin at the same point); from then on nothing of the product is used."""
+
+    def __init__(self, init_from, device, max_steps: int = 30000, lr: float = 1e-2, adam_eps: float = 1e-12, warm_up_end: int = 512):
+        tr = init_from
+        self.cfg, self.R, self.S, self.aabb_list = tr.cfg, tr.R, tr.S, tr.aabb
+        self.dev = torch.device(device)
+        self.aabb = torch.tensor(tr.aabb, dtype=torch.float32, device=self.dev)
+        self.max_steps, self.lr, self.warm_up_end = max_steps, lr, warm_up_end
+        mk = lambda enc: TorchTemporalGrid(enc.embeddings.detach().to(self.dev), enc.offsets.tolist(), float(np.log2(enc.per_level_scale)), enc.base_resolution,
+                                           enc.level_dim, enc.gridtype_id)
+        self.prop_grid = [mk(e) for e in tr.prop_enc]
+        self.grid = mk(tr.enc)
+        lw = lambda net: [w.detach().clone().to(self.dev).requires_grad_(True) for w in net.linear_weights()]
+        self.prop_w = [lw(n) for n in tr.prop_mlp]
+        self.decode_w, self.head_w = lw(tr.decode), lw(tr.head)
+        self.appearance = tr.appearance.weight.detach().clone().to(self.dev).requires_grad_(True)
+        prop = [t for g in self.prop_grid for t in g.levels] + [w for ws in self.prop_w for w in ws]
+        fld = self.grid.levels + self.decode_w + self.head_w + [self.appearance]
+        self.groups = {"proposal_networks": prop, "fields": fld}
+        kw = {"fused": True} if self.dev.type == "cuda" else {}
+        self.opts = {k: torch.optim.Adam(v, lr=lr, eps=adam_eps, **kw) for k, v in self.groups.items()}
+        self.step, self._since = 0, 0
+        self._ld: Dict[str, torch.Tensor] = {}
+        self.tv_rows: Optional[List[int]] = None
+
+    # ---- the model ----
+    def _density(self, k: int, pos, times_rs):
+        R, S = pos.shape[:2]
+        x = KO.normalize_positions(pos, self.aabb).reshape(-1, 3)
+        feat = self.prop_grid[k].encode(x, times_rs.reshape(-1))
+        return KO.trunc_exp(KO.mlp(feat, self.prop_w[k])).view(R, S)
+
+    def _field(self, pos, dirs, times_rs, app_rows):
+        R, S = pos.shape[:2]
+        x = KO.normalize_positions(pos, self.aabb).reshape(-1, 3)
+        h = KO.mlp(self.grid.encode(x, times_rs.reshape(-1)), self.decode_w)
+        density = KO.trunc_exp(h[:, :1]).view(R, S)
+        ex = lambda v: v[:, None, :].expand(R, S, v.shape[-1]).reshape(R * S, -1)
+        rgb = KO.mlp(torch.cat([ex(TO.sh4(dirs)), h[:, 1:], ex(app_rows)], -1), self.head_w, out_act="Sigmoid").view(R, S, 3)
+        return density, rgb
+
+    def _render(self, rays, cams, rng, anneal: float, training: bool, proposal_grad: bool):
+        cfg = self.cfg
+        o, d, t = rays["origins"], rays["directions"], rays["times"].reshape(-1)
+        R = o.shape[0]
+        nears, fars = KO.intersect_aabb(o, d, self.aabb, 0.0, training)  # AABBBoxCollider(scene_box): near_plane 0
+        levels = list(cfg.num_proposal_samples_per_ray) + [cfg.num_nerf_samples_per_ray]
+        weights_list, sdist_list = [], []
+        weights = bins = None
+        for li, S in enumerate(levels):
+            if li == 0:
+                bins = KO.spaced_bins(R, S, rng["t_rand"] if training else None).to(o.device)  # single jitter: one draw per ray (nerfplayer_nerfacto.py:99)
+            else:
+                u = KO.pdf_u(R, S, rng["u"][li - 1] if training else None).to(o.device)
+                bins, _, _ = KO.pdf_sample(torch.pow(weights, anneal), bins, u)
+            eucl = KO.spacing_to_euclidean(bins, nears, fars, kind="piecewise")  # UniformLinDispPiecewiseSampler (ray_samplers.py:238-246)
+            starts, ends = eucl[:, :-1], eucl[:, 1:]
+            pos = KO.sample_positions(o, d, starts, ends)
+            trs = t[:, None].expand(R, S)
+            if li < len(levels) - 1:
+                with (torch.enable_grad() if proposal_grad else torch.no_grad()):
+                    dens = self._density(li, pos, trs)
+                weights = KO.get_weights(ends - starts, dens)
+                weights_list.append(weights)
+                sdist_list.append(bins)
+        if training:
+            app = self.appearance[cams]
+        elif cfg.use_average_appearance_embedding:
+            app = self.appearance.mean(0, keepdim=True).expand(R, -1)  # nerfplayer_nerfacto_field.py:362-372
+        else:
+            app = torch.zeros(R, self.appearance.shape[1], device=o.device)
+        density, rgb = self._field(pos, d, trs, app)
+        weights = KO.get_weights(ends - starts, density)
+        weights_list.append(weights)
+        sdist_list.append(bins)
+        out_rgb = KO.render_rgb(rgb, weights, rng["bg"], training)  # background "random" in training AND eval (renderers.py:102-104)
+        if not training:
+            out_rgb = torch.clamp(out_rgb, 0.0, 1.0)
+        return out_rgb, weights_list, sdist_list
+
+    def train_step(self, rays, cams, target, rng: Optional[Dict] = None):
+        cfg, R = self.cfg, self.R
+        step = self.step
+        anneal = KO.anneal_value(step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope) if cfg.use_proposal_weight_anneal else 1.0
+        sstep = max(step - 1, 0)  # the sampler's counter is set by the AFTER_TRAIN_ITERATION callback (nerfacto.py:249-263)
+        sched = float(np.clip(np.interp(sstep, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1, cfg.proposal_update_every))
+        updated = self._since > sched or sstep < 10
+        if rng is None:
+            flat = torch.rand(R * 6, device=self.dev)
+            rng = {"t_rand": flat[:R].view(R, 1), "u": [flat[R:2 * R].view(R, 1), flat[2 * R:3 * R].view(R, 1)], "bg": flat[3 * R:].view(R, 3)}
+        lr = self.lr * KO.cosine_lr_factor(step, self.warm_up_end, self.max_steps)
+        for opt in self.opts.values():
+            for g in opt.param_groups:
+                g["lr"] = lr
+            opt.zero_grad(set_to_none=False)  # the reference's torch (1.13) zeroes instead of dropping: a proposal net whose backward was skipped is stepped with g = 0
+        rgb, wl, sl = self._render(rays, cams.long(), rng, anneal, True, updated)
+        ld = {"rgb_loss": torch.mean((target - rgb) ** 2), "interlevel_loss": cfg.interlevel_loss_mult * KO.interlevel_loss(wl, sl),
+              "distortion_loss": cfg.distortion_loss_mult * KO.distortion_loss(wl[-1], sl[-1])}
+        if cfg.temporal_tv_weight > 0:
+            grids = [self.grid] + self.prop_grid  # field, proposal 0, proposal 1: the order of the reference's randint draws (nerfplayer_nerfacto.py:311-316)
+            rows = self.tv_rows if self.tv_rows is not None else [int(torch.randint(0, len(g.index_ab), [1]).item()) for g in grids]
+            ld["temporal_tv_loss"] = cfg.temporal_tv_weight * sum(g.tv_loss(r) for g, r in zip(grids, rows))
+        sum(ld.values()).backward()
+        self._ld = {k: v.detach() for k, v in ld.items()}
+        # every parameter that has ever had a gradient is stepped every step (zeroed, not dropped, gradients: see above) -- what the HIP trainer's one sweep does
+        for opt in self.opts.values():
+            opt.step()
+        if updated:
+            self._since = 0
+        self._since += 1
+        self.step += 1
+        return rgb.detach()
+
+    @torch.no_grad()
+    def forward(self, rays, cams, rng, anneal: float, training: bool = False):
+        assert not training
+        return self._render(rays, None, rng, anneal, False, False)[0]
+
+    def loss_dict(self) -> Dict[str, torch.Tensor]:
+        return self._ld
+
+    def synchronize(self):
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)

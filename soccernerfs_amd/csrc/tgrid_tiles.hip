@@ -159,6 +159,8 @@ __global__ __launch_bounds__(1024) void tt_scan_tiles_kernel(int32_t* __restrict
     int total = 0;
     for (int k = 0; k < 16; ++k) total += wsum[k];
     tile_base[n_tiles] = total;
+    tile_base[n_tiles + 1] = 0;  // the wave-specialised tile kernel's ticket and exit counter (it leaves them at zero itself; this covers an aborted launch)
+    tile_base[n_tiles + 2] = 0;
   }
 }
 
@@ -200,18 +202,26 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
   int cur = qa + (int)threadIdx.x;
   if (stream) load(PA, MA, VA, cur);
 
+  // ---- the tile's records: this thread's first record and its position are requested before the LDS image is cleared (two dependent round trips) ----
+  const int rec0 = a.tile_base[tile], rec1 = a.tile_base[tile + 1];
+  int i_next = rec0 + (int)threadIdx.x;
+  uint32_t rec_next = i_next < rec1 ? a.records[i_next] : 0u;
+  float4 ps_next = i_next < rec1 ? a.pos4[rec_next >> 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+
   for (int q = threadIdx.x; q < nq; q += TT_NT) *reinterpret_cast<float4*>(tt_acc + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
   lds_barrier();
 
-  // ---- the tile's records ----
-  const int rec0 = a.tile_base[tile], rec1 = a.tile_base[tile + 1];
   const int n_trows = gc - C - 1;
   const int gstride = a.d.L * C;
-  for (int i = rec0 + (int)threadIdx.x; i < rec1; i += TT_NT) {
-    const uint32_t rec = a.records[i];
+  for (int i = i_next; i < rec1; i += TT_NT) {
+    const uint32_t rec = rec_next;
+    const float4 ps = ps_next;
+    if (i + TT_NT < rec1) {  // the next record of this thread (tiles of the coarse levels hold thousands)
+      rec_next = a.records[i + TT_NT];
+      ps_next = a.pos4[rec_next >> 4];
+    }
     const int64_t b = (int64_t)(rec >> 4);
     const int yz = (int)(rec >> 2) & 3, xm = (int)(rec & 3u);
-    const float4 ps = a.pos4[b];
     const float x[3] = {ps.x, ps.y, ps.z};
     uint32_t pg[3];
     float fr[3];
@@ -251,19 +261,18 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
       }
     }
   }
-  lds_barrier();
-
   if (MODE == 1 && a.col_a >= 0) {
-    // temporal TV (temporal_grid.py:352-376): srow[row] = weight / rows * sign(E[row, a] - E[row, b]) from the OLD table (tgrid_tv_sign_kernel)
+    // temporal TV (temporal_grid.py:352-376): srow[row] = weight / rows * sign(E[row, a] - E[row, b]) from the OLD table (tgrid_tv_sign_kernel); added with
+    // LDS atomics like the records' terms, in the same phase (no barrier of its own)
     for (uint32_t lr = threadIdx.x; lr < nrows; lr += TT_NT) {
       const float s = a.srow[(int64_t)lv.off0 + row0 + lr];
       if (s != 0.f) {
-        tt_acc[ph + (int)lr * gc + a.col_a] += s;
-        tt_acc[ph + (int)lr * gc + a.col_b] -= s;
+        atomicAdd(tt_acc + ph + (int)lr * gc + a.col_a, s);
+        atomicAdd(tt_acc + ph + (int)lr * gc + a.col_b, -s);
       }
     }
-    lds_barrier();
   }
+  lds_barrier();
 
   // ---- epilogue over the float4 groups; a group that straddles the tile's first / last float is handled element by element ----
   const DynConsts dc = {a.step_size, a.inv_sqrt_bc2, 0};
@@ -343,6 +352,236 @@ __global__ __launch_bounds__(TT_NT) void tt_tiles_kernel(TileArgs a) {
   }
 }
 
+// ---- MODE 1, persistent and wave-specialised (round 6, second form) ----
+// tt_tiles_kernel<C, 1> walks a tile's records and THEN streams its rows through Adam: with two workgroups per CU the memory system idles whenever both sit
+// in their record walks (measured: 24 B / parameter at 5.0 TB/s, against 5.85 TB/s for the plain sweep).  Here one workgroup per CU lives for the whole launch
+// and splits its waves by role: TT_WS_BUILD waves sum tile k + 1 into one LDS image while TT_WS_STREAM waves stream tile k from the other one through Adam
+// (and leave it zeroed behind them, so the builders never clear anything).  One workgroup barrier per tile; tiles are handed out by a global ticket
+// (heavy tiles -- the coarse levels, first in tile order -- then simply cost their workgroup a few tickets).
+constexpr int TT_WS_BUILD = 4, TT_WS_STREAM = 8, TT_WS_NT = (TT_WS_BUILD + TT_WS_STREAM) * 64;
+
+struct TileGeo {
+  int level;
+  uint32_t row0, nrows;
+  int64_t gb, ge, q0;
+  int nq, ph, qa, qb;
+};
+__device__ __forceinline__ TileGeo tt_geo(const TileArgs& a, int tile, TgLevel& lv) {
+  TileGeo g;
+  g.level = 0;
+  while (g.level + 1 < a.d.L && tile >= a.pl.tile_start[g.level + 1]) ++g.level;
+  lv = tg_level(a.d, g.level);
+  const int sh = a.pl.tile_rows_log2;
+  g.row0 = (uint32_t)(tile - a.pl.tile_start[g.level]) << sh;
+  g.nrows = (lv.rows - g.row0) < (1u << sh) ? (lv.rows - g.row0) : (1u << sh);
+  g.gb = ((int64_t)lv.off0 + g.row0) * a.d.grid_C;
+  g.ge = g.gb + (int64_t)g.nrows * a.d.grid_C;
+  g.q0 = g.gb >> 2;
+  g.nq = (int)(((g.ge + 3) >> 2) - g.q0);
+  g.ph = (int)(g.gb - (g.q0 << 2));
+  g.qa = g.ph ? 1 : 0;
+  g.qb = g.nq - ((g.ge & 3) ? 1 : 0);
+  return g;
+}
+
+// the record walk + temporal-TV rows of one tile by `nthr` threads (this one is number `tid`), into an LDS image that is ZERO on entry
+template <int C>
+__device__ __forceinline__ void tt_build_tile(const TileArgs& a, int tile, float* acc, int tid, int nthr) {
+  TgLevel lv;
+  const TileGeo g = tt_geo(a, tile, lv);
+  const int gc = a.d.grid_C, level = g.level;
+  const int rec0 = a.tile_base[tile], rec1 = a.tile_base[tile + 1];
+  const int n_trows = gc - C - 1;
+  const int gstride = a.d.L * C;
+  int i = rec0 + tid;
+  uint32_t rec_next = i < rec1 ? a.records[i] : 0u;
+  float4 ps_next = i < rec1 ? a.pos4[rec_next >> 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (; i < rec1; i += nthr) {
+    const uint32_t rec = rec_next;
+    const float4 ps = ps_next;
+    if (i + nthr < rec1) {
+      rec_next = a.records[i + nthr];
+      ps_next = a.pos4[rec_next >> 4];
+    }
+    const int64_t b = (int64_t)(rec >> 4);
+    const int yz = (int)(rec >> 2) & 3, xm = (int)(rec & 3u);
+    const float x[3] = {ps.x, ps.y, ps.z};
+    uint32_t pg[3];
+    float fr[3];
+    tg_cell(lv, a.d.align_corners != 0, x, pg, fr);
+    const float t = ps.w;
+    const float tv = t * (float)(n_trows - 1);
+    int r = (int)tv;
+    if (t == 1.f) r = n_trows - 1;
+    const int pch = r % C;
+    const float wa_p = (float)(r + 1) - tv, wb_p = tv - (float)r;
+    const float* gp = a.gout + b * gstride + level * C;
+    float gch[C];
+#pragma unroll
+    for (int ch = 0; ch < C; ++ch) gch[ch] = gp[ch];
+    const uint32_t cy = pg[1] + (uint32_t)(yz & 1), cz = pg[2] + (uint32_t)(yz >> 1);
+#pragma unroll
+    for (int xb = 0; xb < 2; ++xb) {
+      if (!((xm >> xb) & 1)) continue;
+      float w = 1.f;
+      w *= xb ? fr[0] : 1.f - fr[0];
+      w *= (yz & 1) ? fr[1] : 1.f - fr[1];
+      w *= (yz >> 1) ? fr[2] : 1.f - fr[2];
+      const uint32_t row = lv.row_of(pg[0] + (uint32_t)xb, cy, cz);
+      float* rowp = acc + g.ph + (int)(row - g.row0) * gc;
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        const int occ = r > ch ? C + ch + C * ((r - 1 - ch) / C) : ch;
+        const float wt = ch == pch ? wa_p : 1.f;
+        if (wt != 0.f) {
+          const float val = w * (gch[ch] * wt);
+          if (val != 0.f) atomicAdd(rowp + occ, val);
+        }
+        if (ch == pch && wb_p != 0.f) {
+          const float val = w * (gch[ch] * wb_p);
+          if (val != 0.f) atomicAdd(rowp + C + r, val);
+        }
+      }
+    }
+  }
+  if (a.col_a >= 0) {
+    for (uint32_t lr = (uint32_t)tid; lr < g.nrows; lr += (uint32_t)nthr) {
+      const float s = a.srow[(int64_t)lv.off0 + g.row0 + lr];
+      if (s != 0.f) {
+        atomicAdd(acc + g.ph + (int)lr * gc + a.col_a, s);
+        atomicAdd(acc + g.ph + (int)lr * gc + a.col_b, -s);
+      }
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(TT_WS_NT) void tt_tiles_ws_kernel(TileArgs a, int* ticket, int img_floats) {
+  extern __shared__ float tt_acc[];
+  __shared__ int s_tile[3];
+  const int wave = threadIdx.x >> 6;
+  const bool builder = wave < TT_WS_BUILD;
+  const int n_tiles = a.pl.n_tiles;
+  float* img[2] = {tt_acc, tt_acc + img_floats};
+  if (threadIdx.x == 0) {
+    s_tile[0] = atomicAdd(ticket, 1);
+    s_tile[1] = atomicAdd(ticket, 1);
+  }
+  for (int q = threadIdx.x; q < img_floats / 2; q += TT_WS_NT) *reinterpret_cast<float4*>(tt_acc + 4 * q) = make_float4(0.f, 0.f, 0.f, 0.f);  // both images
+  lds_barrier();
+  if (builder && s_tile[0] < n_tiles) tt_build_tile<C>(a, s_tile[0], img[0], threadIdx.x, TT_WS_BUILD * 64);
+  lds_barrier();
+
+  constexpr int SNT = TT_WS_STREAM * 64;
+  constexpr int TT_U = 2;
+  constexpr int STRIDE = TT_U * SNT;
+  const DynConsts dc = {a.step_size, a.inv_sqrt_bc2, 0};
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int stid = (int)threadIdx.x - TT_WS_BUILD * 64;  // streamer thread number
+  float4 PA[TT_U], MA[TT_U], VA[TT_U], PB[TT_U], MB[TT_U], VB[TT_U];
+  TgLevel lv_cur;
+  TileGeo g = {};
+  int cur_tile = s_tile[0];
+  auto load = [&](float4* P, float4* M, float4* V, const TileGeo& gg, int qbase) {
+#pragma unroll
+    for (int u = 0; u < TT_U; ++u) {
+      const int q = qbase + u * SNT;
+      if (q < gg.qb) {
+        const int64_t f0 = (gg.q0 + q) << 2;
+        P[u] = ldnt4(a.p + f0); M[u] = ldnt4(a.m + f0); V[u] = ldnt4(a.v + f0);
+      }
+    }
+  };
+  bool have_first = false;  // streamers: stage 0 of the current tile is in PA / MA / VA already (requested at the end of the previous tile)
+  if (!builder && cur_tile < n_tiles) {
+    g = tt_geo(a, cur_tile, lv_cur);
+    if (!(g.level < a.pl.first_tiled_level && a.gemb)) { load(PA, MA, VA, g, g.qa + stid); have_first = true; }
+  }
+  for (int k = 0;; ++k) {
+    const int cur = s_tile[k % 3], nxt = s_tile[(k + 1) % 3];
+    if (cur >= n_tiles) break;
+    float* acc = img[k & 1];
+    if (builder) {
+      if (threadIdx.x == 0) s_tile[(k + 2) % 3] = atomicAdd(ticket, 1);  // nobody reads this slot during iteration k
+      if (nxt < n_tiles) tt_build_tile<C>(a, nxt, img[(k + 1) & 1], threadIdx.x, TT_WS_BUILD * 64);
+    } else {
+      const bool coarse = g.level < a.pl.first_tiled_level && a.gemb;
+      if (coarse) {
+        for (int q = g.qa + stid; q < g.qb; q += SNT) {
+          const int64_t f0 = (g.q0 + q) << 2;
+          const float4 gq = *reinterpret_cast<const float4*>(acc + 4 * q);
+          *reinterpret_cast<float4*>(acc + 4 * q) = zero;
+          float4 pp = ldnt4(a.p + f0), mm = ldnt4(a.m + f0), vv = ldnt4(a.v + f0);
+          const float4 extra = ldnt4(a.gemb + f0);
+          if (extra.x != 0.f || extra.y != 0.f || extra.z != 0.f || extra.w != 0.f) stnt4(a.gemb + f0, zero);
+          adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
+          stnt4(a.p + f0, pp); stnt4(a.m + f0, mm); stnt4(a.v + f0, vv);
+        }
+      } else {
+        auto step = [&](float4* P, float4* M, float4* V, int qbase) {
+#pragma unroll
+          for (int u = 0; u < TT_U; ++u) {
+            const int q = qbase + u * SNT;
+            if (q < g.qb) {
+              const int64_t f0 = (g.q0 + q) << 2;
+              const float4 gq = *reinterpret_cast<const float4*>(acc + 4 * q);
+              *reinterpret_cast<float4*>(acc + 4 * q) = zero;  // the image is clean again when the tile has been streamed
+              adam_float4(P[u], M[u], V[u], gq, zero, 1.f, a.b1, a.b2, a.eps, dc);
+              stnt4(a.p + f0, P[u]); stnt4(a.m + f0, M[u]); stnt4(a.v + f0, V[u]);
+            }
+          }
+        };
+        int c = g.qa + stid;
+        if (!have_first) load(PA, MA, VA, g, c);
+        while (c < g.qb) {
+          load(PB, MB, VB, g, c + STRIDE);
+          step(PA, MA, VA, c);
+          c += STRIDE;
+          if (c >= g.qb) break;
+          load(PA, MA, VA, g, c + STRIDE);
+          step(PB, MB, VB, c);
+          c += STRIDE;
+        }
+      }
+      // the (at most two) float4 groups shared with a neighbouring tile: element by element, this tile's floats only
+      if (stid < 2) {
+        const int q = stid == 0 ? 0 : g.nq - 1;
+        const bool partial = stid == 0 ? (g.qa == 1) : (g.qb == g.nq - 1 && g.nq - 1 >= g.qa);
+        if (partial) {
+          const int64_t f0 = (g.q0 + q) << 2;
+          const float4 gq = *reinterpret_cast<const float4*>(acc + 4 * q);
+          *reinterpret_cast<float4*>(acc + 4 * q) = zero;
+          float4 pp = zero, mm = zero, vv = zero, extra = zero;
+          float* P = &pp.x; float* M = &mm.x; float* V = &vv.x; float* E = &extra.x;
+          for (int e = 0; e < 4; ++e)
+            if (f0 + e >= g.gb && f0 + e < g.ge) {
+              P[e] = a.p[f0 + e]; M[e] = a.m[f0 + e]; V[e] = a.v[f0 + e];
+              if (coarse) { E[e] = a.gemb[f0 + e]; if (E[e] != 0.f) a.gemb[f0 + e] = 0.f; }
+            }
+          adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
+          for (int e = 0; e < 4; ++e)
+            if (f0 + e >= g.gb && f0 + e < g.ge) { a.p[f0 + e] = P[e]; a.m[f0 + e] = M[e]; a.v[f0 + e] = V[e]; }
+        }
+      }
+      // stage 0 of the NEXT tile goes out before the barrier: the round trip overlaps the hand-over
+      have_first = false;
+      if (nxt < n_tiles) {
+        g = tt_geo(a, nxt, lv_cur);
+        if (!(g.level < a.pl.first_tiled_level && a.gemb)) { load(PA, MA, VA, g, g.qa + stid); have_first = true; }
+      }
+    }
+    lds_barrier();
+  }
+  // the last workgroup to leave puts the ticket back to zero for the next launch over these tiles
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ticket + 1, 1) == (int)gridDim.x - 1) {
+      ticket[0] = 0;
+      ticket[1] = 0;
+    }
+  }
+}
+
 static int tiles_lds_bytes(const snerf_tgrid_desc* d, int sh) { return (((1 << sh) * d->grid_C + 6) / 4 + 1) * 16; }
 
 static int validate_tiles(const snerf_tgrid_desc* d, const snerf_tgrid_tile_plan* pl, int64_t B) {
@@ -377,6 +616,26 @@ static int bin_launch(const TileArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(tt_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles, t_first);
   hipLaunchKernelGGL((tt_bin_kernel<C, true>), grid, dim3(TT_BIN_NT), lds, st, a);
   SNERF_LAUNCH_CHECK("tgrid_bwd_bin");
+  return 0;
+}
+
+// SNERF_TGRID_TILES_WS=0: dev A-B switch back to one workgroup per tile for the fused form (read per call)
+static bool tiles_ws_on() {
+  const char* e = getenv("SNERF_TGRID_TILES_WS");
+  return !(e && atoi(e) == 0);
+}
+
+template <int C>
+static int tiles_ws_launch(TileArgs& a, int* ticket, hipStream_t st) {
+  const int one = tiles_lds_bytes(&a.d, a.pl.tile_rows_log2);  // a multiple of 16
+  const int lds = 2 * one;
+  SNERF_ALLOW_LDS((tt_tiles_ws_kernel<C>), lds);
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int grid = a.pl.n_tiles < cus ? a.pl.n_tiles : cus;
+  if (grid <= 0) return 0;
+  hipLaunchKernelGGL((tt_tiles_ws_kernel<C>), dim3((unsigned)grid), dim3(TT_WS_NT), (size_t)lds, st, a, ticket, one / 4);
+  SNERF_LAUNCH_CHECK("tgrid_bwd_tiles_adam (wave-specialised)");
   return 0;
 }
 
@@ -477,7 +736,7 @@ extern "C" int snerf_tgrid_bwd_tiles(const snerf_tgrid_desc* desc, const snerf_t
 }
 
 extern "C" int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, int64_t B, const float* grad_out, const float* pos4,
-                                          const int32_t* tile_base, const uint32_t* records, float* grad_embeddings, float* p, float* m, float* v, float lr,
+                                          int32_t* tile_base, const uint32_t* records, float* grad_embeddings, float* p, float* m, float* v, float lr,
                                           float beta1, float beta2, float eps, int32_t step, int32_t col_a, int32_t col_b, const float* srow,
                                           snerf_stream_t stream) {
   int rc = validate_tiles(desc, plan, B);
@@ -492,10 +751,16 @@ extern "C" int snerf_tgrid_bwd_tiles_adam(const snerf_tgrid_desc* desc, const sn
                 col_b);
   TileArgs a = {};
   a.d = *desc; a.pl = *plan; a.B = B; a.gout = grad_out; a.pos4 = reinterpret_cast<float4*>(const_cast<float*>(pos4));
-  a.tile_base = const_cast<int32_t*>(tile_base); a.records = const_cast<uint32_t*>(records); a.gemb = grad_embeddings;
+  a.tile_base = tile_base; a.records = const_cast<uint32_t*>(records); a.gemb = grad_embeddings;
   a.p = p; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
   adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
   a.col_a = col_a; a.col_b = col_b; a.srow = srow;
+  if (tiles_ws_on()) {
+    int* ticket = a.tile_base + plan->n_tiles + 1;
+#define TT_CALL(C_) tiles_ws_launch<C_>(a, ticket, (hipStream_t)stream)
+    TT_DISPATCH_C(desc->C, TT_CALL)
+#undef TT_CALL
+  }
 #define TT_CALL(C_) tiles_launch<C_, 1>(a, (hipStream_t)stream)
   TT_DISPATCH_C(desc->C, TT_CALL)
 #undef TT_CALL

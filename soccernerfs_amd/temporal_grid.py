@@ -198,7 +198,7 @@ class TiledTableBackward:
         _lib.check(_lib.lib().snerf_tgrid_tile_plan_make(C.byref(enc.desc), C.c_int64(B), tile_rows_log2, first_tiled_level, C.byref(self.plan)), "tile_plan_make")
         dev = enc.embeddings.device
         self.counts = torch.empty(max(int(self.plan.count_ints), 1), dtype=torch.int32, device=dev)
-        self.tile_base = torch.empty(self.plan.n_tiles + 1, dtype=torch.int32, device=dev)
+        self.tile_base = torch.zeros(self.plan.n_tiles + 3, dtype=torch.int32, device=dev)  # prefix sums [n_tiles + 1] + the fused pass's ticket words
         self.records = torch.empty(max(int(self.plan.record_capacity), 1), dtype=torch.int32, device=dev)
         self.pos4 = torch.empty(max(self.B, 1), 4, dtype=torch.float32, device=dev)
 

@@ -409,3 +409,43 @@ def test_tiled_field_backward_is_the_same_step(tv, first_level, async_sweep):
     a.synchronize(); b.synchronize()
     assert bool(torch.isfinite(ra).all()) and float((ra - rb).abs().max()) < 5e-2
     assert float((a.params[fo:fo + fn] - b.params[fo:fo + fn]).abs().mean()) < 2e-3
+
+
+def test_stock_pytorch_standin_and_hip_trainer_take_the_same_steps():
+    """oracle/nerfplayer_standin.NerfplayerStandinTrainer (the reference's nerfplayer-nerfacto algorithm in stock PyTorch: the checker that anchors config 4's PSNR)
+    against the fused HIP trainer from the same parameters on the same batches, draws and TV rows: every loss term of six consecutive steps (updated proposal
+    steps, annealed PDF weights, the cosine warm-up) and the parameters afterwards.  Exact fp32 HIP path; float sums in different orders on the two sides."""
+    from oracle.nerfplayer_standin import NerfplayerStandinTrainer
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R, n_img, steps = 128, 9, 6
+    cfg = _cfg()
+    tr = NerfplayerTrainer(cfg, R, n_img, aabb_scale=1.0, device=DEV, seed=5, warm_up_end=4)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(1)
+        for name in ("field.table", "prop0.table", "prop1.table"):
+            tr.views[name].copy_(((torch.rand(tr.views[name].shape, generator=g) * 2 - 1) * 0.5).to(DEV))
+    ref = NerfplayerStandinTrainer(tr, DEV, warm_up_end=4)
+    tr.tv_rows = ref.tv_rows = [2, 1, 3]
+    for k in range(steps):
+        rays, cams, target, rng = _batch(R, n_img, 300 + k)
+        rgb_h = tr.train_step(rays, cams, target, rng).clone()
+        rgb_r = ref.train_step(rays, cams, target, rng)
+        torch.testing.assert_close(rgb_h, rgb_r, rtol=0, atol=2e-4 * (k + 1))
+        lh, lr = {k_: float(v) for k_, v in tr.loss_dict().items()}, {k_: float(v) for k_, v in ref.loss_dict().items()}
+        assert set(lh) == set(lr)
+        for k_ in lr:
+            assert abs(lh[k_] - lr[k_]) <= 2e-3 * (k + 1) * abs(lr[k_]) + 1e-8, (k, k_, lh[k_], lr[k_])
+    tr.synchronize()
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert rel(tr.views["field.table"], ref.grid.table()) < 2e-3
+    for i in range(2):
+        assert rel(tr.views[f"prop{i}.table"], ref.prop_grid[i].table()) < 2e-3
+    for mine, theirs in zip(tr.head.linear_weights(), ref.head_w):
+        assert rel(mine, theirs.detach()) < 5e-3
+    assert rel(tr.appearance.weight.detach(), ref.appearance.detach()) < 1e-3
+    # eval forward: average appearance embedding, no jitter, clamped colours
+    rays, cams, target, rng = _batch(R, n_img, 999)
+    eh = tr.forward(rays, None, rng, 1.0, training=False).clone()
+    er = ref.forward(rays, None, rng, 1.0, training=False)
+    torch.testing.assert_close(eh, er, rtol=0, atol=5e-3)

@@ -75,7 +75,7 @@ def test_tiled_scatter_equals_the_per_sample_atomic_kernel(kw, sh, lc, mode):
         tb.coarse_levels(co, times, S, gout, got)
         tb.scatter(gout, got)
         torch.cuda.synchronize()
-        n_rec = int(tb.tile_base[-1])
+        n_rec = int(tb.tile_base[tb.plan.n_tiles])
         assert n_rec <= tb.plan.record_capacity and (n_rec > 0) == (tb.plan.first_tiled_level < enc.num_levels)
         scale = float(ref.abs().max())
         assert scale > 0
@@ -90,10 +90,15 @@ def test_tiled_scatter_equals_the_per_sample_atomic_kernel(kw, sh, lc, mode):
         torch.testing.assert_close(again, 2 * ref, rtol=1e-5, atol=4e-6 * scale)
 
 
+@pytest.mark.parametrize("ws", ["1", "0"])
 @pytest.mark.parametrize("tv", [False, True])
 @pytest.mark.parametrize("kw,sh,lc", CASES[:4])
-def test_fused_adam_equals_scatter_then_tv_then_adam(kw, sh, lc, tv):
+def test_fused_adam_equals_scatter_then_tv_then_adam(kw, sh, lc, tv, ws, monkeypatch):
+    """ws = 1: the persistent, wave-specialised tile kernel (builder waves sum tile k + 1 while streamer waves run Adam over tile k; tiles handed out by a
+    ticket); ws = 0: one workgroup per tile (SNERF_TGRID_TILES_WS=0).  Three optimiser steps, so the ticket words are reused across launches."""
     from soccernerfs_amd import _lib, ops
+
+    monkeypatch.setenv("SNERF_TGRID_TILES_WS", ws)
     from soccernerfs_amd.temporal_grid import TemporalGridEncoder, TiledTableBackward
 
     gen = torch.Generator().manual_seed(9)

@@ -120,3 +120,32 @@ def test_channel_last_standin_trains_like_the_grid_sample_standin():
     finally:
         KO.USE_GRID_SAMPLE = prev
     assert out.shape == (R, 3) and bool(torch.isfinite(out).all())
+
+
+def test_nerfplayer_standin_grid_equals_the_tgrid_oracle():
+    """oracle/nerfplayer_standin.TorchTemporalGrid (the eight corners vectorised, per-level leaf tables: what lets the config-4 stand-in train on the device)
+    against oracle/tgrid_oracle.encode + temporal_index -- the restatement pinned by the reference's known-answer test and HashEncoding -- value for value,
+    on dense AND hashed levels, with border / out-of-range points and t = 0 / 1; its TV term against temporal_tv_loss; gradients flow to every level."""
+    from oracle import nerfplayer_standin as NS_
+    from oracle import tgrid_oracle as TO
+
+    gen = torch.Generator().manual_seed(4)
+    for C, T, L, log2T, H, scale in ((2, 16, 6, 10, 4, 1.6), (4, 9, 3, 8, 3, 2.0), (1, 5, 2, 12, 5, 1.5)):
+        offs = TO.level_offsets(L, H, scale, log2T)
+        emb = torch.rand(offs[-1], C + T, generator=gen) - 0.5
+        g = NS_.TorchTemporalGrid(emb, offs, float(torch.log2(torch.tensor(scale))), H, C)
+        assert any(m[2] for m in g.meta) or C == 1  # hashed levels present in the first two cases
+        B = 300
+        x = torch.rand(B, 3, generator=gen)
+        x[0, 0], x[1, 2], x[2] = 1.0, 0.0, torch.tensor([-0.1, 0.5, 0.5])
+        t = torch.rand(B, generator=gen)
+        t[3], t[4] = 1.0, 0.0
+        table = TO.channel_table(T, C)
+        want = TO.encode(x, TO.temporal_index(t, table), emb, offs, float(torch.log2(torch.tensor(scale))), H, 0, C)
+        got = g.encode(x, t)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+        assert float(got[2].abs().max()) == 0.0  # the out-of-range point
+        row = 3 % len(g.index_ab)
+        torch.testing.assert_close(g.tv_loss(row), TO.temporal_tv_loss(emb, table["index_ab"][row].tolist()))
+        (got.square().sum() + g.tv_loss(row)).backward()
+        assert all(lv.grad is not None and float(lv.grad.abs().max()) > 0 for lv in g.levels)

@@ -72,7 +72,7 @@ for name, k in (("field", 2), ("prop0", 0), ("prop1", 1)):
         tag = f"tiles[sh={tb.plan.tile_rows_log2},lc={tb.plan.first_tiled_level}]"
         q = {"n_tiles": tb.plan.n_tiles, "lds_bytes": tb.plan.lds_bytes}
         q["bin_ms"] = timed(lambda: tb.bin(co, t, S, gout))
-        q["records"] = int(tb.tile_base[-1])
+        q["records"] = int(tb.tile_base[tb.plan.n_tiles])
         q["coarse_ms"] = timed(lambda: tb.coarse_levels(co, t, S, gout, gtab)) if tb.plan.first_tiled_level > 0 else 0.0
         gtab.zero_()
         tiles0 = lambda: tb.scatter(gout, gtab)

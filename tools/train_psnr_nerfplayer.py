@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20231029)
     ap.add_argument("--mlp-operands", default="fp32", choices=["fp32", "bf16"], help="NerfplayerTrainer(mlp_operands=...): bf16 MFMA operands in the decode net and the colour head")
     ap.add_argument("--async-sweep", action="store_true", help="NerfplayerTrainer(async_field_sweep=True): the main table's optimiser sweep on a side stream")
+    ap.add_argument("--standin", action="store_true", help="train oracle/nerfplayer_standin.NerfplayerStandinTrainer instead (the reference's algorithm in stock PyTorch, started "
+                    "from the HIP trainer's initial parameters): the reference-algorithm arm of config 4's PSNR comparison")
+    ap.add_argument("--train-budget-s", type=float, default=0.0, help="stop training when this much wall-clock is spent (a gpurun call is capped at one hour), evaluate there")
     ap.add_argument("--tiled", action="store_true", help="NerfplayerTrainer(tiled_field_backward=True): the main table's scatter + TV + Adam as one owner-computes pass (round 6)")
     args = ap.parse_args()
     dev = torch.device("cuda:0"); torch.manual_seed(args.seed)
@@ -57,9 +60,18 @@ def main():
     M, H, W = train["images"].shape[:3]
     tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, M, aabb_scale=1.0 if stadium else 1.5, device=dev, max_steps=args.steps,
                            mlp_operands=args.mlp_operands, async_field_sweep=args.async_sweep, tiled_field_backward=args.tiled)
-    log = {"config": f"nerfplayer-nerfacto preset, fused trainer, synthetic {'stadium-players scene' if stadium else 'clip'} ({M} training images {W}x{H}, "
+    if args.standin:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle.nerfplayer_standin import NerfplayerStandinTrainer  # checker code: this dev tool trains it for the PSNR anchor
+
+        hip = tr
+        tr = NerfplayerStandinTrainer(hip, dev, max_steps=args.steps)
+        del hip
+        torch.cuda.empty_cache()
+    log = {"config": f"nerfplayer-nerfacto preset, {'stock-PyTorch stand-in (oracle/nerfplayer_standin.py)' if args.standin else 'fused trainer'}, synthetic {'stadium-players scene' if stadium else 'clip'} ({M} training images {W}x{H}, "
                      f"{len(times)} frames per camera, 6 cameras held out), seed {args.seed}", "scene": args.scene, "mlp_operands": args.mlp_operands,
-           "async_field_sweep": bool(args.async_sweep), "tiled_field_backward": bool(args.tiled), "evals": []}
+           "async_field_sweep": bool(args.async_sweep), "tiled_field_backward": bool(args.tiled), "standin": bool(args.standin), "evals": []}
+    t_begin = time.time()
     t_train = 0.0
     for step in range(args.steps):
         if step % 500 == 0:
@@ -71,12 +83,17 @@ def main():
             torch.cuda.synchronize(); dt = time.time() - t1; t_train += dt
             ld = {k: float(v) for k, v in tr.loss_dict().items()}
             print(f"step {step + 1}: {R * 500 / dt:,.0f} rays/s  " + "  ".join(f"{k} {v:.3e}" for k, v in ld.items()), flush=True)
-        if (step + 1) % args.eval_every == 0 or step + 1 == args.steps:
+        out_of_time = bool(args.train_budget_s and step % 100 == 0 and time.time() - t_begin > args.train_budget_s)
+        if out_of_time:
+            log["stopped_early_at_step"] = step + 1
+        if (step + 1) % args.eval_every == 0 or step + 1 == args.steps or out_of_time:
             ps = eval_psnr(tr, held, 6, anneal_value(step, 1000, 10.0))
             ps_tr = eval_psnr(tr, train, 4, 1.0)
             log["evals"].append({"step": step + 1, "psnr_heldout_mean": sum(ps) / len(ps), "psnr_heldout": ps, "psnr_train_views_mean": sum(ps_tr) / len(ps_tr)})
             print(f"== step {step + 1}: held-out cameras PSNR {sum(ps) / len(ps):.2f} dB; train views {sum(ps_tr) / len(ps_tr):.2f} dB", flush=True)
-    log["train_rays_per_s_mean"] = R * args.steps / max(t_train, 1e-9)
+        if out_of_time:
+            break
+    log["train_rays_per_s_mean"] = R * (log.get("stopped_early_at_step", args.steps) // 500 * 500) / max(t_train, 1e-9)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(log, open(args.out, "w"), indent=1)
     print(json.dumps(log["evals"][-1]))
