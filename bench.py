@@ -27,7 +27,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured achievable copy rate
 DEFAULT_OPERANDS = "bf16"  # BASELINE.json configs[1]: "1xMI355X bf16"
-PROFILE_TAG = "r05"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
+PROFILE_TAG = "r06"        # profiles/<tag>_pmc_traffic.json, profiles/<tag>_psnr_*.json are quoted (with their source) in the JSON line
 
 
 def parse():
@@ -731,15 +731,17 @@ def main():
         # second half of BASELINE.json's metric (PSNR@30k): not re-measured here (a 30 k-step run takes minutes) -- the committed results of
         # tools/train_psnr.py on this workload are read from their files and quoted with their source
         psnr = {}
-        for op in ("bf16", "fp32", "standin"):
+        # (r06) bf16 = the POOLED runs of the round-5 final code (tools/merge_psnr_runs.py: 16 seeds on the default scene, 12 on the textured one; the K-Planes
+        # kernels have not changed since), not a 3-seed mid-round file; the textured scene's arms are quoted beside the default scene's
+        for op in ("bf16", "fp32", "standin", "bf16_textured", "standin_textured"):
             # this round's file if it exists, else the last round's that does (the source is named in the line either way)
-            f = next((c for c in (os.path.join(ROOT, "profiles", f"{tag}_psnr_30k_{op}.json") for tag in (PROFILE_TAG, "r04", "r03")) if os.path.exists(c)), None)
+            f = next((c for c in (os.path.join(ROOT, "profiles", f"{tag}_psnr_30k_{op}.json") for tag in (PROFILE_TAG, "r05", "r04", "r03")) if os.path.exists(c)), None)
             if f is None:
                 continue
             try:
                 d = json.load(open(f))
                 what = ("oracle/torch_standin.StandinTrainer = the reference's algorithm in stock PyTorch, fp32, same scene / sampler / schedule / evaluation"
-                        if op == "standin" else "tools/train_psnr.py: same preset, same synthetic scene")
+                        if op.startswith("standin") else "tools/train_psnr.py: same preset, same synthetic scene")
                 early = [r["stopped_early_at_step"] for r in d["runs"] if r.get("stopped_early_at_step")]
                 psnr[op] = {"source": f"profiles/{os.path.basename(f)} ({what}, {len(d['runs'])} seed(s), eval frames per camera: {d.get('eval_frames', 'all')}"
                                       + (f"; NOT 30 000 steps: the runs were stopped at steps {early} by the one-hour limit of a GPU call and evaluated there" if early else "") + ")",

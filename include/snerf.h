@@ -629,6 +629,29 @@ int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const float* tabl
 int snerf_hashgrid_encode_bwd_fx(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out,
                                  int64_t* grad_table_fx, int64_t* grad_x_fx, snerf_stream_t stream);
 
+/* ABI 14: the backward w.r.t. the hash table in OWNER-COMPUTES form (csrc/hashgrid_tiles.hip; D = 3), as snerf_tgrid_bwd_bin / _tiles / _tiles_adam for the
+ * temporal grid: the batch's (point, level, corner pair) touches are filed under tiles of 2^tile_rows_log2 consecutive table rows by a counting sort without
+ * global atomics; one workgroup per tile sums its rows in LDS and either adds them into the dense gradient (snerf_hashgrid_bwd_tiles: what
+ * snerf_hashgrid_encode_bwd leaves in grad_table, up to the association order of the sums) or runs torch.optim.Adam over them from there
+ * (snerf_hashgrid_bwd_tiles_adam: no dense gradient for the table).  Replaces tcnn's HashGrid table backward (grid.h, kernel_grid_backward) + the optimiser
+ * step of NS/fields/nerfplayer_field.py:242-252's encoding.  The coordinate gradient stays with snerf_hashgrid_encode_bwd (grad_table = NULL). */
+typedef struct {
+  int32_t tile_rows_log2, n_tiles, n_chunks, chunk, lds_bytes, _pad;
+  int32_t tile_start[33];
+  int32_t _pad2;
+  int64_t count_ints;       /* int32 elements of `counts` */
+  int64_t record_capacity;  /* uint32 elements of `records` = B * L * 8 */
+} snerf_hashgrid_tile_plan;
+int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, int64_t B, int32_t tile_rows_log2, snerf_hashgrid_tile_plan* plan);
+/* counts [count_ints], tile_base [n_tiles + 1]: workspaces; x [B,3] and grad_out [B, L*F] must stay valid until the tile pass has run.  B < 2^28. */
+int snerf_hashgrid_bwd_bin(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
+                           int32_t* counts, int32_t* tile_base, uint32_t* records, snerf_stream_t stream);
+int snerf_hashgrid_bwd_tiles(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
+                             const int32_t* tile_base, const uint32_t* records, float* grad_table, snerf_stream_t stream);
+int snerf_hashgrid_bwd_tiles_adam(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
+                                  const int32_t* tile_base, const uint32_t* records, float* p, float* m, float* v, float lr, float beta1, float beta2,
+                                  float eps, int32_t step, snerf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * NeRFPlayer decomposition mixing (NerfplayerField.get_density, NS/fields/nerfplayer_field.py:365-372): probs[N,3] = softmax(logits[N,3])
  * (0 = static, 1 = deforming, 2 = new) and v[N,F] = probs_0 v_static + probs_1 v_deform + probs_2 v_new; F = 4, 8, 16, 32 or 64.

@@ -163,11 +163,14 @@ class NerfplayerFullTrainer:
         self._tv_cols = [(0, 1)] * 4
         self.launches = 0  # libsnerf launches of the last step (diagnostics)
         self.async_table_sweeps = bool(async_table_sweeps)
-        self._tiled = None
+        self._tiled, self._tiled_hash, self._hash_swept = None, None, False
         if tiled_table_backward and not deterministic and cfg.temporal_tv_weight > 0:
             from .temporal_grid import TiledTableBackward
 
             self._tiled = [TiledTableBackward(self.newness, N, first_tiled_level=0), TiledTableBackward(self.decomp, N, first_tiled_level=0)]
+            from .tcnn_compat import TiledHashTableBackward
+
+            self._tiled_hash = TiledHashTableBackward(self.hash, 2 * N)  # both halves of x2 (undeformed and deformed positions) in one pass
         self._side, self._sweeps_done, self._swept, self._in_train_step, self._tv01_done = None, None, (), False, None
 
     # ---- helpers ----
@@ -443,7 +446,7 @@ class NerfplayerFullTrainer:
         target = ops._f32c(target, "target")
         # a backward that raised after its asynchronous sweeps were issued never reached optimizer_step(): start from clean flags, or this step's TV pass
         # and sweep of those tables would be skipped
-        self._swept, self._tv01_done = (), None
+        self._swept, self._tv01_done, self._hash_swept = (), None, False
         early = bool(self.async_table_sweeps and self._in_train_step and cfg.temporal_tv_weight > 0)
         if cfg.temporal_tv_weight > 0:
             b["tv"].zero_()
@@ -489,7 +492,21 @@ class NerfplayerFullTrainer:
                               b["gsx"], 36)
         b["genc2"].copy_(b["gsx"][:, :F])
         # static hash grid: table gradient from both halves, coordinate gradient only for the deformed half (x itself carries no gradient)
-        if self.grads_fx is not None:
+        if self._tiled_hash is not None and self._in_train_step:
+            # owner-computes form (round 6): one binning pass over all 2N points, then scatter + Adam of the table as one pass; the coordinate gradient of
+            # the deformed half is a gather (the atomic kernel without a table gradient)
+            th = self._tiled_hash
+            th.bin(b["x2"], b["genc2"], self._st)
+            lr_h = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+            oh, nh = next((o, n) for name, _, _, o, n in self.segments if name == "field.hash")
+            th.scatter_adam(b["x2"], b["genc2"], self.params[oh:oh + nh], self.exp_avg[oh:oh + nh], self.exp_avg_sq[oh:oh + nh], lr_h, self.step + 1, self.adam_eps,
+                            stream=self._st)
+            self.launches += 5
+            self._hash_swept = True
+            b["gx2"][N:].zero_()
+            self._ck(self.lib.snerf_hashgrid_encode_bwd(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"], 3 * N), C.c_int64(N),
+                                                        self._p(b["genc2"], N * F), None, self._p(b["gx2"], 3 * N), self._st), "hashgrid_bwd (coordinates)")
+        elif self.grads_fx is not None:
             gt = self._pfx(self.gviews["field.hash"])
             self._ck(self.lib.snerf_hashgrid_encode_bwd_fx(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"]), C.c_int64(N), self._p(b["genc2"]),
                                                            gt, None, self._st), "hashgrid_bwd_fx")
@@ -553,21 +570,31 @@ class NerfplayerFullTrainer:
         self.gradients_to_float()
         off = {name: (o, n) for name, _, _, o, n in self.segments}
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        plain = lambda lo, hi: ops.adam_step(self.params[lo:hi], self.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.step + 1, lr,
-                                             eps=self.adam_eps, zero_grad=True)
+        ho, hn = off["field.hash"]
+        hash_done = self._hash_swept  # tiled_table_backward: the hash table has been stepped by its owner-computes pass already
+
+        def plain(lo, hi):
+            """the plain sweep over [lo, hi) -- around the hash table when that has been stepped already"""
+            parts = [(lo, hi)]
+            if hash_done and lo < ho + hn and hi > ho:
+                parts = [(lo, ho), (ho + _align4(hn), hi)]
+            for a_, b_ in parts:
+                if b_ > a_:
+                    ops.adam_step(self.params[a_:b_], self.grads[a_:b_], self.exp_avg[a_:b_], self.exp_avg_sq[a_:b_], self.step + 1, lr, eps=self.adam_eps, zero_grad=True)
+                    self.launches += 1
+
         done = 0
         if self.cfg.temporal_tv_weight > 0:
             for k in sorted(range(4), key=lambda i: off[self._enc_names[i]][0]):
                 o, n = off[self._enc_names[k]]
                 if o > done:
                     plain(done, o)
-                    self.launches += 1
                 if k not in self._swept:
                     self._sweep_table(k, lr, st)
                 done = o + n
         if done < self.n_params:
             plain(done, self.n_params)
-            self.launches += 1
+        self._hash_swept = False
         self._swept = ()
         self.step += 1
 

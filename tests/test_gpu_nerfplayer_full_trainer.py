@@ -265,7 +265,8 @@ def test_tiled_table_backward_is_the_same_step(async_sweeps):
         tr.synchronize()
     assert float(a.grads.abs().max()) == 0.0 and float(b.grads.abs().max()) == 0.0
     off = {name: (o, n) for name, _, _, o, n in a.segments}
-    for name in ("field.newness", "field.decomp"):
+    assert a._tiled_hash is not None
+    for name in ("field.newness", "field.decomp", "field.hash"):  # the three tables the owner-computes passes step
         o, n = off[name]
         ma, mb = a.exp_avg[o:o + n], b.exp_avg[o:o + n]
         scale = float(mb.abs().max())
