@@ -619,10 +619,13 @@ static int bin_launch(const TileArgs& a, hipStream_t st) {
   return 0;
 }
 
-// SNERF_TGRID_TILES_WS=0: dev A-B switch back to one workgroup per tile for the fused form (read per call)
+// SNERF_TGRID_TILES_WS=1: the persistent wave-specialised form of the fused pass (read per call).  OFF by default: alone it takes the same 1.90-1.94 ms as one
+// workgroup per tile (both sit at what this GPU sustains for three read and three write streams), and inside config 4's step it is SLOWER (4.04-4.17 against
+// 3.79-3.83 ms per step, profiles/r06_tgrid_tiles_ab.txt): its one workgroup per CU holds 135 KB of LDS for the whole launch, which keeps the proposal
+// backward and the next step's head -- running beside it on purpose -- off those CUs.
 static bool tiles_ws_on() {
   const char* e = getenv("SNERF_TGRID_TILES_WS");
-  return !(e && atoi(e) == 0);
+  return e && atoi(e) == 1;
 }
 
 template <int C>

@@ -37,7 +37,7 @@ def _align4(n: int) -> int:
 class NerfplayerFullTrainer:
     def __init__(self, cfg: NerfplayerModelConfig, num_rays: int, aabb_scale: float = 1.0, device="cuda:0", lr: float = 1e-2,
                  adam_eps: float = 1e-6, warm_up_end: int = 512, max_steps: int = 30000, seed: int = 0, deterministic: bool = False,
-                 async_table_sweeps: bool = False, mlp_operands: str = "fp32", tiled_table_backward: bool = False):
+                 async_table_sweeps: bool = False, mlp_operands: str = "fp32", tiled_table_backward: bool = False, tiled_hash_backward: bool = False):
         """mlp_operands: "fp32" (exact: every net on the fp32 matrix instructions -- the parity path, what G13 / G13b pin) or "bf16" (round 5: bf16 MFMA
         operands with fp32 accumulation in every net -- the fused kernels for the shapes in their table, csrc/dense_lp.hip's single layers for the
         deformation net, the 33 -> 64 -> 32 MLP and the colour head; the reference itself runs all of them in tcnn's fp16).
@@ -168,9 +168,11 @@ class NerfplayerFullTrainer:
             from .temporal_grid import TiledTableBackward
 
             self._tiled = [TiledTableBackward(self.newness, N, first_tiled_level=0), TiledTableBackward(self.decomp, N, first_tiled_level=0)]
-            from .tcnn_compat import TiledHashTableBackward
+            if tiled_hash_backward:
+                # the static hash grid's table the same way (csrc/hashgrid_tiles.hip); opt-in: see DESIGN section 7 for where it pays
+                from .tcnn_compat import TiledHashTableBackward
 
-            self._tiled_hash = TiledHashTableBackward(self.hash, 2 * N)  # both halves of x2 (undeformed and deformed positions) in one pass
+                self._tiled_hash = TiledHashTableBackward(self.hash, 2 * N)  # both halves of x2 (undeformed and deformed positions) in one pass
         self._side, self._sweeps_done, self._swept, self._in_train_step, self._tv01_done = None, None, (), False, None
 
     # ---- helpers ----

@@ -292,8 +292,9 @@ def test_fix_list_default_cannot_overflow_and_a_small_one_ends_the_run_from_opti
     E = dict(base_res=(16, 16, 16, 4), multiscale=(1, 2), feat_dim=32, prop_res=((24, 24, 24, 4), (32, 32, 32, 4)), prop_feat=8,
              sigma_hidden=128, color_hidden=64, aabb_scale=1.5, seed=5)
     P = KO.make_kplanes_params(**E)
-    for sc in P["field_grids"]:
-        sc[0].zero_()  # the XY plane of every scale all-zero: every feature of every sample vanishes
+    # the XY plane of scale 0 all-zero: the 32 scale-0 features of EVERY sample vanish, while the scale-1 features keep sigma_net's hidden units alive (with all
+    # 64 features zero every pre-activation is exactly 0, relu'(0) = 0, and no feature would receive a gradient at all: nothing to fix)
+    P["field_grids"][0][0].zero_()
     R = 40
     gen = torch.Generator().manual_seed(3)
     dv = lambda z: z.to(DEV).contiguous()
@@ -316,6 +317,7 @@ def test_fix_list_default_cannot_overflow_and_a_small_one_ends_the_run_from_opti
     product = KPlanesTrainer(_default_cfg(E, quotient_scatter=False, **kw), R, DEV)
     g_q, g_p = grads(full), grads(product)
     assert float(g_p.abs().max()) > 0
+    assert int(full._ss.fix_counts.max()) >= full._ss.N * 8  # the fix list really carried this step's vanished-feature terms
     torch.testing.assert_close(g_q, g_p, rtol=1e-3, atol=2e-6 * float(g_p.abs().max()))
     full.optimizer_step()
     full.synchronize()  # no overflow possible

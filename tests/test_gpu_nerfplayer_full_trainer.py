@@ -249,7 +249,7 @@ def test_tiled_table_backward_is_the_same_step(async_sweeps):
     cfg = _cfg(1.0)
 
     def make(tiled):
-        tr = NerfplayerFullTrainer(cfg, R, aabb_scale=1.0, device=DEV, seed=3, async_table_sweeps=async_sweeps, tiled_table_backward=tiled)
+        tr = NerfplayerFullTrainer(cfg, R, aabb_scale=1.0, device=DEV, seed=3, async_table_sweeps=async_sweeps, tiled_table_backward=tiled, tiled_hash_backward=tiled)
         gen = torch.Generator(device=DEV).manual_seed(5)
         with torch.no_grad():
             for name in ("field.hash", "field.newness", "field.decomp", "prop0.table", "prop1.table"):

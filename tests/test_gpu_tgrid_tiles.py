@@ -94,7 +94,7 @@ def test_tiled_scatter_equals_the_per_sample_atomic_kernel(kw, sh, lc, mode):
 @pytest.mark.parametrize("tv", [False, True])
 @pytest.mark.parametrize("kw,sh,lc", CASES[:4])
 def test_fused_adam_equals_scatter_then_tv_then_adam(kw, sh, lc, tv, ws, monkeypatch):
-    """ws = 1: the persistent, wave-specialised tile kernel (builder waves sum tile k + 1 while streamer waves run Adam over tile k; tiles handed out by a
+    """ws = 0 (default): one workgroup per tile; ws = 1: the persistent, wave-specialised tile kernel (builder waves sum tile k + 1 while streamer waves run Adam over tile k; tiles handed out by a
     ticket); ws = 0: one workgroup per tile (SNERF_TGRID_TILES_WS=0).  Three optimiser steps, so the ticket words are reused across launches."""
     from soccernerfs_amd import _lib, ops
 
