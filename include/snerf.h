@@ -636,21 +636,28 @@ int snerf_hashgrid_encode_bwd_fx(const snerf_hashgrid_desc* desc, const float* t
  * (snerf_hashgrid_bwd_tiles_adam: no dense gradient for the table).  Replaces tcnn's HashGrid table backward (grid.h, kernel_grid_backward) + the optimiser
  * step of NS/fields/nerfplayer_field.py:242-252's encoding.  The coordinate gradient stays with snerf_hashgrid_encode_bwd (grad_table = NULL). */
 typedef struct {
-  int32_t tile_rows_log2, n_tiles, n_chunks, chunk, lds_bytes, _pad;
+  int32_t tile_rows_log2, n_tiles, n_chunks, chunk, lds_bytes;
+  int32_t first_tiled_level;  /* levels below it (few rows, every point of the batch in a handful of tiles) go through the atomic kernel */
   int32_t tile_start[33];
   int32_t _pad2;
   int64_t count_ints;       /* int32 elements of `counts` */
-  int64_t record_capacity;  /* uint32 elements of `records` = B * L * 8 */
+  int64_t record_capacity;  /* uint32 elements of `records` = B * (L - first_tiled_level) * 8 */
 } snerf_hashgrid_tile_plan;
-int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, int64_t B, int32_t tile_rows_log2, snerf_hashgrid_tile_plan* plan);
+/* tile_rows_log2 <= 0: 2^11 rows (or fewer when a tile image would not fit 64 KB); first_tiled_level < 0: levels with fewer than 2^18 rows stay atomic. */
+int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, int64_t B, int32_t tile_rows_log2, int32_t first_tiled_level,
+                                  snerf_hashgrid_tile_plan* plan);
+/* snerf_hashgrid_encode_bwd for levels [level_begin, level_end) only. */
+int snerf_hashgrid_encode_bwd_levels(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out, float* grad_table,
+                                     float* grad_x, int32_t level_begin, int32_t level_end, snerf_stream_t stream);
 /* counts [count_ints], tile_base [n_tiles + 1]: workspaces; x [B,3] and grad_out [B, L*F] must stay valid until the tile pass has run.  B < 2^28. */
 int snerf_hashgrid_bwd_bin(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
                            int32_t* counts, int32_t* tile_base, uint32_t* records, snerf_stream_t stream);
 int snerf_hashgrid_bwd_tiles(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
                              const int32_t* tile_base, const uint32_t* records, float* grad_table, snerf_stream_t stream);
+/* grad_table: what snerf_hashgrid_encode_bwd_levels left for levels [0, first_tiled_level) (read and cleared; NULL when every level is tiled). */
 int snerf_hashgrid_bwd_tiles_adam(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
-                                  const int32_t* tile_base, const uint32_t* records, float* p, float* m, float* v, float lr, float beta1, float beta2,
-                                  float eps, int32_t step, snerf_stream_t stream);
+                                  const int32_t* tile_base, const uint32_t* records, float* grad_table, float* p, float* m, float* v, float lr, float beta1,
+                                  float beta2, float eps, int32_t step, snerf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * NeRFPlayer decomposition mixing (NerfplayerField.get_density, NS/fields/nerfplayer_field.py:365-372): probs[N,3] = softmax(logits[N,3])

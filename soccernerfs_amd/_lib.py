@@ -97,7 +97,7 @@ class TgridTilePlan(C.Structure):
 
 class HashgridTilePlan(C.Structure):
     """snerf_hashgrid_tile_plan (ABI 14, csrc/hashgrid_tiles.hip)."""
-    _fields_ = [("tile_rows_log2", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("chunk", C.c_int32), ("lds_bytes", C.c_int32), ("_pad", C.c_int32),
+    _fields_ = [("tile_rows_log2", C.c_int32), ("n_tiles", C.c_int32), ("n_chunks", C.c_int32), ("chunk", C.c_int32), ("lds_bytes", C.c_int32), ("first_tiled_level", C.c_int32),
                 ("tile_start", C.c_int32 * 33), ("_pad2", C.c_int32), ("count_ints", C.c_int64), ("record_capacity", C.c_int64)]
 
 
@@ -157,10 +157,11 @@ def lib():
     l.snerf_tgrid_bwd_tiles.argtypes = [P, P, L, P, P, P, P, P, P]
     l.snerf_tgrid_bwd_tiles_adam.argtypes = [P, P, L, P, P, P, P, P, P, P, P, F, F, F, F, I, I, I, P, P]
     l.snerf_tgrid_encode_bwd_levels.argtypes = [P, P, P, P, I, L, P, P, I, I, P]
-    l.snerf_hashgrid_tile_plan_make.argtypes = [P, L, I, P]
+    l.snerf_hashgrid_tile_plan_make.argtypes = [P, L, I, I, P]
+    l.snerf_hashgrid_encode_bwd_levels.argtypes = [P, P, P, L, P, P, P, I, I, P]
     l.snerf_hashgrid_bwd_bin.argtypes = [P, P, P, L, P, P, P, P, P]
     l.snerf_hashgrid_bwd_tiles.argtypes = [P, P, P, L, P, P, P, P, P]
-    l.snerf_hashgrid_bwd_tiles_adam.argtypes = [P, P, P, L, P, P, P, P, P, P, F, F, F, F, I, P]
+    l.snerf_hashgrid_bwd_tiles_adam.argtypes = [P, P, P, L, P, P, P, P, P, P, P, F, F, F, F, I, P]
     l.snerf_adam_step_tv.argtypes = [P, P, P, P, L, I, I, I, P, F, F, F, F, I, F, I, P, P]
     l.snerf_isg_maps.argtypes = [P, I, I, I, I, I, P, P, P, I, F, P, P, P]
     l.snerf_ist_maps.argtypes = [P, I, I, I, I, P, P, F, P, P]
@@ -233,6 +234,7 @@ EXPORTS = [
     "snerf_tgrid_bwd_tiles_adam",
     "snerf_tgrid_encode_bwd_levels",
     "snerf_hashgrid_tile_plan_make",
+    "snerf_hashgrid_encode_bwd_levels",
     "snerf_hashgrid_bwd_bin",
     "snerf_hashgrid_bwd_tiles",
     "snerf_hashgrid_bwd_tiles_adam",

@@ -29,6 +29,7 @@ struct HgArgs {
   float* gx;            // bwd, may be null: [B, D], accumulated over levels
   long long* gtable_fx; // deterministic mode: the same two accumulators as 2^50-scaled 64-bit cells (common.hpp: fx_atomic_add)
   long long* gx_fx;
+  int level0, level1;   // levels [level0, level1) of this launch (level1 = 0: all; snerf_hashgrid_encode_bwd_levels)
 };
 
 template <int F, bool BWD, int HG_CB>
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void hashgrid_kernel(HgArgs a) {
   const int li = (int)(gid - b * LPS);
   const int fl = li % F;   // this lane's feature (backward)
   const int xb = li / F;   // this lane's low corner bits (backward): x first
-  const int level = blockIdx.y;
+  const int level = blockIdx.y + a.level0;
   if (b >= a.B) return;  // B * F is a multiple of F: the F lanes of a sample leave together
   const float scale = a.d.scale[level];
   const uint32_t resolution = (uint32_t)a.d.resolution[level];
@@ -149,7 +150,7 @@ static int validate(const snerf_hashgrid_desc* d, int64_t B) {
 
 template <bool BWD, int CB>
 static int launch_cb(const HgArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)ceil_div(a.B * (BWD ? (1 << CB) * a.d.F : 1), 256), (unsigned)a.d.L);
+  dim3 grid((unsigned)ceil_div(a.B * (BWD ? (1 << CB) * a.d.F : 1), 256), (unsigned)(a.level1 > 0 ? a.level1 - a.level0 : a.d.L));
   switch (a.d.F) {
     case 1: hipLaunchKernelGGL((hashgrid_kernel<1, BWD, CB>), grid, dim3(256), 0, st, a); break;
     case 2: hipLaunchKernelGGL((hashgrid_kernel<2, BWD, CB>), grid, dim3(256), 0, st, a); break;
@@ -220,6 +221,21 @@ extern "C" int snerf_hashgrid_encode_bwd(const snerf_hashgrid_desc* desc, const 
   SNERF_REQUIRE(!grad_x || table, "hashgrid_encode_bwd: the coordinate gradient needs the table");
   HgArgs a = {};
   a.d = *desc; a.x = x; a.B = B; a.table = table; a.gout = grad_out; a.gtable = grad_table; a.gx = grad_x;
+  return launch<true>(a, (hipStream_t)stream);
+}
+
+// snerf.h (ABI 14): the same for levels [level_begin, level_end) only (the coarse levels beside the tiled form, csrc/hashgrid_tiles.hip)
+extern "C" int snerf_hashgrid_encode_bwd_levels(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out,
+                                                float* grad_table, float* grad_x, int32_t level_begin, int32_t level_end, snerf_stream_t stream) {
+  int rc = validate(desc, B);
+  if (rc) return rc;
+  SNERF_REQUIRE(level_begin >= 0 && level_begin <= level_end && level_end <= desc->L, "hashgrid_encode_bwd_levels: levels [%d, %d) of %d", level_begin, level_end, desc->L);
+  if (B == 0 || level_begin == level_end) return 0;
+  SNERF_REQUIRE(x && grad_out && (grad_table || grad_x), "hashgrid_encode_bwd_levels: null buffer");
+  SNERF_REQUIRE(!grad_x || table, "hashgrid_encode_bwd_levels: the coordinate gradient needs the table");
+  HgArgs a = {};
+  a.d = *desc; a.x = x; a.B = B; a.table = table; a.gout = grad_out; a.gtable = grad_table; a.gx = grad_x;
+  a.level0 = level_begin; a.level1 = level_end;
   return launch<true>(a, (hipStream_t)stream);
 }
 

@@ -26,7 +26,8 @@ struct HtArgs {
   int32_t* counts;
   int32_t* tile_base;
   uint32_t* records;
-  float* gtable;       // MODE 0
+  float* gtable;       // MODE 0: accumulated into; MODE 1: the coarse (atomic) levels' contribution, read and cleared (may be null when every level is tiled)
+  int tile0;           // first tile of the launch
   float* p; float* m; float* v;
   float step_size, b1, b2, inv_sqrt_bc2, eps;
 };
@@ -94,7 +95,7 @@ __device__ __forceinline__ void ht_for_records(const HtArgs& a, const HtLevel& l
 template <int F, bool FILL>
 __global__ __launch_bounds__(HT_BIN_NT) void ht_bin_kernel(HtArgs a) {
   extern __shared__ int ht_hist[];
-  const int level = (int)blockIdx.y, chunk = (int)blockIdx.x;
+  const int level = (int)blockIdx.y + a.pl.first_tiled_level, chunk = (int)blockIdx.x;
   const int T0 = a.pl.tile_start[level], nt = a.pl.tile_start[level + 1] - T0;
   int* hist = ht_hist;
   int* base = ht_hist + nt;
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(HT_BIN_NT) void ht_bin_kernel(HtArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void ht_scan_chunks_kernel(int32_t* __restrict__ counts, int n_chunks, int n_tiles, int32_t* __restrict__ totals) {
-  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+__global__ __launch_bounds__(256) void ht_scan_chunks_kernel(int32_t* __restrict__ counts, int n_chunks, int n_tiles, int t_first, int32_t* __restrict__ totals) {
+  const int t = t_first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (t >= n_tiles) return;
   int run = 0;
   for (int c = 0; c < n_chunks; ++c) {
@@ -130,11 +131,12 @@ __global__ __launch_bounds__(256) void ht_scan_chunks_kernel(int32_t* __restrict
   totals[t] = run;
 }
 
-__global__ __launch_bounds__(1024) void ht_scan_tiles_kernel(int32_t* __restrict__ tile_base, int n_tiles) {
+__global__ __launch_bounds__(1024) void ht_scan_tiles_kernel(int32_t* __restrict__ tile_base, int n_tiles, int t_first) {
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int per = (n_tiles + 1023) / 1024;
-  const int i0 = tid * per;
+  for (int t = tid; t < t_first; t += 1024) tile_base[t] = 0;  // tiles of the coarse (atomic) levels hold no records
+  const int per = (n_tiles - t_first + 1023) / 1024;
+  const int i0 = t_first + tid * per;
   int local = 0;
   for (int k = 0; k < per; ++k)
     if (i0 + k < n_tiles) local += tile_base[i0 + k];
@@ -166,10 +168,11 @@ __global__ __launch_bounds__(1024) void ht_scan_tiles_kernel(int32_t* __restrict
 template <int F, int MODE>
 __global__ __launch_bounds__(HT_NT) void ht_tiles_kernel(HtArgs a) {
   extern __shared__ float ht_acc[];
-  const int tile = (int)blockIdx.x;
+  const int tile = (int)blockIdx.x + a.tile0;
   int level = 0;
   while (level + 1 < a.d.L && tile >= a.pl.tile_start[level + 1]) ++level;
   const HtLevel lv = ht_level(a.d, level);
+  const bool coarse = level < a.pl.first_tiled_level;  // its gradient came through the atomic kernel into gtable
   const int sh = a.pl.tile_rows_log2;
   const uint32_t row0 = (uint32_t)(tile - a.pl.tile_start[level]) << sh;
   const uint32_t nrows = (lv.rows - row0) < (1u << sh) ? (lv.rows - row0) : (1u << sh);
@@ -223,7 +226,12 @@ __global__ __launch_bounds__(HT_NT) void ht_tiles_kernel(HtArgs a) {
       *reinterpret_cast<float4*>(a.gtable + f0) = o;
     } else {
       float4 pp = ldnt4(a.p + f0), mm = ldnt4(a.m + f0), vv = ldnt4(a.v + f0);
-      adam_float4(pp, mm, vv, gq, make_float4(0.f, 0.f, 0.f, 0.f), 1.f, a.b1, a.b2, a.eps, dc);
+      float4 extra = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (coarse && a.gtable) {
+        extra = ldnt4(a.gtable + f0);
+        if (extra.x != 0.f || extra.y != 0.f || extra.z != 0.f || extra.w != 0.f) stnt4(a.gtable + f0, make_float4(0.f, 0.f, 0.f, 0.f));
+      }
+      adam_float4(pp, mm, vv, gq, extra, 1.f, a.b1, a.b2, a.eps, dc);
       stnt4(a.p + f0, pp);
       stnt4(a.m + f0, mm);
       stnt4(a.v + f0, vv);
@@ -240,31 +248,41 @@ static int ht_validate(const snerf_hashgrid_desc* d, const snerf_hashgrid_tile_p
   SNERF_REQUIRE(d->L >= 1 && d->L <= 32 && d->offsets[d->L] > 0, "hashgrid tiles: descriptor not laid out");
   SNERF_REQUIRE(B >= 0 && B < (1LL << 28), "hashgrid tiles: B=%lld (< 2^28)", (long long)B);
   SNERF_REQUIRE(pl->tile_rows_log2 >= 3 && pl->tile_rows_log2 <= 16 && pl->n_tiles == pl->tile_start[d->L] && pl->chunk >= 1 &&
-                    pl->n_chunks == (int)((B + pl->chunk - 1) / pl->chunk),
+                    pl->n_chunks == (int)((B + pl->chunk - 1) / pl->chunk) && pl->first_tiled_level >= 0 && pl->first_tiled_level <= d->L,
                 "hashgrid tiles: the plan does not belong to this descriptor / batch (snerf_hashgrid_tile_plan_make)");
   return 0;
 }
 
 template <int F>
 static int ht_bin_launch(const HtArgs& a, hipStream_t st) {
+  const int L = a.d.L, Lc = a.pl.first_tiled_level;
+  if (Lc >= L || a.B == 0) {
+    hipLaunchKernelGGL(ht_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles, a.pl.n_tiles);
+    SNERF_LAUNCH_CHECK("hashgrid_bwd_bin (empty)");
+    return 0;
+  }
   int max_nt = 0;
-  for (int l = 0; l < a.d.L; ++l) max_nt = a.pl.tile_start[l + 1] - a.pl.tile_start[l] > max_nt ? a.pl.tile_start[l + 1] - a.pl.tile_start[l] : max_nt;
+  for (int l = Lc; l < L; ++l) max_nt = a.pl.tile_start[l + 1] - a.pl.tile_start[l] > max_nt ? a.pl.tile_start[l + 1] - a.pl.tile_start[l] : max_nt;
   const size_t lds = (size_t)max_nt * 2 * sizeof(int);
-  const dim3 grid((unsigned)(a.pl.n_chunks > 0 ? a.pl.n_chunks : 1), (unsigned)a.d.L);
+  const dim3 grid((unsigned)a.pl.n_chunks, (unsigned)(L - Lc));
+  const int t_first = a.pl.tile_start[Lc];
   hipLaunchKernelGGL((ht_bin_kernel<F, false>), grid, dim3(HT_BIN_NT), lds, st, a);
-  hipLaunchKernelGGL(ht_scan_chunks_kernel, dim3((unsigned)ceil_div(a.pl.n_tiles, 256)), dim3(256), 0, st, a.counts, a.pl.n_chunks > 0 ? a.pl.n_chunks : 1, a.pl.n_tiles,
+  hipLaunchKernelGGL(ht_scan_chunks_kernel, dim3((unsigned)ceil_div(a.pl.n_tiles - t_first, 256)), dim3(256), 0, st, a.counts, a.pl.n_chunks, a.pl.n_tiles, t_first,
                      a.tile_base);
-  hipLaunchKernelGGL(ht_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles);
+  hipLaunchKernelGGL(ht_scan_tiles_kernel, dim3(1), dim3(1024), 0, st, a.tile_base, a.pl.n_tiles, t_first);
   hipLaunchKernelGGL((ht_bin_kernel<F, true>), grid, dim3(HT_BIN_NT), lds, st, a);
   SNERF_LAUNCH_CHECK("hashgrid_bwd_bin");
   return 0;
 }
 
 template <int F, int MODE>
-static int ht_tiles_launch(const HtArgs& a, hipStream_t st) {
+static int ht_tiles_launch(HtArgs& a, hipStream_t st) {
   const int lds = ht_lds_bytes(&a.d, a.pl.tile_rows_log2);
   SNERF_ALLOW_LDS((ht_tiles_kernel<F, MODE>), lds);
-  hipLaunchKernelGGL((ht_tiles_kernel<F, MODE>), dim3((unsigned)a.pl.n_tiles), dim3(HT_NT), (size_t)lds, st, a);
+  a.tile0 = MODE == 0 ? a.pl.tile_start[a.pl.first_tiled_level] : 0;  // MODE 0: tiles of the coarse levels hold no records
+  const int n = a.pl.n_tiles - a.tile0;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL((ht_tiles_kernel<F, MODE>), dim3((unsigned)n), dim3(HT_NT), (size_t)lds, st, a);
   SNERF_LAUNCH_CHECK(MODE == 0 ? "hashgrid_bwd_tiles" : "hashgrid_bwd_tiles_adam");
   return 0;
 }
@@ -281,15 +299,18 @@ static int ht_tiles_launch(const HtArgs& a, hipStream_t st) {
 
 using namespace snerf;
 
-extern "C" int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, int64_t B, int32_t tile_rows_log2, snerf_hashgrid_tile_plan* plan) {
+extern "C" int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, int64_t B, int32_t tile_rows_log2, int32_t first_tiled_level,
+                                             snerf_hashgrid_tile_plan* plan) {
   SNERF_REQUIRE(desc && plan, "hashgrid_tile_plan_make: null argument");
   SNERF_REQUIRE(desc->L >= 1 && desc->L <= 32 && desc->offsets[desc->L] > 0 && B >= 0, "hashgrid_tile_plan_make: descriptor not laid out / B=%lld", (long long)B);
   int64_t max_rows = 0;
   for (int l = 0; l < desc->L; ++l) max_rows = desc->offsets[l + 1] - desc->offsets[l] > max_rows ? desc->offsets[l + 1] - desc->offsets[l] : max_rows;
   int sh = tile_rows_log2;
   if (sh <= 0) {
+    // 2^11 rows: a level of 2^19 rows is 256 tiles, so that a batch's ~4.5 records per (point, level) spread over enough workgroups (a tile of 2^13 rows
+    // of the NeRFPlayer preset receives 27 k records: 54 dependent rounds of its 512 threads)
     sh = 3;
-    while (sh < 16 && ht_lds_bytes(desc, sh + 1) <= 64 * 1024) ++sh;  // two workgroups per CU
+    while (sh < 11 && ht_lds_bytes(desc, sh + 1) <= 64 * 1024) ++sh;
   }
   while (sh < 16 && ((max_rows + (1LL << sh) - 1) >> sh) > HT_MAX_LEVEL_TILES) ++sh;
   SNERF_REQUIRE(sh >= 3 && sh <= 16 && ht_lds_bytes(desc, sh) <= 156 * 1024, "hashgrid_tile_plan_make: a tile of 2^%d rows x %d features does not fit LDS", sh, desc->F);
@@ -303,9 +324,16 @@ extern "C" int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, in
   plan->n_tiles = t;
   plan->chunk = 4096;
   plan->n_chunks = (int)((B + plan->chunk - 1) / plan->chunk);
+  int lc = first_tiled_level;
+  if (lc < 0) {
+    // levels with fewer than 2^18 rows stay with the atomic kernel: every point of the batch lands in their few tiles (level 0 of the preset: 4096 rows)
+    lc = 0;
+    while (lc < desc->L && desc->offsets[lc + 1] - desc->offsets[lc] < (1 << 18)) ++lc;
+  }
+  plan->first_tiled_level = lc > desc->L ? desc->L : lc;
   plan->lds_bytes = ht_lds_bytes(desc, sh);
   plan->count_ints = (int64_t)(plan->n_chunks > 0 ? plan->n_chunks : 1) * plan->n_tiles;
-  plan->record_capacity = B * desc->L * 8;
+  plan->record_capacity = B * (desc->L - plan->first_tiled_level) * 8;
   return 0;
 }
 
@@ -336,15 +364,16 @@ extern "C" int snerf_hashgrid_bwd_tiles(const snerf_hashgrid_desc* desc, const s
 }
 
 extern "C" int snerf_hashgrid_bwd_tiles_adam(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
-                                             const int32_t* tile_base, const uint32_t* records, float* p, float* m, float* v, float lr, float beta1, float beta2,
-                                             float eps, int32_t step, snerf_stream_t stream) {
+                                             const int32_t* tile_base, const uint32_t* records, float* grad_table, float* p, float* m, float* v, float lr,
+                                             float beta1, float beta2, float eps, int32_t step, snerf_stream_t stream) {
   int rc = ht_validate(desc, plan, B);
   if (rc) return rc;
   SNERF_REQUIRE(tile_base && (records || B == 0) && (x || B == 0) && (grad_out || B == 0) && p && m && v, "hashgrid_bwd_tiles_adam: null buffer");
-  SNERF_REQUIRE(step >= 1 && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "hashgrid_bwd_tiles_adam: step=%d (1-based) / 16-byte alignment", step);
+  SNERF_REQUIRE(step >= 1 && (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v | (uintptr_t)grad_table) & 15) == 0, "hashgrid_bwd_tiles_adam: step=%d (1-based) / 16-byte alignment", step);
+  SNERF_REQUIRE(plan->first_tiled_level == 0 || grad_table, "hashgrid_bwd_tiles_adam: levels [0, %d) go through the atomic kernel: pass their gradient buffer", plan->first_tiled_level);
   HtArgs a = {};
   a.d = *desc; a.pl = *plan; a.x = x; a.B = B; a.gout = grad_out; a.tile_base = const_cast<int32_t*>(tile_base); a.records = const_cast<uint32_t*>(records);
-  a.p = p; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+  a.gtable = grad_table; a.p = p; a.m = m; a.v = v; a.b1 = beta1; a.b2 = beta2; a.eps = eps;
   adam_consts(lr, beta1, beta2, step, a.step_size, a.inv_sqrt_bc2);
 #define HT_CALL(F_) ht_tiles_launch<F_, 1>(a, (hipStream_t)stream)
   HT_DISPATCH_F(desc->F, HT_CALL)

@@ -498,16 +498,21 @@ class NerfplayerFullTrainer:
             # owner-computes form (round 6): one binning pass over all 2N points, then scatter + Adam of the table as one pass; the coordinate gradient of
             # the deformed half is a gather (the atomic kernel without a table gradient)
             th = self._tiled_hash
+            lc = th.plan.first_tiled_level
+            gth = self.gviews["field.hash"]
             th.bin(b["x2"], b["genc2"], self._st)
-            lr_h = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
-            oh, nh = next((o, n) for name, _, _, o, n in self.segments if name == "field.hash")
-            th.scatter_adam(b["x2"], b["genc2"], self.params[oh:oh + nh], self.exp_avg[oh:oh + nh], self.exp_avg_sq[oh:oh + nh], lr_h, self.step + 1, self.adam_eps,
-                            stream=self._st)
-            self.launches += 5
-            self._hash_swept = True
             b["gx2"][N:].zero_()
+            # the coarse levels (every point of the batch in a handful of tiles) through the atomic kernel: table gradient from both halves ...
+            th.coarse_levels(b["x2"], b["genc2"], gth, self._st)
+            # ... and the coordinate gradient of the deformed half: levels [0, lc) were handled just above for the table, so one gather-only launch per range
             self._ck(self.lib.snerf_hashgrid_encode_bwd(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"], 3 * N), C.c_int64(N),
                                                         self._p(b["genc2"], N * F), None, self._p(b["gx2"], 3 * N), self._st), "hashgrid_bwd (coordinates)")
+            lr_h = self.lr * cosine_lr_factor(self.step, self.warm_up_end, self.max_steps, 0.0)
+            oh, nh = next((o, n) for name, _, _, o, n in self.segments if name == "field.hash")
+            th.scatter_adam(b["x2"], b["genc2"], gth if lc > 0 else None, self.params[oh:oh + nh], self.exp_avg[oh:oh + nh], self.exp_avg_sq[oh:oh + nh], lr_h,
+                            self.step + 1, self.adam_eps, stream=self._st)
+            self.launches += 6
+            self._hash_swept = True
         elif self.grads_fx is not None:
             gt = self._pfx(self.gviews["field.hash"])
             self._ck(self.lib.snerf_hashgrid_encode_bwd_fx(C.byref(self.hash.desc), self._p(self.hash.params), self._p(b["x2"]), C.c_int64(N), self._p(b["genc2"]),

@@ -17,7 +17,7 @@ nerfplayer_field.py:223-226 but never called on the path: construct-only here).
 """
 import ctypes as C
 import math
-from typing import Dict, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 from torch import nn
@@ -132,14 +132,17 @@ class Encoding(nn.Module):
 class TiledHashTableBackward:
     """Owner-computes backward of a HashGrid Encoding's table for a fixed batch size (csrc/hashgrid_tiles.hip, ABI 14): `bin` files the batch's (point, level,
     corner pair) touches under tiles of consecutive table rows; `scatter` adds the tiles into a dense gradient, `scatter_adam` runs torch.optim.Adam over the
-    table straight from the tiles' LDS images (no dense gradient).  x [B,3] and gout [B, L*F] must stay valid until the tile pass has run."""
+    table straight from the tiles' LDS images (no dense gradient).  Levels below plan.first_tiled_level (few rows: every point of the batch lands in a handful of
+    tiles) go through the atomic kernel (`coarse_levels`) into the dense gradient, which `scatter_adam` then reads and clears for those rows.  x [B,3] and
+    gout [B, L*F] must stay valid until the tile pass has run."""
 
-    def __init__(self, enc: Encoding, B: int, tile_rows_log2: int = 0):
+    def __init__(self, enc: Encoding, B: int, tile_rows_log2: int = 0, first_tiled_level: int = -1):
         import ctypes as C
 
         self.enc, self.B = enc, int(B)
         self.plan = _lib.HashgridTilePlan()
-        _lib.check(_lib.lib().snerf_hashgrid_tile_plan_make(C.byref(enc.desc), C.c_int64(B), tile_rows_log2, C.byref(self.plan)), "hashgrid_tile_plan_make")
+        _lib.check(_lib.lib().snerf_hashgrid_tile_plan_make(C.byref(enc.desc), C.c_int64(B), tile_rows_log2, first_tiled_level, C.byref(self.plan)),
+                   "hashgrid_tile_plan_make")
         dev = enc.params.device
         self.counts = torch.empty(max(int(self.plan.count_ints), 1), dtype=torch.int32, device=dev)
         self.tile_base = torch.empty(self.plan.n_tiles + 1, dtype=torch.int32, device=dev)
@@ -152,18 +155,28 @@ class TiledHashTableBackward:
         _lib.check(_lib.lib().snerf_hashgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), ops._ptr(x), C.c_int64(self.B), ops._ptr(gout), ops._ptr(self.counts),
                                                      ops._ptr(self.tile_base), ops._ptr(self.records), st), "hashgrid_bwd_bin")
 
+    def coarse_levels(self, x: torch.Tensor, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
+        import ctypes as C
+
+        lc = self.plan.first_tiled_level
+        if lc > 0:
+            st = stream if stream is not None else ops._stream()
+            _lib.check(_lib.lib().snerf_hashgrid_encode_bwd_levels(C.byref(self.enc.desc), None, ops._ptr(x), C.c_int64(self.B), ops._ptr(gout), ops._ptr(gtable), None, 0, lc,
+                                                                   st), "hashgrid_encode_bwd_levels")
+
     def scatter(self, x: torch.Tensor, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
+        """gtable += the tiled levels' share (after `bin`; `coarse_levels` adds the rest)."""
         import ctypes as C
 
         st = stream if stream is not None else ops._stream()
         _lib.check(_lib.lib().snerf_hashgrid_bwd_tiles(C.byref(self.enc.desc), C.byref(self.plan), ops._ptr(x), C.c_int64(self.B), ops._ptr(gout), ops._ptr(self.tile_base),
                                                        ops._ptr(self.records), ops._ptr(gtable), st), "hashgrid_bwd_tiles")
 
-    def scatter_adam(self, x: torch.Tensor, gout: torch.Tensor, p: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step: int, eps: float,
-                     betas=(0.9, 0.999), stream=None):
+    def scatter_adam(self, x: torch.Tensor, gout: torch.Tensor, gtable: Optional[torch.Tensor], p: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, step: int,
+                     eps: float, betas=(0.9, 0.999), stream=None):
         import ctypes as C
 
         st = stream if stream is not None else ops._stream()
         _lib.check(_lib.lib().snerf_hashgrid_bwd_tiles_adam(C.byref(self.enc.desc), C.byref(self.plan), ops._ptr(x), C.c_int64(self.B), ops._ptr(gout),
-                                                            ops._ptr(self.tile_base), ops._ptr(self.records), ops._ptr(p), ops._ptr(m), ops._ptr(v), lr, betas[0], betas[1],
-                                                            eps, step, st), "hashgrid_bwd_tiles_adam")
+                                                            ops._ptr(self.tile_base), ops._ptr(self.records), ops._ptr(gtable) if gtable is not None else None, ops._ptr(p),
+                                                            ops._ptr(m), ops._ptr(v), lr, betas[0], betas[1], eps, step, st), "hashgrid_bwd_tiles_adam")

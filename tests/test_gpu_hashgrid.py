@@ -236,14 +236,14 @@ def test_full_nerfplayer_preset_trains():
     torch.testing.assert_close(out["probs"].sum(-1), out["accumulation"][:, 0], rtol=1e-4, atol=1e-5)  # softmax rows sum to 1
 
 
-@pytest.mark.parametrize("cfg,sh", [
-    (dict(n_levels=16, n_features_per_level=2, base_resolution=16, per_level_scale=1.4472692012786865, log2_hashmap_size=15), 0),  # NeRFPlayer's, default tiles
-    (dict(n_levels=16, n_features_per_level=2, base_resolution=16, per_level_scale=1.4472692012786865, log2_hashmap_size=15), 6),  # small tiles: boundaries inside levels
-    (dict(n_levels=3, n_features_per_level=4, base_resolution=4, per_level_scale=2.0, log2_hashmap_size=12), 4),                   # all dense
-    (dict(n_levels=5, n_features_per_level=8, base_resolution=5, per_level_scale=1.5, log2_hashmap_size=9), 3),
-    (dict(n_levels=4, n_features_per_level=1, base_resolution=7, per_level_scale=1.6, log2_hashmap_size=11), 5),
+@pytest.mark.parametrize("cfg,sh,lc", [
+    (dict(n_levels=16, n_features_per_level=2, base_resolution=16, per_level_scale=1.4472692012786865, log2_hashmap_size=15), 0, 0),  # NeRFPlayer's, default tile size
+    (dict(n_levels=16, n_features_per_level=2, base_resolution=16, per_level_scale=1.4472692012786865, log2_hashmap_size=15), 6, 3),  # small tiles; levels 0-2 atomic
+    (dict(n_levels=3, n_features_per_level=4, base_resolution=4, per_level_scale=2.0, log2_hashmap_size=12), 4, 0),                   # all dense
+    (dict(n_levels=5, n_features_per_level=8, base_resolution=5, per_level_scale=1.5, log2_hashmap_size=9), 3, 1),
+    (dict(n_levels=4, n_features_per_level=1, base_resolution=7, per_level_scale=1.6, log2_hashmap_size=11), 5, 2),
 ])
-def test_tiled_table_backward_equals_the_atomic_kernel_and_its_fused_adam_equals_scatter_then_adam(cfg, sh):
+def test_tiled_table_backward_equals_the_atomic_kernel_and_its_fused_adam_equals_scatter_then_adam(cfg, sh, lc):
     """csrc/hashgrid_tiles.hip (round 6, ABI 14): the owner-computes table backward against hashgrid_kernel's atomic scatter (itself pinned against the oracle's
     autograd above) -- same entries, summation-order accuracy, ACCUMULATING -- and its fused Adam form against scatter -> snerf_adam_step over three steps."""
     import ctypes as C
@@ -263,32 +263,36 @@ def test_tiled_table_backward_equals_the_atomic_kernel_and_its_fused_adam_equals
         gout[7:11] = 0.0
         ref = torch.zeros_like(enc.params)
         _lib.check(L.snerf_hashgrid_encode_bwd(C.byref(enc.desc), None, ops._ptr(x), C.c_int64(B), ops._ptr(gout), ops._ptr(ref), None, ops._stream()))
-        tb = TiledHashTableBackward(enc, B, tile_rows_log2=sh)
-        assert tb.plan.n_tiles == tb.plan.tile_start[cfg["n_levels"]] and (sh == 0 or tb.plan.tile_rows_log2 == sh)
+        tb = TiledHashTableBackward(enc, B, tile_rows_log2=sh, first_tiled_level=lc)
+        assert tb.plan.n_tiles == tb.plan.tile_start[cfg["n_levels"]] and (sh == 0 or tb.plan.tile_rows_log2 == sh) and tb.plan.first_tiled_level == lc
         got = torch.zeros_like(ref)
         tb.bin(x, gout)
+        tb.coarse_levels(x, gout, got)
         tb.scatter(x, gout, got)
         torch.cuda.synchronize()
         assert 0 < int(tb.tile_base[-1]) <= tb.plan.record_capacity
         scale = float(ref.abs().max())
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6 * scale)
         assert bool(((got != 0) == (ref != 0)).all())
+        tb.coarse_levels(x, gout, got)
         tb.scatter(x, gout, got)
         torch.testing.assert_close(got, 2 * ref, rtol=1e-5, atol=4e-6 * scale)
     # fused Adam
     p_ref, p_new = enc.params.detach().clone(), enc.params.detach().clone()
     z = lambda: torch.zeros_like(p_ref)
-    m_ref, v_ref, m_new, v_new, g_ref = z(), z(), z(), z(), z()
+    m_ref, v_ref, m_new, v_new, g_ref, g_new = z(), z(), z(), z(), z(), z()
     B = 3000
-    tb = TiledHashTableBackward(enc, B, tile_rows_log2=sh)
+    tb = TiledHashTableBackward(enc, B, tile_rows_log2=sh, first_tiled_level=lc)
     for step in range(1, 4):
         x = torch.rand(B, 3, generator=gen).to(DEV)
         gout = ((torch.rand(B, cfg["n_levels"] * F, generator=gen) - 0.5) * 1e-3).to(DEV)
         _lib.check(L.snerf_hashgrid_encode_bwd(C.byref(enc.desc), None, ops._ptr(x), C.c_int64(B), ops._ptr(gout), ops._ptr(g_ref), None, ops._stream()))
         ops.adam_step(p_ref, g_ref, m_ref, v_ref, step, 1e-2, eps=1e-6, zero_grad=True)
         tb.bin(x, gout)
-        tb.scatter_adam(x, gout, p_new, m_new, v_new, 1e-2, step, 1e-6)
+        tb.coarse_levels(x, gout, g_new)
+        tb.scatter_adam(x, gout, g_new if lc > 0 else None, p_new, m_new, v_new, 1e-2, step, 1e-6)
         torch.cuda.synchronize()
+        assert float(g_new.abs().max()) == 0.0  # the coarse levels' gradient was read AND cleared
         torch.testing.assert_close(m_new, m_ref, rtol=1e-4, atol=1e-9)
         torch.testing.assert_close(v_new, v_ref, rtol=2e-4, atol=1e-15)
         assert float(((p_new - p_ref).abs() > 1e-5).float().mean()) < 1e-4
