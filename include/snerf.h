@@ -560,7 +560,8 @@ int snerf_tgrid_tile_plan_make(const snerf_tgrid_desc* desc, int64_t B, int32_t 
 /* counts [count_ints] and tile_base [n_tiles + 3] are workspaces (no initialisation needed: n_tiles + 1 prefix sums, then two words the fused tile pass
  * uses to hand out tiles); records [record_capacity]; pos4 [B,4] (16-byte aligned)
  * receives (x, y, z, time) per sample -- the later passes read ONLY pos4, grad_out, tile_base and records, never `coords`, so they may run on another
- * stream while the caller's ray buffers are rewritten.  B < 2^28. */
+ * stream while the caller's ray buffers are rewritten.  grad_out may be NULL: the pass then files every in-range sample (it depends on the sample positions
+ * only, so it can run as soon as those exist -- beside the forward); with grad_out, (sample, level) pairs whose gradient is all zero are left out.  B < 2^28. */
 int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgrid_tile_plan* plan, const snerf_coords* coords, const float* times,
                         int32_t samples_per_row, int64_t B, const float* grad_out, float* pos4, int32_t* counts, int32_t* tile_base, uint32_t* records,
                         snerf_stream_t stream);

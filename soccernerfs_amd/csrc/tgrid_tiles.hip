@@ -60,11 +60,13 @@ __device__ __forceinline__ void tt_for_records(const TileArgs& a, const TgLevel&
   const float4 ps = a.pos4[b];
   const float x[3] = {ps.x, ps.y, ps.z};
   if ((x[0] < 0.f) || (x[0] > 1.f) || (x[1] < 0.f) || (x[1] > 1.f) || (x[2] < 0.f) || (x[2] > 1.f)) return;  // .cu:119-124
-  const float* g = a.gout + b * (a.d.L * C) + level * C;
-  bool any = false;
+  if (a.gout) {  // binning may run before the gradient exists (grad_out = NULL: every in-range sample is filed; a zero gradient then adds nothing in the tile pass)
+    const float* g = a.gout + b * (a.d.L * C) + level * C;
+    bool any = false;
 #pragma unroll
-  for (int ch = 0; ch < C; ++ch) any |= g[ch] != 0.f;
-  if (!any) return;  // nothing to add for this (sample, level)
+    for (int ch = 0; ch < C; ++ch) any |= g[ch] != 0.f;
+    if (!any) return;  // nothing to add for this (sample, level)
+  }
   uint32_t pg[3];
   float fr[3];
   tg_cell(lv, a.d.align_corners != 0, x, pg, fr);
@@ -712,7 +714,7 @@ extern "C" int snerf_tgrid_bwd_bin(const snerf_tgrid_desc* desc, const snerf_tgr
   SNERF_REQUIRE(coords->mode == 0 || coords->mode == 1, "tgrid_bwd_bin: coords.mode=%d", coords->mode);
   if (coords->mode == 0) SNERF_REQUIRE(coords->pts || B == 0, "tgrid_bwd_bin: pts is null");
   if (coords->mode == 1) SNERF_REQUIRE(coords->S >= 1 && B % coords->S == 0 && coords->origins && coords->dirs && coords->ebins, "tgrid_bwd_bin: bad ray coords");
-  SNERF_REQUIRE(counts && tile_base && (pos4 || B == 0) && (records || plan->record_capacity == 0) && (grad_out || B == 0), "tgrid_bwd_bin: null buffer");
+  SNERF_REQUIRE(counts && tile_base && (pos4 || B == 0) && (records || plan->record_capacity == 0), "tgrid_bwd_bin: null buffer");
   SNERF_REQUIRE(((uintptr_t)pos4 & 15) == 0, "tgrid_bwd_bin: pos4 must be 16-byte aligned");
   TileArgs a = {};
   a.d = *desc; a.c = *coords; a.pl = *plan; a.times = times; a.spr = samples_per_row; a.B = B; a.gout = grad_out;

@@ -142,7 +142,7 @@ class NerfplayerTrainer:
         self._tv_cols = [(0, 1)] * 3
         self.async_field_sweep = bool(async_field_sweep)
         self.tiled_field_backward = bool(tiled_field_backward) and not deterministic
-        self._tiled = None
+        self._tiled, self._bin_done, self.early_bin = None, None, True
         if self.tiled_field_backward:
             from .temporal_grid import TiledTableBackward
 
@@ -339,6 +339,16 @@ class NerfplayerTrainer:
                 self._resample(lvl, rng["u"][lvl] if training else None, anneal)
             else:
                 self.wait_params()  # the field table's sweep of the last step (async_field_sweep) must be complete before the table is read
+                if self._tiled is not None and self._in_train_step and training and self.early_bin:
+                    # the binning pass of the tiled backward needs the sample positions only: on a side stream NOW, beside the field forward and the MLP
+                    # backward, instead of between the decode net's backward and the tile pass on the critical chain (~0.19 ms).  Behind wait_params(): the
+                    # previous step's tile pass has read the tiler's buffers by then.
+                    main = torch.cuda.current_stream()
+                    sb = side_stream(self.dev, "sort")
+                    sb.wait_stream(main)
+                    with torch.cuda.stream(sb), self._span("tgrid_bin.field"):
+                        self._tiled.bin(co, t, S, None, C.c_void_p(sb.cuda_stream))
+                        self._bin_done = sb.record_event()
                 self._tgrid_fwd(self.enc, self.enc.embeddings, co, t, S, N, b["feat"])
                 self._mlp_fwd(self.decode, b["feat"], self.enc.output_dim, N, b["h"], 16, 0, b["dens"][2])
                 # colour head input [SH 16 | geo 15 | appearance 32 | 0] in one launch (csrc/nerfplayer.hip; ~35 ATen kernels before round 5)
@@ -393,9 +403,13 @@ class NerfplayerTrainer:
                       self.enc.output_dim)
         if self._tiled is not None and self._in_train_step:
             # owner-computes form: bin on this stream (it reads the ray buffers), then scatter + Adam of the table as ONE pass where the sweep would go
-            with self._span("tgrid_bin.field"):
-                self._tiled.bin(self._coords[2], t, S2, b["gfeat"], self._st)
-                self._tiled.coarse_levels(self._coords[2], t, S2, b["gfeat"], self.gviews["field.table"], self._st)
+            if self._bin_done is not None:  # binned beside the forward (early_bin): the tile pass's stream waits for it below
+                torch.cuda.current_stream().wait_event(self._bin_done)
+                self._bin_done = None
+            else:
+                with self._span("tgrid_bin.field"):
+                    self._tiled.bin(self._coords[2], t, S2, b["gfeat"], self._st)
+            self._tiled.coarse_levels(self._coords[2], t, S2, b["gfeat"], self.gviews["field.table"], self._st)
             if cfg.temporal_tv_weight > 0 and not early:
                 self._tv_sign(0)  # the fused pass adds the TV step itself: its per-row signs must exist first (row draw order unchanged: field first)
             self._field_table_fused_adam(early)

@@ -202,10 +202,11 @@ class TiledTableBackward:
         self.records = torch.empty(max(int(self.plan.record_capacity), 1), dtype=torch.int32, device=dev)
         self.pos4 = torch.empty(max(self.B, 1), 4, dtype=torch.float32, device=dev)
 
-    def bin(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, stream=None):
+    def bin(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: Optional[torch.Tensor], stream=None):
+        """gout = None: file every in-range sample (the pass then needs the sample positions only and can run beside the forward)."""
         st = stream if stream is not None else ops._stream()
-        _lib.check(_lib.lib().snerf_tgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B), ops._ptr(gout),
-                                                  ops._ptr(self.pos4), ops._ptr(self.counts), ops._ptr(self.tile_base), ops._ptr(self.records), st), "tgrid_bwd_bin")
+        _lib.check(_lib.lib().snerf_tgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), C.byref(coords), ops._ptr(times), spr, C.c_int64(self.B),
+                                                  ops._ptr(gout) if gout is not None else None, ops._ptr(self.pos4), ops._ptr(self.counts), ops._ptr(self.tile_base), ops._ptr(self.records), st), "tgrid_bwd_bin")
 
     def coarse_levels(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: torch.Tensor, gtable: torch.Tensor, stream=None):
         """Levels [0, first_tiled_level) through the run-length atomic kernel into gtable; reads the ray buffers, so it belongs on their stream."""

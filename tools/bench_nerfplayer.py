@@ -22,6 +22,7 @@ ap.add_argument("--mlp-operands", default="bf16", choices=["fp32", "bf16"], help
 ap.add_argument("--sync-sweep", action="store_true", help="A/B (--fused): the field table's optimiser sweep in order on the main stream instead of on a side stream behind its gradient scatter")
 ap.add_argument("--tiled", action="store_true", help="with --fused: the field table through the owner-computes backward + fused Adam (csrc/tgrid_tiles.hip)")
 ap.add_argument("--tiled-first-level", type=int, default=0)
+ap.add_argument("--late-bin", action="store_true", help="A/B (--tiled): the binning pass behind the decode net's backward on the caller's stream instead of beside the field forward")
 ap.add_argument("--stadium", action="store_true", help="with --fused: camera rays of the synthetic stadium-players scene (30 cameras in the bleachers, aabb [-1,1]^3, uniform "
                 "pixels) instead of random rays through the box -- what bench.py's config-4 leg times")
 args = ap.parse_args()
@@ -44,6 +45,7 @@ if args.fused:
         full_index = (data["cam_id"] * 100 + frame_ids.to(dev).repeat(30)).contiguous()
         tr = NerfplayerTrainer(NerfplayerNerfactoModelConfig(), R, 3000, aabb_scale=1.0, device=dev, async_field_sweep=not args.sync_sweep, mlp_operands=args.mlp_operands, tiled_field_backward=args.tiled, tiled_first_level=args.tiled_first_level)
         tr.step = 600
+    tr.early_bin = not args.late_bin
 
     def fstep():
         if args.stadium:
