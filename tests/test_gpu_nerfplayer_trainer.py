@@ -374,6 +374,7 @@ def test_tiled_field_backward_is_the_same_step(tv, first_level, async_sweep):
     a, b = make(True), make(False)
     assert a._tiled is not None and b._tiled is None
     assert a._tiled.plan.first_tiled_level == first_level
+    a.early_bin = first_level == 0  # the binning pass beside the field forward (default) / behind the decode net's backward with the zero-gradient filter
     off = {name: (o, n) for name, _, _, o, n in a.segments}
     fo, fn = off["field.table"]
     rays, cams, target, rng = _batch(R, n_img, 100)
