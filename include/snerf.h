@@ -650,7 +650,8 @@ int snerf_hashgrid_tile_plan_make(const snerf_hashgrid_desc* desc, int64_t B, in
 /* snerf_hashgrid_encode_bwd for levels [level_begin, level_end) only. */
 int snerf_hashgrid_encode_bwd_levels(const snerf_hashgrid_desc* desc, const float* table, const float* x, int64_t B, const float* grad_out, float* grad_table,
                                      float* grad_x, int32_t level_begin, int32_t level_end, snerf_stream_t stream);
-/* counts [count_ints], tile_base [n_tiles + 1]: workspaces; x [B,3] and grad_out [B, L*F] must stay valid until the tile pass has run.  B < 2^28. */
+/* counts [count_ints], tile_base [n_tiles + 1]: workspaces; x [B,3] and grad_out [B, L*F] must stay valid until the tile pass has run; grad_out may be NULL
+ * in the binning pass (every point is filed: the pass then depends on the positions only).  B < 2^28. */
 int snerf_hashgrid_bwd_bin(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,
                            int32_t* counts, int32_t* tile_base, uint32_t* records, snerf_stream_t stream);
 int snerf_hashgrid_bwd_tiles(const snerf_hashgrid_desc* desc, const snerf_hashgrid_tile_plan* plan, const float* x, int64_t B, const float* grad_out,

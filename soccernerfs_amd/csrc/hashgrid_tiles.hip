@@ -73,11 +73,13 @@ __device__ __forceinline__ void ht_cell(const HtLevel& lv, const float* x, uint3
 
 template <int F, typename EMIT>
 __device__ __forceinline__ void ht_for_records(const HtArgs& a, const HtLevel& lv, int level, int64_t b, EMIT&& emit) {
-  const float* g = a.gout + b * (a.d.L * F) + level * F;
-  bool any = false;
+  if (a.gout) {  // grad_out = NULL: binning before the gradient exists files every point (a zero gradient then adds nothing in the tile pass)
+    const float* g = a.gout + b * (a.d.L * F) + level * F;
+    bool any = false;
 #pragma unroll
-  for (int f = 0; f < F; ++f) any |= g[f] != 0.f;
-  if (!any) return;
+    for (int f = 0; f < F; ++f) any |= g[f] != 0.f;
+    if (!any) return;
+  }
   const float x[3] = {a.x[b * 3], a.x[b * 3 + 1], a.x[b * 3 + 2]};
   uint32_t pg[3];
   float fr[3];
@@ -341,7 +343,7 @@ extern "C" int snerf_hashgrid_bwd_bin(const snerf_hashgrid_desc* desc, const sne
                                       int32_t* counts, int32_t* tile_base, uint32_t* records, snerf_stream_t stream) {
   int rc = ht_validate(desc, plan, B);
   if (rc) return rc;
-  SNERF_REQUIRE(counts && tile_base && (records || B == 0) && (x || B == 0) && (grad_out || B == 0), "hashgrid_bwd_bin: null buffer");
+  SNERF_REQUIRE(counts && tile_base && (records || B == 0) && (x || B == 0), "hashgrid_bwd_bin: null buffer");
   HtArgs a = {};
   a.d = *desc; a.pl = *plan; a.x = x; a.B = B; a.gout = grad_out; a.counts = counts; a.tile_base = tile_base; a.records = records;
 #define HT_CALL(F_) ht_bin_launch<F_>(a, (hipStream_t)stream)

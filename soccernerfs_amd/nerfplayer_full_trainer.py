@@ -163,11 +163,12 @@ class NerfplayerFullTrainer:
         self._tv_cols = [(0, 1)] * 4
         self.launches = 0  # libsnerf launches of the last step (diagnostics)
         self.async_table_sweeps = bool(async_table_sweeps)
-        self._tiled, self._tiled_hash, self._hash_swept = None, None, False
+        self._tiled, self._tiled_hash, self._hash_swept, self._bin_done, self._hash_bin_done, self.early_bin = None, None, False, None, None, True
         if tiled_table_backward and not deterministic and cfg.temporal_tv_weight > 0:
             from .temporal_grid import TiledTableBackward
 
             self._tiled = [TiledTableBackward(self.newness, N, first_tiled_level=0), TiledTableBackward(self.decomp, N, first_tiled_level=0)]
+            self._tiled[1].share_bins_of(self._tiled[0])  # both grids are evaluated at the same (undeformed) positions and times: one binning pass (early_bin)
             if tiled_hash_backward:
                 # the static hash grid's table the same way (csrc/hashgrid_tiles.hip); opt-in: see DESIGN section 7 for where it pays
                 from .tcnn_compat import TiledHashTableBackward
@@ -415,6 +416,20 @@ class NerfplayerFullTrainer:
         self._dense_chain_fwd(self.stat_mlp, ("relu", "none"), b["sx"], 36, 0, 2 * N, [b["sh"], b["sv"]])
         self._pts = ops.coords_from_points(b["x2"])                         # explicit points for the temporal grids (pts [N,3], mode 0)
         self.wait_params()  # the newness / decomposition tables' sweeps of the last step (async_table_sweeps)
+        if self._tiled is not None and self._in_train_step and training and self.early_bin:
+            # the binning passes of the tiled backward need positions only: on a side stream NOW, beside the rest of the forward and the backward's MLP chain,
+            # instead of on the critical chain in front of the tile passes.  ONE pass for the newness and decomposition grids (same positions, same times).
+            main = torch.cuda.current_stream()
+            sb = side_stream(self.dev, "sort")
+            sb.wait_stream(main)
+            with torch.cuda.stream(sb):
+                stb = C.c_void_p(sb.cuda_stream)
+                self._tiled[0].bin(self._pts, b["tN"], 1, None, stb)
+                self._bin_done = sb.record_event()
+                if self._tiled_hash is not None:
+                    self._tiled_hash.bin(b["x2"], None, stb)
+                    self._hash_bin_done = sb.record_event()
+            self.launches += 5 + (5 if self._tiled_hash is not None else 0)
         self._tgrid_fwd(self.newness, self._pts, b["tN"], 1, N, b["vnew"])
         self._tgrid_fwd(self.decomp, self._pts, b["tN"], 1, N, b["dfeat"])
         self._mlp_fwd(self.decomp_mlp, b["dfeat"], F, N, b["logits"], 3)
@@ -478,8 +493,12 @@ class NerfplayerFullTrainer:
         if self._tiled is not None and self._in_train_step:
             # owner-computes form: bin both tables' touches here (the pass reads the deformed positions), then scatter + TV + Adam per table as one pass
             gouts = (b["gvnew"], b["gdfeat"])
-            for k in (0, 1):
-                self._tiled[k].bin(self._pts, b["tN"], 1, gouts[k], self._st)
+            if self._bin_done is not None:  # binned beside the forward (early_bin, one pass for both tables)
+                torch.cuda.current_stream().wait_event(self._bin_done)
+                self._bin_done = None
+            else:
+                # late binning without the zero-gradient filter as well: the two tables share ONE set of records (share_bins_of)
+                self._tiled[0].bin(self._pts, b["tN"], 1, None, self._st)
                 self.launches += 5
             if not early:
                 for k in (0, 1):
@@ -500,7 +519,11 @@ class NerfplayerFullTrainer:
             th = self._tiled_hash
             lc = th.plan.first_tiled_level
             gth = self.gviews["field.hash"]
-            th.bin(b["x2"], b["genc2"], self._st)
+            if self._hash_bin_done is not None:
+                torch.cuda.current_stream().wait_event(self._hash_bin_done)
+                self._hash_bin_done = None
+            else:
+                th.bin(b["x2"], b["genc2"], self._st)
             b["gx2"][N:].zero_()
             # the coarse levels (every point of the batch in a handful of tiles) through the atomic kernel: table gradient from both halves ...
             th.coarse_levels(b["x2"], b["genc2"], gth, self._st)

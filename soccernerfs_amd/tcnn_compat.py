@@ -148,11 +148,13 @@ class TiledHashTableBackward:
         self.tile_base = torch.empty(self.plan.n_tiles + 1, dtype=torch.int32, device=dev)
         self.records = torch.empty(max(int(self.plan.record_capacity), 1), dtype=torch.int32, device=dev)
 
-    def bin(self, x: torch.Tensor, gout: torch.Tensor, stream=None):
+    def bin(self, x: torch.Tensor, gout: Optional[torch.Tensor], stream=None):
+        """gout = None: file every point (the pass then needs the positions only and can run beside the forward)."""
         import ctypes as C
 
         st = stream if stream is not None else ops._stream()
-        _lib.check(_lib.lib().snerf_hashgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), ops._ptr(x), C.c_int64(self.B), ops._ptr(gout), ops._ptr(self.counts),
+        _lib.check(_lib.lib().snerf_hashgrid_bwd_bin(C.byref(self.enc.desc), C.byref(self.plan), ops._ptr(x), C.c_int64(self.B),
+                                                     ops._ptr(gout) if gout is not None else None, ops._ptr(self.counts),
                                                      ops._ptr(self.tile_base), ops._ptr(self.records), st), "hashgrid_bwd_bin")
 
     def coarse_levels(self, x: torch.Tensor, gout: torch.Tensor, gtable: torch.Tensor, stream=None):

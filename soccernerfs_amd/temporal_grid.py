@@ -202,6 +202,15 @@ class TiledTableBackward:
         self.records = torch.empty(max(int(self.plan.record_capacity), 1), dtype=torch.int32, device=dev)
         self.pos4 = torch.empty(max(self.B, 1), 4, dtype=torch.float32, device=dev)
 
+    def share_bins_of(self, other: "TiledTableBackward"):
+        """Two tables of the same geometry evaluated at the SAME positions and times (the full NeRFPlayer's newness and decomposition grids) need one binning
+        pass between them when it runs without the gradient filter (bin(gout=None)): alias `other`'s buffers; only `other.bin` is then called."""
+        a, b = self.enc.desc, other.enc.desc
+        same = (a.D, a.C, a.L, a.grid_C, a.H, a.gridtype, a.align_corners, a.S, list(a.offsets)) == (b.D, b.C, b.L, b.grid_C, b.H, b.gridtype, b.align_corners, b.S, list(b.offsets))
+        if not same or self.B != other.B or self.plan.tile_rows_log2 != other.plan.tile_rows_log2 or self.plan.first_tiled_level != other.plan.first_tiled_level:
+            raise ValueError("share_bins_of: the two tables' geometry / batch / tiling differ")
+        self.counts, self.tile_base, self.records, self.pos4 = other.counts, other.tile_base, other.records, other.pos4
+
     def bin(self, coords: _lib.Coords, times: torch.Tensor, spr: int, gout: Optional[torch.Tensor], stream=None):
         """gout = None: file every in-range sample (the pass then needs the sample positions only and can run beside the forward)."""
         st = stream if stream is not None else ops._stream()

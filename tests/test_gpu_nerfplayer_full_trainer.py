@@ -259,6 +259,8 @@ def test_tiled_table_backward_is_the_same_step(async_sweeps):
 
     a, b = make(True), make(False)
     assert a._tiled is not None and b._tiled is None
+    a.early_bin = async_sweeps  # binning beside the forward (default) / on the caller's stream in front of the tile passes; one shared pass either way
+    assert a._tiled[1].records.data_ptr() == a._tiled[0].records.data_ptr()
     rays, target, rng = _batch(R, 11)
     for tr in (a, b):
         tr.train_step(rays, target, rng)

@@ -23,6 +23,7 @@ ap.add_argument("--rays", type=int, default=4096)
 ap.add_argument("--mlp-operands", default="bf16", choices=["fp32", "bf16"], help="fp32: every net on the fp32 matrix instructions (the parity path); bf16: 16-bit MFMA operands everywhere")
 ap.add_argument("--sync-sweeps", action="store_true", help="A/B: the newness / decomposition tables' optimiser sweeps in order on the main stream (round 4) instead of on a side stream")
 ap.add_argument("--tiled", action="store_true", help="the newness / decomposition tables through the owner-computes backward + fused Adam (round 6, csrc/tgrid_tiles.hip)")
+ap.add_argument("--late-bin", action="store_true", help="A/B (--tiled): binning passes on the caller's stream in front of the tile passes instead of beside the forward")
 ap.add_argument("--tiled-hash", action="store_true", help="with --tiled: the static hash grid's table through its owner-computes pass too (csrc/hashgrid_tiles.hip)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -30,6 +31,7 @@ torch.manual_seed(0)
 R = args.rays
 tr = NerfplayerFullTrainer(NerfplayerModelConfig(), R, aabb_scale=1.0, device=dev, max_steps=30000, seed=0, async_table_sweeps=not args.sync_sweeps, mlp_operands=args.mlp_operands, tiled_table_backward=args.tiled, tiled_hash_backward=args.tiled_hash)
 tr.step = 600
+tr.early_bin = not args.late_bin
 
 
 def step():
