@@ -223,3 +223,48 @@ def test_sigma_net_rows_backward_matches_tile_kernel(d_in, N, quotient, operands
         # residue in the other (a ReLU-dead row): compare through the symmetric difference
         sa, sb = res["1"][2], res["0"][2]
         assert len(sa ^ sb) <= max(2, len(sb) // 200), (len(sa), len(sb), len(sa ^ sb))
+
+
+@pytest.mark.parametrize("d_in,N,quotient", [(160, 777, False), (160, 777, True), (192, 333, True), (32, 130, False)])
+def test_sigma_net_rows_backward_with_a_padded_row_stride_is_the_same_bits(d_in, N, quotient):
+    """csrc/mlp_rows128.hip on a ROW-STRIDED 16-bit input (ldx = d_in + 8, the pad columns holding large garbage; N not a multiple of its 128-row
+    tile) must give the bits it gives on the contiguous copy of the same rows -- gX / G, the weight gradients' value (order of the sums aside), the fix list --
+    so a layout or tail bug of the default sigma_net backward cannot hide inside the rows-vs-tile tolerance above."""
+    from soccernerfs_amd import _lib, ops
+    from soccernerfs_amd.tcnn_compat import Network
+
+    net = Network(d_in, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 128, "n_hidden_layers": 1}, operands="bf16").to(DEV)
+    gen = torch.Generator().manual_seed(31 + d_in)
+    x = torch.rand(N, d_in, generator=gen) - 0.3
+    x[torch.rand(N, d_in, generator=gen) < 0.01] = 0.0
+    xc = x.to(DEV).to(torch.bfloat16).contiguous()
+    ld = d_in + 8
+    xp = torch.full((N, ld), 1.0e4, device=DEV, dtype=torch.bfloat16)
+    xp[:, :d_in] = xc
+    gy = (torch.rand(N, 16, generator=gen) - 0.5).to(DEV)
+    gy[:, 15] = 0.0
+    gaux = (torch.rand(N, generator=gen) - 0.5).to(DEV)
+    L = _lib.lib()
+    res = []
+    for X, ldx in ((xc, d_in), (xp, ld)):
+        out, gw = torch.full((N, d_in), 7.0, device=DEV), torch.zeros_like(net.params)
+        if quotient:
+            cap = N * d_in
+            fl = torch.full((2 * cap,), -1, dtype=torch.int32, device=DEV)
+            cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
+            _lib.check(L.snerf_mlp_bwd_x16_quotient(C.byref(net.desc), ops._ptr(net.params), ops._ptr(X), ldx, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux),
+                                                    ops._ptr(out), d_in, ops._ptr(fl), cap, ops._ptr(cnt[0:1]), ops._ptr(cnt[1:2]), ops._ptr(gw), ops._stream()))
+            torch.cuda.synchronize()
+            n = int(cnt[0])
+            ent = fl[:2 * n].view(n, 2).cpu()
+            res.append((out, gw, sorted(zip(ent[:, 0].tolist(), ent[:, 1].tolist()))))
+        else:
+            _lib.check(L.snerf_mlp_bwd_x16(C.byref(net.desc), ops._ptr(net.params), ops._ptr(X), ldx, C.c_int64(N), ops._ptr(gy), 16, 15, ops._ptr(gaux), ops._ptr(out),
+                                           d_in, ops._ptr(gw), ops._stream()))
+            torch.cuda.synchronize()
+            res.append((out, gw, None))
+    assert float(res[0][0].abs().max()) > 0
+    assert torch.equal(res[0][0], res[1][0])  # per-sample quantities: the same bits whatever the row stride
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-4, atol=1e-5 * float(res[0][1].abs().max()))  # summed across workgroups: order of the atomics
+    if quotient:
+        assert res[0][2] == res[1][2] and len(res[0][2]) > 0  # the same (element, gradient bits) entries

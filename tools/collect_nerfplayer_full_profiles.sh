@@ -7,14 +7,15 @@ set -o pipefail
 TAG=${1:-r05}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p $OUT
 fail() { echo "collect_nerfplayer_full_profiles.sh: $1" >&2; exit 1; }
-python tools/bench_nerfplayer_full.py > $OUT/${TAG}_npf_bench.log 2> $OUT/${TAG}_npf_bench.err || fail "bench_nerfplayer_full.py failed (see $OUT/${TAG}_npf_bench.err)"
+NPFLAGS=${NPFLAGS---tiled}   # round 6: the newness / decomposition tables through the owner-computes pass; NPFLAGS= for the round-5 form
+python tools/bench_nerfplayer_full.py $NPFLAGS > $OUT/${TAG}_npf_bench.log 2> $OUT/${TAG}_npf_bench.err || fail "bench_nerfplayer_full.py failed (see $OUT/${TAG}_npf_bench.err)"
 tail -n 1 $OUT/${TAG}_npf_bench.log > $OUT/${TAG}_nerfplayer_full_bench.json
 STEPS=30; WARM=5
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_npf_stats -- python3 $ROOT/tools/bench_nerfplayer_full.py --steps $STEPS --warmup $WARM > $OUT/${TAG}_npf_stats.log 2>&1 ) \
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_npf_stats -- python3 $ROOT/tools/bench_nerfplayer_full.py $NPFLAGS --steps $STEPS --warmup $WARM > $OUT/${TAG}_npf_stats.log 2>&1 ) \
   || fail "rocprofv3 --stats pass failed (see $OUT/${TAG}_npf_stats.log)"
 S=$(find $OUT/${TAG}_npf_stats -name '*kernel_stats.csv' | head -1); T=$(find $OUT/${TAG}_npf_stats -name '*kernel_trace.csv' | head -1)
 [ -n "$S" ] && [ -n "$T" ] || fail "no kernel_stats.csv / kernel_trace.csv"
-{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_nerfplayer_full.py --steps $STEPS --warmup $WARM   ($((STEPS + WARM)) steps in the trace; every row)"; cat "$S"; } > $OUT/${TAG}_nerfplayer_full_kernel_stats.csv
+{ echo "# rocprofv3 --kernel-trace --stats -- python3 tools/bench_nerfplayer_full.py $NPFLAGS --steps $STEPS --warmup $WARM   ($((STEPS + WARM)) steps in the trace; every row)"; cat "$S"; } > $OUT/${TAG}_nerfplayer_full_kernel_stats.csv
 python tools/timeline.py "$T" 3 1 spaced_bins_kernel > $OUT/${TAG}_nerfplayer_full_timeline.txt || fail "timeline.py failed"
 TAG=$TAG STEPS=$((STEPS + WARM)) python - <<'PY'
 import csv, json, os
@@ -22,14 +23,16 @@ tag, out, steps = os.environ["TAG"], "gpurun_out", int(os.environ["STEPS"])
 bench = json.load(open(f"{out}/{tag}_nerfplayer_full_bench.json"))
 rows = [r for r in csv.DictReader(l for l in open(f"{out}/{tag}_nerfplayer_full_kernel_stats.csv") if not l.startswith("#"))]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-sweep = [r for r in rows if "adam" in r["Name"]]
-# the optimiser sweep: Adam (+ temporal TV on the four temporal tables), 32 B per parameter (p, g, m, v read; p, m, v written; g cleared)
+sweep = [r for r in rows if "adam" in r["Name"] or "tt_tiles_kernel" in r["Name"] or "ht_tiles_kernel" in r["Name"]]
+# the optimiser sweep: Adam (+ temporal TV on the four temporal tables), 32 B per parameter (p, g, m, v read; p, m, v written; g cleared); round 6: the two big
+# temporal tables (2 x 403 911 024 floats) are stepped by tt_tiles_kernel at 24 B per parameter (no dense gradient), the rest by the plain kernels
 sweep_ms = sum(float(r["TotalDurationNs"]) for r in sweep) / steps / 1e6
-alg = 32 * bench["params"]
+tiled = any("tt_tiles_kernel" in r["Name"] for r in rows)
+alg = 32 * bench["params"] - (8 * 2 * 403911024 if tiled else 0)
 top = sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:12]
 roof = {"workload": bench["config"], "ms_per_step": bench["ms_per_step"], "rays_per_s": bench["rays_per_s"], "params": bench["params"],
         "gpu_kernel_ms_per_step": tot / steps / 1e6,
-        "roofline": {"bound": "hbm", "kernel": "optimiser sweep over the flat buffer: " + ", ".join(sorted({r["Name"].split("(")[0][-40:] for r in sweep})) + " (32 B / parameter)",
+        "roofline": {"bound": "hbm", "kernel": "optimiser sweep over the flat buffer: " + ", ".join(sorted({r["Name"].split("(")[0][-40:] for r in sweep})) + " (32 B / parameter; 24 for the tables stepped by the tile pass)",
                      "achieved": alg / (sweep_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": alg / (sweep_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
                      "algorithmic_per_step": alg, "ms_per_step": sweep_ms, "launches_per_step": sum(int(r["Calls"]) for r in sweep) / steps},
         "top_kernels_ms_per_step": {r["Name"].split("(")[0][-60:]: round(float(r["TotalDurationNs"]) / steps / 1e6, 4) for r in top}}
