@@ -148,6 +148,7 @@ class NerfplayerTrainer:
 
             self._tiled = TiledTableBackward(self.enc, R * S2, first_tiled_level=tiled_first_level)
         self._side, self._field_sweep_done, self._field_swept, self._in_train_step, self._tv0_done = None, None, False, False, None
+        self._tv12_done = None
 
     # ---- helpers ----
     def _p(self, t):
@@ -223,6 +224,19 @@ class NerfplayerTrainer:
             finally:
                 self._st = keep
             self._tv0_done = self._side.record_event()
+        # (r06) the two proposal tables' TV passes read parameters only as well: on the "sort" stream now, beside the field's backward, instead of behind the
+        # proposal backward on the caller's stream -- where they shared the memory system with the tile pass / sweep of the main table (0.5 ms of column reads
+        # over the tables inside the window of the step's critical kernel).  Same order of the reference's row draws: field, proposal 0, proposal 1.
+        sb = side_stream(self.dev, "sort")
+        sb.wait_stream(main)
+        with torch.cuda.stream(sb):
+            self._st = C.c_void_p(sb.cuda_stream)
+            try:
+                self._tv_sign(1)
+                self._tv_sign(2)
+            finally:
+                self._st = keep
+            self._tv12_done = sb.record_event()
 
     def _field_table_sweep_async(self):
         """async_field_sweep: the field table's Adam sweep on the side stream, behind everything the caller's stream holds (the table's gradient scatter)
@@ -436,10 +450,14 @@ class NerfplayerTrainer:
         # gives the value and the per-row signed step; the gradient itself is added inside the Adam sweep (optimizer_step)
         if cfg.temporal_tv_weight > 0:
             for k in range(3):
-                if not ((early or (self._tiled is not None and self._in_train_step)) and k == 0):  # the same order of row draws either way: field, proposal 0, proposal 1
+                if early:  # all three passes were issued at the start of the backward (_field_tv_early)
+                    continue
+                if not (self._tiled is not None and self._in_train_step and k == 0):  # the same order of row draws either way: field, proposal 0, proposal 1
                     self._tv_sign(k)
             if early:
-                torch.cuda.current_stream().wait_event(self._tv0_done)  # loss_dict reads the field table's TV value on the caller's stream
+                # loss_dict reads the TV values and optimizer_step the proposal tables' per-row signs on the caller's stream
+                torch.cuda.current_stream().wait_event(self._tv0_done)
+                torch.cuda.current_stream().wait_event(self._tv12_done)
 
     def materialize_tv_gradient(self):
         """Adds the temporal-TV gradient into self.grads explicitly (what the Adam sweep otherwise does on the fly); for parity tests."""

@@ -318,7 +318,12 @@ def test_fix_list_default_cannot_overflow_and_a_small_one_ends_the_run_from_opti
     g_q, g_p = grads(full), grads(product)
     assert float(g_p.abs().max()) > 0
     assert int(full._ss.fix_counts.max()) >= full._ss.N * 8  # the fix list really carried this step's vanished-feature terms
-    torch.testing.assert_close(g_q, g_p, rtol=1e-3, atol=2e-6 * float(g_p.abs().max()))
+    # quotient form = the bf16-rounded feature over the fp32 plane value: 2^-9 per element against the product form; what matters here is that NO term is
+    # missing -- the zeroed plane's own gradient consists of fix-list terms only (its value vanishes in every quotient)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    n_xy0 = full.field_planes.offsets[0][1]  # the XY plane of scale 0 = floats [0, offset of XZ)
+    assert float(g_p[:n_xy0].norm()) > 0 and rel(g_q[:n_xy0], g_p[:n_xy0]) < 5e-3, rel(g_q[:n_xy0], g_p[:n_xy0])
+    assert rel(g_q, g_p) < 5e-3, rel(g_q, g_p)
     full.optimizer_step()
     full.synchronize()  # no overflow possible
 
