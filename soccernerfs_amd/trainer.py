@@ -948,19 +948,19 @@ class KPlanesTrainer:
             torch.cuda.current_stream().wait_event(ev)
             self._field_adam_done = None
 
-    def synchronize(self):
+    def synchronize(self, check_overflow: bool = True):
         """Join every stream the trainer uses; call before reading parameters / Adam state from outside a train step."""
         self._join_prop()
         self._wait_params()
         torch.cuda.synchronize(self.dev)
-        if getattr(self, "_fix_peak_host", None) is not None:
+        if check_overflow and getattr(self, "_fix_peak_host", None) is not None:
             self._ss.check_fix_overflow()
 
     @torch.no_grad()
     def restart(self, params: Optional[torch.Tensor] = None):
         """Back to optimiser step 0: Adam moments, gradients and the device-side step / skip counters cleared; `params` (a flat copy of
         self.params taken earlier, e.g. right after construction) restores the parameters too.  bench.py's trained-state leg starts from here."""
-        self.synchronize()
+        self.synchronize(check_overflow=False)  # a new run starts here: an overflow recorded by the old one is cleared below, not raised
         if params is not None:
             self.params.copy_(params)
         for t in (self.exp_avg, self.exp_avg_sq, self.grads) + ((self.grads_fx,) if self.grads_fx is not None else ()):
