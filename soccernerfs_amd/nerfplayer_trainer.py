@@ -149,6 +149,7 @@ class NerfplayerTrainer:
             self._tiled = TiledTableBackward(self.enc, R * S2, first_tiled_level=tiled_first_level)
         self._side, self._field_sweep_done, self._field_swept, self._in_train_step, self._tv0_done = None, None, False, False, None
         self._tv12_done = None
+        self.fused_ray_loss, self._ray_deferred = True, False  # train_step: the nerf level's per-ray work as one launch (snerf_ray_train_fwd_bwd)
 
     # ---- helpers ----
     def _p(self, t):
@@ -376,7 +377,13 @@ class NerfplayerTrainer:
                 _lib.check(self.lib.snerf_nerfacto_head_input_fwd(self._p(dd), self._p(b["h"]), self._p(app) if app is not None else None,
                                                                   self._p(cm) if cm is not None else None, S, R, self._p(b["hx"]), self._st), "head_input_fwd")
                 self._mlp_fwd(self.head, b["hx"], 64, N, b["rgb"], 3)
-                _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, S, self._p(b["w"][2]), self._st), "weights_fwd")
+                self._ray_deferred = bool(training and self._in_train_step and self.fused_ray_loss)
+                if not self._ray_deferred:
+                    _lib.check(self.lib.snerf_weights_fwd(self._p(b["dens"][2]), self._p(b["eb"][2]), R, S, self._p(b["w"][2]), self._st), "weights_fwd")
+        if self._ray_deferred:
+            # train_step: weights, compositing, MSE backward, distortion and the weights' backward are ONE launch at the start of backward()
+            # (snerf_ray_train_fwd_bwd, bit-identical to the five kernels); the expected depth (an output no loss of this model reads) is not rendered
+            return b["rgb_out"]
         a = _lib.RenderArgs()
         a.weights, a.rgb, a.ebins = b["w"][2].data_ptr(), b["rgb"].data_ptr(), b["eb"][2].data_ptr()
         a.bg_mode, a.bg = 0, rng["bg"].data_ptr()
@@ -399,12 +406,23 @@ class NerfplayerTrainer:
             b["tv"].zero_()
             if early:
                 self._field_tv_early()
-        _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
-                                                 2.0 / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]), self._st), "render_mse_bwd")
-        _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, cfg.distortion_loss_mult / R, self._p(b["dist_rays"]),
-                                             self._p(b["gw"][2]), 1, self._st), "distortion")
-        _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0, None,
-                                              self._st), "weights_bwd")
+        if self._ray_deferred:
+            ra = _lib.RayTrainArgs()
+            ra.density, ra.ebins, ra.sbins, ra.rgb = b["dens"][2].data_ptr(), b["eb"][2].data_ptr(), b["sb"][2].data_ptr(), b["rgb"].data_ptr()
+            ra.bg, ra.target, ra.R, ra.S, ra.bg_mode = rng["bg"].data_ptr(), target.data_ptr(), R, S2, 0
+            ra.go_scale, ra.dist_scale = 2.0 / (3 * R), cfg.distortion_loss_mult / R
+            ra.weights, ra.rgb_out, ra.acc_out, ra.depth_median = b["w"][2].data_ptr(), b["rgb_out"].data_ptr(), b["acc"].data_ptr(), None
+            ra.sqerr_rays, ra.dist_rays, ra.g_rgb, ra.g_density = b["sqerr"].data_ptr(), b["dist_rays"].data_ptr(), b["grgb"].data_ptr(), b["gdens"][2].data_ptr()
+            ra.g_weights, ra.nonfinite_flag = None, None
+            _lib.check(self.lib.snerf_ray_train_fwd_bwd(C.byref(ra), self._st), "ray_train_fwd_bwd")
+            self._ray_deferred = False
+        else:
+            _lib.check(self.lib.snerf_render_mse_bwd(self._p(b["w"][2]), self._p(b["rgb"]), self._p(rng["bg"]), 0, self._p(b["rgb_out"]), self._p(target),
+                                                     2.0 / (3 * R), R, S2, self._p(b["gw"][2]), self._p(b["grgb"]), self._p(b["sqerr"]), self._st), "render_mse_bwd")
+            _lib.check(self.lib.snerf_distortion(self._p(b["w"][2]), self._p(b["sb"][2]), R, S2, cfg.distortion_loss_mult / R, self._p(b["dist_rays"]),
+                                                 self._p(b["gw"][2]), 1, self._st), "distortion")
+            _lib.check(self.lib.snerf_weights_bwd(self._p(b["dens"][2]), self._p(b["eb"][2]), self._p(b["gw"][2]), R, S2, self._p(b["gdens"][2]), 0, None,
+                                                  self._st), "weights_bwd")
         # colour head: gX = [dSH (unused) | d geo | d appearance | pad]
         self._mlp_bwd(self.head, self.gviews["field.head"], b["hx"], 64, N2, b["grgb"], 3, -1, None, b["ghx"], 64)
         # gh[:, 1:16] = ghx[:, 16:31] (column 0, the density, enters through gaux below); appearance gradient = per-ray sums of ghx[:, 31:63] added to the

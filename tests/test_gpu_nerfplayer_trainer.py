@@ -450,3 +450,35 @@ def test_stock_pytorch_standin_and_hip_trainer_take_the_same_steps():
     eh = tr.forward(rays, None, rng, 1.0, training=False).clone()
     er = ref.forward(rays, None, rng, 1.0, training=False)
     torch.testing.assert_close(eh, er, rtol=0, atol=5e-3)
+
+
+def test_one_launch_ray_kernel_in_train_step_gives_the_same_bits():
+    """(r06) train_step runs the nerf level's per-ray work -- get_weights, compositing, MSE backward, distortion loss + gradient, get_weights backward -- as ONE
+    launch (snerf_ray_train_fwd_bwd, already pinned bit-identical to the five kernels in tests/test_gpu_render_loss.py) instead of five: deterministic mode, eight
+    steps, parameters / moments / every loss term identical to the five-kernel step, rendered colours of the batch identical."""
+    from soccernerfs_amd.nerfplayer_trainer import NerfplayerTrainer
+
+    R, n_img = 128, 9
+    cfg = _cfg()
+
+    def run(fused):
+        tr = NerfplayerTrainer(cfg, R, n_img, aabb_scale=1.0, device=DEV, seed=5, deterministic=True, warm_up_end=4)
+        tr.fused_ray_loss = fused
+        with torch.no_grad():
+            g = torch.Generator().manual_seed(1)
+            for name in ("field.table", "prop0.table", "prop1.table"):
+                tr.views[name].copy_((torch.rand(tr.views[name].shape, generator=g) * 2 - 1).to(DEV))
+        tr.tv_rows = [2, 1, 3]
+        losses, rgbs = [], []
+        for k in range(8):
+            rays, cams, target, rng = _batch(R, n_img, 400 + k)
+            rgbs.append(tr.train_step(rays, cams, target, rng).clone())
+            losses.append({k_: float(v) for k_, v in tr.loss_dict().items()})
+        tr.synchronize()
+        return tr.params.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), losses, torch.stack(rgbs)
+
+    a, b = run(True), run(False)
+    assert a[3] == b[3]
+    for x, y in zip(a[:3], b[:3]):
+        assert torch.equal(x, y)
+    assert torch.equal(a[4], b[4]) and bool(torch.isfinite(a[4]).all())
