@@ -473,7 +473,9 @@ def test_one_launch_ray_kernel_in_train_step_gives_the_same_bits():
         for k in range(8):
             rays, cams, target, rng = _batch(R, n_img, 400 + k)
             rgbs.append(tr.train_step(rays, cams, target, rng).clone())
-            losses.append({k_: float(v) for k_, v in tr.loss_dict().items()})
+            # (the temporal-TV VALUE is a float-atomic sum of per-workgroup partials in every mode: order-dependent in its last bit, excluded as in the
+            # asynchronous-sweep test above; its GRADIENT -- the per-row signs -- is exact and enters the parameters compared below)
+            losses.append({k_: float(v) for k_, v in tr.loss_dict().items() if k_ != "temporal_tv_loss"})
         tr.synchronize()
         return tr.params.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), losses, torch.stack(rgbs)
 
