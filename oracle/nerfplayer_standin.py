@@ -150,7 +150,7 @@ class NerfplayerStandinTrainer:
         R = o.shape[0]
         nears, fars = KO.intersect_aabb(o, d, self.aabb, 0.0, training)  # AABBBoxCollider(scene_box): near_plane 0
         levels = list(cfg.num_proposal_samples_per_ray) + [cfg.num_nerf_samples_per_ray]
-        weights_list, sdist_list = [], []
+        weights_list, sdist_list, self._last_ebins = [], [], []
         weights = bins = None
         for li, S in enumerate(levels):
             if li == 0:
@@ -159,6 +159,7 @@ class NerfplayerStandinTrainer:
                 u = KO.pdf_u(R, S, rng["u"][li - 1] if training else None).to(o.device)
                 bins, _, _ = KO.pdf_sample(torch.pow(weights, anneal), bins, u)
             eucl = KO.spacing_to_euclidean(bins, nears, fars, kind="piecewise")  # UniformLinDispPiecewiseSampler (ray_samplers.py:238-246)
+            self._last_ebins.append(eucl.detach())
             starts, ends = eucl[:, :-1], eucl[:, 1:]
             pos = KO.sample_positions(o, d, starts, ends)
             trs = t[:, None].expand(R, S)
@@ -183,6 +184,22 @@ class NerfplayerStandinTrainer:
             out_rgb = torch.clamp(out_rgb, 0.0, 1.0)
         return out_rgb, weights_list, sdist_list
 
+    def loss_and_backward(self, rays, cams, target, rng: Dict, anneal: float, proposal_grad: bool = True):
+        """One training forward, the loss dict of NerfplayerNerfactoModel.get_loss_dict (nerfplayer_nerfacto.py:289-318) and its backward; gradients land in the
+        leaves' .grad.  Returns (rgb, loss dict).  tests/test_standin_cpu.py checks exactly this against golden G12 = the reference's own model on the same rays,
+        draws, anneal value and TV row: rendered colours, weights of every level, every loss term and the gradient of every parameter tensor."""
+        cfg = self.cfg
+        rgb, wl, sl = self._render(rays, cams.long().reshape(-1), rng, anneal, True, proposal_grad)
+        ld = {"rgb_loss": torch.mean((target - rgb) ** 2), "interlevel_loss": cfg.interlevel_loss_mult * KO.interlevel_loss(wl, sl),
+              "distortion_loss": cfg.distortion_loss_mult * KO.distortion_loss(wl[-1], sl[-1])}
+        if cfg.temporal_tv_weight > 0:
+            grids = [self.grid] + self.prop_grid  # field, proposal 0, proposal 1: the order of the reference's randint draws (nerfplayer_nerfacto.py:311-316)
+            rows = self.tv_rows if self.tv_rows is not None else [int(torch.randint(0, len(g.index_ab), [1]).item()) for g in grids]
+            ld["temporal_tv_loss"] = cfg.temporal_tv_weight * sum(g.tv_loss(r) for g, r in zip(grids, rows))
+        sum(ld.values()).backward()
+        self._last = {"weights": [w.detach() for w in wl], "sbins": [b.detach() for b in sl]}
+        return rgb, ld
+
     def train_step(self, rays, cams, target, rng: Optional[Dict] = None):
         cfg, R = self.cfg, self.R
         step = self.step
@@ -198,14 +215,7 @@ class NerfplayerStandinTrainer:
             for g in opt.param_groups:
                 g["lr"] = lr
             opt.zero_grad(set_to_none=False)  # the reference's torch (1.13) zeroes instead of dropping: a proposal net whose backward was skipped is stepped with g = 0
-        rgb, wl, sl = self._render(rays, cams.long(), rng, anneal, True, updated)
-        ld = {"rgb_loss": torch.mean((target - rgb) ** 2), "interlevel_loss": cfg.interlevel_loss_mult * KO.interlevel_loss(wl, sl),
-              "distortion_loss": cfg.distortion_loss_mult * KO.distortion_loss(wl[-1], sl[-1])}
-        if cfg.temporal_tv_weight > 0:
-            grids = [self.grid] + self.prop_grid  # field, proposal 0, proposal 1: the order of the reference's randint draws (nerfplayer_nerfacto.py:311-316)
-            rows = self.tv_rows if self.tv_rows is not None else [int(torch.randint(0, len(g.index_ab), [1]).item()) for g in grids]
-            ld["temporal_tv_loss"] = cfg.temporal_tv_weight * sum(g.tv_loss(r) for g, r in zip(grids, rows))
-        sum(ld.values()).backward()
+        rgb, ld = self.loss_and_backward(rays, cams, target, rng, anneal, updated)
         self._ld = {k: v.detach() for k, v in ld.items()}
         # every parameter that has ever had a gradient is stepped every step (zeroed, not dropped, gradients: see above) -- what the HIP trainer's one sweep does
         for opt in self.opts.values():

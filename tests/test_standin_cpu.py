@@ -149,3 +149,72 @@ def test_nerfplayer_standin_grid_equals_the_tgrid_oracle():
         torch.testing.assert_close(g.tv_loss(row), TO.temporal_tv_loss(emb, table["index_ab"][row].tolist()))
         (got.square().sum() + g.tv_loss(row)).backward()
         assert all(lv.grad is not None and float(lv.grad.abs().max()) > 0 for lv in g.levels)
+
+
+def test_nerfplayer_standin_reproduces_the_reference_models_own_step():
+    """oracle/nerfplayer_standin.NerfplayerStandinTrainer -- the reference-ALGORITHM arm of config 4's PSNR -- against golden G12 = the
+    REFERENCE'S OWN NerfplayerNerfactoModel run on the CPU (oracle/gen_golden_nerfplayer.py imports it): built from G12's parameters and fed G12's rays, uniform
+    draws, anneal value and TV row, the stand-in must give the reference's sample bins and weights at all three levels, its rendered colours, every term of its
+    loss dict and the gradient of every parameter tensor (sum, sum of magnitudes, 64 probes)."""
+    from types import SimpleNamespace as NS
+
+    import numpy as np
+
+    from oracle import tgrid_oracle as TO
+    from oracle.nerfplayer_standin import NerfplayerStandinTrainer
+    from soccernerfs_amd.nerfplayer_nerfacto import NerfplayerNerfactoModelConfig
+    from tests.conftest import load_golden
+
+    g = load_golden("g12_nerfplayer")
+    # the golden's model configuration (oracle/gen_golden_nerfplayer.py: CFG; restated here so that the test never imports the generator, which imports the reference)
+    CFG = dict(disable_scene_contraction=True, num_levels=4, features_per_level=2, log2_hashmap_size=10, temporal_dim=8,
+               proposal_net_args_list=[{"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 32},
+                                       {"hidden_dim": 16, "temporal_dim": 4, "log2_hashmap_size": 9, "num_levels": 3, "max_res": 64}],
+               num_proposal_samples_per_ray=(32, 16), num_nerf_samples_per_ray=8)
+    cfg = NerfplayerNerfactoModelConfig(**CFG)
+
+    def enc(prefix, num_levels, log2, max_res=None):
+        scale = float(np.exp2(np.log2(2048 / 16) / (num_levels - 1))) if max_res is None else float(np.exp((np.log(max_res) - np.log(16)) / (num_levels - 1)))
+        offs = TO.level_offsets(num_levels, 16, scale, log2)
+        emb = g[f"param_{prefix}.embeddings"]
+        assert offs[-1] == emb.shape[0]
+        return NS(embeddings=emb, offsets=torch.tensor(offs), per_level_scale=scale, base_resolution=16, level_dim=2, gridtype_id=0)
+
+    lin = lambda prefix, n: NS(linear_weights=lambda: [g[f"param_{prefix}.layers.{i}.weight"] for i in range(n)])
+    R = int(g["R"])
+    src = NS(cfg=cfg, R=R, S=(32, 16, 8), aabb=[[-1.0] * 3, [1.0] * 3],
+             prop_enc=[enc(f"proposal_networks.{i}.encoding", 3, 9, max_res=(32, 64)[i]) for i in range(2)], enc=enc("field.mlp_base", 4, 10),
+             prop_mlp=[lin(f"proposal_networks.{i}.linear", 2) for i in range(2)], decode=lin("field.mlp_base_decode", 2), head=lin("field.mlp_head", 3),
+             appearance=NS(weight=g["param_field.embedding_appearance.embedding.weight"]))
+    tr = NerfplayerStandinTrainer(src, "cpu")
+    tr.tv_rows = [int(g["tv_row"])] * 3
+    rays = {"origins": g["origins"], "directions": g["directions"], "times": g["times"]}
+    rng = {"t_rand": g["t_rand"], "u": [g["u0"], g["u1"]], "bg": g["bg"]}
+    rgb, ld = tr.loss_and_backward(rays, g["cams"], g["target"], rng, float(g["anneal"]), True)
+    for i in range(3):
+        torch.testing.assert_close(tr._last_ebins[i], g[f"ebins_{i}"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(tr._last["weights"][i], g[f"weights_{i}"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(rgb.detach(), g["rgb"], rtol=1e-4, atol=1e-6)
+    assert set(ld) == {"rgb_loss", "interlevel_loss", "distortion_loss", "temporal_tv_loss"}
+    for k, v in ld.items():
+        torch.testing.assert_close(v.detach(), torch.as_tensor(g["loss_" + k]), rtol=1e-4, atol=1e-9, msg=lambda m: f"{k}: {m}")
+    torch.testing.assert_close(sum(ld.values()).detach(), torch.as_tensor(g["loss_total"]), rtol=1e-4, atol=1e-9)
+    table_grad = lambda grid: torch.cat([lv.grad for lv in grid.levels], 0)
+    mine = {"field.embedding_appearance.embedding.weight": tr.appearance.grad, "field.mlp_base.embeddings": table_grad(tr.grid)}
+    for i, w in enumerate(tr.decode_w):
+        mine[f"field.mlp_base_decode.layers.{i}.weight"] = w.grad
+    for i, w in enumerate(tr.head_w):
+        mine[f"field.mlp_head.layers.{i}.weight"] = w.grad
+    for k in range(2):
+        mine[f"proposal_networks.{k}.encoding.embeddings"] = table_grad(tr.prop_grid[k])
+        for i, w in enumerate(tr.prop_w[k]):
+            mine[f"proposal_networks.{k}.linear.layers.{i}.weight"] = w.grad
+    names = [str(n) for n in g["param_names"]]
+    assert set(names) == set(mine)
+    for name in names:
+        got = mine[name]
+        gabs = float(g["gabs_" + name])
+        assert abs(float(got.double().sum()) - float(g["gsum_" + name])) <= 1e-4 * gabs + 1e-10, name
+        assert abs(float(got.double().abs().sum()) - gabs) <= 1e-4 * gabs + 1e-10, name
+        probe = got.flatten()[:: max(1, got.numel() // 64)][:64]
+        torch.testing.assert_close(probe, g["gprobe_" + name], rtol=1e-3, atol=1e-7 + 1e-4 * float(g["gprobe_" + name].abs().max()), msg=lambda m: f"{name}: {m}")
