@@ -534,6 +534,9 @@ class NerfplayerTrainer:
         return {"t_rand": flat[:R].view(R, 1), "u": [flat[R:2 * R].view(R, 1), flat[2 * R:3 * R].view(R, 1)], "bg": flat[3 * R:].view(R, 3)}
 
     def train_step(self, rays: Dict[str, torch.Tensor], cams: torch.Tensor, target: torch.Tensor, rng: Optional[Dict[str, torch.Tensor]] = None):
+        """One optimiser step; returns the rendered colours of the batch (a work buffer, valid until the next call).  With fused_ray_loss (default) the nerf
+        level's weights, compositing, MSE backward, distortion term and weights' backward are one launch and the expected DEPTH of the batch is not rendered
+        (no loss of this model reads it: buf["depth"] keeps the last forward(training=False)'s values); forward() + backward() called separately render it."""
         cfg = self.cfg
         anneal = anneal_value(self.step, cfg.proposal_weights_anneal_max_num_iters, cfg.proposal_weights_anneal_slope) \
             if cfg.use_proposal_weight_anneal else 1.0
